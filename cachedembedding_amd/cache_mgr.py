@@ -1,0 +1,303 @@
+"""CachedParamMgr: the Python mirror of ColossalAI's software-cache manager over the C ABI.
+
+Same names, argument meaning and error behaviour as the class the reference drives
+(`embed.cache_weight_mgr.prepare_ids(...)` recsys/dlrm_main.py:259, `print_comm_stats`
+benchmark/benchmark_cache.py:75, hit/miss histories recsys/dlrm_main.py:286-289); semantics
+per SURVEY.md Appendix A.1-A.6.  All cache work is HIP kernels in libce_hip.so
+(csrc/ce_cache.hip); torch only owns the device arrays and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import sys
+import weakref
+from enum import Enum
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CeCacheConfig, CeCallStats, check, lib, ptr, stream_ptr
+
+
+class EvictionStrategy(Enum):
+    """recsys/models/dlrm.py:66,80 choose between these two."""
+    LFU = 1
+    DATASET = 2
+
+
+class HostTable:
+    """[N, D] fp32 table in pinned, device-mapped host DRAM (CachedParamMgr.weight, A.1)."""
+
+    def __init__(self, tensor: torch.Tensor, host_ptr: int, dev_ptr: int, owned: bool, registered: bool):
+        self.tensor = tensor
+        self.host_ptr = host_ptr
+        self.dev_ptr = dev_ptr
+        self._fin = weakref.finalize(self, HostTable._release, host_ptr, owned, registered)
+
+    @staticmethod
+    def _release(host_ptr: int, owned: bool, registered: bool):
+        try:
+            if owned:
+                lib.ce_host_free(ctypes.c_void_p(host_ptr))
+            elif registered:
+                lib.ce_host_unregister(ctypes.c_void_p(host_ptr))
+        except Exception:
+            pass
+
+    @classmethod
+    def allocate(cls, num_embeddings: int, dim: int, threads: int = 0) -> "HostTable":
+        _lib.require_gpu()
+        nbytes = num_embeddings * dim * 4
+        hp, dp = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib.ce_host_alloc(nbytes, threads or _default_threads(), ctypes.byref(hp), ctypes.byref(dp)))
+        arr = np.ctypeslib.as_array((ctypes.c_float * (num_embeddings * dim)).from_address(hp.value))
+        t = torch.from_numpy(arr).view(num_embeddings, dim)
+        return cls(t, hp.value, dp.value, owned=True, registered=False)
+
+    @classmethod
+    def wrap(cls, weight: torch.Tensor) -> "HostTable":
+        """Pin + map a tensor the caller owns (the `_weight` / from_pretrained path)."""
+        _lib.require_gpu()
+        assert weight.device.type == "cpu" and weight.dtype == torch.float32 and weight.is_contiguous()
+        dp = ctypes.c_void_p()
+        check(lib.ce_host_register(ctypes.c_void_p(weight.data_ptr()), weight.numel() * 4, ctypes.byref(dp)))
+        return cls(weight, weight.data_ptr(), dp.value, owned=False, registered=True)
+
+    def fill_uniform_(self, lo: float, hi: float, seed: int, threads: int = 0):
+        check(lib.ce_host_fill_uniform(ctypes.c_void_p(self.host_ptr), self.tensor.numel(), lo, hi, seed,
+                                       threads or _default_threads()))
+        return self
+
+
+def _default_threads() -> int:
+    import os
+    return max(1, min(64, (os.cpu_count() or 1)))
+
+
+class CachedParamMgr(torch.nn.Module):
+    """Manages a [cuda_row_num, D] HBM cache of rows of a host-resident [N, D] table.
+
+    Args mirror upstream: weight (CPU fp32 [N, D], or a HostTable), cuda_row_num,
+    buffer_size (accepted; the zero-copy / staged transports make LimitBuffIndexCopyer
+    unnecessary), pin_weight (the table is always pinned + mapped here), evict_strategy,
+    async_copy (maps to the staged hipMemcpyAsync transport when True)."""
+
+    def __init__(self, weight, cuda_row_num: int = 0, buffer_size: int = 0, pin_weight: bool = True,
+                 evict_strategy: EvictionStrategy = EvictionStrategy.DATASET, async_copy: bool = False,
+                 device: Optional[torch.device] = None, strict: bool = True, use_idx_map: Optional[bool] = None):
+        super().__init__()
+        _lib.require_gpu()
+        if cuda_row_num == 0:
+            raise NotImplementedError("cuda_row_num == 0 (no cache) is not implemented")
+        self._table = weight if isinstance(weight, HostTable) else HostTable.wrap(weight)
+        self.weight = self._table.tensor
+        self.num_embeddings, self.embedding_dim = self.weight.shape
+        self.cuda_row_num = int(cuda_row_num)
+        self.buffer_size = buffer_size
+        self.pin_weight = pin_weight
+        self._evict_strategy = evict_strategy
+        self._async_copy = async_copy
+        self.strict = strict           # True: prepare_ids raises on overflow like upstream (one tiny sync)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        N, C, D = self.num_embeddings, self.cuda_row_num, self.embedding_dim
+        assert N < 2 ** 31 - 1, "row ids are int32 on the device"
+        dev = self.device
+        # the only trainable parameter the optimiser sees (A.1)
+        self.cuda_cached_weight = torch.nn.Parameter(torch.zeros(C, D, device=dev, dtype=torch.float32))
+        # DATASET+freq re-rank needs idx_map; identity otherwise (kept None = no array, no gather)
+        self._idx_map: Optional[torch.Tensor] = None
+        if use_idx_map:
+            self._idx_map = torch.arange(N, device=dev, dtype=torch.int32)
+        self.register_buffer("cached_idx_map", torch.empty(C, device=dev, dtype=torch.int32), persistent=False)
+        self.register_buffer("inverted_cached_idx", torch.empty(N, device=dev, dtype=torch.int32), persistent=False)
+        if evict_strategy == EvictionStrategy.LFU:
+            self.register_buffer("freq_cnter", torch.empty(C, device=dev, dtype=torch.int64), persistent=False)
+        else:
+            self.freq_cnter = None
+        self._max_ids = 2 ** 31 - 2
+        self._handle = None
+        self._workspace = None
+        self._create_handle()
+        self._hist_seen = 0
+        self.num_hits_history: List[int] = []
+        self.num_miss_history: List[int] = []
+        self.num_write_back_history: List[int] = []
+
+    # ------------------------------------------------------------------ handle plumbing
+    def _create_handle(self):
+        N, C = self.num_embeddings, self.cuda_row_num
+        ws_bytes = lib.ce_cache_workspace_bytes(N, C, self._max_ids)
+        self._workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        base = self._workspace.data_ptr()
+        aligned = (base + 255) & ~255
+        cfg = CeCacheConfig()
+        cfg.num_embeddings = N
+        cfg.cuda_row_num = C
+        cfg.embedding_dim = self.embedding_dim
+        cfg.evict_strategy = _lib.CE_EVICT_LFU if self._evict_strategy == EvictionStrategy.LFU else _lib.CE_EVICT_DATASET
+        cfg.transport = _lib.CE_TRANSPORT_STAGED if self._async_copy else _lib.CE_TRANSPORT_ZEROCOPY
+        cfg.protect_depth = 0
+        cfg.max_ids_per_call = self._max_ids
+        cfg.host_weight = self._table.host_ptr
+        cfg.host_weight_dev = self._table.dev_ptr
+        cfg.cache_weight = self.cuda_cached_weight.data_ptr()
+        cfg.idx_map = ptr(self._idx_map)
+        cfg.inverted_cached_idx = self.inverted_cached_idx.data_ptr()
+        cfg.cached_idx_map = self.cached_idx_map.data_ptr()
+        cfg.freq_cnter = ptr(self.freq_cnter)
+        cfg.workspace = aligned
+        cfg.workspace_bytes = ws_bytes
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.ce_cache_create(ctypes.byref(cfg), stream_ptr(), ctypes.byref(h)))
+        self._handle = h
+        self._fin = weakref.finalize(self, lib.ce_cache_destroy, h)
+
+    @property
+    def idx_map(self) -> torch.Tensor:
+        """id -> cpu_row_idx (identity unless DATASET + ids_freq_mapping)."""
+        if self._idx_map is None:
+            return torch.arange(self.num_embeddings, device=self.device, dtype=torch.int32)
+        return self._idx_map
+
+    @property
+    def cuda_available_row_num(self) -> int:
+        out = ctypes.c_int64()
+        check(lib.ce_cache_free_rows(self._handle, ctypes.byref(out)))
+        return out.value
+
+    # ------------------------------------------------------------------ A.2
+    @torch.no_grad()
+    def reorder(self, ids_freq_mapping=None, warmup_ratio: float = 0.7):
+        N, C = self.num_embeddings, self.cuda_row_num
+        freq = None
+        order = None
+        if ids_freq_mapping is not None:
+            freq = torch.as_tensor(ids_freq_mapping).to(device=self.device, dtype=torch.int64).view(-1)
+            assert freq.numel() == N
+            # canonical tie rule (SURVEY B#2): stable descending
+            order = torch.argsort(freq, descending=True, stable=True)
+            if self._evict_strategy == EvictionStrategy.DATASET:
+                inv = torch.empty(N, device=self.device, dtype=torch.int32)
+                inv[order] = torch.arange(N, device=self.device, dtype=torch.int32)
+                if self._idx_map is None:
+                    self._idx_map = inv
+                    self._recreate_with_idx_map()
+                else:
+                    self._idx_map.copy_(inv)
+        n = min(int(math.ceil(C * warmup_ratio)), N)
+        if n > 0:
+            rows = None
+            fvals = None
+            if self._evict_strategy == EvictionStrategy.LFU and freq is not None:
+                rows = order[:n].to(torch.int32).contiguous()
+                fvals = freq[order[:n]].contiguous()
+            with torch.cuda.device(self.device):
+                check(lib.ce_cache_preload(self._handle, ptr(rows), ptr(fvals), n, stream_ptr()))
+                torch.cuda.current_stream().synchronize()
+
+    def _recreate_with_idx_map(self):
+        # only legal while the cache is still empty (reorder runs once, right after construction)
+        assert self.cuda_available_row_num == self.cuda_row_num, "reorder() after rows were cached"
+        self._fin.detach()
+        lib.ce_cache_destroy(self._handle)
+        self._create_handle()
+        self._hist_seen = 0
+
+    # ------------------------------------------------------------------ A.3
+    @torch.no_grad()
+    def prepare_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        assert ids.is_cuda, "ids must live on the GPU (recsys/dlrm_main.py:250 moves the batch first)"
+        shape = ids.shape
+        flat = ids.reshape(-1)
+        if flat.dtype != torch.int64:
+            flat = flat.long()
+        flat = flat.contiguous()
+        slots = torch.empty_like(flat)
+        with torch.cuda.device(self.device):
+            check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+        if self.strict:
+            st = CeCallStats()
+            rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))
+            self._pull_history()
+            if rc == _lib.CE_ERR_CAPACITY:
+                raise AssertionError(_lib.last_error())
+            if rc == _lib.CE_ERR_RANGE:
+                raise IndexError(_lib.last_error())
+            check(rc)
+        return slots.view(shape)
+
+    def _id_to_cached_cuda_id(self, ids: torch.Tensor) -> torch.Tensor:
+        flat = ids.reshape(-1).long().contiguous()
+        slots = torch.empty_like(flat)
+        check(lib.ce_cache_lookup_slots(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+        return slots.view(ids.shape)
+
+    # ------------------------------------------------------------------ A.7 flush
+    @torch.no_grad()
+    def flush(self):
+        with torch.cuda.device(self.device):
+            check(lib.ce_cache_flush(self._handle, stream_ptr()))
+            st = CeCallStats()
+            check(lib.ce_cache_last_stats(self._handle, ctypes.byref(st)))
+        self._pull_history()
+        assert self.cuda_available_row_num == self.cuda_row_num
+
+    # ------------------------------------------------------------------ stats
+    def sync_stats(self) -> CeCallStats:
+        st = CeCallStats()
+        rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))
+        self._pull_history()
+        if rc not in (_lib.CE_OK, _lib.CE_ERR_CAPACITY, _lib.CE_ERR_RANGE):
+            check(rc)
+        return st
+
+    def _pull_history(self):
+        cap = 4096
+        buf = (CeCallStats * cap)()
+        while True:
+            n = lib.ce_cache_history(self._handle, self._hist_seen + 1, buf, cap)
+            for i in range(n):
+                r = buf[i]
+                self._hist_seen = max(self._hist_seen, r.seq)
+                if r.kind != _lib.CE_CALL_PREPARE:
+                    continue
+                self.num_hits_history.append(int(r.n_unique - r.n_miss))
+                self.num_miss_history.append(int(r.n_miss))
+                self.num_write_back_history.append(int(r.n_evict) if r.status == _lib.CE_OK else 0)
+            if n < cap:
+                break
+
+    def totals(self):
+        a, b, c, d, e = (ctypes.c_int64() for _ in range(5))
+        check(lib.ce_cache_totals(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
+                                  ctypes.byref(e)))
+        return dict(cpu_to_cuda_numel=a.value, cuda_to_cpu_numel=b.value, cache_miss=c.value,
+                    total_cache=d.value, calls=e.value)
+
+    def print_comm_stats(self):
+        self.sync_stats()
+        t = self.totals()
+        esz = 4
+        msg = (f"CUDA->CPU {t['cuda_to_cpu_numel'] * esz / 1e6:.2f} MB, CPU->CUDA "
+               f"{t['cpu_to_cuda_numel'] * esz / 1e6:.2f} MB, cache miss {t['cache_miss']} / {t['total_cache']} "
+               f"lookups ({100.0 * t['cache_miss'] / max(1, t['total_cache']):.2f} %)")
+        print(msg)
+        return msg
+
+    def set_protect_depth(self, depth: int):
+        check(lib.ce_cache_set_protect_depth(self._handle, int(depth)))
+
+    def set_async_copy(self, flag: bool):
+        self._async_copy = bool(flag)
+        check(lib.ce_cache_set_transport(self._handle,
+                                         _lib.CE_TRANSPORT_STAGED if flag else _lib.CE_TRANSPORT_ZEROCOPY))
+
+    def cuda_weight_data(self, slot: int) -> torch.Tensor:
+        return self.cuda_cached_weight.data[slot]
+
+    def cpu_weight_data(self, row_idx: int) -> torch.Tensor:
+        return self.weight[row_idx]

@@ -1,0 +1,392 @@
+// EmbeddingBag gather-reduce forward (K12) and gradient scatter backward (K13/K14) for
+// gfx950.  Replaces F.embedding_bag + autograd + SGD.step on the cache parameter
+// (reference call sites: recsys/models/dlrm.py:99-110, benchmark/benchmark_cache.py:62-65,
+// recsys/dlrm_main.py:274-279).  Bandwidth-bound gather: no MFMA, no LDS tiles -- the
+// bag descriptors of a 64-bag tile live in one VGPR per lane and are broadcast with
+// ds_bpermute (__shfl), each row is moved by a lane group with 16-byte accesses.
+//
+// Mapping: a wave owns tiles of 64 consecutive bags.  A group of G lanes (G*16 B >= one
+// row, G = 32 for D = 128) handles one bag at a time, so a wave works on 64/G bags per
+// step.  When every bag of the tile holds exactly one id (all Criteo / Avazu batches:
+// recsys/datasets/criteo.py:129-130) the tile takes the single-id path: 64 ids are
+// fetched with one coalesced load and U independent row loads per lane are put in flight
+// before the first store.  Output stores are non-temporal (never re-read here); row loads
+// use the default policy so hot rows stay in L2 / Infinity Cache.
+#include "ce_common.h"
+
+namespace ce {
+
+struct BagParams {
+  const float* weight;      // fwd: rows to gather from
+  float* dst;               // fwd: out; bwd: grad_weight / weight / grad_rows
+  const float* grad_out;    // bwd only
+  const int64_t* indices;
+  const void* offsets;
+  const float* psw;
+  int64_t nnz;
+  int32_t num_bags;
+  int32_t rowlen;           // vector chunks per row (dim/4 or dim)
+  int32_t g_log2;           // log2(lanes per group)
+  int32_t off64;
+  int32_t include_last;
+  int32_t mode;
+  int32_t hookF;            // 0 = plain [num_bags, D]
+  int32_t hookB;            // num_bags / hookF
+  float alpha;              // bwd scale (1 or -lr)
+};
+
+__device__ __forceinline__ int ld_off(const BagParams& p, int i) {
+  return p.off64 ? (int)((const int64_t*)p.offsets)[i] : ((const int32_t*)p.offsets)[i];
+}
+__device__ __forceinline__ int bag_end(const BagParams& p, int b) {
+  return (p.include_last || b + 1 < p.num_bags) ? ld_off(p, b + 1) : (int)p.nnz;
+}
+// row of the [B, F, D] output that feature-major bag g = f*B + b lands in
+__device__ __forceinline__ int64_t out_row(const BagParams& p, int g) {
+  if (p.hookF == 0) return g;
+  int f = g / p.hookB;
+  int b = g - f * p.hookB;
+  return (int64_t)b * p.hookF + f;
+}
+
+template <typename VT, int NCH>
+__global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
+  constexpr int U = (NCH == 1) ? 8 : (NCH == 2 ? 4 : 2);
+  const int lane = threadIdx.x & 63;
+  const int G = 1 << p.g_log2;
+  const int gpw = 64 >> p.g_log2;
+  const int grp = lane >> p.g_log2;
+  const int gl = lane & (G - 1);
+  const int wpb = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  const int ntiles = (p.num_bags + 63) >> 6;
+  const VT* __restrict__ W = (const VT*)p.weight;
+  VT* __restrict__ O = (VT*)p.dst;
+  const int rowlen = p.rowlen;
+
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int b0 = (int)(tile << 6);
+    const int nb = min(64, p.num_bags - b0);
+    int lo = 0, hi = 0;
+    if (lane < nb) {
+      lo = ld_off(p, b0 + lane);
+      hi = bag_end(p, b0 + lane);
+    }
+    const bool single = (hi - lo == 1) || (lane >= nb);
+    if (__all(single)) {
+      // ---- single-id tile: pure indexed row copy, U rows in flight per lane group
+      int idx = 0;
+      float w = 1.f;
+      if (lane < nb) {
+        idx = (int)p.indices[lo];
+        if (p.psw) w = p.psw[lo];
+      }
+      for (int base = 0; base < nb; base += gpw * U) {
+        VT v[U][NCH];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bi = base + u * gpw + grp;
+          const int ri = __shfl(idx, bi & 63);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int ch = gl + c * G;
+            v[u][c] = vzero<VT>();
+            if (bi < nb && ch < rowlen) v[u][c] = W[(int64_t)ri * rowlen + ch];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bi = base + u * gpw + grp;
+          const float wi = __shfl(w, bi & 63);
+          if (bi < nb) {
+            const int64_t orow = out_row(p, b0 + bi);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const int ch = gl + c * G;
+              if (ch < rowlen) {
+                VT val = p.psw ? v[u][c] * wi : v[u][c];
+                __builtin_nontemporal_store(val, &O[orow * rowlen + ch]);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      // ---- general tile: each lane group walks its bag, 4 rows in flight
+      for (int base = 0; base < nb; base += gpw) {
+        const int bi = base + grp;
+        int blo = __shfl(lo, bi & 63);
+        int bhi = __shfl(hi, bi & 63);
+        if (bi >= nb) blo = bhi = 0;
+        VT acc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
+        for (int j = blo; j < bhi; j += 4) {
+          int r[4];
+          float w[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            r[t] = 0;
+            w[t] = 1.f;
+            if (j + t < bhi) {
+              r[t] = (int)p.indices[j + t];
+              if (p.psw) w[t] = p.psw[j + t];
+            }
+          }
+          VT v[4][NCH];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const int ch = gl + c * G;
+              v[t][c] = vzero<VT>();
+              if (j + t < bhi && ch < rowlen) v[t][c] = W[(int64_t)r[t] * rowlen + ch];
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (j + t < bhi) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) acc[c] = p.psw ? acc[c] + v[t][c] * w[t] : acc[c] + v[t][c];
+            }
+          }
+        }
+        if (p.mode == CE_MODE_MEAN && bhi - blo > 1) {
+          const float inv = 1.f / (float)(bhi - blo);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[c] = acc[c] * inv;
+        }
+        if (bi < nb) {
+          const int64_t orow = out_row(p, b0 + bi);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int ch = gl + c * G;
+            if (ch < rowlen) __builtin_nontemporal_store(acc[c], &O[orow * rowlen + ch]);
+          }
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void atomic_add_vec(float* dst, float v) {
+  __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_add_vec(f32x4* dst, f32x4 v) {
+  float* d = (float*)dst;
+  __hip_atomic_fetch_add(d + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(d + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(d + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(d + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// OP 0: dst[indices[j]] += alpha*scale*psw[j]*grad_out[bag(j)]  (fp32 atomics)
+// OP 1: dst[j]           = alpha*scale*psw[j]*grad_out[bag(j)]  (COO values)
+template <typename VT, int NCH, int OP>
+__global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
+  constexpr int U = (NCH == 1) ? 4 : (NCH == 2 ? 2 : 1);
+  const int lane = threadIdx.x & 63;
+  const int G = 1 << p.g_log2;
+  const int gpw = 64 >> p.g_log2;
+  const int grp = lane >> p.g_log2;
+  const int gl = lane & (G - 1);
+  const int wpb = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  const int ntiles = (p.num_bags + 63) >> 6;
+  const VT* __restrict__ GO = (const VT*)p.grad_out;
+  VT* __restrict__ DST = (VT*)p.dst;
+  const int rowlen = p.rowlen;
+
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int b0 = (int)(tile << 6);
+    const int nb = min(64, p.num_bags - b0);
+    int lo = 0, hi = 0;
+    if (lane < nb) {
+      lo = ld_off(p, b0 + lane);
+      hi = bag_end(p, b0 + lane);
+    }
+    for (int base = 0; base < nb; base += gpw * U) {
+      VT g[U][NCH];
+      int blo[U], bhi[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int bi = base + u * gpw + grp;
+        blo[u] = __shfl(lo, bi & 63);
+        bhi[u] = __shfl(hi, bi & 63);
+        if (bi >= nb) blo[u] = bhi[u] = 0;
+        const int64_t orow = out_row(p, b0 + min(bi, nb - 1));
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = gl + c * G;
+          g[u][c] = vzero<VT>();
+          if (bhi[u] > blo[u] && ch < rowlen) g[u][c] = GO[orow * rowlen + ch];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float scale = p.alpha;
+        if (p.mode == CE_MODE_MEAN && bhi[u] - blo[u] > 1) scale = scale / (float)(bhi[u] - blo[u]);
+        for (int j = blo[u]; j < bhi[u]; ++j) {
+          const float s = p.psw ? scale * p.psw[j] : scale;
+          const int64_t r = (OP == 0) ? p.indices[j] : (int64_t)j;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int ch = gl + c * G;
+            if (ch < rowlen) {
+              VT val = g[u][c] * s;
+              if (OP == 0) atomic_add_vec(&DST[r * rowlen + ch], val);
+              else __builtin_nontemporal_store(val, &DST[r * rowlen + ch]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_t nnz, const void* offsets,
+                       int32_t off64, int64_t num_bags, int32_t include_last, const float* psw, int32_t mode,
+                       int64_t hookF, bool* vec, int* nch, const void* a0, const void* a1, const void* a2) {
+  CE_REQUIRE(dim > 0, CE_ERR_INVALID, "embedding dim must be positive");
+  CE_REQUIRE(num_bags >= 0 && nnz >= 0, CE_ERR_INVALID, "negative sizes");
+  CE_REQUIRE(num_bags < (int64_t)INT32_MAX - 64 && nnz < (int64_t)INT32_MAX, CE_ERR_UNSUPPORTED,
+             "more than 2^31 bags / lookups in one launch");
+  CE_REQUIRE(mode == CE_MODE_SUM || mode == CE_MODE_MEAN, CE_ERR_UNSUPPORTED, "mode must be sum or mean");
+  CE_REQUIRE(!(mode == CE_MODE_MEAN && psw), CE_ERR_INVALID, "per_sample_weights needs mode='sum'");
+  CE_REQUIRE(hookF >= 0 && (hookF == 0 || num_bags % hookF == 0), CE_ERR_INVALID,
+             "hook_features must divide num_bags");
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  *vec = (dim % 4 == 0) && al16(a0) && al16(a1) && al16(a2);
+  const int rowlen = *vec ? dim / 4 : dim;
+  int g = 1, gl2 = 0;
+  while (g < rowlen && g < 64) { g <<= 1; ++gl2; }
+  const int need = (rowlen + g - 1) / g;
+  int n = 1;
+  while (n < need) n <<= 1;
+  CE_REQUIRE(n <= 4, CE_ERR_UNSUPPORTED, "embedding dim %d too large for this build", dim);
+  *nch = n;
+  p.indices = indices;
+  p.offsets = offsets;
+  p.psw = psw;
+  p.nnz = nnz;
+  p.num_bags = (int32_t)num_bags;
+  p.rowlen = rowlen;
+  p.g_log2 = gl2;
+  p.off64 = off64;
+  p.include_last = include_last;
+  p.mode = mode;
+  p.hookF = (int32_t)hookF;
+  p.hookB = hookF ? (int32_t)(num_bags / hookF) : 0;
+  p.alpha = 1.f;
+  return CE_OK;
+}
+
+static int bag_grid(int64_t num_bags) {
+  int64_t tiles = cdiv(num_bags, 64);
+  return grid_for(tiles, 4);
+}
+
+template <int OP>
+static int launch_bwd(const BagParams& p, bool vec, int nch, hipStream_t s) {
+  dim3 grid(bag_grid(p.num_bags)), block(256);
+#define CE_BWD(VT, N) hipLaunchKernelGGL((k_bag_bwd<VT, N, OP>), grid, block, 0, s, p)
+  if (vec) {
+    if (nch == 1) CE_BWD(f32x4, 1); else if (nch == 2) CE_BWD(f32x4, 2); else CE_BWD(f32x4, 4);
+  } else {
+    if (nch == 1) CE_BWD(float, 1); else if (nch == 2) CE_BWD(float, 2); else CE_BWD(float, 4);
+  }
+#undef CE_BWD
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+}  // namespace ce
+
+using namespace ce;
+
+extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                              int64_t nnz, const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                              int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                              int64_t hook_features, float* out, ce_stream_t stream) {
+  (void)num_rows;
+  if (num_bags == 0) return CE_OK;
+  CE_REQUIRE(weight && out && offsets && (indices || nnz == 0), CE_ERR_INVALID, "null pointer");
+  BagParams p{};
+  bool vec;
+  int nch;
+  int rc = fill_params(p, dim, indices, nnz, offsets, offsets_are_i64, num_bags, include_last_offset,
+                       per_sample_weights, mode, hook_features, &vec, &nch, weight, out, nullptr);
+  if (rc) return rc;
+  p.weight = weight;
+  p.dst = out;
+  dim3 grid(bag_grid(num_bags)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define CE_FWD(VT, N) hipLaunchKernelGGL((k_bag_fwd<VT, N>), grid, block, 0, s, p)
+  if (vec) {
+    if (nch == 1) CE_FWD(f32x4, 1); else if (nch == 2) CE_FWD(f32x4, 2); else CE_FWD(f32x4, 4);
+  } else {
+    if (nch == 1) CE_FWD(float, 1); else if (nch == 2) CE_FWD(float, 2); else CE_FWD(float, 4);
+  }
+#undef CE_FWD
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                                     int64_t nnz, const void* offsets, int32_t offsets_are_i64,
+                                     int64_t num_bags, int32_t include_last_offset,
+                                     const float* per_sample_weights, int32_t mode, int64_t hook_features,
+                                     const float* grad_out, ce_stream_t stream) {
+  (void)num_rows;
+  if (num_bags == 0 || nnz == 0) return CE_OK;
+  CE_REQUIRE(grad_weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
+  BagParams p{};
+  bool vec;
+  int nch;
+  int rc = fill_params(p, dim, indices, nnz, offsets, offsets_are_i64, num_bags, include_last_offset,
+                       per_sample_weights, mode, hook_features, &vec, &nch, grad_weight, grad_out, nullptr);
+  if (rc) return rc;
+  p.dst = grad_weight;
+  p.grad_out = grad_out;
+  p.alpha = 1.f;
+  return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                                   int64_t nnz, const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                                   int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream) {
+  (void)num_rows;
+  if (num_bags == 0 || nnz == 0) return CE_OK;
+  CE_REQUIRE(weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
+  BagParams p{};
+  bool vec;
+  int nch;
+  int rc = fill_params(p, dim, indices, nnz, offsets, offsets_are_i64, num_bags, include_last_offset,
+                       per_sample_weights, mode, hook_features, &vec, &nch, weight, grad_out, nullptr);
+  if (rc) return rc;
+  p.dst = weight;
+  p.grad_out = grad_out;
+  p.alpha = -lr;
+  return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_backward_rows(float* grad_rows, int32_t dim, int64_t nnz, const void* offsets,
+                                    int32_t offsets_are_i64, int64_t num_bags, int32_t include_last_offset,
+                                    const float* per_sample_weights, int32_t mode, int64_t hook_features,
+                                    const float* grad_out, ce_stream_t stream) {
+  if (num_bags == 0 || nnz == 0) return CE_OK;
+  CE_REQUIRE(grad_rows && grad_out && offsets, CE_ERR_INVALID, "null pointer");
+  BagParams p{};
+  bool vec;
+  int nch;
+  int rc = fill_params(p, dim, nullptr, nnz, offsets, offsets_are_i64, num_bags, include_last_offset,
+                       per_sample_weights, mode, hook_features, &vec, &nch, grad_rows, grad_out, nullptr);
+  if (rc) return rc;
+  p.dst = grad_rows;
+  p.grad_out = grad_out;
+  p.alpha = 1.f;
+  return launch_bwd<1>(p, vec, nch, (hipStream_t)stream);
+}

@@ -1,0 +1,1104 @@
+// Device-resident restatement of CachedParamMgr (reference call
+// sites recsys/dlrm_main.py:259, benchmark/benchmark_cache.py:62) for gfx950.
+//
+// The reference runs prepare_ids as a chain of torch ops with a device sync after every
+// phase (unique -> isin -> topk -> index_select/.cpu()/.cuda() -> index_copy_).  Here one
+// prepare_ids call is a fixed sequence of kernels on one stream with no host round trip:
+// every count the host would need (unique rows, misses, victims) stays in a device-side
+// control block, and the per-call statistics are stored straight into a pinned host ring.
+//
+//   mark      ids -> rows (idx_map) -> bits in a row bitmap (N/8 bytes)       [unique, K2/K3]
+//   count     popcount the bitmap per 32768-row chunk; miss = inverted[row] < 0     [K4]
+//   plan      one block: exclusive scan of chunk counts, capacity check, k = miss - free
+//   emit      miss rows in ascending order; hit slots stamped with the call epoch; bitmap cleared
+//   keys/hist/pick x8/victims   exact k-smallest selection over all slots          [K5]
+//   evict     victims' rows written back to the host table, maps cleared           [K6]
+//   free      first n_miss free slots ascending (ordered compaction)              [K7]
+//   admit     miss rows host -> cache rows, maps + counters updated               [K8/K9]
+//   slots     inverted[idx_map[id]] for every id, LFU counters += multiplicity    [K10/K11]
+//
+// A bitmap replaces torch.unique's sort: it yields the unique rows already in ascending
+// order (the order A.4 pairs missing rows with free slots in) for N/8 bytes of streaming
+// traffic instead of a multi-pass radix sort of every id.  Victim selection is a radix
+// select on 64-bit keys that encode the canonical order of SURVEY.md Appendix B#1
+// (LFU: (freq asc, slot asc); DATASET: cpu_row_idx desc), so evict sets are id-exact
+// against oracle/cache_oracle.py.  Row payloads move either by zero-copy kernels that
+// address the mapped pinned host table directly over PCIe, or (CE_TRANSPORT_STAGED) through
+// pinned staging + hipMemcpyAsync with host worker threads doing the table gather/scatter.
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "ce_common.h"
+
+namespace ce {
+
+constexpr int kChunkRows = 32768;     // rows covered by one 256-thread block of the bitmap scan (uint4/thread)
+constexpr int kSlotsPerBlock = 1024;  // slots covered by one block of the slot-space scans (4/thread)
+constexpr int kRing = 1024;           // pinned host ring of per-call stats
+constexpr int32_t kEpochNever = -(1 << 30);
+
+struct Ctl {                 // device control block (one per manager)
+  long long n_free;          // persistent: free slots
+  long long n_unique;        // per call
+  long long n_miss;
+  long long k_evict;
+  long long miss_lookups;
+  unsigned long long sel_prefix;   // radix-select state
+  long long sel_krem;
+  int victims_count;
+  int status;
+};
+
+struct Layout {              // byte offsets inside the caller-provided workspace
+  size_t ctl, bitmap, blk_unique, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
+      total;
+  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words;
+};
+
+static Layout make_layout(int64_t N, int64_t C, int64_t max_ids) {
+  Layout L{};
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  L.n_chunks = cdiv(N, kChunkRows);
+  L.bitmap_words = L.n_chunks * (kChunkRows / 32);
+  L.n_slot_blocks = cdiv(C, kSlotsPerBlock);
+  L.list_cap = std::max<int64_t>(1, std::min<int64_t>(C, std::max<int64_t>(max_ids, 1)));
+  size_t o = 0;
+  L.ctl = o;        o = al(o + sizeof(Ctl));
+  L.bitmap = o;     o = al(o + (size_t)L.bitmap_words * 4);
+  L.blk_unique = o; o = al(o + (size_t)(L.n_chunks + 1) * 4);
+  L.blk_miss = o;   o = al(o + (size_t)(L.n_chunks + 1) * 4);
+  L.miss_list = o;  o = al(o + (size_t)L.list_cap * 4);
+  L.slot_epoch = o; o = al(o + (size_t)C * 4);
+  L.keys = o;       o = al(o + (size_t)C * 8);
+  L.hist = o;       o = al(o + 256 * 4);
+  L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
+  L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
+  L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
+  L.total = o;
+  return L;
+}
+
+// ----------------------------------------------------------------------------- device helpers
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one int per thread over a 256-thread block; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan_256(int v, int* total) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = wave_incl_scan(v, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < w) base += wsum[i];
+    tot += wsum[i];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// ----------------------------------------------------------------------------- kernels
+
+__global__ void k_begin(Ctl* ctl) {
+  ctl->n_unique = 0;
+  ctl->n_miss = 0;
+  ctl->k_evict = 0;
+  ctl->miss_lookups = 0;
+  ctl->sel_prefix = 0;
+  ctl->sel_krem = 0;
+  ctl->victims_count = 0;
+  ctl->status = CE_OK;
+}
+
+__global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, int64_t n,
+                                              const int32_t* __restrict__ idx_map,
+                                              const int32_t* __restrict__ inverted, int64_t N,
+                                              uint32_t* bitmap, Ctl* ctl) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int cold = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t id = ids[i];
+    if ((unsigned long long)id >= (unsigned long long)N) {
+      ctl->status = CE_ERR_RANGE;
+      continue;
+    }
+    const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
+    const uint32_t bit = 1u << (row & 31);
+    uint32_t* w = bitmap + (row >> 5);
+    if (!(*(volatile uint32_t*)w & bit)) atomicOr(w, bit);
+    cold += (inverted[row] < 0);
+  }
+  cold = wave_sum(cold);
+  if ((threadIdx.x & 63) == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
+}
+
+// one uint4 (128 rows) per thread
+__global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4,
+                                               const int32_t* __restrict__ inverted, int64_t N,
+                                               int32_t* blk_unique, int32_t* blk_miss) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 q = bitmap4[v];
+  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+  int u = 0, m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t bits = wds[k];
+    u += __popc(bits);
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const int64_t row = v * 128 + k * 32 + b;
+      m += (inverted[row] < 0);
+    }
+  }
+  __shared__ int su[4], sm[4];
+  u = wave_sum(u);
+  m = wave_sum(m);
+  if ((threadIdx.x & 63) == 0) {
+    su[threadIdx.x >> 6] = u;
+    sm[threadIdx.x >> 6] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    blk_unique[blockIdx.x] = su[0] + su[1] + su[2] + su[3];
+    blk_miss[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+  }
+}
+
+// single block of 1024 threads: in-place exclusive scan of `a` (and `b` if non-null) over n entries,
+// totals returned through shared memory to thread 0 which runs the planner lambda-equivalent below.
+__device__ void scan_inplace_1024(int32_t* a, int64_t n, long long* total_out) {
+  __shared__ long long carry;
+  __shared__ int wtot[16];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = (i < n) ? a[i] : 0;
+    int inc = wave_incl_scan(v, lane);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < w) pre += wtot[k];
+      tot += wtot[k];
+    }
+    const long long c = carry;
+    // block offsets fit int32: they index lists bounded by cuda_row_num < 2^31
+    if (i < n) a[i] = (int32_t)(c + pre + inc - v);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  *total_out = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk_miss, int64_t n_chunks,
+                                               int64_t C, int64_t n_ids, long long seq, Ctl* ctl,
+                                               ce_call_stats_t* ring_slot) {
+  long long tu, tm;
+  scan_inplace_1024(blk_unique, n_chunks, &tu);
+  scan_inplace_1024(blk_miss, n_chunks, &tm);
+  if (threadIdx.x == 0) {
+    int status = ctl->status;
+    if (status == CE_OK && tu > C) status = CE_ERR_CAPACITY;
+    long long k = 0;
+    if (status == CE_OK) {
+      k = tm - ctl->n_free;
+      if (k < 0) k = 0;
+      ctl->n_free = ctl->n_free + k - tm;
+    }
+    ctl->status = status;
+    ctl->n_unique = tu;
+    ctl->n_miss = tm;
+    ctl->k_evict = k;
+    ctl->sel_krem = k;
+    ring_slot->n_ids = n_ids;
+    ring_slot->n_unique = tu;
+    ring_slot->n_miss = tm;
+    ring_slot->n_evict = k;
+    ring_slot->miss_lookups = (status == CE_OK) ? ctl->miss_lookups : 0;
+    ring_slot->n_free_after = ctl->n_free;
+    ring_slot->status = status;
+    ring_slot->kind = CE_CALL_PREPARE;
+    __threadfence_system();
+    ring_slot->seq = seq;   // written last: a slot whose seq matches is complete
+  }
+}
+
+__global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted,
+                                              const int32_t* __restrict__ blk_miss_off, int32_t* miss_list,
+                                              int32_t* slot_epoch, int32_t epoch, const Ctl* ctl) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 q = bitmap4[v];
+  const bool ok = (ctl->status == CE_OK);
+  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+  int m = 0;
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t bits = wds[k];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        m += (inverted[v * 128 + k * 32 + b] < 0);
+      }
+    }
+  }
+  int tot;
+  int pos = block_excl_scan_256(m, &tot) + blk_miss_off[blockIdx.x];
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t bits = wds[k];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const int64_t row = v * 128 + k * 32 + b;
+        const int32_t slot = inverted[row];
+        if (slot < 0) miss_list[pos++] = (int32_t)row;
+        else slot_epoch[slot] = epoch;        // evict_backlist membership [A.3-3]
+      }
+    }
+  }
+  if (q.x | q.y | q.z | q.w) bitmap4[v] = make_uint4(0, 0, 0, 0);
+}
+
+// selection keys: smaller = evicted first.  Ineligible (empty / protected) = all ones.
+__global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached_idx_map,
+                                              const int64_t* __restrict__ freq,
+                                              const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
+                                              int32_t epoch, int32_t depth, int slot_bits, int lfu,
+                                              unsigned long long* keys, uint32_t* hist, const Ctl* ctl) {
+  if (ctl->k_evict == 0) return;
+  if (blockIdx.x == 0) hist[threadIdx.x] = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const unsigned long long fmax = (1ull << (63 - slot_bits)) - 1;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
+    const int32_t row = cached_idx_map[s];
+    const bool prot = (epoch - slot_epoch[s]) <= depth;
+    unsigned long long key = ~0ull;
+    if (row >= 0 && !prot) {
+      if (lfu) {
+        long long f = freq[s];
+        unsigned long long uf = f < 0 ? 0ull : (unsigned long long)f;
+        if (uf > fmax) uf = fmax;
+        key = (uf << slot_bits) | (unsigned long long)s;
+      } else {
+        key = (unsigned long long)(N - 1 - row);
+      }
+    }
+    keys[s] = key;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restrict__ keys, int64_t C, int pass,
+                                              uint32_t* hist, const Ctl* ctl) {
+  if (ctl->k_evict == 0) return;
+  __shared__ uint32_t sh[256];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int shift = pass * 8;
+  const unsigned long long prefix = ctl->sel_prefix;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
+    const unsigned long long key = keys[s];
+    const bool match = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+    if (match) atomicAdd(&sh[(key >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// one block of 256: pick the digit holding the k-th smallest key, refine prefix/k, clear the histogram
+__global__ __launch_bounds__(256) void k_pick(uint32_t* hist, int pass, Ctl* ctl, ce_call_stats_t* ring_slot) {
+  if (ctl->k_evict == 0) return;
+  __shared__ uint32_t sh[256];
+  const uint32_t mine = hist[threadIdx.x];
+  sh[threadIdx.x] = mine;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long krem = ctl->sel_krem;
+    if (pass == 7) {
+      // bin 255 of the top byte holds exactly the ineligible (empty / protected) slots.  With
+      // protect_depth > 0 the protected set can leave fewer than k candidates: that is the
+      // capacity overflow of the overlapped pipeline (unique(window k u k+1) > cuda_row_num).
+      long long eligible = 0;
+      for (int d = 0; d < 255; ++d) eligible += sh[d];
+      if (eligible < krem) {
+        ctl->n_free = ctl->n_free - ctl->k_evict + ctl->n_miss;
+        ctl->k_evict = 0;
+        ctl->status = CE_ERR_CAPACITY;
+        ring_slot->status = CE_ERR_CAPACITY;
+        ring_slot->n_evict = 0;
+        ring_slot->n_free_after = ctl->n_free;
+        __threadfence_system();
+        return;
+      }
+    }
+    long long cum = 0;
+    int d = 0;
+    for (; d < 256; ++d) {
+      if (cum + (long long)sh[d] >= krem) break;
+      cum += sh[d];
+    }
+    if (d > 255) d = 255;
+    ctl->sel_prefix |= ((unsigned long long)d) << (pass * 8);
+    ctl->sel_krem = krem - cum;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
+                                                 int32_t* victims, int64_t cap, Ctl* ctl) {
+  if (ctl->k_evict == 0) return;
+  const unsigned long long T = ctl->sel_prefix;   // k-th smallest key; keys are unique
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
+    const unsigned long long key = keys[s];
+    if (key <= T && key != ~0ull) {
+      const int pos = atomicAdd(&ctl->victims_count, 1);
+      if (pos < cap) victims[pos] = (int32_t)s;
+    }
+  }
+}
+
+// group of G lanes per row, 16 B per lane (or 4 B when the row is not 16-B sized)
+template <typename VT>
+__device__ __forceinline__ void copy_row(const VT* __restrict__ src, VT* __restrict__ dst, int rowlen, int gl, int G) {
+  for (int c = gl; c < rowlen; c += G) dst[c] = src[c];
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_evict(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
+                                               int32_t* inverted, const VT* __restrict__ cache, VT* host,
+                                               int rowlen, int g_log2, const Ctl* ctl) {
+  const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < k; i += gstride) {
+    const int32_t slot = victims[i];
+    const int32_t row = cached_idx_map[slot];
+    if (host) copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)row * rowlen, rowlen, gl, G);
+  }
+}
+// map updates run after the payload pass (rows read cached_idx_map above)
+__global__ __launch_bounds__(256) void k_evict_maps(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
+                                                    int32_t* inverted, int32_t* evicted_rows, const Ctl* ctl) {
+  const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) {
+    const int32_t slot = victims[i];
+    const int32_t row = cached_idx_map[slot];
+    if (evicted_rows) evicted_rows[i] = row;
+    inverted[row] = -1;
+    cached_idx_map[slot] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_free_count(const int32_t* __restrict__ cached_idx_map, int64_t C,
+                                                    int32_t* blk_free, const Ctl* ctl) {
+  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
+  const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  int f = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (s0 + t < C) f += (cached_idx_map[s0 + t] < 0);
+  __shared__ int sf[4];
+  f = wave_sum(f);
+  if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_free[blockIdx.x] = sf[0] + sf[1] + sf[2] + sf[3];
+}
+
+__global__ __launch_bounds__(1024) void k_free_scan(int32_t* blk_free, int64_t nb, const Ctl* ctl) {
+  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
+  long long tot;
+  scan_inplace_1024(blk_free, nb, &tot);
+}
+
+__global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ cached_idx_map, int64_t C,
+                                                   const int32_t* __restrict__ blk_free_off, int32_t* free_list,
+                                                   const Ctl* ctl) {
+  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
+  const long long need = ctl->n_miss;
+  if (blk_free_off[blockIdx.x] >= need) return;   // block-uniform
+  const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  int fl[4];
+  int f = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    fl[t] = (s0 + t < C) && (cached_idx_map[s0 + t] < 0);
+    f += fl[t];
+  }
+  int tot;
+  long long pos = block_excl_scan_256(f, &tot) + blk_free_off[blockIdx.x];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (fl[t]) {
+      if (pos < need) free_list[pos] = (int32_t)(s0 + t);
+      ++pos;
+    }
+  }
+}
+
+// rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i)
+template <typename VT>
+__global__ __launch_bounds__(256) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
+                                               const long long* n_ptr, long long n_imm,
+                                               const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
+                                               const Ctl* ctl) {
+  if (ctl && ctl->status != CE_OK) return;
+  const long long n = n_ptr ? *n_ptr : n_imm;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride) {
+    const int64_t row = rows ? rows[i] : i;
+    const int64_t slot = slots ? slots[i] : i;
+    copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ rows,
+                                                    const int32_t* __restrict__ slots, const long long* n_ptr,
+                                                    long long n_imm, int32_t* cached_idx_map, int32_t* inverted,
+                                                    int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
+                                                    int32_t epoch, const Ctl* ctl) {
+  if (ctl && ctl->status != CE_OK) return;
+  const long long n = n_ptr ? *n_ptr : n_imm;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t row = rows ? rows[i] : (int32_t)i;
+    const int32_t slot = slots ? slots[i] : (int32_t)i;
+    cached_idx_map[slot] = row;
+    inverted[row] = slot;
+    if (freq) freq[slot] = freq_vals ? freq_vals[i] : 0;
+    slot_epoch[slot] = epoch;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, int64_t n,
+                                               const int32_t* __restrict__ idx_map,
+                                               const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out,
+                                               int64_t* freq, const Ctl* ctl) {
+  if (ctl && ctl->status != CE_OK) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t id = ids[i];
+    int64_t slot = -1;
+    if ((unsigned long long)id < (unsigned long long)N) {
+      const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
+      slot = inverted[row];
+    }
+    slots_out[i] = slot;
+    if (freq && slot >= 0) atomicAdd((unsigned long long*)&freq[slot], 1ull);   // [A.3-7]
+  }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_flush_rows(const int32_t* __restrict__ cached_idx_map, int64_t C,
+                                                    const VT* __restrict__ cache, VT* host, int rowlen,
+                                                    int g_log2) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; s < C; s += gstride) {
+    const int32_t row = cached_idx_map[s];
+    if (row >= 0) copy_row(cache + s * rowlen, host + (int64_t)row * rowlen, rowlen, gl, G);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_flush_maps(int32_t* cached_idx_map, int64_t C, int32_t* inverted,
+                                                    int64_t* freq, int32_t* slot_epoch, Ctl* ctl) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int n = 0;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
+    const int32_t row = cached_idx_map[s];
+    if (row >= 0) {
+      inverted[row] = -1;
+      cached_idx_map[s] = -1;
+      ++n;
+    }
+    if (freq) freq[s] = INT64_MAX;
+    slot_epoch[s] = kEpochNever;
+  }
+  n = wave_sum(n);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd((unsigned long long*)&ctl->k_evict, (unsigned long long)n);
+}
+
+__global__ void k_flush_end(int64_t C, Ctl* ctl, ce_call_stats_t* ring_slot, long long seq) {
+  ctl->n_free = C;
+  ring_slot->n_ids = 0;
+  ring_slot->n_unique = 0;
+  ring_slot->n_miss = 0;
+  ring_slot->n_evict = ctl->k_evict;
+  ring_slot->miss_lookups = 0;
+  ring_slot->n_free_after = C;
+  ring_slot->status = CE_OK;
+  ring_slot->kind = CE_CALL_FLUSH;
+  __threadfence_system();
+  ring_slot->seq = seq;
+}
+
+__global__ void k_preload_end(long long n, Ctl* ctl, ce_call_stats_t* ring_slot, long long seq) {
+  ctl->n_free -= n;
+  ring_slot->n_ids = 0;
+  ring_slot->n_unique = n;
+  ring_slot->n_miss = n;
+  ring_slot->n_evict = 0;
+  ring_slot->miss_lookups = 0;
+  ring_slot->n_free_after = ctl->n_free;
+  ring_slot->status = CE_OK;
+  ring_slot->kind = CE_CALL_PRELOAD;
+  __threadfence_system();
+  ring_slot->seq = seq;
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__(256) void k_fill_i64(int64_t* p, int64_t n, int64_t v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// staged transport helpers: pack rows (by slot list) into / out of a contiguous device buffer
+template <typename VT>
+__global__ __launch_bounds__(256) void k_pack_rows(const int32_t* __restrict__ slots, long long n,
+                                                   const VT* __restrict__ cache, VT* staging, int rowlen,
+                                                   int g_log2) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride)
+    copy_row(cache + (int64_t)slots[i] * rowlen, staging + i * rowlen, rowlen, gl, G);
+}
+template <typename VT>
+__global__ __launch_bounds__(256) void k_unpack_rows(const int32_t* __restrict__ slots, long long n,
+                                                     const VT* __restrict__ staging, VT* cache, int rowlen,
+                                                     int g_log2) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride)
+    copy_row(staging + i * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
+}
+
+// host-side row gather/scatter for the staged transport: `threads` workers over contiguous ranges
+static void parallel_rows(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn);
+
+}  // namespace ce
+
+// ----------------------------------------------------------------------------- handle
+
+namespace ce {
+
+static void parallel_rows(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
+  if (n <= 0) return;
+  int t = (int)std::min<int64_t>(threads, cdiv(n, 2048));
+  if (t <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = cdiv(n, t);
+  for (int i = 0; i < t; ++i) {
+    const int64_t lo = i * per, hi = std::min<int64_t>(n, lo + per);
+    if (lo >= hi) break;
+    pool.emplace_back([=, &fn] { fn(lo, hi); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+}  // namespace ce
+
+struct ce_cache {
+  ce_cache_config_t cfg;
+  ce::Layout L;
+  char* ws;
+  ce::Ctl* ctl;
+  uint32_t* bitmap;
+  int32_t *blk_unique, *blk_miss, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
+  unsigned long long* keys;
+  uint32_t* hist;
+  ce_call_stats_t* ring;       // pinned host
+  ce_call_stats_t* ring_dev;   // device-visible alias
+  hipEvent_t ev;
+  long long seq;               // calls issued
+  long long drained;           // calls whose stats were folded into history
+  std::vector<ce_call_stats_t> history;
+  int64_t cpu_to_cuda_numel, cuda_to_cpu_numel, cache_miss, total_cache;
+  int vec;                     // rows moved as 16-B vectors
+  int rowlen, g_log2, slot_bits;
+  // staged transport
+  int host_threads;
+  float* stage_dev;            // device staging [stage_rows, D]
+  float* stage_host;           // pinned host staging
+  int32_t* list_host;          // pinned host copy of row/slot lists
+  ce::Ctl* ctl_host;           // pinned host copy of the control block
+  int64_t stage_rows;
+};
+
+using namespace ce;
+
+static void drain(ce_cache* h) {
+  while (h->drained < h->seq) {
+    const long long s = h->drained + 1;
+    const ce_call_stats_t& r = h->ring[s % kRing];
+    if (r.seq != s) break;
+    h->history.push_back(r);
+    if (r.status == CE_OK) {
+      h->cpu_to_cuda_numel += r.n_miss * h->cfg.embedding_dim;
+      h->cuda_to_cpu_numel += r.n_evict * h->cfg.embedding_dim;
+      h->cache_miss += r.miss_lookups;
+      h->total_cache += r.n_ids;
+    }
+    h->drained = s;
+  }
+}
+
+static int sync_and_drain(ce_cache* h) {
+  CE_HIP_CHECK(hipEventSynchronize(h->ev));
+  drain(h);
+  return CE_OK;
+}
+
+extern "C" size_t ce_cache_workspace_bytes(int64_t num_embeddings, int64_t cuda_row_num, int64_t max_ids_per_call) {
+  if (num_embeddings <= 0 || cuda_row_num <= 0) return 0;
+  return make_layout(num_embeddings, cuda_row_num, max_ids_per_call).total;
+}
+
+extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream, ce_cache_t** out) {
+  CE_REQUIRE(cfg && out, CE_ERR_INVALID, "null config");
+  CE_REQUIRE(cfg->num_embeddings > 0 && cfg->num_embeddings < (int64_t)INT32_MAX, CE_ERR_UNSUPPORTED,
+             "num_embeddings must be in (0, 2^31)");
+  if (cfg->cuda_row_num == 0) {
+    set_error("cuda_row_num == 0 is not implemented (NotImplementedError upstream, A.1)");
+    return CE_ERR_UNSUPPORTED;
+  }
+  CE_REQUIRE(cfg->cuda_row_num > 0 && cfg->cuda_row_num <= cfg->num_embeddings, CE_ERR_INVALID,
+             "cuda_row_num must be in (0, num_embeddings]");
+  CE_REQUIRE(cfg->embedding_dim > 0, CE_ERR_INVALID, "embedding_dim must be positive");
+  CE_REQUIRE(cfg->evict_strategy == CE_EVICT_DATASET || cfg->evict_strategy == CE_EVICT_LFU, CE_ERR_INVALID,
+             "unknown eviction strategy");
+  CE_REQUIRE(cfg->cache_weight && cfg->inverted_cached_idx && cfg->cached_idx_map && cfg->workspace,
+             CE_ERR_INVALID, "null device array");
+  CE_REQUIRE(cfg->evict_strategy != CE_EVICT_LFU || cfg->freq_cnter, CE_ERR_INVALID, "LFU needs freq_cnter");
+  CE_REQUIRE(cfg->host_weight && cfg->host_weight_dev, CE_ERR_INVALID, "null host table");
+  Layout L = make_layout(cfg->num_embeddings, cfg->cuda_row_num, cfg->max_ids_per_call);
+  CE_REQUIRE(cfg->workspace_bytes >= L.total, CE_ERR_INVALID, "workspace too small: need %zu bytes", L.total);
+  CE_REQUIRE((((uintptr_t)cfg->workspace) & 255) == 0, CE_ERR_INVALID, "workspace must be 256-byte aligned");
+
+  ce_cache* h = new ce_cache();
+  h->cfg = *cfg;
+  h->L = L;
+  h->ws = (char*)cfg->workspace;
+  h->ctl = (Ctl*)(h->ws + L.ctl);
+  h->bitmap = (uint32_t*)(h->ws + L.bitmap);
+  h->blk_unique = (int32_t*)(h->ws + L.blk_unique);
+  h->blk_miss = (int32_t*)(h->ws + L.blk_miss);
+  h->miss_list = (int32_t*)(h->ws + L.miss_list);
+  h->slot_epoch = (int32_t*)(h->ws + L.slot_epoch);
+  h->keys = (unsigned long long*)(h->ws + L.keys);
+  h->hist = (uint32_t*)(h->ws + L.hist);
+  h->victims = (int32_t*)(h->ws + L.victims);
+  h->blk_free = (int32_t*)(h->ws + L.blk_free);
+  h->free_list = (int32_t*)(h->ws + L.free_list);
+  h->seq = h->drained = 0;
+  h->cpu_to_cuda_numel = h->cuda_to_cpu_numel = h->cache_miss = h->total_cache = 0;
+  const int D = cfg->embedding_dim;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  h->vec = (D % 4 == 0) && al16(cfg->cache_weight) && al16(cfg->host_weight_dev);
+  h->rowlen = h->vec ? D / 4 : D;
+  int g = 1, gl2 = 0;
+  while (g < h->rowlen && g < 64) { g <<= 1; ++gl2; }
+  h->g_log2 = gl2;
+  int sb = 1;
+  while ((1ll << sb) < cfg->cuda_row_num) ++sb;
+  h->slot_bits = sb;
+  h->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  h->stage_dev = nullptr;
+  h->stage_host = nullptr;
+  h->list_host = nullptr;
+  h->ctl_host = nullptr;
+  h->stage_rows = 0;
+
+  hipStream_t s = (hipStream_t)stream;
+  void* ring_host = nullptr;
+  if (hipHostMalloc(&ring_host, sizeof(ce_call_stats_t) * kRing, hipHostMallocMapped) != hipSuccess) {
+    delete h;
+    set_error("hipHostMalloc(stats ring) failed");
+    return CE_ERR_HIP;
+  }
+  memset(ring_host, 0, sizeof(ce_call_stats_t) * kRing);
+  h->ring = (ce_call_stats_t*)ring_host;
+  void* ring_dev = nullptr;
+  if (hipHostGetDevicePointer(&ring_dev, ring_host, 0) != hipSuccess) ring_dev = ring_host;
+  h->ring_dev = (ce_call_stats_t*)ring_dev;
+  if (hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipHostFree(ring_host);
+    delete h;
+    set_error("hipEventCreate failed");
+    return CE_ERR_HIP;
+  }
+  // empty-cache state of A.1
+  const int64_t N = cfg->num_embeddings, C = cfg->cuda_row_num;
+  (void)hipMemsetAsync(h->ws, 0, L.total, s);
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(N, 256)), dim3(256), 0, s, cfg->inverted_cached_idx, N, -1);
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, cfg->cached_idx_map, C, -1);
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, h->slot_epoch, C, kEpochNever);
+  if (cfg->freq_cnter)
+    hipLaunchKernelGGL(k_fill_i64, dim3(grid_for(C, 256)), dim3(256), 0, s, cfg->freq_cnter, C, (int64_t)INT64_MAX);
+  Ctl init{};
+  init.n_free = C;
+  (void)hipMemcpyAsync(h->ctl, &init, sizeof(Ctl), hipMemcpyHostToDevice, s);
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("cache state initialisation failed: %s", hipGetErrorString(e));
+    (void)hipEventDestroy(h->ev);
+    (void)hipHostFree(ring_host);
+    delete h;
+    return CE_ERR_HIP;
+  }
+  (void)hipEventRecord(h->ev, s);
+  *out = h;
+  return CE_OK;
+}
+
+extern "C" int ce_cache_destroy(ce_cache_t* h) {
+  if (!h) return CE_OK;
+  (void)hipEventSynchronize(h->ev);
+  (void)hipEventDestroy(h->ev);
+  (void)hipHostFree(h->ring);
+  if (h->stage_dev) (void)hipFree(h->stage_dev);
+  if (h->stage_host) (void)hipHostFree(h->stage_host);
+  if (h->list_host) (void)hipHostFree(h->list_host);
+  if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+  delete h;
+  return CE_OK;
+}
+
+static int before_call(ce_cache* h) {
+  // never let the device overwrite a ring slot the host has not folded into the history yet
+  if (h->seq - h->drained >= kRing - 2) return sync_and_drain(h);
+  drain(h);
+  return CE_OK;
+}
+
+static int ensure_staging(ce_cache* h, int64_t rows) {
+  if (rows <= h->stage_rows) return CE_OK;
+  if (h->stage_dev) (void)hipFree(h->stage_dev);
+  if (h->stage_host) (void)hipHostFree(h->stage_host);
+  if (h->list_host) (void)hipHostFree(h->list_host);
+  h->stage_dev = nullptr; h->stage_host = nullptr; h->list_host = nullptr;
+  const size_t bytes = (size_t)rows * h->cfg.embedding_dim * sizeof(float);
+  CE_HIP_CHECK(hipMalloc((void**)&h->stage_dev, bytes));
+  CE_HIP_CHECK(hipHostMalloc((void**)&h->stage_host, bytes, hipHostMallocDefault));
+  CE_HIP_CHECK(hipHostMalloc((void**)&h->list_host, (size_t)rows * 2 * sizeof(int32_t), hipHostMallocDefault));
+  if (!h->ctl_host) CE_HIP_CHECK(hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl), hipHostMallocDefault));
+  h->stage_rows = rows;
+  return CE_OK;
+}
+
+extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_vals, int64_t n,
+                                ce_stream_t stream) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  CE_REQUIRE(n >= 0 && n <= h->cfg.cuda_row_num, CE_ERR_INVALID, "preload count out of range");
+  if (n == 0) return CE_OK;
+  int rc = before_call(h);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const ce_cache_config_t& c = h->cfg;
+  h->seq += 1;
+  const int32_t epoch = (int32_t)(h->seq & 0x3fffffff);
+  const int64_t groups_per_block = 256 >> h->g_log2;
+  if (h->vec)
+    hipLaunchKernelGGL((k_admit<f32x4>), dim3(grid_for(n, (int)groups_per_block)), dim3(256), 0, s, rows,
+                       (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
+                       (const f32x4*)c.host_weight_dev, (f32x4*)c.cache_weight, h->rowlen, h->g_log2,
+                       (const Ctl*)nullptr);
+  else
+    hipLaunchKernelGGL((k_admit<float>), dim3(grid_for(n, (int)groups_per_block)), dim3(256), 0, s, rows,
+                       (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
+                       (const float*)c.host_weight_dev, (float*)c.cache_weight, h->rowlen, h->g_log2,
+                       (const Ctl*)nullptr);
+  // preloaded rows must not look "protected" to the first prepare_ids: stamp them as never used
+  hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(n, 256)), dim3(256), 0, s, rows, (const int32_t*)nullptr,
+                     (const long long*)nullptr, (long long)n, c.cached_idx_map, c.inverted_cached_idx,
+                     c.freq_cnter, freq_vals, h->slot_epoch, kEpochNever, (const Ctl*)nullptr);
+  (void)epoch;
+  hipLaunchKernelGGL(k_preload_end, dim3(1), dim3(1), 0, s, (long long)n, h->ctl, h->ring_dev + (h->seq % kRing),
+                     h->seq);
+  CE_LAUNCH_CHECK();
+  CE_HIP_CHECK(hipEventRecord(h->ev, s));
+  return CE_OK;
+}
+
+// staged transport: rows move through pinned staging with host worker threads touching the table
+static int staged_swap(ce_cache* h, hipStream_t s) {
+  const ce_cache_config_t& c = h->cfg;
+  const int D = c.embedding_dim;
+  const size_t rowbytes = (size_t)D * sizeof(float);
+  // the host needs the counts and the lists: one sync point per call (the reference has one per phase)
+  CE_HIP_CHECK(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+  CE_HIP_CHECK(hipStreamSynchronize(s));
+  const Ctl ctl = *h->ctl_host;
+  if (ctl.status != CE_OK) return CE_OK;
+  const int64_t k = ctl.k_evict, m = ctl.n_miss;
+  int rc = ensure_staging(h, std::max<int64_t>(std::max(k, m), 1));
+  if (rc) return rc;
+  const int gpb = 256 >> h->g_log2;
+  if (k > 0) {
+    // D2H: evicted rows packed on the device, copied, scattered into the table by worker threads
+    int32_t* evicted_rows_dev = h->free_list;   // free_list is not live yet: reuse as the row list
+    hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(k, 256)), dim3(256), 0, s, h->victims, c.cached_idx_map,
+                       c.inverted_cached_idx, evicted_rows_dev, h->ctl);
+    if (h->vec)
+      hipLaunchKernelGGL((k_pack_rows<f32x4>), dim3(grid_for(k, gpb)), dim3(256), 0, s, (const int32_t*)h->victims,
+                         (long long)k, (const f32x4*)c.cache_weight, (f32x4*)h->stage_dev, h->rowlen, h->g_log2);
+    else
+      hipLaunchKernelGGL((k_pack_rows<float>), dim3(grid_for(k, gpb)), dim3(256), 0, s, (const int32_t*)h->victims,
+                         (long long)k, (const float*)c.cache_weight, (float*)h->stage_dev, h->rowlen, h->g_log2);
+    CE_HIP_CHECK(hipMemcpyAsync(h->stage_host, h->stage_dev, (size_t)k * rowbytes, hipMemcpyDeviceToHost, s));
+    CE_HIP_CHECK(hipMemcpyAsync(h->list_host, evicted_rows_dev, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+    CE_HIP_CHECK(hipStreamSynchronize(s));
+    float* table = c.host_weight;
+    const float* st = h->stage_host;
+    const int32_t* rows = h->list_host;
+    parallel_rows(k, h->host_threads, [=](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; ++i) memcpy(table + (size_t)rows[i] * D, st + (size_t)i * D, rowbytes);
+    });
+  }
+  return CE_OK;
+}
+
+extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                    ce_stream_t stream) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  CE_REQUIRE(n >= 0 && n <= std::max<int64_t>(h->cfg.max_ids_per_call, 0), CE_ERR_INVALID,
+             "n=%lld exceeds max_ids_per_call=%lld", (long long)n, (long long)h->cfg.max_ids_per_call);
+  CE_REQUIRE(n == 0 || (ids && slots_out), CE_ERR_INVALID, "null ids/slots");
+  int rc = before_call(h);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  const int64_t N = c.num_embeddings, C = c.cuda_row_num;
+  h->seq += 1;
+  const int32_t epoch = (int32_t)(h->seq & 0x3fffffff);
+  ce_call_stats_t* slot = h->ring_dev + (h->seq % kRing);
+  const int lfu = c.evict_strategy == CE_EVICT_LFU;
+  const int gpb = 256 >> h->g_log2;
+  const int cap_groups = (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb)));
+
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
+  if (n > 0)
+    hipLaunchKernelGGL(k_mark, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map,
+                       c.inverted_cached_idx, N, h->bitmap, h->ctl);
+  hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
+                     c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n,
+                     (long long)h->seq, h->ctl, slot);
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap,
+                     c.inverted_cached_idx, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl);
+  // ---- victim selection (all kernels return at once when k == 0)
+  const int cgrid = grid_for(C, 256 * 4);
+  hipLaunchKernelGGL(k_keys, dim3(cgrid), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
+                     epoch, c.protect_depth, h->slot_bits, lfu, h->keys, h->hist, h->ctl);
+  for (int pass = 7; pass >= 0; --pass) {
+    hipLaunchKernelGGL(k_hist, dim3(cgrid), dim3(256), 0, s, h->keys, C, pass, h->hist, h->ctl);
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, h->hist, pass, h->ctl, slot);
+  }
+  hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl);
+  if (c.transport == CE_TRANSPORT_ZEROCOPY) {
+    // ---- write-back + map clear, free-slot list, admit: all device-side
+    if (h->vec)
+      hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), dim3(256), 0, s, h->victims, c.cached_idx_map,
+                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, h->rowlen,
+                         h->g_log2, h->ctl);
+    else
+      hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), dim3(256), 0, s, h->victims, c.cached_idx_map,
+                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, h->rowlen,
+                         h->g_log2, h->ctl);
+    hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
+                       c.cached_idx_map, c.inverted_cached_idx, (int32_t*)nullptr, h->ctl);
+  } else {
+    rc = staged_swap(h, s);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
+                     h->blk_free, h->ctl);
+  hipLaunchKernelGGL(k_free_scan, dim3(1), dim3(1024), 0, s, h->blk_free, L.n_slot_blocks, h->ctl);
+  hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
+                     h->blk_free, h->free_list, h->ctl);
+  if (c.transport == CE_TRANSPORT_ZEROCOPY) {
+    if (h->vec)
+      hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), dim3(256), 0, s, h->miss_list, h->free_list,
+                         (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
+                         (f32x4*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+    else
+      hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), dim3(256), 0, s, h->miss_list, h->free_list,
+                         (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
+                         (float*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+  } else {
+    // H2D: worker threads gather the missed rows out of the table into pinned staging
+    const Ctl ctl = *h->ctl_host;   // filled by staged_swap
+    const int64_t m = (ctl.status == CE_OK) ? ctl.n_miss : 0;
+    if (m > 0) {
+      const int D = c.embedding_dim;
+      const size_t rowbytes = (size_t)D * sizeof(float);
+      CE_HIP_CHECK(hipMemcpyAsync(h->list_host, h->miss_list, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+      CE_HIP_CHECK(hipStreamSynchronize(s));
+      const float* table = c.host_weight;
+      float* st = h->stage_host;
+      const int32_t* rows = h->list_host;
+      parallel_rows(m, h->host_threads, [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) memcpy(st + (size_t)i * D, table + (size_t)rows[i] * D, rowbytes);
+      });
+      CE_HIP_CHECK(hipMemcpyAsync(h->stage_dev, h->stage_host, (size_t)m * rowbytes, hipMemcpyHostToDevice, s));
+      if (h->vec)
+        hipLaunchKernelGGL((k_unpack_rows<f32x4>), dim3(grid_for(m, gpb)), dim3(256), 0, s,
+                           (const int32_t*)h->free_list, (long long)m, (const f32x4*)h->stage_dev,
+                           (f32x4*)c.cache_weight, h->rowlen, h->g_log2);
+      else
+        hipLaunchKernelGGL((k_unpack_rows<float>), dim3(grid_for(m, gpb)), dim3(256), 0, s,
+                           (const int32_t*)h->free_list, (long long)m, (const float*)h->stage_dev,
+                           (float*)c.cache_weight, h->rowlen, h->g_log2);
+    }
+  }
+  hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
+                     (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
+                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl);
+  if (n > 0)
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map, c.inverted_cached_idx,
+                       N, slots_out, lfu ? c.freq_cnter : (int64_t*)nullptr, (const Ctl*)h->ctl);
+  CE_LAUNCH_CHECK();
+  CE_HIP_CHECK(hipEventRecord(h->ev, s));
+  return CE_OK;
+}
+
+extern "C" int ce_cache_last_stats(ce_cache_t* h, ce_call_stats_t* out) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  int rc = sync_and_drain(h);
+  if (rc) return rc;
+  if (h->history.empty()) {
+    if (out) memset(out, 0, sizeof(*out));
+    return CE_OK;
+  }
+  const ce_call_stats_t& r = h->history.back();
+  if (out) *out = r;
+  if (r.status == CE_ERR_CAPACITY)
+    set_error("You move %lld embedding rows from CPU to CUDA. %lld rows are available on CUDA. "
+              "Please increase cuda_row_num or decrease the training batch size.",
+              (long long)r.n_unique, (long long)h->cfg.cuda_row_num);
+  else if (r.status == CE_ERR_RANGE)
+    set_error("an id is outside [0, %lld)", (long long)h->cfg.num_embeddings);
+  return r.status;
+}
+
+extern "C" int ce_cache_totals(ce_cache_t* h, int64_t* cpu_to_cuda_numel, int64_t* cuda_to_cpu_numel,
+                               int64_t* cache_miss, int64_t* total_cache, int64_t* n_calls) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  drain(h);
+  if (cpu_to_cuda_numel) *cpu_to_cuda_numel = h->cpu_to_cuda_numel;
+  if (cuda_to_cpu_numel) *cuda_to_cpu_numel = h->cuda_to_cpu_numel;
+  if (cache_miss) *cache_miss = h->cache_miss;
+  if (total_cache) *total_cache = h->total_cache;
+  if (n_calls) *n_calls = h->drained;
+  return CE_OK;
+}
+
+extern "C" int64_t ce_cache_history(ce_cache_t* h, int64_t first_seq, ce_call_stats_t* out, int64_t cap) {
+  if (!h || !out || cap <= 0) return 0;
+  drain(h);
+  int64_t w = 0;
+  for (const auto& r : h->history) {
+    if (r.seq < first_seq) continue;
+    if (w >= cap) break;
+    out[w++] = r;
+  }
+  return w;
+}
+
+extern "C" int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                     ce_stream_t stream) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  if (n == 0) return CE_OK;
+  CE_REQUIRE(ids && slots_out && n > 0, CE_ERR_INVALID, "null ids/slots");
+  const ce_cache_config_t& c = h->cfg;
+  hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, c.idx_map,
+                     c.inverted_cached_idx, c.num_embeddings, slots_out, (int64_t*)nullptr, (const Ctl*)nullptr);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  int rc = before_call(h);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const ce_cache_config_t& c = h->cfg;
+  const int64_t C = c.cuda_row_num;
+  h->seq += 1;
+  const int gpb = 256 >> h->g_log2;
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
+  if (h->vec)
+    hipLaunchKernelGGL((k_flush_rows<f32x4>), dim3(grid_for(C, gpb)), dim3(256), 0, s, c.cached_idx_map, C,
+                       (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, h->rowlen, h->g_log2);
+  else
+    hipLaunchKernelGGL((k_flush_rows<float>), dim3(grid_for(C, gpb)), dim3(256), 0, s, c.cached_idx_map, C,
+                       (const float*)c.cache_weight, (float*)c.host_weight_dev, h->rowlen, h->g_log2);
+  hipLaunchKernelGGL(k_flush_maps, dim3(grid_for(C, 256)), dim3(256), 0, s, c.cached_idx_map, C,
+                     c.inverted_cached_idx, c.freq_cnter, h->slot_epoch, h->ctl);
+  hipLaunchKernelGGL(k_flush_end, dim3(1), dim3(1), 0, s, C, h->ctl, h->ring_dev + (h->seq % kRing),
+                     (long long)h->seq);
+  CE_LAUNCH_CHECK();
+  CE_HIP_CHECK(hipEventRecord(h->ev, s));
+  return CE_OK;
+}
+
+extern "C" int ce_cache_set_protect_depth(ce_cache_t* h, int32_t depth) {
+  CE_REQUIRE(h && depth >= 0 && depth < 1024, CE_ERR_INVALID, "bad protect depth");
+  h->cfg.protect_depth = depth;
+  return CE_OK;
+}
+
+extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
+  CE_REQUIRE(h && (transport == CE_TRANSPORT_ZEROCOPY || transport == CE_TRANSPORT_STAGED), CE_ERR_INVALID,
+             "bad transport");
+  h->cfg.transport = transport;
+  return CE_OK;
+}
+
+extern "C" int ce_cache_free_rows(ce_cache_t* h, int64_t* out) {
+  CE_REQUIRE(h && out, CE_ERR_INVALID, "null argument");
+  int rc = sync_and_drain(h);
+  if (rc) return rc;
+  *out = h->history.empty() ? h->cfg.cuda_row_num : h->history.back().n_free_after;
+  // a failed call leaves the count untouched but reports the pre-call value too
+  return CE_OK;
+}

@@ -1,0 +1,60 @@
+// Shared helpers for the HIP sources of libce_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ce_api.h"
+
+namespace ce {
+
+void set_error(const char* fmt, ...);
+
+#define CE_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      ce::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return CE_ERR_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+#define CE_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      ce::set_error(__VA_ARGS__);    \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+#define CE_LAUNCH_CHECK() CE_HIP_CHECK(hipGetLastError())
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename VT> __device__ __forceinline__ VT vzero();
+template <> __device__ __forceinline__ float vzero<float>() { return 0.f; }
+template <> __device__ __forceinline__ f32x4 vzero<f32x4>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// MI355X: 256 CUs; memory-bound grid-stride kernels are capped at 8 blocks of 256 per CU.
+constexpr int kNumCU = 256;
+constexpr int kMaxBlocks = kNumCU * 8;
+
+static inline int grid_for(int64_t work_items, int per_block) {
+  int64_t b = cdiv(work_items, per_block);
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// lanes cooperating on one embedding row: 16 B per lane, power of two, at most one wave
+static inline int group_lanes_for_dim(int dim) {
+  int v = (dim + 3) / 4;
+  int g = 1;
+  while (g < v && g < 64) g <<= 1;
+  return g;
+}
+
+}  // namespace ce

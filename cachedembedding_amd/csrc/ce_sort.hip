@@ -1,0 +1,369 @@
+// Stable multi-way split on gfx950 and the two things built on it:
+//  * ce_bucketize_rows: owner-bucketing of looked-up rows for row-wise sharding (the build's
+//    replacement for KJTAllToAll's all-gather, recsys/datasets/utils.py:20-54);
+//  * ce_bag_backward_sgd_sorted: deterministic K13+K14 -- lookups are stably radix-sorted by
+//    target row, each row's gradients are summed in lookup order and applied once, which is
+//    the coalesce()-then-add order torch uses for sparse grads (recsys/dlrm_main.py:274-279).
+//
+// One split pass = histogram per 4096-lookup tile (digit-major), one-block exclusive scan,
+// stable scatter.  Ranks inside a tile come from wave64 ballots (8 ballots give each lane
+// the mask of lanes holding the same digit) plus per-wave digit counters in LDS.
+#include <algorithm>
+
+#include "ce_common.h"
+
+namespace ce {
+
+constexpr int kTile = 4096;      // lookups per block per pass
+constexpr int kRounds = kTile / 256;
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// in-place exclusive scan of n ints by one 1024-thread block
+__global__ __launch_bounds__(1024) void k_scan1024(int32_t* a, int64_t n, int32_t* total_out) {
+  __shared__ long long carry;
+  __shared__ int wtot[16];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = (i < n) ? a[i] : 0;
+    const int inc = wave_incl_scan_i(v, lane);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < w) pre += wtot[k];
+      tot += wtot[k];
+    }
+    const long long c = carry;
+    if (i < n) a[i] = (int32_t)(c + pre + inc - v);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = (int32_t)carry;
+}
+
+// DIGIT: 0 = (key >> shift) & 255 ; 1 = key % world
+template <int DIGIT>
+__device__ __forceinline__ int digit_of(int32_t key, int shift, int world) {
+  return DIGIT == 0 ? ((key >> shift) & 255) : (key % world);
+}
+
+// KEYSRC: 0 = keys_in[i] ; 1 = idx_map[ids[i]] (or ids[i]) ; 2 = (int32)ids64[i]
+struct SplitArgs {
+  const int32_t* keys_in;
+  const int32_t* vals_in;     // nullptr: value = i
+  const int64_t* ids;
+  const int32_t* idx_map;
+  int32_t* keys_out;
+  int32_t* vals_out;
+  int64_t* rows_out64;        // bucketize: local row = key / world
+  int64_t* perm_out64;        // bucketize: position of lookup i
+  int32_t* hist;              // [nb][ntiles] digit-major
+  int64_t n;
+  int ntiles;
+  int shift;
+  int world;
+  int nb;
+};
+
+template <int KEYSRC>
+__device__ __forceinline__ int32_t load_key(const SplitArgs& a, int64_t i) {
+  if (KEYSRC == 0) return a.keys_in[i];
+  const int64_t id = a.ids[i];
+  if (KEYSRC == 1 && a.idx_map) return a.idx_map[id];
+  return (int32_t)id;
+}
+
+template <int DIGIT, int KEYSRC>
+__global__ __launch_bounds__(256) void k_split_hist(SplitArgs a) {
+  __shared__ int cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < a.n) atomicAdd(&cnt[digit_of<DIGIT>(load_key<KEYSRC>(a, i), a.shift, a.world)], 1);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.nb) a.hist[(int64_t)threadIdx.x * a.ntiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+template <int DIGIT, int KEYSRC, bool BUCKETIZE>
+__global__ __launch_bounds__(256) void k_split_scatter(SplitArgs a) {
+  __shared__ int run[256];         // running position of each digit for this tile
+  __shared__ int wcnt[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if ((int)threadIdx.x < a.nb) run[threadIdx.x] = a.hist[(int64_t)threadIdx.x * a.ntiles + blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kRounds; ++r) {
+    for (int d = threadIdx.x; d < 4 * 256; d += 256) (&wcnt[0][0])[d] = 0;
+    __syncthreads();
+    const int64_t i = base + r * 256 + threadIdx.x;
+    const bool valid = i < a.n;
+    int32_t key = 0;
+    int dg = 0;
+    if (valid) {
+      key = load_key<KEYSRC>(a, i);
+      dg = digit_of<DIGIT>(key, a.shift, a.world);
+    }
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((dg >> b) & 1);
+      peers &= ((dg >> b) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & lt);
+    if (valid && rank == 0) wcnt[w][dg] = __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      int pre = 0;
+      for (int k = 0; k < w; ++k) pre += wcnt[k][dg];
+      const int pos = run[dg] + pre + rank;
+      if (BUCKETIZE) {
+        a.rows_out64[pos] = (int64_t)(key / a.world);
+        a.perm_out64[i] = pos;
+      } else {
+        a.keys_out[pos] = key;
+        a.vals_out[pos] = a.vals_in ? a.vals_in[i] : (int32_t)i;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.nb)
+      run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    // next round's zeroing of wcnt is ordered by the __syncthreads at its top
+    __syncthreads();
+  }
+}
+
+__global__ void k_bucket_counts(const int32_t* hist_scanned, int32_t total, int ntiles, int world, int64_t* counts) {
+  const int w = threadIdx.x;
+  if (w < world) {
+    const int32_t lo = hist_scanned[(int64_t)w * ntiles];
+    const int32_t hi = (w + 1 < world) ? hist_scanned[(int64_t)(w + 1) * ntiles] : total;
+    counts[w] = (int64_t)(hi - lo);
+  }
+}
+
+// lookup -> bag id
+__global__ __launch_bounds__(256) void k_expand_bags(const void* offsets, int off64, int64_t num_bags, int64_t nnz,
+                                                     int include_last, int32_t* bag_of) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < num_bags; b += stride) {
+    const int64_t lo = off64 ? ((const int64_t*)offsets)[b] : ((const int32_t*)offsets)[b];
+    const int64_t hi = (include_last || b + 1 < num_bags)
+                           ? (off64 ? ((const int64_t*)offsets)[b + 1] : ((const int32_t*)offsets)[b + 1])
+                           : nnz;
+    for (int64_t j = lo; j < hi; ++j) bag_of[j] = (int32_t)b;
+  }
+}
+
+struct SegArgs {
+  float* weight;
+  const float* grad_out;
+  const int32_t* rows_sorted;
+  const int32_t* lookup_sorted;
+  const int32_t* bag_of;
+  const void* offsets;
+  const float* psw;
+  int64_t nnz;
+  int64_t num_bags;
+  int rowlen, g_log2, off64, include_last, mode, hookF, hookB;
+  float lr;
+};
+
+// a lane group owns a sorted position; only segment heads work: sum the segment in order, update once
+template <typename VT>
+__global__ __launch_bounds__(256) void k_seg_sgd(SegArgs a) {
+  const int G = 1 << a.g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> a.g_log2;
+  VT* W = (VT*)a.weight;
+  const VT* GO = (const VT*)a.grad_out;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> a.g_log2; i < a.nnz; i += gstride) {
+    const int32_t row = a.rows_sorted[i];
+    if (i > 0 && a.rows_sorted[i - 1] == row) continue;
+    for (int c = gl; c < a.rowlen; c += G) {
+      VT acc = vzero<VT>();
+      for (int64_t t = i; t < a.nnz && a.rows_sorted[t] == row; ++t) {
+        const int32_t j = a.lookup_sorted[t];
+        const int32_t bag = a.bag_of[j];
+        float s = a.psw ? a.psw[j] : 1.f;
+        if (a.mode == CE_MODE_MEAN) {
+          const int64_t lo = a.off64 ? ((const int64_t*)a.offsets)[bag] : ((const int32_t*)a.offsets)[bag];
+          const int64_t hi = (a.include_last || bag + 1 < a.num_bags)
+                                 ? (a.off64 ? ((const int64_t*)a.offsets)[bag + 1] : ((const int32_t*)a.offsets)[bag + 1])
+                                 : a.nnz;
+          if (hi - lo > 1) s = s / (float)(hi - lo);
+        }
+        int64_t orow = bag;
+        if (a.hookF) {
+          const int f = bag / a.hookB;
+          orow = (int64_t)(bag - f * a.hookB) * a.hookF + f;
+        }
+        const VT g = GO[orow * a.rowlen + c];
+        acc = (s == 1.f) ? acc + g : acc + g * s;
+      }
+      W[(int64_t)row * a.rowlen + c] = W[(int64_t)row * a.rowlen + c] - acc * a.lr;
+    }
+  }
+}
+
+struct SortWs {
+  int32_t *keys[2], *vals[2], *bag_of, *hist, *total;
+  size_t bytes;
+};
+
+static SortWs carve(void* ws, int64_t nnz) {
+  SortWs s{};
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const int64_t ntiles = std::max<int64_t>(1, cdiv(nnz, kTile));
+  char* p = (char*)ws;
+  size_t o = 0;
+  for (int i = 0; i < 2; ++i) { s.keys[i] = (int32_t*)(p + o); o = al(o + (size_t)nnz * 4); }
+  for (int i = 0; i < 2; ++i) { s.vals[i] = (int32_t*)(p + o); o = al(o + (size_t)nnz * 4); }
+  s.bag_of = (int32_t*)(p + o); o = al(o + (size_t)nnz * 4);
+  s.hist = (int32_t*)(p + o);   o = al(o + (size_t)256 * ntiles * 4);
+  s.total = (int32_t*)(p + o);  o = al(o + 256);
+  s.bytes = o;
+  return s;
+}
+
+}  // namespace ce
+
+using namespace ce;
+
+extern "C" size_t ce_bucketize_workspace(int64_t n, int32_t world) {
+  if (n < 0 || world < 1) return 0;
+  const int64_t ntiles = std::max<int64_t>(1, cdiv(n, kTile));
+  return (size_t)world * ntiles * 4 + 512;
+}
+
+extern "C" int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int32_t world,
+                                 int64_t* local_rows_out, int64_t* perm_out, int64_t* counts_out, void* workspace,
+                                 size_t workspace_bytes, ce_stream_t stream) {
+  CE_REQUIRE(world >= 1 && world <= 256, CE_ERR_UNSUPPORTED, "world size must be in [1, 256]");
+  CE_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX, CE_ERR_UNSUPPORTED, "too many lookups");
+  CE_REQUIRE(counts_out && workspace, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(workspace_bytes >= ce_bucketize_workspace(n, world), CE_ERR_INVALID, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    CE_HIP_CHECK(hipMemsetAsync(counts_out, 0, sizeof(int64_t) * world, s));
+    return CE_OK;
+  }
+  CE_REQUIRE(ids && local_rows_out && perm_out, CE_ERR_INVALID, "null pointer");
+  const int ntiles = (int)cdiv(n, kTile);
+  SplitArgs a{};
+  a.ids = ids;
+  a.idx_map = idx_map;
+  a.rows_out64 = local_rows_out;
+  a.perm_out64 = perm_out;
+  a.hist = (int32_t*)workspace;
+  int32_t* total = a.hist + (int64_t)world * ntiles;
+  a.n = n;
+  a.ntiles = ntiles;
+  a.world = world;
+  a.nb = world;
+  hipLaunchKernelGGL((k_split_hist<1, 1>), dim3(ntiles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_scan1024, dim3(1), dim3(1024), 0, s, a.hist, (int64_t)world * ntiles, total);
+  hipLaunchKernelGGL(k_bucket_counts, dim3(1), dim3(256), 0, s, (const int32_t*)a.hist, n > 0 ? (int32_t)n : 0,
+                     ntiles, world, counts_out);
+  hipLaunchKernelGGL((k_split_scatter<1, 1, true>), dim3(ntiles), dim3(256), 0, s, a);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" size_t ce_bag_backward_sgd_sorted_workspace(int64_t num_rows, int64_t nnz) {
+  (void)num_rows;
+  if (nnz < 0) return 0;
+  return carve(nullptr, std::max<int64_t>(nnz, 1)).bytes;
+}
+
+extern "C" int ce_bag_backward_sgd_sorted(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                                          int64_t nnz, const void* offsets, int32_t offsets_are_i64,
+                                          int64_t num_bags, int32_t include_last_offset,
+                                          const float* per_sample_weights, int32_t mode, int64_t hook_features,
+                                          const float* grad_out, float lr, void* workspace, size_t workspace_bytes,
+                                          ce_stream_t stream) {
+  if (num_bags == 0 || nnz == 0) return CE_OK;
+  CE_REQUIRE(weight && grad_out && offsets && indices && workspace, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX && nnz < (int64_t)INT32_MAX &&
+                 num_bags < (int64_t)INT32_MAX,
+             CE_ERR_UNSUPPORTED, "sizes beyond 2^31");
+  CE_REQUIRE(mode == CE_MODE_SUM || mode == CE_MODE_MEAN, CE_ERR_UNSUPPORTED, "mode must be sum or mean");
+  CE_REQUIRE(hook_features >= 0 && (hook_features == 0 || num_bags % hook_features == 0), CE_ERR_INVALID,
+             "hook_features must divide num_bags");
+  CE_REQUIRE(workspace_bytes >= ce_bag_backward_sgd_sorted_workspace(num_rows, nnz), CE_ERR_INVALID,
+             "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  SortWs ws = carve(workspace, nnz);
+  const int ntiles = (int)cdiv(nnz, kTile);
+  int bits = 1;
+  while ((1ll << bits) < num_rows) ++bits;
+  const int passes = (bits + 7) / 8;
+  hipLaunchKernelGGL(k_expand_bags, dim3(grid_for(num_bags, 256)), dim3(256), 0, s, offsets, offsets_are_i64,
+                     num_bags, nnz, include_last_offset, ws.bag_of);
+  int cur = 0;
+  for (int p = 0; p < passes; ++p) {
+    SplitArgs a{};
+    a.n = nnz;
+    a.ntiles = ntiles;
+    a.shift = 8 * p;
+    a.world = 1;
+    a.nb = 256;
+    a.hist = ws.hist;
+    a.keys_out = ws.keys[cur ^ 1];
+    a.vals_out = ws.vals[cur ^ 1];
+    if (p == 0) {
+      a.ids = indices;
+      hipLaunchKernelGGL((k_split_hist<0, 2>), dim3(ntiles), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_scan1024, dim3(1), dim3(1024), 0, s, a.hist, (int64_t)256 * ntiles, ws.total);
+      hipLaunchKernelGGL((k_split_scatter<0, 2, false>), dim3(ntiles), dim3(256), 0, s, a);
+    } else {
+      a.keys_in = ws.keys[cur];
+      a.vals_in = ws.vals[cur];
+      hipLaunchKernelGGL((k_split_hist<0, 0>), dim3(ntiles), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_scan1024, dim3(1), dim3(1024), 0, s, a.hist, (int64_t)256 * ntiles, ws.total);
+      hipLaunchKernelGGL((k_split_scatter<0, 0, false>), dim3(ntiles), dim3(256), 0, s, a);
+    }
+    cur ^= 1;
+  }
+  SegArgs g{};
+  g.weight = weight;
+  g.grad_out = grad_out;
+  g.rows_sorted = ws.keys[cur];
+  g.lookup_sorted = ws.vals[cur];
+  g.bag_of = ws.bag_of;
+  g.offsets = offsets;
+  g.psw = per_sample_weights;
+  g.nnz = nnz;
+  g.num_bags = num_bags;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  const bool vec = (dim % 4 == 0) && al16(weight) && al16(grad_out);
+  g.rowlen = vec ? dim / 4 : dim;
+  int gl = 1, gl2 = 0;
+  while (gl < g.rowlen && gl < 64) { gl <<= 1; ++gl2; }
+  g.g_log2 = gl2;
+  g.off64 = offsets_are_i64;
+  g.include_last = include_last_offset;
+  g.mode = mode;
+  g.hookF = (int)hook_features;
+  g.hookB = hook_features ? (int)(num_bags / hook_features) : 0;
+  g.lr = lr;
+  const int gpb = 256 >> gl2;
+  if (vec) hipLaunchKernelGGL((k_seg_sgd<f32x4>), dim3(grid_for(nnz, gpb)), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((k_seg_sgd<float>), dim3(grid_for(nnz, gpb)), dim3(256), 0, s, g);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}

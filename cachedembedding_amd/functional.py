@@ -1,0 +1,147 @@
+"""torch-facing wrappers of the HIP EmbeddingBag kernels (ce_bag_* in include/ce_api.h).
+
+`embedding_bag` mirrors the call the reference makes through ColossalAI:
+``F.embedding_bag(slots, cuda_cached_weight, offsets, max_norm, norm_type, scale_grad_by_freq,
+mode, sparse, per_sample_weights, include_last_offset, padding_idx)`` (SURVEY.md A.7;
+call sites recsys/models/dlrm.py:99-110, benchmark/benchmark_cache.py:62), with two
+additions the reference does not have: `hook_features` folds sparse_embedding_shape_hook
+(recsys/models/dlrm.py:26-27) into the output store, and `fused_sgd_lr` applies
+SGD.step (recsys/dlrm_main.py:279) inside the backward pass.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+_MODES = {"sum": _lib.CE_MODE_SUM, "mean": _lib.CE_MODE_MEAN}
+
+
+def _prep(indices: torch.Tensor, offsets: Optional[torch.Tensor], include_last_offset: bool):
+    if indices.dim() == 2:
+        if offsets is not None:
+            raise ValueError("if input is 2D, then offsets has to be None, as input is treated is a "
+                             "mini-batch of fixed length sequences")
+        rows, length = indices.shape
+        offsets = torch.arange(0, rows * length + 1, length, device=indices.device, dtype=torch.int64)
+        indices = indices.reshape(-1)
+        include_last_offset = True
+    elif indices.dim() == 1:
+        if offsets is None:
+            raise ValueError("offsets has to be a 1D Tensor but got None")
+        if offsets.dim() != 1:
+            raise ValueError("offsets has to be a 1D Tensor")
+    else:
+        raise ValueError(f"input has to be 1D or 2D Tensor, but got Tensor of dimension {indices.dim()}")
+    if indices.dtype != torch.int64:
+        indices = indices.long()
+    if offsets.dtype not in (torch.int32, torch.int64):
+        offsets = offsets.long()
+    indices = indices.contiguous()
+    offsets = offsets.contiguous()
+    num_bags = offsets.numel() - 1 if include_last_offset else offsets.numel()
+    return indices, offsets, include_last_offset, num_bags
+
+
+class _BagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, indices, offsets, psw, mode, include_last, hook_features, sparse, fused):
+        _lib.require_gpu()
+        assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+        num_bags = offsets.numel() - 1 if include_last else offsets.numel()
+        dim = weight.shape[1]
+        if hook_features:
+            out = torch.empty(num_bags // hook_features, hook_features, dim, device=weight.device,
+                              dtype=torch.float32)
+        else:
+            out = torch.empty(num_bags, dim, device=weight.device, dtype=torch.float32)
+        check(lib.ce_bag_forward(ptr(weight), weight.shape[0], dim, ptr(indices), indices.numel(), ptr(offsets),
+                                 int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw), mode,
+                                 hook_features, ptr(out), stream_ptr()))
+        ctx.save_for_backward(indices, offsets, psw)
+        ctx.weight = weight
+        ctx.args = (mode, include_last, hook_features, sparse, fused, num_bags)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        indices, offsets, psw = ctx.saved_tensors
+        weight = ctx.weight
+        mode, include_last, hook_features, sparse, fused, num_bags = ctx.args
+        grad_out = grad_out.contiguous()
+        dim = weight.shape[1]
+        off64 = int(offsets.dtype == torch.int64)
+        nnz = indices.numel()
+        gw = None
+        if fused is not None and fused.lr is not None:
+            # K13+K14 in one pass; the optimizer sees grad=None for the cache parameter
+            with torch.no_grad():
+                if fused.deterministic:
+                    ws = fused.workspace(weight.shape[0], nnz, weight.device)
+                    check(lib.ce_bag_backward_sgd_sorted(ptr(weight), weight.shape[0], dim, ptr(indices), nnz,
+                                                         ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
+                                                         mode, hook_features, ptr(grad_out), float(fused.lr),
+                                                         ptr(ws), ws.numel(), stream_ptr()))
+                else:
+                    check(lib.ce_bag_backward_sgd(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets),
+                                                  off64, num_bags, int(include_last), ptr(psw), mode, hook_features,
+                                                  ptr(grad_out), float(fused.lr), stream_ptr()))
+        elif sparse:
+            rows = torch.empty(nnz, dim, device=weight.device, dtype=torch.float32)
+            check(lib.ce_bag_backward_rows(ptr(rows), dim, nnz, ptr(offsets), off64, num_bags, int(include_last),
+                                           ptr(psw), mode, hook_features, ptr(grad_out), stream_ptr()))
+            gw = torch.sparse_coo_tensor(indices.view(1, -1), rows, weight.shape, check_invariants=False)
+        else:
+            gw = torch.zeros_like(weight)
+            check(lib.ce_bag_backward_dense(ptr(gw), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
+                                            num_bags, int(include_last), ptr(psw), mode, hook_features,
+                                            ptr(grad_out), stream_ptr()))
+        return gw, None, None, None, None, None, None, None, None
+
+
+class FusedSGD:
+    """Switch for the fused backward+SGD path of one embedding module.
+
+    lr=None disables fusion (the module behaves exactly like nn.EmbeddingBag under
+    torch.optim.SGD); deterministic=True uses the sorted segmented update instead of atomics."""
+
+    def __init__(self, lr: Optional[float] = None, deterministic: bool = False):
+        self.lr = lr
+        self.deterministic = deterministic
+        self._ws = None
+
+    def workspace(self, num_rows: int, nnz: int, device) -> torch.Tensor:
+        need = lib.ce_bag_backward_sgd_sorted_workspace(num_rows, nnz)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+
+def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional[torch.Tensor] = None,
+                  max_norm: Optional[float] = None, norm_type: float = 2.0, scale_grad_by_freq: bool = False,
+                  mode: str = "mean", sparse: bool = False, per_sample_weights: Optional[torch.Tensor] = None,
+                  include_last_offset: bool = False, padding_idx: Optional[int] = None, *,
+                  hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None) -> torch.Tensor:
+    if max_norm is not None:
+        raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
+    if scale_grad_by_freq:
+        raise NotImplementedError("scale_grad_by_freq is not implemented by the HIP path")
+    if mode not in _MODES:
+        raise NotImplementedError(f"mode={mode!r}: only 'sum' and 'mean' are implemented")
+    if per_sample_weights is not None:
+        if mode != "sum":
+            raise NotImplementedError("embedding_bag: per_sample_weights was not None. per_sample_weights is "
+                                      f"only supported for mode='sum' (got mode='{mode}').")
+        if per_sample_weights.requires_grad:
+            raise NotImplementedError("gradient w.r.t. per_sample_weights is not implemented")
+        per_sample_weights = per_sample_weights.reshape(-1).float().contiguous()
+    indices, offsets, include_last_offset, num_bags = _prep(indices, offsets, include_last_offset)
+    if per_sample_weights is not None and per_sample_weights.numel() != indices.numel():
+        raise ValueError("per_sample_weights must have the same number of elements as input")
+    if hook_features and num_bags % hook_features:
+        raise ValueError("hook_features must divide the number of bags")
+    return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
+                        int(hook_features), bool(sparse), fused_sgd)

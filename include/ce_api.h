@@ -1,0 +1,231 @@
+/*
+ * ce_api.h -- C ABI of the MI355X-native frequency-aware cached EmbeddingBag.
+ *
+ * The reference (hpcaitech/CachedEmbedding) has no FFI: its boundary for this path is a
+ * Python nn.Module API implemented by ColossalAI's CachedParamMgr / CachedEmbeddingBag in
+ * pure torch ops.  Each entry point below replaces one of those torch-op sequences; the
+ * Python mirror in cachedembedding_amd/ (ctypes) is what a reference maintainer binds
+ * (see INTEGRATION.md).  Citations are relative to /root/reference; "[A.x]" refers to the
+ * upstream semantics recorded in SURVEY.md Appendix A.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every device pointer is a
+ * raw HIP device address; `stream` is a hipStream_t passed as void*; all work is enqueued
+ * asynchronously on that stream with NO hidden host synchronisation unless a function
+ * says it blocks; every function returns an int status (CE_OK == 0) and
+ * ce_last_error() gives the message of the last failure on the calling thread.
+ * Handles are not thread-safe (the reference is single-threaded per process too).
+ */
+#ifndef CE_API_H
+#define CE_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CE_API_VERSION 1
+
+/* status codes */
+#define CE_OK 0
+#define CE_ERR_INVALID 1     /* bad argument */
+#define CE_ERR_HIP 2         /* a HIP runtime call failed */
+#define CE_ERR_CAPACITY 3    /* unique rows of one prepare_ids call exceed cuda_row_num:
+                                the reference's AssertionError caught at
+                                benchmark/benchmark_cache.py:106-108 */
+#define CE_ERR_NOMEM 4
+#define CE_ERR_UNSUPPORTED 5
+#define CE_ERR_RANGE 6       /* an id outside [0, num_embeddings) */
+
+/* EvictionStrategy (recsys/models/dlrm.py:66,80) */
+#define CE_EVICT_DATASET 0
+#define CE_EVICT_LFU 1
+
+/* nn.EmbeddingBag mode (recsys/models/dlrm.py:74 passes 'sum') */
+#define CE_MODE_SUM 0
+#define CE_MODE_MEAN 1
+
+/* how missed / evicted rows move between the host table and the HBM cache */
+#define CE_TRANSPORT_ZEROCOPY 0  /* swap kernels read/write the mapped pinned host table over PCIe */
+#define CE_TRANSPORT_STAGED 1    /* host threads gather/scatter through pinned staging + hipMemcpyAsync */
+
+typedef void* ce_stream_t; /* hipStream_t */
+typedef struct ce_cache ce_cache_t;
+
+int ce_version(void);
+const char* ce_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Host table (the `weight` of CachedParamMgr, A.1; `pin_weight=True` at
+ * benchmark/benchmark_fbgemm_uvm.py:98-105).  Pinned + device-mapped host memory.
+ * ce_host_alloc pins `bytes` (first-touched by `threads` workers so a 91 GB table is
+ * spread over the NUMA nodes); ce_host_register pins memory the caller already owns
+ * (e.g. a `_weight` tensor).  Both return in *dev_ptr the address device code must use.
+ */
+int ce_host_alloc(size_t bytes, int threads, void** host_ptr, void** dev_ptr);
+int ce_host_free(void* host_ptr);
+int ce_host_register(void* host_ptr, size_t bytes, void** dev_ptr);
+int ce_host_unregister(void* host_ptr);
+/* weight init of CachedEmbeddingBag: uniform_(-1/N, 1/N) (A.7); counter-based RNG so the
+ * result is independent of `threads`. */
+int ce_host_fill_uniform(float* dst, int64_t n, float lo, float hi, uint64_t seed, int threads);
+
+/* ---------------------------------------------------------------------------------------
+ * K12: F.embedding_bag(slots, cuda_cached_weight, offsets, mode, per_sample_weights,
+ * include_last_offset) -- reached from recsys/models/dlrm.py:99-110 and
+ * benchmark/benchmark_cache.py:62 [A.7].  fp32 rows, int64 indices, int32 or int64 offsets.
+ *   out[bag] = sum_j psw[j] * weight[indices[j]]   (/ len for CE_MODE_MEAN)
+ * hook_features == 0: out is [num_bags, dim].  hook_features == F > 0 folds
+ * sparse_embedding_shape_hook (recsys/models/dlrm.py:26-27) into the store: bags are
+ * feature-major (bag = f*B + b, B = num_bags/F) and out is written as [B, F, dim].
+ * include_last_offset == 0: offsets has num_bags entries and the last bag ends at nnz.
+ */
+int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim,
+                   const int64_t* indices, int64_t nnz,
+                   const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                   int64_t hook_features, float* out, ce_stream_t stream);
+
+/* K13 (dense form): grad_weight[indices[j]] += psw[j]*scale*grad_out[bag(j)] accumulated
+ * with fp32 atomics into a caller-zeroed [num_rows, dim] buffer -- the `sparse=False`
+ * autograd backward of K12.  grad_out uses the same layout convention as `out` above. */
+int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32_t dim,
+                          const int64_t* indices, int64_t nnz,
+                          const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                          int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                          int64_t hook_features, const float* grad_out, ce_stream_t stream);
+
+/* K13 (sparse form): values of the COO gradient that `sparse=True` produces
+ * (scripts/kaggle.sh:71 --use_sparse_embed_grad): grad_rows[j] = psw[j]*scale*grad_out[bag(j)],
+ * one row per lookup, paired with `indices` as the COO indices. */
+int ce_bag_backward_rows(float* grad_rows, int32_t dim, int64_t nnz,
+                         const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                         int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                         int64_t hook_features, const float* grad_out, ce_stream_t stream);
+
+/* K13+K14 fused: weight[indices[j]] -= lr * psw[j]*scale*grad_out[bag(j)] -- autograd
+ * backward + torch.optim.SGD.step on the cache parameter (recsys/dlrm_main.py:274-279,
+ * 455-461) in one pass, fp32 atomics (order of duplicate-row updates is not fixed). */
+int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
+                        const int64_t* indices, int64_t nnz,
+                        const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                        int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                        int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream);
+
+/* Deterministic variant of the fused update: lookups are bucketed by target row with a
+ * stable counting pass (workspace from ce_bag_backward_sgd_sorted_workspace), each row's
+ * gradients are summed in lookup order and applied once:  W[r] -= lr * sum.  Matches the
+ * reference's coalesce-then-add order for sparse grads. */
+size_t ce_bag_backward_sgd_sorted_workspace(int64_t num_rows, int64_t nnz);
+int ce_bag_backward_sgd_sorted(float* weight, int64_t num_rows, int32_t dim,
+                               const int64_t* indices, int64_t nnz,
+                               const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                               int32_t include_last_offset, const float* per_sample_weights,
+                               int32_t mode, int64_t hook_features, const float* grad_out, float lr,
+                               void* workspace, size_t workspace_bytes, ce_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * CachedParamMgr [A.1-A.6].  Device state arrays are owned by the caller (so the Python
+ * mirror can expose them as tensors: cached_idx_map, inverted_cached_idx, idx_map,
+ * freq_cnter, cuda_cached_weight); the library owns only the opaque scratch it is handed.
+ * Row ids are int32 on the device (num_embeddings < 2^31), counters int64.
+ */
+typedef struct ce_cache_config {
+  int64_t num_embeddings;        /* N: rows of the host table                              */
+  int64_t cuda_row_num;          /* C: rows resident in HBM (int(N*cache_ratio), A.7)       */
+  int32_t embedding_dim;         /* D (fp32 elements per row)                              */
+  int32_t evict_strategy;        /* CE_EVICT_*                                             */
+  int32_t transport;             /* CE_TRANSPORT_*                                         */
+  int32_t protect_depth;         /* 0 = reference semantics; d>0 also protects the rows of
+                                    the previous d prepare_ids calls (overlapped pipeline)  */
+  int64_t max_ids_per_call;      /* upper bound of n in ce_cache_prepare_ids                */
+  float* host_weight;            /* [N, D] host table, HOST address                        */
+  float* host_weight_dev;        /* same memory, DEVICE-visible address (ce_host_*)        */
+  float* cache_weight;           /* device [C, D]  cuda_cached_weight                      */
+  int32_t* idx_map;              /* device int32[N] id -> cpu_row_idx, NULL = identity     */
+  int32_t* inverted_cached_idx;  /* device int32[N] cpu_row_idx -> slot, -1 = absent       */
+  int32_t* cached_idx_map;       /* device int32[C] slot -> cpu_row_idx, -1 = empty        */
+  int64_t* freq_cnter;           /* device int64[C] (LFU) or NULL                          */
+  void* workspace;               /* device scratch, ce_cache_workspace_bytes() bytes       */
+  size_t workspace_bytes;
+} ce_cache_config_t;
+
+/* per-call statistics [A.3-4]: what num_hits_history / num_miss_history /
+ * num_write_back_history record (recsys/dlrm_main.py:286-289) */
+typedef struct ce_call_stats {
+  int64_t seq;          /* call number, 1-based                      */
+  int64_t n_ids;        /* ids in the call                           */
+  int64_t n_unique;     /* unique rows                               */
+  int64_t n_miss;       /* unique rows not resident                  */
+  int64_t n_evict;      /* rows written back + evicted               */
+  int64_t miss_lookups; /* sum of multiplicities of missed rows      */
+  int64_t n_free_after; /* free slots after the call                 */
+  int32_t status;       /* CE_OK, CE_ERR_CAPACITY or CE_ERR_RANGE    */
+  int32_t kind;         /* CE_CALL_*                                 */
+} ce_call_stats_t;
+
+#define CE_CALL_PREPARE 0
+#define CE_CALL_PRELOAD 1
+#define CE_CALL_FLUSH 2
+
+size_t ce_cache_workspace_bytes(int64_t num_embeddings, int64_t cuda_row_num, int64_t max_ids_per_call);
+
+/* Builds the manager over caller-owned arrays and initialises them to the empty-cache
+ * state of A.1 (maps = -1, freq_cnter = INT64_MAX, cache rows untouched).  Blocks. */
+int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream, ce_cache_t** out);
+int ce_cache_destroy(ce_cache_t* h);
+
+/* Warm-up preload of reorder() [A.2-2]: rows[i] (device int32, NULL = i) -> slot i for
+ * i < n, with freq_vals (device int64, NULL = 0) written to freq_cnter under LFU. */
+int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_vals, int64_t n,
+                     ce_stream_t stream);
+
+/* prepare_ids [A.3] -- recsys/dlrm_main.py:259: unique rows of `ids` (device int64[n]) are
+ * made resident (victim selection A.5 with the canonical tie rule, write-back, admit A.4),
+ * slots_out (device int64[n]) receives inverted_cached_idx[idx_map[ids]] [A.6], LFU
+ * counters gain the multiplicities.  Fully asynchronous on `stream`.  On overflow or a bad
+ * id the call leaves every piece of state untouched and flags the status in its stats. */
+int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                         ce_stream_t stream);
+
+/* Blocks until the most recent prepare_ids/preload/flush has finished on the device and
+ * returns that call's statistics; returns its status (CE_ERR_CAPACITY ...). */
+int ce_cache_last_stats(ce_cache_t* h, ce_call_stats_t* out);
+/* Non-blocking totals accumulated from finished calls (call ce_cache_last_stats first for
+ * exact values): _cpu_to_cuda_numel, _cuda_to_cpu_numel, _cache_miss, _total_cache. */
+int ce_cache_totals(ce_cache_t* h, int64_t* cpu_to_cuda_numel, int64_t* cuda_to_cpu_numel,
+                    int64_t* cache_miss, int64_t* total_cache, int64_t* n_calls);
+/* Copies up to `cap` per-call records of finished calls starting at call `first_seq`. */
+int64_t ce_cache_history(ce_cache_t* h, int64_t first_seq, ce_call_stats_t* out, int64_t cap);
+
+/* _id_to_cached_cuda_id [A.6] alone (no cache maintenance): slots_out = inverted[idx_map[ids]] */
+int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                          ce_stream_t stream);
+
+/* flush() [A.7]: every resident row is written back to the host table, maps emptied,
+ * freq_cnter reset.  Asynchronous on `stream`. */
+int ce_cache_flush(ce_cache_t* h, ce_stream_t stream);
+
+int ce_cache_set_protect_depth(ce_cache_t* h, int32_t depth);
+int ce_cache_set_transport(ce_cache_t* h, int32_t transport);
+/* number of free slots as of the last finished call (blocks like ce_cache_last_stats) */
+int ce_cache_free_rows(ce_cache_t* h, int64_t* out);
+
+/* ---------------------------------------------------------------------------------------
+ * Row-wise sharding helpers (BASELINE.json north_star): the build's
+ * replacement for KJTAllToAll (recsys/datasets/utils.py:20-54).  Rows are owned by
+ * rank = row % world, local row = row / world.
+ * ce_bucketize_rows: ids (device int64[n]) -> rows via idx_map (NULL = identity), stable
+ * counting sort by owner: local_rows_out[perm position] = row / world (int64),
+ * perm_out[j] = position of lookup j in the bucketed order, counts_out[w] (device int64[world]).
+ */
+size_t ce_bucketize_workspace(int64_t n, int32_t world);
+int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int32_t world,
+                      int64_t* local_rows_out, int64_t* perm_out, int64_t* counts_out,
+                      void* workspace, size_t workspace_bytes, ce_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CE_API_H */

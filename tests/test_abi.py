@@ -1,0 +1,88 @@
+"""CPU tests of the drop-in boundary: libce_hip.so loads without a GPU, exports every
+symbol include/ce_api.h declares, and the ctypes mirror matches the header's structs."""
+import ctypes
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "ce_api.h").read_text()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(ce_[a-z0-9_]+)\s*\(", body)))
+
+
+def test_build_and_load():
+    import __graft_entry__ as g
+    g.build()
+    import cachedembedding_amd as ce
+    assert ce.LIB_PATH.exists()
+    assert ce._lib.lib.ce_version() == 1
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from cachedembedding_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ce_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert set(names) == set(_lib.SIGNATURES), (set(names) ^ set(_lib.SIGNATURES))
+    for n in names:
+        assert getattr(_lib.lib, n) is not None
+
+
+def _struct_fields(name):
+    m = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (name, name), HEADER, flags=re.S)
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    return [re.split(r"[\s\*]+", d.strip())[-1] for d in body.split(";") if d.strip()]
+
+
+def test_struct_mirrors_match_header():
+    from cachedembedding_amd import _lib
+    assert [f for f, _ in _lib.CeCacheConfig._fields_] == _struct_fields("ce_cache_config")
+    assert [f for f, _ in _lib.CeCallStats._fields_] == _struct_fields("ce_call_stats")
+    assert ctypes.sizeof(_lib.CeCallStats) == 64
+    assert ctypes.sizeof(_lib.CeCacheConfig) == 112
+
+
+def test_constants_match_header():
+    from cachedembedding_amd import _lib
+    for name, val in re.findall(r"#define (CE_[A-Z_]+) (\d+)", HEADER):
+        if hasattr(_lib, name):
+            assert getattr(_lib, name) == int(val), name
+
+
+def test_argument_validation_without_gpu():
+    """Pure host-side checks run before any HIP call, so they are testable here."""
+    from cachedembedding_amd import _lib
+    lib = _lib.lib
+    assert lib.ce_cache_workspace_bytes(0, 0, 0) == 0
+    assert lib.ce_cache_workspace_bytes(1000, 50, 64) > 0
+    assert lib.ce_bucketize_workspace(4096, 8) > 0
+    rc = lib.ce_bag_forward(None, 10, 0, None, 0, None, 0, 4, 1, None, 0, 0, None, None)
+    assert rc == _lib.CE_ERR_INVALID and "null pointer" in _lib.last_error()
+    rc = lib.ce_cache_create(None, None, None)
+    assert rc == _lib.CE_ERR_INVALID
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import cachedembedding_amd as ce
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ce.CachedEmbeddingBag(100, 8, cache_ratio=0.1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ce.embedding_bag(torch.zeros(4, dtype=torch.long), torch.zeros(10, 8), torch.arange(5), mode="sum",
+                         include_last_offset=True)
+
+
+def test_product_never_imports_oracle():
+    for p in (ROOT / "cachedembedding_amd").rglob("*.py"):
+        txt = p.read_text()
+        assert "oracle" not in re.sub(r'""".*?"""', "", txt, flags=re.S).replace("# oracle", ""), p

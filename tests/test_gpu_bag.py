@@ -1,0 +1,173 @@
+"""GPU parity of the HIP EmbeddingBag kernels (through the C ABI) against the CPU oracle.
+Tolerance: fp32 1e-5 relative (BASELINE.json north_star); bit-exact when every bag has one id."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden"
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _ce():
+    import cachedembedding_amd as ce
+    return ce
+
+
+def _case(seed, N, D, nb, maxlen, minlen=0, weighted=False, off_dtype=torch.int64):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(N, D, generator=g)
+    lens = torch.randint(minlen, maxlen + 1, (nb,), generator=g)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)]).to(off_dtype)
+    nnz = int(offsets[-1])
+    idx = torch.randint(0, N, (nnz,), generator=g)
+    psw = torch.rand(nnz, generator=g) if weighted else None
+    go = torch.randn(nb, D, generator=g)
+    return w, idx, offsets, psw, go
+
+
+@pytest.mark.parametrize("name,mode,weighted", [("bag_sum", "sum", False), ("bag_sum_weighted", "sum", True),
+                                                ("bag_mean", "mean", False)])
+def test_golden_forward_backward(name, mode, weighted):
+    ce = _ce()
+    z = np.load(GOLD / f"{name}.npz")
+    w = torch.from_numpy(z["weight"]).cuda().requires_grad_(True)
+    idx = torch.from_numpy(z["indices"]).cuda()
+    off = torch.from_numpy(z["offsets"]).cuda()
+    psw = torch.from_numpy(z["psw"]).cuda() if weighted else None
+    out = ce.embedding_bag(idx, w, off, mode=mode, per_sample_weights=psw, include_last_offset=True)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=RTOL, atol=ATOL)
+    out.backward(torch.from_numpy(z["grad_out"]).cuda())
+    np.testing.assert_allclose(w.grad.cpu().numpy(), z["grad_weight"], rtol=RTOL, atol=ATOL)
+    # sparse COO gradient form
+    w2 = torch.from_numpy(z["weight"]).cuda().requires_grad_(True)
+    out2 = ce.embedding_bag(idx, w2, off, mode=mode, per_sample_weights=psw, include_last_offset=True, sparse=True)
+    out2.backward(torch.from_numpy(z["grad_out"]).cuda())
+    assert w2.grad.is_sparse
+    np.testing.assert_allclose(w2.grad.to_dense().cpu().numpy(), z["grad_weight"], rtol=RTOL, atol=ATOL)
+    # fused backward+SGD (atomic and deterministic) == oracle SGD.step
+    for det in (False, True):
+        w3 = torch.from_numpy(z["weight"]).cuda().requires_grad_(True)
+        fused = ce.FusedSGD(0.5, deterministic=det)
+        out3 = ce.embedding_bag(idx, w3, off, mode=mode, per_sample_weights=psw, include_last_offset=True,
+                                sparse=True, fused_sgd=fused)
+        out3.backward(torch.from_numpy(z["grad_out"]).cuda())
+        assert w3.grad is None
+        np.testing.assert_allclose(w3.detach().cpu().numpy(), z["weight_after_sgd"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("D", [4, 8, 32, 64, 128, 256, 512, 100, 130, 7])
+@pytest.mark.parametrize("off_dtype", [torch.int32, torch.int64])
+def test_forward_dims_and_ragged(D, off_dtype):
+    ce = _ce()
+    from oracle import bag_oracle
+    w, idx, off, psw, go = _case(D, 513, D, 301, 7, off_dtype=off_dtype)
+    out = ce.embedding_bag(idx.cuda(), w.cuda(), off.cuda(), mode="sum", include_last_offset=True)
+    ref = bag_oracle.bag_forward(w, idx, off, None, "sum", True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+    # include_last_offset=False form
+    out2 = ce.embedding_bag(idx.cuda(), w.cuda(), off[:-1].cuda(), mode="sum", include_last_offset=False)
+    torch.testing.assert_close(out2.cpu(), ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("D", [128, 32, 96])
+@pytest.mark.parametrize("nb", [1, 63, 64, 65, 4099])
+def test_single_id_bags_bit_exact(D, nb):
+    """L=1 (every Criteo/Avazu batch): a pure row copy -- must be bit-exact."""
+    ce = _ce()
+    w, idx, off, _, _ = _case(nb + D, 1000, D, nb, 1, minlen=1, off_dtype=torch.int32)
+    out = ce.embedding_bag(idx.cuda(), w.cuda(), off.cuda(), mode="sum", include_last_offset=True)
+    assert torch.equal(out.cpu(), w[idx])
+
+
+def test_empty_inputs():
+    ce = _ce()
+    w = torch.randn(10, 16).cuda()
+    # all bags empty
+    off = torch.zeros(9, dtype=torch.long).cuda()
+    out = ce.embedding_bag(torch.zeros(0, dtype=torch.long).cuda(), w, off, mode="sum", include_last_offset=True)
+    assert out.shape == (8, 16) and torch.count_nonzero(out) == 0
+    # zero bags
+    out = ce.embedding_bag(torch.zeros(0, dtype=torch.long).cuda(), w, torch.zeros(1, dtype=torch.long).cuda(),
+                           mode="sum", include_last_offset=True)
+    assert out.shape == (0, 16)
+
+
+def test_2d_input_and_errors():
+    ce = _ce()
+    from oracle import bag_oracle
+    w = torch.randn(50, 32)
+    idx = torch.randint(0, 50, (9, 4))
+    out = ce.embedding_bag(idx.cuda(), w.cuda(), mode="mean")
+    ref = torch.nn.functional.embedding_bag(idx, w, mode="mean")
+    torch.testing.assert_close(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+    with pytest.raises(ValueError):
+        ce.embedding_bag(idx.cuda(), w.cuda(), torch.arange(3).cuda())
+    with pytest.raises(NotImplementedError):
+        ce.embedding_bag(idx.cuda(), w.cuda(), mode="max")
+
+
+@pytest.mark.parametrize("F,B,D", [(26, 512, 128), (13, 100, 32), (3, 7, 64)])
+def test_shape_hook_fold(F, B, D):
+    """hook_features folds sparse_embedding_shape_hook (recsys/models/dlrm.py:26-27) into the store."""
+    ce = _ce()
+    g = torch.Generator().manual_seed(F)
+    w = torch.randn(2000, D, generator=g)
+    idx = torch.randint(0, 2000, (F * B,), generator=g)
+    off = torch.arange(F * B + 1, dtype=torch.int32)
+    wc = w.cuda().requires_grad_(True)
+    out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, hook_features=F)
+    ref = w[idx].view(F, B, D).transpose(0, 1)
+    assert out.shape == (B, F, D) and torch.equal(out.cpu(), ref.contiguous())
+    go = torch.randn(B, F, D, generator=g)
+    out.backward(go.cuda())
+    wr = w.clone().requires_grad_(True)
+    torch.nn.functional.embedding_bag(idx, wr, off.long(), mode="sum", include_last_offset=True) \
+        .view(F, B, D).transpose(0, 1).backward(go)
+    torch.testing.assert_close(wc.grad.cpu(), wr.grad, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("det", [False, True])
+def test_fused_sgd_heavy_duplicates(det):
+    """Hot rows hit thousands of times in one batch: atomic and sorted updates agree with SGD.step."""
+    ce = _ce()
+    from oracle import bag_oracle
+    g = torch.Generator().manual_seed(9)
+    N, D, nb = 64, 128, 8192
+    w = torch.randn(N, D, generator=g)
+    idx = (torch.rand(nb, generator=g) ** 4 * N).long().clamp_(0, N - 1)
+    off = torch.arange(nb + 1, dtype=torch.int32)
+    go = torch.randn(nb, D, generator=g) * 0.01
+    wc = w.cuda().requires_grad_(True)
+    out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
+                           fused_sgd=ce.FusedSGD(1.0, deterministic=det))
+    out.backward(go.cuda())
+    ref = bag_oracle.sgd_step(w, idx, off, go, 1.0)
+    torch.testing.assert_close(wc.detach().cpu(), ref, rtol=1e-4, atol=1e-5)
+    if det:
+        wc2 = w.cuda().requires_grad_(True)
+        out = ce.embedding_bag(idx.cuda(), wc2, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
+                               fused_sgd=ce.FusedSGD(1.0, deterministic=True))
+        out.backward(go.cuda())
+        assert torch.equal(wc2.detach(), wc.detach()), "sorted update must be run-to-run deterministic"
+
+
+def test_full_size_batch_properties():
+    """BASELINE config-3 batch shape (B=16384, F=26, D=128, L=1): checks that do not need the oracle at
+    full size -- linearity in the table and the gather identity on a sampled subset."""
+    ce = _ce()
+    B, F, D, C = 16384, 26, 128, 200_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn(C, D, device="cuda", generator=g)
+    idx = torch.randint(0, C, (B * F,), device="cuda", generator=g)
+    off = torch.arange(B * F + 1, dtype=torch.int32, device="cuda")
+    out = ce.embedding_bag(idx, w, off, mode="sum", include_last_offset=True, hook_features=F)
+    out2 = ce.embedding_bag(idx, 2 * w, off, mode="sum", include_last_offset=True, hook_features=F)
+    assert torch.equal(out2, 2 * out)
+    pick = torch.randint(0, B * F, (4096,), device="cuda", generator=g)
+    f, b = pick // B, pick % B
+    assert torch.equal(out[b, f], w[idx[pick]])
+    assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))

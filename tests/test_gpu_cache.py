@@ -1,0 +1,224 @@
+"""GPU parity of the device-resident cache manager (ce_cache_* through the Python mirror)
+against the CPU oracle: slots, cached_idx_map, inverted_cached_idx, freq_cnter, hit/miss
+histories and evicted-row sets are compared BIT-EXACTLY after every call."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _ce():
+    import cachedembedding_amd as ce
+    return ce
+
+
+def _strat(ce, s):
+    return ce.EvictionStrategy.LFU if s == "lfu" else ce.EvictionStrategy.DATASET
+
+
+def _mk(ce, w, C, strategy, freq, warmup, async_copy=False):
+    table = torch.from_numpy(w.copy())
+    mgr = ce.CachedParamMgr(table, C, evict_strategy=_strat(ce, strategy), async_copy=async_copy)
+    mgr.reorder(freq, warmup)
+    return mgr
+
+
+def _state_equal(mgr, ora, lfu):
+    assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+    assert np.array_equal(mgr.inverted_cached_idx.cpu().numpy().astype(np.int64), ora.inverted_cached_idx)
+    if lfu:
+        assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+    np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
+
+
+LFU_SCRIPT = [[2], [1, 2], [0, 2], [0, 1, 2], [0, 1, 2], [0, 1, 2], [0, 1, 2], [0, 2], [0, 2], [0, 2], [0, 2],
+              [0], [0], [0], [0], [0, 1, 2], [0, 1, 2], [3], [2], [4], [2], [0]]
+
+
+@pytest.mark.parametrize("init_freq", [False, True])
+def test_lfu_known_answer(init_freq):
+    """upstream ColossalAI test_lfu_strategy: num_hits_history[-6:] == [3,0,1,0,1,1]"""
+    ce = _ce()
+    w = torch.randn(5, 5)
+    bag = ce.CachedEmbeddingBag(5, 5, cache_ratio=3 / 5, buffer_size=0, pin_weight=True, _weight=w,
+                                ids_freq_mapping=[4, 2, 1, 3, 1] if init_freq else None, warmup_ratio=1.0,
+                                evict_strategy=ce.EvictionStrategy.LFU)
+    offsets = torch.tensor([0], device="cuda")
+    for ids in LFU_SCRIPT:
+        bag(torch.tensor(ids, device="cuda"), offsets)
+    assert bag.num_hits_history[-6:] == [3, 0, 1, 0, 1, 1]
+
+
+@pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"),
+                                           ("cache_lfu_freq", "lfu"), ("cache_lfu_nofreq", "lfu")])
+@pytest.mark.parametrize("async_copy", [False, True])
+def test_golden_streams(name, strategy, async_copy):
+    ce = _ce()
+    z = np.load(GOLD / f"{name}.npz")
+    N, C, D, n_ids, calls, warm = (int(v) for v in z["meta"])
+    freq = z["freq"] if z["freq"].size else None
+    mgr = _mk(ce, z["weight"], C, strategy, freq, warm / 1000.0, async_copy)
+    assert np.array_equal(mgr.idx_map.cpu().numpy().astype(np.int64), z["idx_map"])
+    assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), z["cached_idx_map_0"])
+    for c in range(calls):
+        before = mgr.cached_idx_map.cpu().numpy().astype(np.int64)
+        slots = mgr.prepare_ids(torch.from_numpy(z["ids"][c]).cuda())
+        assert np.array_equal(slots.cpu().numpy(), z["slots"][c])
+        after = mgr.cached_idx_map.cpu().numpy().astype(np.int64)
+        assert np.array_equal(after, z["cached_idx_map"][c])
+        ev = z["evicted_rows"][c]
+        gone = set(before[before >= 0].tolist()) - set(after[after >= 0].tolist())
+        assert gone == set(ev[ev >= 0].tolist()), "evicted id set differs"
+        if strategy == "lfu":
+            assert np.array_equal(mgr.freq_cnter.cpu().numpy(), z["freq_cnter"][c])
+        with torch.no_grad():
+            u = torch.unique(slots)
+            mgr.cuda_cached_weight[u] += 0.5
+    assert mgr.num_hits_history == z["hits"].tolist()
+    assert mgr.num_miss_history == z["misses"].tolist()
+    mgr.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), z["weight_after_flush"])
+    assert (mgr.cached_idx_map == -1).all() and (mgr.inverted_cached_idx == -1).all()
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+@pytest.mark.parametrize("N,C,D,n_ids,s", [(20000, 2000, 128, 3000, 1.05), (50000, 512, 32, 400, 0.25),
+                                           (3000, 3000, 16, 2500, 0.5), (70001, 4097, 100, 4096, 1.05)])
+def test_seeded_streams_vs_oracle(strategy, N, C, D, n_ids, s):
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr, id_freq_map, power_law_ids
+    rng = np.random.default_rng(N + C)
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    perm = rng.permutation(N)
+    freq = id_freq_map(perm[power_law_ids(rng, N, 200000, s)], N)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+    ora.reorder(freq, 0.7)
+    mgr = _mk(ce, w, C, strategy, freq, 0.7)
+    _state_equal(mgr, ora, strategy == "lfu")
+    for c in range(12):
+        ids = perm[power_law_ids(rng, N, n_ids, s)]
+        if len(np.unique(ids)) > C:
+            ids = ids[:C // 2]
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        # emulate a training step on the touched rows so write-backs carry fresh payloads
+        ora.cuda_cached_weight[np.unique(eslots)] *= np.float32(1.25)
+        with torch.no_grad():
+            mgr.cuda_cached_weight[torch.unique(slots)] *= 1.25
+        _state_equal(mgr, ora, strategy == "lfu")
+    assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
+    assert mgr.num_write_back_history == ora.num_write_back_history
+    t = mgr.totals()
+    assert t["cache_miss"] == ora.cache_miss and t["total_cache"] == ora.total_cache
+    assert t["cpu_to_cuda_numel"] == ora.cpu_to_cuda_numel - int(np.ceil(C * 0.7)) * 0 and \
+        t["cuda_to_cpu_numel"] == ora.cuda_to_cpu_numel
+    mgr.flush()
+    ora.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+
+
+def test_capacity_overflow_is_assertion_and_state_untouched():
+    ce = _ce()
+    w = torch.randn(1000, 8)
+    mgr = ce.CachedParamMgr(w, 50, evict_strategy=ce.EvictionStrategy.DATASET)
+    mgr.reorder(None, 0.5)
+    before = mgr.cached_idx_map.clone()
+    with pytest.raises(AssertionError, match="increase cuda_row_num"):
+        mgr.prepare_ids(torch.arange(100, 151, device="cuda"))
+    assert torch.equal(before, mgr.cached_idx_map)
+    assert mgr.cuda_available_row_num == 25
+    # and the manager keeps working afterwards
+    s = mgr.prepare_ids(torch.arange(100, 150, device="cuda"))
+    assert s.min() >= 0 and len(torch.unique(s)) == 50
+    with pytest.raises(IndexError):
+        mgr.prepare_ids(torch.tensor([5, 1000], device="cuda"))
+    with pytest.raises(NotImplementedError):
+        ce.CachedParamMgr(w, 0)
+
+
+def test_empty_and_duplicate_only_calls():
+    ce = _ce()
+    mgr = ce.CachedParamMgr(torch.randn(100, 4), 10, evict_strategy=ce.EvictionStrategy.LFU)
+    mgr.reorder(None, 0.0)
+    s = mgr.prepare_ids(torch.zeros(0, dtype=torch.long, device="cuda"))
+    assert s.numel() == 0
+    s = mgr.prepare_ids(torch.full((1000,), 7, dtype=torch.long, device="cuda"))
+    assert (s == 0).all() and mgr.freq_cnter[0].item() == 1000
+    assert mgr.num_hits_history == [0, 0] and mgr.num_miss_history == [0, 1]
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+def test_protect_depth_matches_oracle(strategy):
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+    rng = np.random.default_rng(17)
+    N, C, D = 5000, 300, 16
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+    ora.protect_depth = 1
+    ora.reorder(None, 0.7)
+    mgr = _mk(ce, w, C, strategy, None, 0.7)
+    mgr.set_protect_depth(1)
+    for c in range(20):
+        ids = rng.integers(0, N, size=120)
+        e = ora.prepare_ids(ids)
+        s = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(s.cpu().numpy(), e)
+        _state_equal(mgr, ora, strategy == "lfu")
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+@pytest.mark.parametrize("mode", ["sum", "mean"])
+def test_module_equivalence_with_plain_embedding_bag(strategy, mode):
+    """upstream's contract test: CachedEmbeddingBag == nn.EmbeddingBag over several SGD steps, and the
+    host table equals the reference weight after flush()."""
+    ce = _ce()
+    torch.manual_seed(4)
+    N, D = 800, 32
+    w0 = torch.randn(N, D)
+    freq = torch.randint(0, 20, (N,))
+    model = ce.CachedEmbeddingBag(N, D, sparse=True, _weight=w0.clone(), mode=mode, include_last_offset=True,
+                                  cache_ratio=0.1, ids_freq_mapping=freq, warmup_ratio=0.7,
+                                  evict_strategy=_strat(ce, strategy))
+    ref = torch.nn.EmbeddingBag.from_pretrained(w0.clone(), freeze=False, mode=mode, include_last_offset=True,
+                                                sparse=True)
+    assert [n for n, _ in model.named_parameters()] == ["weight"]
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    id2row = model.cache_weight_mgr.idx_map.cpu().long()
+    for step in range(6):
+        lens = torch.randint(0, 5, (20,))
+        off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
+        ids = torch.randint(0, N, (int(off[-1]),))
+        go = torch.randn(20, D)
+        out = model(ids.cuda(), off.cuda())
+        rout = ref(id2row[ids], off)          # DATASET re-rank permutes logical rows (SURVEY B#3)
+        torch.testing.assert_close(out.cpu(), rout, rtol=1e-5, atol=1e-6)
+        opt.zero_grad(); ropt.zero_grad()
+        out.backward(go.cuda()); rout.backward(go)
+        opt.step(); ropt.step()
+    model.flush()
+    torch.testing.assert_close(model.weight, ref.weight.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_window_prepare_then_cache_op_false_forwards():
+    """_train's window semantics (recsys/dlrm_main.py:245-269): one prepare_ids over P concatenated
+    batches, torch.chunk the slots, forward each batch with cache_op=False."""
+    ce = _ce()
+    torch.manual_seed(0)
+    N, D, F, B, P = 3000, 64, 4, 32, 4
+    w0 = torch.randn(N, D)
+    model = ce.CachedEmbeddingBag(N, D, sparse=True, _weight=w0.clone(), mode="sum", include_last_offset=True,
+                                  cuda_row_num=F * B * P)
+    off = torch.arange(F * B + 1, dtype=torch.int32, device="cuda")
+    batches = [torch.randint(0, N, (F * B,), device="cuda") for _ in range(P)]
+    slots = model.cache_weight_mgr.prepare_ids(torch.cat(batches))
+    model.set_cache_op(False)
+    for ids, sl in zip(batches, torch.chunk(slots, P)):
+        out = model(sl, off, shape_hook=lambda x: x.view(F, B, -1).transpose(0, 1))
+        assert torch.equal(out.cpu(), w0[ids.cpu()].view(F, B, D).transpose(0, 1))

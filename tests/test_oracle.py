@@ -1,0 +1,143 @@
+"""CPU tests of the oracle itself: upstream's LFU known-answer, the cached==uncached
+invariant, the idx_map rank property, and the committed golden vectors."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bag_oracle
+from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr, id_freq_map, power_law_ids
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+# the 22 scripted lookups of upstream ColossalAI tests/test_layers/test_cache_embedding.py::test_lfu_strategy
+LFU_SCRIPT = [[2], [1, 2], [0, 2], [0, 1, 2], [0, 1, 2], [0, 1, 2], [0, 1, 2], [0, 2], [0, 2], [0, 2], [0, 2],
+              [0], [0], [0], [0], [0, 1, 2], [0, 1, 2], [3], [2], [4], [2], [0]]
+
+
+@pytest.mark.parametrize("init_freq", [False, True])
+def test_lfu_known_answer(init_freq):
+    w = np.random.default_rng(0).standard_normal((5, 5)).astype(np.float32)
+    mgr = OracleCachedParamMgr(w, 3, LFU)
+    mgr.reorder([4, 2, 1, 3, 1] if init_freq else None, warmup_ratio=1.0)
+    for ids in LFU_SCRIPT:
+        mgr.prepare_ids(np.array(ids))
+    assert mgr.num_hits_history[-6:] == [3, 0, 1, 0, 1, 1]
+    assert set(mgr.traces[-5].evicted_rows.tolist()) == {1}      # "[3]: miss, evict 1"
+    assert set(mgr.traces[-3].evicted_rows.tolist()) == {3}      # "[4]: miss, evict 3"
+
+
+def test_reorder_rank_map():
+    rng = np.random.default_rng(3)
+    freq = rng.integers(0, 20, size=500)
+    mgr = OracleCachedParamMgr(np.zeros((500, 4), np.float32), 50, DATASET)
+    mgr.reorder(freq, 0.7)
+    order = np.argsort(-freq, kind="stable")
+    assert np.array_equal(mgr.idx_map[order], np.arange(500))
+    # rank by descending frequency, ties by ascending id
+    for a, b in zip(order[:-1], order[1:]):
+        assert freq[a] > freq[b] or (freq[a] == freq[b] and a < b)
+    # warm-up: the 35 hottest rows sit in slots 0..34
+    assert np.array_equal(mgr.cached_idx_map[:35], np.arange(35))
+    assert mgr.cuda_available_row_num == 15
+
+
+@pytest.mark.parametrize("strategy", [DATASET, LFU])
+@pytest.mark.parametrize("mode", ["sum", "mean"])
+def test_equivalence_invariant(strategy, mode):
+    """cached EmbeddingBag == plain EmbeddingBag for outputs, and host weights after flush
+    (the contract of upstream's test_cache_embedding.py)."""
+    rng = np.random.default_rng(11)
+    N, D, C, lr = 300, 16, 40, 0.1
+    w0 = rng.standard_normal((N, D)).astype(np.float32)
+    freq = rng.integers(0, 9, size=N)
+    mgr = OracleCachedParamMgr(w0.copy(), C, strategy)
+    mgr.reorder(freq, 0.7)
+    ref = torch.from_numpy(w0.copy())
+    # DATASET re-rank permutes logical rows (SURVEY B#3): id x lives at row idx_map[x]
+    id2row = mgr.idx_map
+    for step in range(6):
+        nb = 12
+        lens = rng.integers(0, 4, size=nb)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        ids = rng.integers(0, N, size=int(offs[-1]))
+        go = torch.from_numpy(rng.standard_normal((nb, D)).astype(np.float32))
+        slots = mgr.prepare_ids(ids)
+        cw = torch.from_numpy(mgr.cuda_cached_weight)
+        out_c = bag_oracle.bag_forward(cw, torch.from_numpy(slots), torch.from_numpy(offs), None, mode)
+        out_r = bag_oracle.bag_forward(ref, torch.from_numpy(id2row[ids]), torch.from_numpy(offs), None, mode)
+        torch.testing.assert_close(out_c, out_r, rtol=1e-6, atol=1e-6)
+        mgr.cuda_cached_weight[:] = bag_oracle.sgd_step(cw, torch.from_numpy(slots), torch.from_numpy(offs), go, lr,
+                                                        None, mode).numpy()
+        ref = bag_oracle.sgd_step(ref, torch.from_numpy(id2row[ids]), torch.from_numpy(offs), go, lr, None, mode)
+    mgr.flush()
+    np.testing.assert_allclose(mgr.weight, ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_capacity_overflow_asserts():
+    mgr = OracleCachedParamMgr(np.zeros((100, 4), np.float32), 10, DATASET)
+    with pytest.raises(AssertionError, match="increase cuda_row_num"):
+        mgr.prepare_ids(np.arange(11))
+    assert mgr.cuda_available_row_num == 10 and (mgr.cached_idx_map == -1).all()
+    with pytest.raises(NotImplementedError):
+        OracleCachedParamMgr(np.zeros((10, 4), np.float32), 0, DATASET)
+
+
+def test_bag_oracle_pinned_by_loops():
+    for name, mode, weighted in (("bag_sum", "sum", False), ("bag_sum_weighted", "sum", True),
+                                 ("bag_mean", "mean", False)):
+        z = np.load(GOLD / f"{name}.npz")
+        psw = z["psw"] if weighted else None
+        loop = bag_oracle.bag_forward_numpy(z["weight"], z["indices"], z["offsets"], psw, mode)
+        np.testing.assert_allclose(loop, z["out"], rtol=1e-6, atol=1e-6)
+        t = bag_oracle.bag_forward(torch.from_numpy(z["weight"]), torch.from_numpy(z["indices"]),
+                                   torch.from_numpy(z["offsets"]), None if psw is None else torch.from_numpy(psw), mode)
+        np.testing.assert_array_equal(t.numpy(), z["out"])
+
+
+@pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", DATASET), ("cache_dataset_nofreq", DATASET),
+                                           ("cache_lfu_freq", LFU), ("cache_lfu_nofreq", LFU)])
+def test_cache_golden_replay(name, strategy):
+    z = np.load(GOLD / f"{name}.npz")
+    N, C, D, n_ids, calls, warm = z["meta"]
+    mgr = OracleCachedParamMgr(z["weight"].copy(), int(C), strategy)
+    mgr.reorder(z["freq"] if z["freq"].size else None, warm / 1000.0)
+    assert np.array_equal(mgr.idx_map, z["idx_map"])
+    assert np.array_equal(mgr.cached_idx_map, z["cached_idx_map_0"])
+    for c in range(int(calls)):
+        slots = mgr.prepare_ids(z["ids"][c])
+        mgr.cuda_cached_weight[np.unique(slots)] += np.float32(0.5)
+        assert np.array_equal(slots, z["slots"][c])
+        assert np.array_equal(mgr.cached_idx_map, z["cached_idx_map"][c])
+        ev = z["evicted_rows"][c]
+        assert set(mgr.traces[-1].evicted_rows.tolist()) == set(ev[ev >= 0].tolist())
+        if strategy == LFU:
+            assert np.array_equal(mgr.freq_cnter, z["freq_cnter"][c])
+    assert mgr.num_hits_history == z["hits"].tolist() and mgr.num_miss_history == z["misses"].tolist()
+    mgr.flush()
+    np.testing.assert_array_equal(mgr.weight, z["weight_after_flush"])
+
+
+def test_protect_depth_extension():
+    """protect_depth=1 (overlapped pipeline) never evicts a row of the previous call."""
+    rng = np.random.default_rng(5)
+    mgr = OracleCachedParamMgr(np.zeros((400, 4), np.float32), 60, LFU)
+    mgr.protect_depth = 1
+    prev = None
+    for _ in range(30):
+        ids = rng.integers(0, 400, size=25)
+        mgr.prepare_ids(ids)
+        if prev is not None:
+            assert not set(mgr.traces[-1].evicted_rows.tolist()) & set(np.unique(prev).tolist())
+            assert np.all(mgr.inverted_cached_idx[np.unique(prev)] >= 0)
+        prev = ids
+
+
+def test_power_law_generator_shape():
+    rng = np.random.default_rng(0)
+    ids = power_law_ids(rng, 10_000, 200_000, 0.25)
+    assert ids.min() >= 0 and ids.max() < 10_000
+    f = id_freq_map(ids, 10_000)
+    assert f.sum() == 200_000 and f[0] > f[100] > f[5000]
