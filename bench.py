@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py -- embedding lookups/s of the cached-EmbeddingBag hot path on MI355X.
+
+One "step" = one training iteration of the embedding operator on one batch of synthetic
+KJT input that is already resident in HBM:
+    every P steps : ONE prepare_ids over the ids of the next P batches
+                    (cache-index lookup, LFU/DATASET victim selection, write-back of evicted rows to the
+                     pinned host table, admission of missed rows, id -> slot translation)
+    every step    : EmbeddingBag forward gather-reduce  -> [B, F, D]
+                    backward grad scatter + SGD update of the cached rows (fused)
+which is the embedding part of the reference's `_train` loop (recsys/dlrm_main.py:243-279).
+lookups/s = steps * B * F * L / time; it/s = steps / time.
+
+Default workload (N=1): BASELINE.json configs[2] -- Criteo-1TB shaped table (177,944,275 rows x 128 fp32 =
+91.1 GB in pinned host DRAM), cache_ratio 0.01, B=16384, F=26, prefetch_num=8, DATASET eviction with an
+id-frequency map, per-table long-tail ids (baselines/data/custom.py generator, s=0.25).
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (HIP-event timed in
+here; bytes are ALGORITHMIC bytes per launch) and "cpu_baseline" (stock torch CPU
+EmbeddingBag+SGD over the same host table, bounded sample, rank 0 / N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default="criteo_1tb", choices=["criteo_1tb", "criteo_kaggle", "avazu", "custom"])
+    ap.add_argument("--batch_size", type=int, default=16384)
+    ap.add_argument("--embedding_dim", type=int, default=128)
+    ap.add_argument("--cache_ratio", type=float, default=0.01)
+    ap.add_argument("--prefetch_num", type=int, default=8)
+    ap.add_argument("--pooling", type=int, default=1)
+    ap.add_argument("--use_lfu", action="store_true")
+    ap.add_argument("--no_freq", action="store_true")
+    ap.add_argument("--warmup_ratio", type=float, default=0.7)
+    ap.add_argument("--dist", default="power_law", choices=["power_law", "uniform"])
+    ap.add_argument("--skew", type=float, default=0.25)
+    ap.add_argument("--table_scale", type=float, default=1.0, help="shrink every table (hosts that cannot pin 91 GB)")
+    ap.add_argument("--lr", type=float, default=1.0)
+    ap.add_argument("--overlap", action="store_true", help="cache op of window k+1 on a side stream")
+    ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
+    ap.add_argument("--deterministic", action="store_true", help="sorted segmented SGD update instead of atomics")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--seed", type=int, default=1024)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cachedembedding_amd as ce
+    from cachedembedding_amd import synthetic
+    from cachedembedding_amd.pipeline import PrefetchWindow
+
+    sizes = synthetic.TABLES[args.workload]
+    if args.table_scale != 1.0:
+        sizes = synthetic.scale_tables(sizes, args.table_scale)
+    F, B, L, D, P = len(sizes), args.batch_size, args.pooling, args.embedding_dim, args.prefetch_num
+    N = sum(sizes)
+    K, W = args.steps, args.warmup
+
+    if world > 1:
+        from cachedembedding_amd.parallel import RowwiseShardedBench
+        return RowwiseShardedBench(args, sizes, rank, world, dev).run()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.time() - t0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t0 = time.time()
+    gen = synthetic.SyntheticKJT(sizes, B, L, args.dist, args.skew, seed=args.seed + rank, device=dev)
+    freq = None if args.no_freq else gen.id_freq_map(sample_batches=4 * P)
+    note(f"id_freq_map over {N} rows built")
+    strategy = ce.EvictionStrategy.LFU if args.use_lfu else ce.EvictionStrategy.DATASET
+    embed = ce.CachedEmbeddingBag(N, D, sparse=True, mode="sum", include_last_offset=True,
+                                  cache_ratio=args.cache_ratio, ids_freq_mapping=freq, warmup_ratio=args.warmup_ratio,
+                                  pin_weight=True, evict_strategy=strategy, init_seed=args.seed, strict=False)
+    del freq
+    if args.async_copy:
+        embed.set_cache_mgr_async_copy(True)
+    embed.set_fused_sgd(args.lr, deterministic=args.deterministic)
+    embed.set_cache_op(False)
+    mgr = embed.cache_weight_mgr
+    C = mgr.cuda_row_num
+    setup_s = time.time() - t0
+    note(f"host table {N * D * 4 / 1e9:.1f} GB pinned+initialised, cache C={C} rows warmed up")
+
+    total = W + K
+    n_windows = (total + P - 1) // P
+    # inputs resident in HBM before the timed region
+    windows = [gen.next_values(P) for _ in range(n_windows)]          # each [P, F*B*L]
+    offsets = gen.offsets
+    grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
+    win = PrefetchWindow(embed, P, overlap=args.overlap)
+
+    def run_steps(first, count, ev_pairs=None):
+        slots = None
+        if args.overlap and win._pending is not None:
+            win.collect()      # drop a window submitted by an earlier, non-contiguous call
+        for step in range(first, first + count):
+            wi, bi = divmod(step, P)
+            if bi == 0 or slots is None:
+                if args.overlap:
+                    if win._pending is None:
+                        win.submit([windows[wi][i] for i in range(P)])
+                    slots = win.collect()
+                    if wi + 1 < n_windows:
+                        win.submit([windows[wi + 1][i] for i in range(P)])
+                else:
+                    slots = win.prepare([windows[wi][i] for i in range(P)])
+            if ev_pairs is not None:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            out = embed(slots[bi], offsets, hook_features=F)
+            if ev_pairs is not None:
+                e1.record()
+            out.backward(grad)
+            if ev_pairs is not None:
+                e2.record()
+                ev_pairs.append((e0, e1, e2))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(0, W)
+    barrier()
+    note("warmup done")
+    t1 = time.perf_counter()
+    run_steps(W, K)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    note(f"timed region done: {elapsed:.3f}s for {K} steps")
+    st = mgr.sync_stats()
+    if st.status != 0:
+        raise AssertionError(f"cache op failed with status {st.status}: unique rows of a window exceed cuda_row_num={C}")
+
+    lookups = K * B * F * L
+    value = lookups / elapsed
+    hits, miss = sum(mgr.num_hits_history), sum(mgr.num_miss_history)
+    tot = mgr.totals()
+
+    # ---- per-kernel launch duration with HIP events on the launch stream (separate pass, same data)
+    evs = []
+    run_steps(W, min(K, 4 * P), evs)
+    torch.cuda.synchronize()
+    fwd_ms = sorted(e0.elapsed_time(e1) for e0, e1, _ in evs)
+    bwd_ms = sorted(e1.elapsed_time(e2) for _, e1, e2 in evs)
+    fwd_avg = sum(fwd_ms) / len(fwd_ms)
+    bwd_avg = sum(bwd_ms) / len(bwd_ms)
+    row_b = 4 * D
+    fwd_bytes = B * F * (L * (row_b + 8) + 8 + row_b)            # 1040 B/lookup at D=128, L=1
+    bwd_bytes = B * F * (row_b + L * (8 + 2 * row_b)) + B * F * 8     # grad row read + RMW of each target row
+    fwd_roof = dict(kernel="k_bag_fwd", bound="hbm", achieved=fwd_bytes / fwd_avg / 1e6, peak=HBM_PEAK_GBPS,
+                    unit="GB/s", avg_ms=fwd_avg, bytes_per_launch=fwd_bytes)
+    bwd_roof = dict(kernel="k_bag_bwd(sgd)", bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
+                    unit="GB/s", avg_ms=bwd_avg, bytes_per_launch=bwd_bytes)
+    for r in (fwd_roof, bwd_roof):
+        r["frac"] = r["achieved"] / r["peak"]
+        r["traffic"] = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            tj = json.loads(tfile.read_text())
+            key = f"{args.workload}:B{B}:D{D}"
+            for r in (fwd_roof, bwd_roof):
+                r["traffic"] = tj.get(key, {}).get(r["kernel"])
+        except Exception:
+            pass
+    dominant, other = (fwd_roof, bwd_roof) if fwd_avg >= bwd_avg else (bwd_roof, fwd_roof)
+
+    result = {
+        "metric": "embedding lookups/sec (cache op + EmbeddingBag fwd + bwd/SGD), Criteo-1TB table @1% cache",
+        "value": value, "unit": "lookups/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
+                   "embedding_dim": D, "features": F, "batch_size": B, "pooling": L, "cache_ratio": args.cache_ratio,
+                   "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
+                   "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
+                   "transport": "staged" if args.async_copy else "zerocopy", "overlap": bool(args.overlap),
+                   "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
+        "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
+                  "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,
+                  "setup_s": setup_s},
+        "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} |
+                    {"kernel": dominant["kernel"], "avg_ms": dominant["avg_ms"], "bytes_per_launch": dominant["bytes_per_launch"]},
+        "roofline_other": other,
+    }
+
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        result["cpu_baseline"] = cpu_baseline(embed, gen, args, B, F, L, D)
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(embed, gen, args, B, F, L, D):
+    """The repo's pure-PyTorch CPU EmbeddingBag path (cache_ratio=1.0 == whole table in RAM):
+    F.embedding_bag fwd + sparse backward + SGD.step over the SAME pinned host table, timed on the host's own
+    cores.  Runs last: it updates the table in place."""
+    from oracle import bag_oracle
+    torch.cuda.synchronize()
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    table = embed.weight                      # CPU view of the pinned [N, D] host table
+    w = torch.nn.Parameter(table)             # shares memory, no 91 GB clone
+    opt = torch.optim.SGD([w], lr=args.lr)
+    offsets = gen.offsets.cpu().long()
+    grad = (torch.randn(B * F, D) * 1e-3)
+    batches = gen.next_values(8).cpu()
+    times = []
+    t_end = time.perf_counter() + args.cpu_seconds
+    i = 0
+    while (time.perf_counter() < t_end or len(times) < 3) and len(times) < 200:
+        ids = batches[i % batches.shape[0]]
+        t0 = time.perf_counter()
+        bag_oracle.cpu_train_step_inplace(w, opt, ids, offsets, grad)
+        times.append(time.perf_counter() - t0)
+        i += 1
+    times = times[1:] if len(times) > 3 else times
+    med = sorted(times)[len(times) // 2]
+    return {"value": B * F * L / med, "unit": "lookups/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} iterations of torch-CPU F.embedding_bag fwd+bwd(sparse)+SGD.step, B={B} F={F} L={L} "
+                      f"D={D} over the full {table.shape[0]}-row host table, median; host has {cores} hw threads",
+            "it_per_s": 1.0 / med}
+
+
+if __name__ == "__main__":
+    main()

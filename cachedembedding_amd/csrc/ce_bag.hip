@@ -33,6 +33,7 @@ struct BagParams {
   int32_t hookF;            // 0 = plain [num_bags, D]
   int32_t hookB;            // num_bags / hookF
   float alpha;              // bwd scale (1 or -lr)
+  int32_t idx_bits;         // bits needed to tell two row indices apart (bwd duplicate matching)
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -207,6 +208,98 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
       lo = ld_off(p, b0 + lane);
       hi = bag_end(p, b0 + lane);
     }
+    if (OP == 0 && __all((hi - lo == 1) || (lane >= nb))) {
+      // ---- single-id tile (all Criteo/Avazu batches).  Small tables make most of the 64 lookups of a
+      // tile hit the same few rows, and fp32 atomics on one row serialise (~12 ns each), so duplicates
+      // are combined inside the wave first: 1 ballot per index bit gives every lane the mask of lanes
+      // with the same row; the lowest lane of each mask ("leader") sums its peers' gradient rows in
+      // lane order and issues ONE atomic row update.
+      int idx = -1 - lane;              // out-of-range lanes never match anything
+      float w = 1.f;
+      if (lane < nb) {
+        idx = (int)p.indices[lo];
+        if (p.psw) w = p.psw[lo];
+      }
+      unsigned long long peers = __ballot(lane < nb);
+      if (lane >= nb) peers = 0;
+      for (int b = 0; b < p.idx_bits; ++b) {
+        const unsigned long long m = __ballot((idx >> b) & 1);
+        peers &= ((idx >> b) & 1) ? m : ~m;
+      }
+      const unsigned plo = (unsigned)peers, phi = (unsigned)(peers >> 32);
+      for (int base = 0; base < nb; base += gpw * U) {
+        VT g[U][NCH];
+        unsigned long long rest[U];
+        int ri[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bi = base + u * gpw + grp;
+          const int src = bi & 63;
+          const unsigned long long pm =
+              ((unsigned long long)(unsigned)__shfl((int)phi, src) << 32) | (unsigned)__shfl((int)plo, src);
+          ri[u] = __shfl(idx, src);
+          const float wi = __shfl(w, src);
+          const bool lead = (bi < nb) && ((__ffsll((long long)pm) - 1) == bi);
+          rest[u] = lead ? pm : 0ull;
+          const int64_t orow = out_row(p, b0 + min(bi, nb - 1));
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int ch = gl + c * G;
+            g[u][c] = vzero<VT>();
+            if (lead && ch < rowlen) g[u][c] = p.psw ? GO[orow * rowlen + ch] * wi : GO[orow * rowlen + ch];
+          }
+          rest[u] &= ~(1ull << src);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          unsigned long long r = rest[u];
+          while (r) {      // remaining peers, 4 gradient rows in flight
+            int pl[4];
+            VT t[4][NCH];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              pl[q] = r ? (__ffsll((long long)r) - 1) : -1;
+              if (r) r &= r - 1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int64_t orow = out_row(p, b0 + max(pl[q], 0));
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                const int ch = gl + c * G;
+                t[q][c] = vzero<VT>();
+                if (pl[q] >= 0 && ch < rowlen) t[q][c] = GO[orow * rowlen + ch];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (pl[q] >= 0) {
+                // (no cross-lane op here: the two lane groups of a wave run different trip counts)
+                const float wq = p.psw ? p.psw[ld_off(p, b0 + pl[q])] : 1.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) g[u][c] = p.psw ? g[u][c] + t[q][c] * wq : g[u][c] + t[q][c];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bi = base + u * gpw + grp;
+          const int src = bi & 63;
+          const unsigned long long pm =
+              ((unsigned long long)(unsigned)__shfl((int)phi, src) << 32) | (unsigned)__shfl((int)plo, src);
+          const bool lead = (bi < nb) && ((__ffsll((long long)pm) - 1) == bi);
+          if (lead) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const int ch = gl + c * G;
+              if (ch < rowlen) atomic_add_vec(&DST[(int64_t)ri[u] * rowlen + ch], g[u][c] * p.alpha);
+            }
+          }
+        }
+      }
+      continue;
+    }
     for (int base = 0; base < nb; base += gpw * U) {
       VT g[U][NCH];
       int blo[U], bhi[U];
@@ -280,6 +373,7 @@ static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_
   p.hookF = (int32_t)hookF;
   p.hookB = hookF ? (int32_t)(num_bags / hookF) : 0;
   p.alpha = 1.f;
+  p.idx_bits = 31;
   return CE_OK;
 }
 
@@ -339,7 +433,6 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
                                      int64_t num_bags, int32_t include_last_offset,
                                      const float* per_sample_weights, int32_t mode, int64_t hook_features,
                                      const float* grad_out, ce_stream_t stream) {
-  (void)num_rows;
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(grad_weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -351,6 +444,8 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
   p.dst = grad_weight;
   p.grad_out = grad_out;
   p.alpha = 1.f;
+  p.idx_bits = 1;
+  while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
 
@@ -358,7 +453,6 @@ extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
                                    int64_t nnz, const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                                    int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                    int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream) {
-  (void)num_rows;
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -370,6 +464,8 @@ extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
   p.dst = weight;
   p.grad_out = grad_out;
   p.alpha = -lr;
+  p.idx_bits = 1;
+  while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
 

@@ -670,7 +670,7 @@ static void drain(ce_cache* h) {
     const ce_call_stats_t& r = h->ring[s % kRing];
     if (r.seq != s) break;
     h->history.push_back(r);
-    if (r.status == CE_OK) {
+    if (r.status == CE_OK && r.kind != CE_CALL_PRELOAD) {   // warm-up preload is not counted upstream either
       h->cpu_to_cuda_numel += r.n_miss * h->cfg.embedding_dim;
       h->cuda_to_cpu_numel += r.n_evict * h->cfg.embedding_dim;
       h->cache_miss += r.miss_lookups;
@@ -819,7 +819,6 @@ static int ensure_staging(ce_cache* h, int64_t rows) {
   CE_HIP_CHECK(hipMalloc((void**)&h->stage_dev, bytes));
   CE_HIP_CHECK(hipHostMalloc((void**)&h->stage_host, bytes, hipHostMallocDefault));
   CE_HIP_CHECK(hipHostMalloc((void**)&h->list_host, (size_t)rows * 2 * sizeof(int32_t), hipHostMallocDefault));
-  if (!h->ctl_host) CE_HIP_CHECK(hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl), hipHostMallocDefault));
   h->stage_rows = rows;
   return CE_OK;
 }
@@ -864,6 +863,7 @@ static int staged_swap(ce_cache* h, hipStream_t s) {
   const int D = c.embedding_dim;
   const size_t rowbytes = (size_t)D * sizeof(float);
   // the host needs the counts and the lists: one sync point per call (the reference has one per phase)
+  if (!h->ctl_host) CE_HIP_CHECK(hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl), hipHostMallocDefault));
   CE_HIP_CHECK(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
   CE_HIP_CHECK(hipStreamSynchronize(s));
   const Ctl ctl = *h->ctl_host;

@@ -78,3 +78,14 @@ def sgd_step(weight: torch.Tensor, indices: torch.Tensor, offsets: torch.Tensor,
     out.backward(grad_out.float().cpu())
     opt.step()
     return w.detach()
+
+
+def cpu_train_step_inplace(param: torch.nn.Parameter, opt: torch.optim.Optimizer, indices: torch.Tensor,
+                           offsets: torch.Tensor, grad_out: torch.Tensor, mode: str = "sum") -> torch.Tensor:
+    """One embedding training step of the reference's CPU path on a table that is updated in place
+    (used by bench.py's cpu_baseline leg, where cloning a 91 GB table per step is not an option)."""
+    out = F.embedding_bag(indices, param, offsets, mode=mode, sparse=True, include_last_offset=True)
+    opt.zero_grad(set_to_none=True)
+    out.backward(grad_out)
+    opt.step()
+    return out.detach()

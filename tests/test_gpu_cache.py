@@ -115,8 +115,7 @@ def test_seeded_streams_vs_oracle(strategy, N, C, D, n_ids, s):
     assert mgr.num_write_back_history == ora.num_write_back_history
     t = mgr.totals()
     assert t["cache_miss"] == ora.cache_miss and t["total_cache"] == ora.total_cache
-    assert t["cpu_to_cuda_numel"] == ora.cpu_to_cuda_numel - int(np.ceil(C * 0.7)) * 0 and \
-        t["cuda_to_cpu_numel"] == ora.cuda_to_cpu_numel
+    assert t["cpu_to_cuda_numel"] == ora.cpu_to_cuda_numel and t["cuda_to_cpu_numel"] == ora.cuda_to_cpu_numel
     mgr.flush()
     ora.flush()
     np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
