@@ -40,8 +40,8 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=96)
     ap.add_argument("--workload", default="criteo_1tb", choices=["criteo_1tb", "criteo_kaggle", "avazu", "custom"])
     ap.add_argument("--batch_size", type=int, default=16384)
     ap.add_argument("--embedding_dim", type=int, default=128)

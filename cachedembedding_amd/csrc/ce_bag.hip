@@ -12,6 +12,10 @@
 // fetched with one coalesced load and U independent row loads per lane are put in flight
 // before the first store.  Output stores are non-temporal (never re-read here); row loads
 // use the default policy so hot rows stay in L2 / Infinity Cache.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "ce_common.h"
 
 namespace ce {
@@ -339,6 +343,211 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tile-sorted scatter (K13/K14 main path).  fp32 atomics aimed at one row serialise, and Criteo-
+// shaped batches hammer a few rows (tables of 3..100 rows get B lookups each; power-law heads).
+// So a workgroup takes 1024 consecutive lookups, sorts (row, lookup) keys in LDS (bitonic, 8 KB),
+// and reduces every run of equal rows BEFORE touching HBM: short runs are summed by one lane group
+// in lookup order, long runs by all groups with an LDS combine, and each (row, tile) pair costs ONE
+// atomic row update.  Gradient rows are read exactly once, coalesced per lane group.
+constexpr int kBwdTile = 1024;
+constexpr int kLongRun = 32;
+
+__device__ __forceinline__ int find_bag(const BagParams& p, int j) {
+  // bag whose [offsets[b], end(b)) holds lookup j; single-id layouts (offsets == arange) hit the first test
+  if (j < p.num_bags && ld_off(p, j) == j && bag_end(p, j) == j + 1) return j;
+  int lo = 0, hi = p.num_bags - 1;
+  while (lo < hi) {                       // last b with offsets[b] <= j
+    const int mid = (lo + hi + 1) >> 1;
+    if (ld_off(p, mid) <= j) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <typename VT, int NCH>
+__global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
+  __shared__ unsigned long long keys[kBwdTile];
+  __shared__ int bagl[kBwdTile];
+  __shared__ float scl[kBwdTile];
+  __shared__ short heads[kBwdTile + 1];
+  __shared__ short longs[kBwdTile / kLongRun + 1];
+  __shared__ int wsum[4];
+  __shared__ int n_long;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // ngroups x row partials
+  VT* part = (VT*)dyn_lds;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int G = 1 << p.g_log2;
+  const int ngroups = 256 >> p.g_log2;
+  const int grp = tid >> p.g_log2;
+  const int gl = tid & (G - 1);
+  const int rowlen = p.rowlen;
+  const VT* __restrict__ GO = (const VT*)p.grad_out;
+  VT* __restrict__ DST = (VT*)p.dst;
+  const int ntiles = (int)((p.nnz + kBwdTile - 1) / kBwdTile);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int j0 = tile * kBwdTile;
+    const int nv = min(kBwdTile, (int)(p.nnz - j0));
+    // ---- a. keys, bag and scale of every lookup of the tile
+    for (int i = tid; i < kBwdTile; i += 256) {
+      unsigned long long key = ~0ull;
+      if (i < nv) {
+        const int j = j0 + i;
+        const int bag = find_bag(p, j);
+        float sc = p.alpha;
+        if (p.psw) sc *= p.psw[j];
+        if (p.mode == CE_MODE_MEAN) {
+          const int len = bag_end(p, bag) - ld_off(p, bag);
+          if (len > 1) sc = sc / (float)len;
+        }
+        bagl[i] = bag;
+        scl[i] = sc;
+        key = ((unsigned long long)(unsigned)p.indices[j] << 32) | (unsigned)i;
+      }
+      keys[i] = key;
+    }
+    if (tid == 0) n_long = 0;
+    __syncthreads();
+    // ---- b. bitonic sort (row major, lookup minor) -> runs are in lookup order
+    for (int k = 2; k <= kBwdTile; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int c = tid + t * 256;
+          const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+          const int l = i | j;
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- c. run heads (ordered compaction), long-run list
+    int hf[4], cnt = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tid * 4 + t;
+      hf[t] = (i < nv) && (i == 0 || (unsigned)(keys[i] >> 32) != (unsigned)(keys[i - 1] >> 32));
+      cnt += hf[t];
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int pos = inc - cnt, nruns = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < (tid >> 6)) pos += wsum[w];
+      nruns += wsum[w];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (hf[t]) heads[pos++] = (short)(tid * 4 + t);
+    if (tid == 0) heads[nruns] = (short)nv;
+    __syncthreads();
+    for (int r = tid; r < nruns; r += 256)
+      if (heads[r + 1] - heads[r] > kLongRun) longs[atomicAdd(&n_long, 1)] = (short)r;
+    __syncthreads();
+    // ---- d. short runs: one lane group per run
+    for (int r = grp; r < nruns; r += ngroups) {
+      const int s0 = heads[r], s1 = heads[r + 1];
+      if (s1 - s0 > kLongRun) continue;
+      VT acc[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
+      for (int q = s0; q < s1; q += 4) {
+        VT v[4][NCH];
+        float sc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool on = q + t < s1;
+          const int li = on ? (int)(unsigned)keys[q + t] : 0;
+          sc[t] = on ? scl[li] : 0.f;
+          const int64_t orow = out_row(p, bagl[li]);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int ch = gl + c * G;
+            v[t][c] = vzero<VT>();
+            if (on && ch < rowlen) v[t][c] = GO[orow * rowlen + ch];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * sc[t];
+      }
+      const int64_t row = (int64_t)(unsigned)(keys[s0] >> 32);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = gl + c * G;
+        if (ch < rowlen) atomic_add_vec(&DST[row * rowlen + ch], acc[c]);
+      }
+    }
+    // ---- e. long runs: every group takes an interleaved share, partials combined through LDS
+    const int nl = n_long;
+    for (int x = 0; x < nl; ++x) {
+      const int r = longs[x];
+      const int s0 = heads[r], s1 = heads[r + 1];
+      VT acc[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
+      for (int q = s0 + grp; q < s1; q += 4 * ngroups) {
+        VT v[4][NCH];
+        float sc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int qq = q + t * ngroups;
+          const bool on = qq < s1;
+          const int li = on ? (int)(unsigned)keys[qq] : 0;
+          sc[t] = on ? scl[li] : 0.f;
+          const int64_t orow = out_row(p, bagl[li]);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int ch = gl + c * G;
+            v[t][c] = vzero<VT>();
+            if (on && ch < rowlen) v[t][c] = GO[orow * rowlen + ch];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * sc[t];
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = gl + c * G;
+        if (ch < rowlen) part[(grp * NCH + c) * G + gl] = acc[c];
+      }
+      __syncthreads();
+      if (grp == 0) {
+        const int64_t row = (int64_t)(unsigned)(keys[s0] >> 32);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = gl + c * G;
+          if (ch < rowlen) {
+            VT sum = part[c * G + gl];
+            for (int g2 = 1; g2 < ngroups; ++g2) sum = sum + part[(g2 * NCH + c) * G + gl];
+            atomic_add_vec(&DST[row * rowlen + ch], sum);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+}
+
 static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_t nnz, const void* offsets,
                        int32_t off64, int64_t num_bags, int32_t include_last, const float* psw, int32_t mode,
                        int64_t hookF, bool* vec, int* nch, const void* a0, const void* a1, const void* a2) {
@@ -382,8 +591,32 @@ static int bag_grid(int64_t num_bags) {
   return grid_for(tiles, 4);
 }
 
+static bool use_wave_bwd() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CE_BWD_IMPL");      // "wave": per-wave duplicate matching (A/B testing only)
+    v = (e && strcmp(e, "wave") == 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <int OP>
 static int launch_bwd(const BagParams& p, bool vec, int nch, hipStream_t s) {
+  if (OP == 0 && !use_wave_bwd()) {
+    const int ntiles = (int)cdiv(p.nnz, kBwdTile);
+    dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
+    const int G = 1 << p.g_log2;
+    const size_t lds = (size_t)(256 / G) * nch * G * (vec ? 16 : 4);
+#define CE_BWT(VT, N) hipLaunchKernelGGL((k_bag_bwd_tile<VT, N>), grid, block, lds, s, p)
+    if (vec) {
+      if (nch == 1) CE_BWT(f32x4, 1); else if (nch == 2) CE_BWT(f32x4, 2); else CE_BWT(f32x4, 4);
+    } else {
+      if (nch == 1) CE_BWT(float, 1); else if (nch == 2) CE_BWT(float, 2); else CE_BWT(float, 4);
+    }
+#undef CE_BWT
+    CE_LAUNCH_CHECK();
+    return CE_OK;
+  }
   dim3 grid(bag_grid(p.num_bags)), block(256);
 #define CE_BWD(VT, N) hipLaunchKernelGGL((k_bag_bwd<VT, N, OP>), grid, block, 0, s, p)
   if (vec) {

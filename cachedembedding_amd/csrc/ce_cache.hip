@@ -129,26 +129,57 @@ __global__ void k_begin(Ctl* ctl) {
   ctl->status = CE_OK;
 }
 
+// Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window
+// sends >100k ids at a 3-row table, so per-id atomicOr on one word would serialise.  Each wave first
+// merges its 64 ids: ballots over the word-index bits give every lane the mask of lanes aiming at the
+// same word, 32 more ballots OR their bits together, and only the lowest lane of each mask issues
+// ONE atomicOr -- and only if a plain load did not already show the bits set.
 __global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, int64_t n,
                                               const int32_t* __restrict__ idx_map,
-                                              const int32_t* __restrict__ inverted, int64_t N,
+                                              const int32_t* __restrict__ inverted, int64_t N, int word_bits,
                                               uint32_t* bitmap, Ctl* ctl) {
+  const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int cold = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t id = ids[i];
-    if ((unsigned long long)id >= (unsigned long long)N) {
-      ctl->status = CE_ERR_RANGE;
-      continue;
+  // wave-uniform trip count: every lane of a wave runs the same number of iterations
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
+    const int64_t i = i0 + lane;
+    bool valid = i < n;
+    int32_t row = 0;
+    if (valid) {
+      const int64_t id = ids[i];
+      if ((unsigned long long)id >= (unsigned long long)N) {
+        ctl->status = CE_ERR_RANGE;
+        valid = false;
+      } else {
+        row = idx_map ? idx_map[id] : (int32_t)id;
+      }
     }
-    const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
-    const uint32_t bit = 1u << (row & 31);
-    uint32_t* w = bitmap + (row >> 5);
-    if (!(*(volatile uint32_t*)w & bit)) atomicOr(w, bit);
-    cold += (inverted[row] < 0);
+    const int word = row >> 5;
+    const int bidx = row & 31;
+    bool need = false;
+    if (valid) {
+      need = ((*(volatile uint32_t*)(bitmap + word)) & (1u << bidx)) == 0;
+      cold += (inverted[row] < 0);
+    }
+    if (__any(need)) {
+      unsigned long long pm = __ballot(need);
+      if (!need) pm = 0;
+      for (int b = 0; b < word_bits; ++b) {
+        const unsigned long long m = __ballot((word >> b) & 1);
+        pm &= ((word >> b) & 1) ? m : ~m;
+      }
+      uint32_t orbits = 0;
+#pragma unroll
+      for (int b = 0; b < 32; ++b) {
+        const unsigned long long m = __ballot(need && bidx == b);
+        if (m & pm) orbits |= (1u << b);
+      }
+      if (need && (__ffsll((long long)pm) - 1) == lane) atomicOr(bitmap + word, orbits);
+    }
   }
   cold = wave_sum(cold);
-  if ((threadIdx.x & 63) == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
+  if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
 }
 
 // one uint4 (128 rows) per thread
@@ -652,7 +683,7 @@ struct ce_cache {
   std::vector<ce_call_stats_t> history;
   int64_t cpu_to_cuda_numel, cuda_to_cpu_numel, cache_miss, total_cache;
   int vec;                     // rows moved as 16-B vectors
-  int rowlen, g_log2, slot_bits;
+  int rowlen, g_log2, slot_bits, word_bits;
   // staged transport
   int host_threads;
   float* stage_dev;            // device staging [stage_rows, D]
@@ -739,6 +770,9 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   int sb = 1;
   while ((1ll << sb) < cfg->cuda_row_num) ++sb;
   h->slot_bits = sb;
+  int wb = 1;
+  while ((1ll << wb) < cdiv(cfg->num_embeddings, 32)) ++wb;
+  h->word_bits = wb;
   h->host_threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   h->stage_dev = nullptr;
   h->stage_host = nullptr;
@@ -918,7 +952,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
   if (n > 0)
     hipLaunchKernelGGL(k_mark, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map,
-                       c.inverted_cached_idx, N, h->bitmap, h->ctl);
+                       c.inverted_cached_idx, N, h->word_bits, h->bitmap, h->ctl);
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n,
