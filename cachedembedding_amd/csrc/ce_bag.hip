@@ -38,6 +38,7 @@ struct BagParams {
   int32_t hookB;            // num_bags / hookF
   float alpha;              // bwd scale (1 or -lr)
   int32_t idx_bits;         // bits needed to tell two row indices apart (bwd duplicate matching)
+  int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -184,6 +185,49 @@ __device__ __forceinline__ void atomic_add_vec(f32x4* dst, f32x4 v) {
   __hip_atomic_fetch_add(d + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_fetch_add(d + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_fetch_add(d + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Row update of the tile-sorted scatter.  A lane holds 4 consecutive floats (16-B loads), but four
+// scalar atomics issued that way each touch EVERY 128-B line of the row (16-B lane stride), and the L2
+// atomic path is paid per line request.  A 4x4 butterfly transpose across the lane blocks of the group
+// (2 x 2 xor-shuffles) regroups the data so that atomic instruction c covers one contiguous block of G
+// floats: 4x fewer line requests per row (255 -> ~150 us/step measured).
+__device__ __forceinline__ void flush_chunk(float* row_base, f32x4 v, int gl, int G, int c, int rowlen, int debug) {
+  if (G >= 4 && debug == 0 && (c + 1) * G <= rowlen) {      // group-uniform: whole chunk present
+    const int q = G >> 2;                     // lanes per lane block
+    const int kb = gl / q;                    // my lane block 0..3
+    const int m = gl - kb * q;
+    const bool b1 = kb & 2, b0 = kb & 1;
+    float r0 = v.x, r1 = v.y, r2 = v.z, r3 = v.w;
+    float x = b1 ? r0 : r2, y = __shfl_xor(x, 2 * q);
+    if (b1) r0 = y; else r2 = y;
+    x = b1 ? r1 : r3; y = __shfl_xor(x, 2 * q);
+    if (b1) r1 = y; else r3 = y;
+    x = b0 ? r0 : r1; y = __shfl_xor(x, q);
+    if (b0) r0 = y; else r1 = y;
+    x = b0 ? r2 : r3; y = __shfl_xor(x, q);
+    if (b0) r2 = y; else r3 = y;
+    float* d = row_base + c * G * 4 + 4 * m + kb;       // register k -> element k*G + 4m + kb of the chunk
+    __hip_atomic_fetch_add(d, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(d + G, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(d + 2 * G, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(d + 3 * G, r3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int ch = gl + c * G;
+  if (ch >= rowlen) return;
+  f32x4* dst = (f32x4*)row_base + ch;
+  if (debug == 0 || debug == 5) atomic_add_vec(dst, v);
+  else if (debug == 1) *dst = *dst + v;                      // ablation: plain read-modify-write (racy)
+  else if (debug == 2) { if (v.x == 12345.678f) *dst = v; }  // ablation: no update traffic
+}
+__device__ __forceinline__ void flush_chunk(float* row_base, float v, int gl, int G, int c, int rowlen, int debug) {
+  const int ch = gl + c * G;
+  if (ch >= rowlen) return;
+  float* dst = row_base + ch;
+  if (debug == 0 || debug == 5) atomic_add_vec(dst, v);
+  else if (debug == 1) *dst = *dst + v;
+  else if (debug == 2) { if (v == 12345.678f) *dst = v; }
 }
 
 // OP 0: dst[indices[j]] += alpha*scale*psw[j]*grad_out[bag(j)]  (fp32 atomics)
@@ -348,11 +392,9 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
 // Tile-sorted scatter (K13/K14 main path).  fp32 atomics aimed at one row serialise, and Criteo-
 // shaped batches hammer a few rows (tables of 3..100 rows get B lookups each; power-law heads).
 // So a workgroup takes 1024 consecutive lookups, sorts (row, lookup) keys in LDS (bitonic, 8 KB),
-// and reduces every run of equal rows BEFORE touching HBM: short runs are summed by one lane group
-// in lookup order, long runs by all groups with an LDS combine, and each (row, tile) pair costs ONE
-// atomic row update.  Gradient rows are read exactly once, coalesced per lane group.
+// and folds runs of equal rows BEFORE touching HBM.  Gradient rows are read exactly once, coalesced
+// per lane group, 8 in flight per lane.
 constexpr int kBwdTile = 1024;
-constexpr int kLongRun = 32;
 
 __device__ __forceinline__ int find_bag(const BagParams& p, int j) {
   // bag whose [offsets[b], end(b)) holds lookup j; single-id layouts (offsets == arange) hit the first test
@@ -370,22 +412,15 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   __shared__ unsigned long long keys[kBwdTile];
   __shared__ int bagl[kBwdTile];
   __shared__ float scl[kBwdTile];
-  __shared__ short heads[kBwdTile + 1];
-  __shared__ short longs[kBwdTile / kLongRun + 1];
-  __shared__ int wsum[4];
-  __shared__ int n_long;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // ngroups x row partials
-  VT* part = (VT*)dyn_lds;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int G = 1 << p.g_log2;
   const int ngroups = 256 >> p.g_log2;
   const int grp = tid >> p.g_log2;
   const int gl = tid & (G - 1);
   const int rowlen = p.rowlen;
+  const int dim = rowlen * (int)(sizeof(VT) / 4);
   const VT* __restrict__ GO = (const VT*)p.grad_out;
-  VT* __restrict__ DST = (VT*)p.dst;
   const int ntiles = (int)((p.nnz + kBwdTile - 1) / kBwdTile);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -409,8 +444,8 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       }
       keys[i] = key;
     }
-    if (tid == 0) n_long = 0;
     __syncthreads();
+    if (p.debug == 3) continue;
     // ---- b. bitonic sort (row major, lookup minor) -> runs are in lookup order
     for (int k = 2; k <= kBwdTile; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
@@ -429,50 +464,28 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         __syncthreads();
       }
     }
-    // ---- c. run heads (ordered compaction), long-run list
-    int hf[4], cnt = 0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = tid * 4 + t;
-      hf[t] = (i < nv) && (i == 0 || (unsigned)(keys[i] >> 32) != (unsigned)(keys[i - 1] >> 32));
-      cnt += hf[t];
-    }
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(inc, d);
-      if (lane >= d) inc += t;
-    }
-    if (lane == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    int pos = inc - cnt, nruns = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < (tid >> 6)) pos += wsum[w];
-      nruns += wsum[w];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (hf[t]) heads[pos++] = (short)(tid * 4 + t);
-    if (tid == 0) heads[nruns] = (short)nv;
-    __syncthreads();
-    for (int r = tid; r < nruns; r += 256)
-      if (heads[r + 1] - heads[r] > kLongRun) longs[atomicAdd(&n_long, 1)] = (short)r;
-    __syncthreads();
-    // ---- d. short runs: one lane group per run
-    for (int r = grp; r < nruns; r += ngroups) {
-      const int s0 = heads[r], s1 = heads[r + 1];
-      if (s1 - s0 > kLongRun) continue;
+    // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, 8 gradient rows in flight,
+    // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated R
+    // times in the tile costs R/kChunk+1 atomics instead of R.
+    constexpr int kChunk = 32;
+    if (p.debug == 4) continue;
+    const int nchunks = (nv + kChunk - 1) / kChunk;
+    for (int ck = grp; ck < nchunks; ck += ngroups) {
+      const int s0 = ck * kChunk, s1 = min(nv, s0 + kChunk);
       VT acc[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
-      for (int q = s0; q < s1; q += 4) {
-        VT v[4][NCH];
-        float sc[4];
+      unsigned cur = (unsigned)(keys[s0] >> 32);
+      for (int q = s0; q < s1; q += 8) {
+        VT v[8][NCH];
+        float sc[8];
+        unsigned rw[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 8; ++t) {
           const bool on = q + t < s1;
-          const int li = on ? (int)(unsigned)keys[q + t] : 0;
+          const unsigned long long key = on ? keys[q + t] : 0ull;
+          const int li = (int)(unsigned)key;
+          rw[t] = on ? (unsigned)(key >> 32) : 0xffffffffu;
           sc[t] = on ? scl[li] : 0.f;
           const int64_t orow = out_row(p, bagl[li]);
 #pragma unroll
@@ -483,66 +496,25 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
           }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 8; ++t) {
+          if (rw[t] != 0xffffffffu) {          // group-uniform
+            if (rw[t] != cur) {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * sc[t];
-      }
-      const int64_t row = (int64_t)(unsigned)(keys[s0] >> 32);
+              for (int c = 0; c < NCH; ++c) {
+                flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+                acc[c] = vzero<VT>();
+              }
+              cur = rw[t];
+            }
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int ch = gl + c * G;
-        if (ch < rowlen) atomic_add_vec(&DST[row * rowlen + ch], acc[c]);
-      }
-    }
-    // ---- e. long runs: every group takes an interleaved share, partials combined through LDS
-    const int nl = n_long;
-    for (int x = 0; x < nl; ++x) {
-      const int r = longs[x];
-      const int s0 = heads[r], s1 = heads[r + 1];
-      VT acc[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
-      for (int q = s0 + grp; q < s1; q += 4 * ngroups) {
-        VT v[4][NCH];
-        float sc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int qq = q + t * ngroups;
-          const bool on = qq < s1;
-          const int li = on ? (int)(unsigned)keys[qq] : 0;
-          sc[t] = on ? scl[li] : 0.f;
-          const int64_t orow = out_row(p, bagl[li]);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int ch = gl + c * G;
-            v[t][c] = vzero<VT>();
-            if (on && ch < rowlen) v[t][c] = GO[orow * rowlen + ch];
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * sc[t];
-      }
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int ch = gl + c * G;
-        if (ch < rowlen) part[(grp * NCH + c) * G + gl] = acc[c];
-      }
-      __syncthreads();
-      if (grp == 0) {
-        const int64_t row = (int64_t)(unsigned)(keys[s0] >> 32);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int ch = gl + c * G;
-          if (ch < rowlen) {
-            VT sum = part[c * G + gl];
-            for (int g2 = 1; g2 < ngroups; ++g2) sum = sum + part[(g2 * NCH + c) * G + gl];
-            atomic_add_vec(&DST[row * rowlen + ch], sum);
+            for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * sc[t];
           }
         }
       }
-      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+      }
     }
     __syncthreads();
   }
@@ -603,11 +575,23 @@ static bool use_wave_bwd() {
 template <int OP>
 static int launch_bwd(const BagParams& p, bool vec, int nch, hipStream_t s) {
   if (OP == 0 && !use_wave_bwd()) {
+    const char* dbg = getenv("CE_BWD_DEBUG");
+    BagParams q = p;
+    q.debug = dbg ? atoi(dbg) : 0;
+    const char* sv = getenv("CE_BWD_SCALAR");
+    if (sv && atoi(sv) && vec) {       // experiment: dword-strided lanes (contiguous 256 B per atomic instr)
+      vec = false;
+      q.rowlen = p.rowlen * 4;
+      int g = 1, gl2 = 0;
+      while (g < q.rowlen && g < 64) { g <<= 1; ++gl2; }
+      q.g_log2 = gl2;
+      nch = 1;
+      while (nch * g < q.rowlen) nch <<= 1;
+      if (nch > 4) return CE_ERR_UNSUPPORTED;
+    }
     const int ntiles = (int)cdiv(p.nnz, kBwdTile);
     dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
-    const int G = 1 << p.g_log2;
-    const size_t lds = (size_t)(256 / G) * nch * G * (vec ? 16 : 4);
-#define CE_BWT(VT, N) hipLaunchKernelGGL((k_bag_bwd_tile<VT, N>), grid, block, lds, s, p)
+#define CE_BWT(VT, N) hipLaunchKernelGGL((k_bag_bwd_tile<VT, N>), grid, block, 0, s, q)
     if (vec) {
       if (nch == 1) CE_BWT(f32x4, 1); else if (nch == 2) CE_BWT(f32x4, 2); else CE_BWT(f32x4, 4);
     } else {

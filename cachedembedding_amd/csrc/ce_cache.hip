@@ -137,7 +137,13 @@ __global__ void k_begin(Ctl* ctl) {
 __global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, int64_t n,
                                               const int32_t* __restrict__ idx_map,
                                               const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                              uint32_t* bitmap, Ctl* ctl) {
+                                              int hot_words, uint32_t* bitmap, Ctl* ctl) {
+  // Under DATASET ordering the frequency re-rank packs the hot rows of ALL tables into the lowest
+  // row indices, i.e. into a handful of bitmap words every wave wants.  Those words are staged in an
+  // LDS window per workgroup and flushed once, so a hot word sees one global atomic per workgroup.
+  extern __shared__ uint32_t hot[];
+  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int cold = 0;
@@ -159,8 +165,9 @@ __global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, i
     const int bidx = row & 31;
     bool need = false;
     if (valid) {
-      need = ((*(volatile uint32_t*)(bitmap + word)) & (1u << bidx)) == 0;
       cold += (inverted[row] < 0);
+      if (word < hot_words) atomicOr(&hot[word], 1u << bidx);
+      else need = ((*(volatile uint32_t*)(bitmap + word)) & (1u << bidx)) == 0;
     }
     if (__any(need)) {
       unsigned long long pm = __ballot(need);
@@ -180,6 +187,11 @@ __global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, i
   }
   cold = wave_sum(cold);
   if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
+  __syncthreads();
+  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) {
+    const uint32_t v = hot[w];
+    if (v && ((*(volatile uint32_t*)(bitmap + w)) & v) != v) atomicOr(bitmap + w, v);
+  }
 }
 
 // one uint4 (128 rows) per thread
@@ -950,9 +962,12 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   const int cap_groups = (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb)));
 
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
-  if (n > 0)
-    hipLaunchKernelGGL(k_mark, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map,
-                       c.inverted_cached_idx, N, h->word_bits, h->bitmap, h->ctl);
+  {
+    const int hot_words = (int)std::min<int64_t>(L.bitmap_words, 8192);
+    if (n > 0)
+      hipLaunchKernelGGL(k_mark, dim3(std::min(grid_for(n, 1024), 1024)), dim3(256), hot_words * 4, s, ids, n,
+                         c.idx_map, c.inverted_cached_idx, N, h->word_bits, hot_words, h->bitmap, h->ctl);
+  }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n,
