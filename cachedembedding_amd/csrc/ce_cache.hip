@@ -545,18 +545,35 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, int64_t n,
                                                const int32_t* __restrict__ idx_map,
                                                const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out,
-                                               int64_t* freq, const Ctl* ctl) {
+                                               int64_t* freq, int slot_bits, const Ctl* ctl) {
   if (ctl && ctl->status != CE_OK) return;
+  const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t id = ids[i];
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
+    const int64_t i = i0 + lane;
     int64_t slot = -1;
-    if ((unsigned long long)id < (unsigned long long)N) {
-      const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
-      slot = inverted[row];
+    if (i < n) {
+      const int64_t id = ids[i];
+      if ((unsigned long long)id < (unsigned long long)N) {
+        const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
+        slot = inverted[row];
+      }
+      slots_out[i] = slot;
     }
-    slots_out[i] = slot;
-    if (freq && slot >= 0) atomicAdd((unsigned long long*)&freq[slot], 1ull);   // [A.3-7]
+    if (freq) {
+      // LFU [A.3-7]: counter += multiplicity.  A hot slot collects >100k lookups per window, so equal
+      // slots of a wave are merged first (ballot match) and the lowest lane adds the whole count.
+      const bool on = slot >= 0;
+      const int sl = (int)slot;
+      unsigned long long pm = __ballot(on);
+      if (!on) pm = 0;
+      for (int b = 0; b < slot_bits; ++b) {
+        const unsigned long long m = __ballot((sl >> b) & 1);
+        pm &= ((sl >> b) & 1) ? m : ~m;
+      }
+      if (on && (__ffsll((long long)pm) - 1) == lane)
+        atomicAdd((unsigned long long*)&freq[slot], (unsigned long long)__popcll(pm));
+    }
   }
 }
 
@@ -1044,7 +1061,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                      c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl);
   if (n > 0)
     hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map, c.inverted_cached_idx,
-                       N, slots_out, lfu ? c.freq_cnter : (int64_t*)nullptr, (const Ctl*)h->ctl);
+                       N, slots_out, lfu ? c.freq_cnter : (int64_t*)nullptr, h->slot_bits, (const Ctl*)h->ctl);
   CE_LAUNCH_CHECK();
   CE_HIP_CHECK(hipEventRecord(h->ev, s));
   return CE_OK;
@@ -1100,7 +1117,8 @@ extern "C" int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t 
   CE_REQUIRE(ids && slots_out && n > 0, CE_ERR_INVALID, "null ids/slots");
   const ce_cache_config_t& c = h->cfg;
   hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, c.idx_map,
-                     c.inverted_cached_idx, c.num_embeddings, slots_out, (int64_t*)nullptr, (const Ctl*)nullptr);
+                     c.inverted_cached_idx, c.num_embeddings, slots_out, (int64_t*)nullptr, h->slot_bits,
+                     (const Ctl*)nullptr);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }
