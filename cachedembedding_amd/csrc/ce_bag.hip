@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
         if (p.mode == CE_MODE_MEAN && bhi[u] - blo[u] > 1) scale = scale / (float)(bhi[u] - blo[u]);
         for (int j = blo[u]; j < bhi[u]; ++j) {
           const float s = p.psw ? scale * p.psw[j] : scale;
-          const int64_t r = (OP == 0) ? p.indices[j] : (int64_t)j;
+          const int64_t r = (OP == 0 || p.indices) ? p.indices[j] : (int64_t)j;
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const int ch = gl + c * G;
@@ -686,16 +686,16 @@ extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
 
-extern "C" int ce_bag_backward_rows(float* grad_rows, int32_t dim, int64_t nnz, const void* offsets,
-                                    int32_t offsets_are_i64, int64_t num_bags, int32_t include_last_offset,
-                                    const float* per_sample_weights, int32_t mode, int64_t hook_features,
-                                    const float* grad_out, ce_stream_t stream) {
+extern "C" int ce_bag_backward_rows(float* grad_rows, const int64_t* dest_index, int32_t dim, int64_t nnz,
+                                    const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                                    int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                                    int64_t hook_features, const float* grad_out, ce_stream_t stream) {
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(grad_rows && grad_out && offsets, CE_ERR_INVALID, "null pointer");
   BagParams p{};
   bool vec;
   int nch;
-  int rc = fill_params(p, dim, nullptr, nnz, offsets, offsets_are_i64, num_bags, include_last_offset,
+  int rc = fill_params(p, dim, dest_index, nnz, offsets, offsets_are_i64, num_bags, include_last_offset,
                        per_sample_weights, mode, hook_features, &vec, &nch, grad_rows, grad_out, nullptr);
   if (rc) return rc;
   p.dst = grad_rows;

@@ -91,7 +91,7 @@ class _BagFn(torch.autograd.Function):
                                                   ptr(grad_out), float(fused.lr), stream_ptr()))
         elif sparse:
             rows = torch.empty(nnz, dim, device=weight.device, dtype=torch.float32)
-            check(lib.ce_bag_backward_rows(ptr(rows), dim, nnz, ptr(offsets), off64, num_bags, int(include_last),
+            check(lib.ce_bag_backward_rows(ptr(rows), None, dim, nnz, ptr(offsets), off64, num_bags, int(include_last),
                                            ptr(psw), mode, hook_features, ptr(grad_out), stream_ptr()))
             gw = torch.sparse_coo_tensor(indices.view(1, -1), rows, weight.shape, check_invariants=False)
         else:

@@ -1,0 +1,450 @@
+"""Multi-GPU forms of the cached EmbeddingBag (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+* ROW-WISE sharding (BASELINE.json north_star) -- the build's own design.  After the
+  frequency re-rank, row r is owned by rank r % W as local row r // W (interleaving keeps every
+  shard's hot set equal).  Per window: lookups are bucketed by owner on the device
+  (ce_bucketize_rows), counts then ids travel in one all-to-all-v each; per step the owner gathers
+  the requested cache rows, one all-to-all-v returns them, the requester pools them per bag; the
+  backward sends per-lookup gradient rows the reverse way and the owner applies the fused SGD update.
+  This replaces the reference's KJT all-gather (recsys/datasets/utils.py:20-54) + column-wise
+  dual_all_to_all: every GPU touches only B_loc*F lookups instead of the global batch, and the
+  all-to-all uses all 7 xGMI links of a GPU concurrently.
+
+* COLUMN-WISE sharding -- the contract of the reference's ParallelCachedEmbeddingBag
+  (recsys/models/dlrm.py:70-81): every rank holds all rows x D/W columns, looks up the
+  GLOBAL batch, and dual_all_to_all turns [B_glob, F, D/W] into [B_glob/W, F, D].
+
+The communication/layout logic (RowwiseExchange) is device-agnostic and takes the local
+compute as a `ShardOps` object; the product wires in HipShardOps (C ABI, no fallback).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .cache_mgr import CachedParamMgr, EvictionStrategy, HostTable
+from .cached_embedding import CachedEmbeddingBag
+from .functional import _MODES
+
+
+def get_partition(embedding_dim: int, rank: int, world_size: int) -> Tuple[int, int, bool]:
+    """Column split rule of the reference (recsys/utils/misc.py:138-154 == torch.tensor_split)."""
+    if world_size == 1:
+        return 0, embedding_dim, True
+    assert embedding_dim >= world_size, \
+        f"Embedding dimension {embedding_dim} must be larger than the world size {world_size} of the process group"
+    chunk, rem = divmod(embedding_dim, world_size)
+    if rem == 0:
+        return rank * chunk, (rank + 1) * chunk, True
+    sizes = [chunk + 1 if i < rem else chunk for i in range(world_size)]
+    off = sum(sizes[:rank])
+    return off, off + sizes[rank], False
+
+
+# ----------------------------------------------------------------------------------------------
+# dual_all_to_all: forward scatters dim `scatter_dim`, gathers `gather_dim`;
+# backward is the same exchange with the dims swapped.
+
+
+def _all_to_all_dims(x: torch.Tensor, group, scatter_dim: int, gather_dim: int) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    if world == 1:
+        return x
+    ins = [t.contiguous() for t in torch.tensor_split(x, world, dim=scatter_dim)]
+    rank = dist.get_rank(group)
+    # peer p sends me its slice `rank` of ITS tensor: same scatter-dim extent as my own slice `rank`,
+    # and ITS gather-dim extent
+    g_sizes = _gather_sizes(x.shape[gather_dim], group, x.device)
+    shapes = []
+    for p in range(world):
+        shp = list(ins[rank].shape)
+        shp[gather_dim] = g_sizes[p]
+        shapes.append(shp)
+    out_splits = [int(torch.Size(s).numel()) for s in shapes]
+    flat_in = torch.cat([t.reshape(-1) for t in ins])
+    flat_out = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
+    # one all-to-all-v on flat buffers (also what gloo supports in the CPU tests)
+    dist.all_to_all_single(flat_out, flat_in, out_splits, [t.numel() for t in ins], group=group)
+    outs = [c.view(s) for c, s in zip(torch.split(flat_out, out_splits), shapes)]
+    return torch.cat(outs, dim=gather_dim)
+
+
+_GATHER_SIZE_CACHE = {}
+
+
+def _gather_sizes(mine: int, group, device) -> List[int]:
+    world = dist.get_world_size(group)
+    key = (id(group), mine, world)
+    if key not in _GATHER_SIZE_CACHE:
+        t = torch.tensor([mine], dtype=torch.int64, device=device)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        _GATHER_SIZE_CACHE[key] = [int(o.item()) for o in out]
+    return _GATHER_SIZE_CACHE[key]
+
+
+class _DualAllToAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group, scatter_dim, gather_dim):
+        ctx.group, ctx.sd, ctx.gd = group, scatter_dim, gather_dim
+        return _all_to_all_dims(x, group, scatter_dim, gather_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _all_to_all_dims(g.contiguous(), ctx.group, ctx.gd, ctx.sd), None, None, None
+
+
+def dual_all_to_all(x: torch.Tensor, group=None, scatter_dim: int = 0, gather_dim: int = -1) -> torch.Tensor:
+    group = group if group is not None else dist.group.WORLD
+    sd = scatter_dim % x.dim()
+    gd = gather_dim % x.dim()
+    return _DualAllToAll.apply(x, group, sd, gd)
+
+
+# ----------------------------------------------------------------------------------------------
+# KJT collective of the reference (recsys/datasets/utils.py:8-54): an all-gather of (lengths, values)
+# whose output is ordered [key][rank][sample].  Done with all_gather (no cloned send lists) and ONE
+# host sync for the per-rank value counts.
+
+
+class KJTAllToAll:
+    def __init__(self, group=None):
+        self.group = group if group is not None else dist.group.WORLD
+        self.rank = dist.get_rank(self.group)
+        self.world_size = dist.get_world_size(self.group)
+
+    @torch.no_grad()
+    def all_to_all(self, values: torch.Tensor, lengths: torch.Tensor, num_keys: int):
+        """values int64[sum(lengths)] and lengths int32[num_keys * B_loc] of the local KJT (key-major)
+        -> (all_values, all_lengths) of the global batch, key-major with samples ordered [rank][sample]."""
+        W = self.world_size
+        if W == 1:
+            return values, lengths
+        b_loc = lengths.numel() // num_keys
+        all_len = [torch.empty_like(lengths) for _ in range(W)]
+        dist.all_gather(all_len, lengths, group=self.group)
+        per_key = torch.stack([l.view(num_keys, b_loc).sum(dim=1) for l in all_len])      # [W, K]
+        per_key_host = per_key.cpu()
+        totals = per_key_host.sum(dim=1).tolist()
+        n_max = max(totals)
+        pad = torch.zeros(n_max, dtype=values.dtype, device=values.device)
+        pad[:values.numel()] = values
+        all_val = [torch.empty_like(pad) for _ in range(W)]
+        dist.all_gather(all_val, pad, group=self.group)
+        pieces = []
+        starts = torch.cumsum(per_key_host, dim=1) - per_key_host
+        for k in range(num_keys):
+            for r in range(W):
+                s, n = int(starts[r, k]), int(per_key_host[r, k])
+                pieces.append(all_val[r][s:s + n])
+        all_values = torch.cat(pieces)
+        all_lengths = torch.cat([l.view(num_keys, b_loc) for l in all_len], dim=1).reshape(-1)
+        return all_values, all_lengths
+
+
+# ----------------------------------------------------------------------------------------------
+# row-wise sharding
+
+
+class ShardOps:
+    """Local compute of one shard.  HipShardOps is the product implementation."""
+
+    world: int
+    rank: int
+    dim: int
+
+    def bucketize(self, ids: torch.Tensor):                   # -> local_rows[n] (bucket order), perm[n], counts[W]
+        raise NotImplementedError
+
+    def owner_prepare(self, local_rows: torch.Tensor):       # -> slots[n_recv]
+        raise NotImplementedError
+
+    def owner_gather(self, slots: torch.Tensor):             # -> rows fp32[n_recv, D]
+        raise NotImplementedError
+
+    def pool(self, rows, perm, offsets, psw, mode, include_last, hook_features):   # -> pooled
+        raise NotImplementedError
+
+    def grad_rows(self, grad_out, perm, offsets, psw, mode, include_last, hook_features, n):  # -> fp32[n, D]
+        raise NotImplementedError
+
+    def owner_update(self, slots, grad_rows, lr):            # cache rows -= lr * grad (duplicates summed)
+        raise NotImplementedError
+
+
+class HipShardOps(ShardOps):
+    """ShardOps over libce_hip.so: ce_bucketize_rows, the local CachedParamMgr, ce_bag_* kernels."""
+
+    def __init__(self, mgr: CachedParamMgr, idx_map: Optional[torch.Tensor], world: int, rank: int):
+        _lib.require_gpu()
+        self.mgr = mgr
+        self.idx_map = idx_map            # GLOBAL id -> global rank row (replicated), None = identity
+        self.world, self.rank = world, rank
+        self.dim = mgr.embedding_dim
+        self._ws = None
+
+    def bucketize(self, ids):
+        ids = ids.reshape(-1).long().contiguous()
+        n = ids.numel()
+        dev = ids.device
+        rows = torch.empty(n, dtype=torch.int64, device=dev)
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        counts = torch.empty(self.world, dtype=torch.int64, device=dev)
+        need = lib.ce_bucketize_workspace(n, self.world)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+        check(lib.ce_bucketize_rows(ptr(ids), n, ptr(self.idx_map), self.world, ptr(rows), ptr(perm), ptr(counts),
+                                    ptr(self._ws), self._ws.numel(), stream_ptr()))
+        return rows, perm, counts
+
+    def owner_prepare(self, local_rows):
+        return self.mgr.prepare_ids(local_rows)
+
+    def owner_gather(self, slots):
+        n = slots.numel()
+        w = self.mgr.cuda_cached_weight
+        out = torch.empty(n, self.dim, dtype=torch.float32, device=w.device)
+        if n:
+            off = _arange_offsets(n, w.device)
+            check(lib.ce_bag_forward(ptr(w), w.shape[0], self.dim, ptr(slots), n, ptr(off), 0, n, 1, None,
+                                     _lib.CE_MODE_SUM, 0, ptr(out), stream_ptr()))
+        return out
+
+    def pool(self, rows, perm, offsets, psw, mode, include_last, hook_features):
+        num_bags = offsets.numel() - 1 if include_last else offsets.numel()
+        if hook_features:
+            out = torch.empty(num_bags // hook_features, hook_features, self.dim, dtype=torch.float32,
+                              device=rows.device)
+        else:
+            out = torch.empty(num_bags, self.dim, dtype=torch.float32, device=rows.device)
+        check(lib.ce_bag_forward(ptr(rows), rows.shape[0], self.dim, ptr(perm), perm.numel(), ptr(offsets),
+                                 int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
+                                 _MODES[mode], hook_features, ptr(out), stream_ptr()))
+        return out
+
+    def grad_rows(self, grad_out, perm, offsets, psw, mode, include_last, hook_features, n):
+        num_bags = offsets.numel() - 1 if include_last else offsets.numel()
+        g = torch.empty(n, self.dim, dtype=torch.float32, device=grad_out.device)
+        check(lib.ce_bag_backward_rows(ptr(g), ptr(perm), self.dim, n, ptr(offsets),
+                                       int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
+                                       _MODES[mode], hook_features, ptr(grad_out.contiguous()), stream_ptr()))
+        return g
+
+    def owner_update(self, slots, grad_rows, lr):
+        n = slots.numel()
+        if n == 0:
+            return
+        w = self.mgr.cuda_cached_weight
+        off = _arange_offsets(n, w.device)
+        check(lib.ce_bag_backward_sgd(ptr(w), w.shape[0], self.dim, ptr(slots), n, ptr(off), 0, n, 1, None,
+                                      _lib.CE_MODE_SUM, 0, ptr(grad_rows), float(lr), stream_ptr()))
+
+
+_ARANGE = {}
+
+
+def _arange_offsets(n: int, device) -> torch.Tensor:
+    key = str(device)
+    t = _ARANGE.get(key)
+    if t is None or t.numel() < n + 1:
+        t = torch.arange(0, max(n + 1, 1 << 20), dtype=torch.int32, device=device)
+        _ARANGE[key] = t
+    return t[:n + 1]
+
+
+@dataclass
+class BatchPlan:
+    n: int
+    perm: torch.Tensor
+    send_splits: List[int]      # lookups I send to each peer (== rows each peer returns to me)
+    recv_splits: List[int]      # lookups each peer sends me (rows I own)
+    recv_rows: torch.Tensor     # local row ids I serve, peer-major
+    slots: Optional[torch.Tensor] = None
+
+
+class RowwiseExchange:
+    """Exchange logic of the row-wise sharded lookup (device-agnostic; collectives via torch.distributed)."""
+
+    def __init__(self, ops: ShardOps, group=None):
+        self.ops = ops
+        self.group = group if group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        assert ops.world == self.world and ops.rank == self.rank
+
+    @torch.no_grad()
+    def plan_window(self, ids_list: Sequence[torch.Tensor]) -> List[BatchPlan]:
+        """Bucket every batch of the window by owner, exchange counts (one host sync per WINDOW) and
+        ids, then run ONE owner-side cache op over all rows this rank serves in the window."""
+        W, P = self.world, len(ids_list)
+        buck = [self.ops.bucketize(ids) for ids in ids_list]
+        send = torch.stack([b[2] for b in buck], dim=1).contiguous()          # [W, P]
+        recv = torch.empty_like(send)
+        if W > 1:
+            dist.all_to_all_single(recv, send, group=self.group)
+        else:
+            recv.copy_(send)
+        send_h, recv_h = send.cpu(), recv.cpu()
+        plans: List[BatchPlan] = []
+        for b in range(P):
+            rows, perm, _ = buck[b]
+            ss = [int(v) for v in send_h[:, b]]
+            rs = [int(v) for v in recv_h[:, b]]
+            got = torch.empty(sum(rs), dtype=rows.dtype, device=rows.device)
+            if W > 1:
+                dist.all_to_all_single(got, rows, rs, ss, group=self.group)
+            else:
+                got.copy_(rows)
+            plans.append(BatchPlan(rows.numel(), perm, ss, rs, got))
+        all_rows = plans[0].recv_rows if P == 1 else torch.cat([p.recv_rows for p in plans])
+        slots = self.ops.owner_prepare(all_rows)
+        for p, s in zip(plans, torch.split(slots, [p.recv_rows.numel() for p in plans])):
+            p.slots = s
+        return plans
+
+    def fetch_rows(self, plan: BatchPlan) -> torch.Tensor:
+        """owner gathers -> all-to-all-v -> fp32[n, D] in my bucket order."""
+        mine = self.ops.owner_gather(plan.slots)
+        if self.world == 1:
+            return mine
+        got = torch.empty(plan.n, self.ops.dim, dtype=mine.dtype, device=mine.device)
+        dist.all_to_all_single(got, mine, plan.send_splits, plan.recv_splits, group=self.group)
+        return got
+
+    def return_grads(self, plan: BatchPlan, grad_rows: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return grad_rows
+        got = torch.empty(plan.recv_rows.numel(), self.ops.dim, dtype=grad_rows.dtype, device=grad_rows.device)
+        dist.all_to_all_single(got, grad_rows.contiguous(), plan.recv_splits, plan.send_splits, group=self.group)
+        return got
+
+
+class _RowwiseFn(torch.autograd.Function):
+    """pooled = pool(fetch_rows(plan)); backward ships per-lookup grads to the owners, which apply SGD."""
+
+    @staticmethod
+    def forward(ctx, anchor, ex: RowwiseExchange, plan: BatchPlan, offsets, psw, mode, include_last, hook, lr_box):
+        rows = ex.fetch_rows(plan)
+        out = ex.ops.pool(rows, plan.perm, offsets, psw, mode, include_last, hook)
+        ctx.ex, ctx.plan, ctx.lr_box = ex, plan, lr_box
+        ctx.args = (offsets, psw, mode, include_last, hook)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ex, plan = ctx.ex, ctx.plan
+        offsets, psw, mode, include_last, hook = ctx.args
+        with torch.no_grad():
+            g = ex.ops.grad_rows(grad_out, plan.perm, offsets, psw, mode, include_last, hook, plan.n)
+            g_own = ex.return_grads(plan, g)
+            lr = ctx.lr_box[0]
+            if lr is None:
+                raise RuntimeError("row-wise sharded embedding needs set_fused_sgd(lr): the update is applied "
+                                   "by the owner inside backward")
+            ex.ops.owner_update(plan.slots, g_own, lr)
+        return (None,) * 9
+
+
+class RowwiseShardedEmbeddingBag(nn.Module):
+    """Row-wise sharded cached EmbeddingBag: local batch in ([values, offsets] of B_loc samples),
+    pooled [B_loc*F, D] (or [B_loc, F, D] with hook_features) out."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, mode: str = "sum", include_last_offset: bool = True,
+                 cache_ratio: float = 0.01, ids_freq_mapping=None, warmup_ratio: float = 0.7,
+                 evict_strategy: EvictionStrategy = EvictionStrategy.DATASET, group=None,
+                 _weight_shard: Optional[torch.Tensor] = None, init_seed: int = 1024,
+                 cuda_row_num: Optional[int] = None):
+        super().__init__()
+        _lib.require_gpu()
+        self.group = group if group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.mode, self.include_last_offset = mode, include_last_offset
+        dev = torch.device("cuda", torch.cuda.current_device())
+        W, r = self.world, self.rank
+        n_local = (num_embeddings - r + W - 1) // W
+        c_total = int(num_embeddings * cache_ratio) if cuda_row_num is None else int(cuda_row_num)
+        c_local = max(1, min(n_local, c_total // W))
+        # global id -> frequency rank (replicated); the owner split is taken on the RANK so every shard
+        # gets an equal share of the hot rows
+        self.idx_map = None
+        if ids_freq_mapping is not None and evict_strategy == EvictionStrategy.DATASET:
+            freq = torch.as_tensor(ids_freq_mapping).to(device=dev, dtype=torch.int64).view(-1)
+            order = torch.argsort(freq, descending=True, stable=True)
+            inv = torch.empty(num_embeddings, device=dev, dtype=torch.int32)
+            inv[order] = torch.arange(num_embeddings, device=dev, dtype=torch.int32)
+            self.idx_map = inv
+            del freq, order
+        if _weight_shard is None:
+            table = HostTable.allocate(n_local, embedding_dim)
+            table.fill_uniform_(-1.0 / num_embeddings, 1.0 / num_embeddings, init_seed + 7919 * r)
+        else:
+            assert tuple(_weight_shard.shape) == (n_local, embedding_dim)
+            table = HostTable.wrap(_weight_shard.detach().to("cpu", torch.float32).contiguous())
+        self.cache_weight_mgr = CachedParamMgr(table, c_local, evict_strategy=evict_strategy, device=dev)
+        local_freq = None
+        if ids_freq_mapping is not None and evict_strategy == EvictionStrategy.LFU:
+            local_freq = torch.as_tensor(ids_freq_mapping).view(-1)[r::W]
+        self.cache_weight_mgr.reorder(local_freq, warmup_ratio)
+        self.ops = HipShardOps(self.cache_weight_mgr, self.idx_map, W, r)
+        self.exchange = RowwiseExchange(self.ops, self.group)
+        self._lr = [None]
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+
+    @property
+    def weight(self):
+        return self.cache_weight_mgr.weight
+
+    def set_fused_sgd(self, lr: Optional[float]):
+        self._lr[0] = lr
+
+    def plan_window(self, ids_list: Sequence[torch.Tensor]) -> List[BatchPlan]:
+        return self.exchange.plan_window(ids_list)
+
+    def forward(self, input, offsets: Optional[torch.Tensor] = None, per_sample_weights=None,
+                shape_hook: Optional[Callable] = None, *, hook_features: int = 0):
+        """`input` is either a BatchPlan from plan_window (prefetch mode) or the local id tensor."""
+        plan = input if isinstance(input, BatchPlan) else self.exchange.plan_window([input])[0]
+        out = _RowwiseFn.apply(self._anchor, self.exchange, plan, offsets, per_sample_weights, self.mode,
+                               self.include_last_offset, int(hook_features), self._lr)
+        return shape_hook(out) if shape_hook is not None else out
+
+    def flush(self):
+        self.cache_weight_mgr.flush()
+
+
+class ParallelCachedEmbeddingBag(CachedEmbeddingBag):
+    """Column-wise parallel cached EmbeddingBag -- the class recsys/models/dlrm.py:70-81 builds.
+    Every rank holds num_embeddings x (embedding_dim / W) and receives the GLOBAL batch; forward returns
+    shape_hook(local pooled) exchanged with dual_all_to_all(scatter batch, gather dim)."""
+
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, max_norm=None, norm_type=2.0,
+                 scale_grad_by_freq=False, sparse=False, _weight=None, mode="mean", include_last_offset=False,
+                 dtype=None, device=None, cache_ratio=0.01, ids_freq_mapping=None, warmup_ratio=0.7, buffer_size=0,
+                 pin_weight=False, evict_strategy: EvictionStrategy = EvictionStrategy.DATASET, group=None, **kw):
+        self.group = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+        self.rank = dist.get_rank(self.group) if self.group is not None else 0
+        self.world_size = dist.get_world_size(self.group) if self.group is not None else 1
+        self.full_embedding_dim = embedding_dim
+        lo, hi, _ = get_partition(embedding_dim, self.rank, self.world_size)
+        self.partition_start_index, self.partition_end_index = lo, hi
+        if _weight is not None:
+            _weight = _weight[:, lo:hi].contiguous()
+        super().__init__(num_embeddings, hi - lo, padding_idx, max_norm, norm_type, scale_grad_by_freq, sparse,
+                         _weight, mode, include_last_offset, dtype, device, cache_ratio, ids_freq_mapping,
+                         warmup_ratio, buffer_size, pin_weight, evict_strategy, **kw)
+
+    def forward(self, indices, offsets=None, per_sample_weights=None, shape_hook=None, scatter_dim=0, gather_dim=-1,
+                *, hook_features: int = 0):
+        out = super().forward(indices, offsets, per_sample_weights, shape_hook, hook_features=hook_features)
+        if self.world_size == 1:
+            return out
+        return dual_all_to_all(out, self.group, scatter_dim=scatter_dim, gather_dim=gather_dim)

@@ -98,8 +98,10 @@ int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32_t dim,
 
 /* K13 (sparse form): values of the COO gradient that `sparse=True` produces
  * (scripts/kaggle.sh:71 --use_sparse_embed_grad): grad_rows[j] = psw[j]*scale*grad_out[bag(j)],
- * one row per lookup, paired with `indices` as the COO indices. */
-int ce_bag_backward_rows(float* grad_rows, int32_t dim, int64_t nnz,
+ * one row per lookup, paired with `indices` as the COO indices.  dest_index (device int64[nnz],
+ * NULL = identity) redirects row j to grad_rows[dest_index[j]] -- the row-wise sharded backward
+ * uses it to emit the rows already in owner-bucket order. */
+int ce_bag_backward_rows(float* grad_rows, const int64_t* dest_index, int32_t dim, int64_t nnz,
                          const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                          int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                          int64_t hook_features, const float* grad_out, ce_stream_t stream);
