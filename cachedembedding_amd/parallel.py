@@ -53,59 +53,75 @@ def get_partition(embedding_dim: int, rank: int, world_size: int) -> Tuple[int, 
 # backward is the same exchange with the dims swapped.
 
 
-def _all_to_all_dims(x: torch.Tensor, group, scatter_dim: int, gather_dim: int) -> torch.Tensor:
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group) -> None:
+    """all_to_all_single; with the gloo backend (CPU tests, or several ranks sharing one GPU in the GPU
+    tests) device tensors are staged through host memory because gloo only moves CPU buffers."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _split_sizes(n: int, world: int) -> List[int]:
+    chunk, rem = divmod(n, world)
+    return [chunk + 1 if i < rem else chunk for i in range(world)]        # torch.tensor_split rule
+
+
+def _all_to_all_dims(x: torch.Tensor, group, scatter_dim: int, gather_dim: int, scatter_sizes: List[int],
+                     gather_sizes: List[int]) -> torch.Tensor:
+    """Split x along scatter_dim into `scatter_sizes`, send piece p to peer p; receive from peer p a piece
+    whose gather_dim extent is gather_sizes[p]; concatenate along gather_dim.  One all-to-all-v on flat
+    buffers (the only all-to-all form gloo offers, used by the CPU tests)."""
     world = dist.get_world_size(group)
-    if world == 1:
-        return x
-    ins = [t.contiguous() for t in torch.tensor_split(x, world, dim=scatter_dim)]
     rank = dist.get_rank(group)
-    # peer p sends me its slice `rank` of ITS tensor: same scatter-dim extent as my own slice `rank`,
-    # and ITS gather-dim extent
-    g_sizes = _gather_sizes(x.shape[gather_dim], group, x.device)
+    ins = [t.contiguous() for t in torch.split(x, scatter_sizes, dim=scatter_dim)]
     shapes = []
     for p in range(world):
         shp = list(ins[rank].shape)
-        shp[gather_dim] = g_sizes[p]
+        shp[gather_dim] = gather_sizes[p]
         shapes.append(shp)
     out_splits = [int(torch.Size(s).numel()) for s in shapes]
     flat_in = torch.cat([t.reshape(-1) for t in ins])
     flat_out = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
-    # one all-to-all-v on flat buffers (also what gloo supports in the CPU tests)
-    dist.all_to_all_single(flat_out, flat_in, out_splits, [t.numel() for t in ins], group=group)
+    _a2a(flat_out, flat_in, out_splits, [t.numel() for t in ins], group)
     outs = [c.view(s) for c, s in zip(torch.split(flat_out, out_splits), shapes)]
     return torch.cat(outs, dim=gather_dim)
 
 
-_GATHER_SIZE_CACHE = {}
-
-
-def _gather_sizes(mine: int, group, device) -> List[int]:
-    world = dist.get_world_size(group)
-    key = (id(group), mine, world)
-    if key not in _GATHER_SIZE_CACHE:
-        t = torch.tensor([mine], dtype=torch.int64, device=device)
-        out = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(out, t, group=group)
-        _GATHER_SIZE_CACHE[key] = [int(o.item()) for o in out]
-    return _GATHER_SIZE_CACHE[key]
-
-
 class _DualAllToAll(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, group, scatter_dim, gather_dim):
+    def forward(ctx, x, group, scatter_dim, gather_dim, gather_sizes):
+        world = dist.get_world_size(group)
+        scatter_sizes = _split_sizes(x.shape[scatter_dim], world)
         ctx.group, ctx.sd, ctx.gd = group, scatter_dim, gather_dim
-        return _all_to_all_dims(x, group, scatter_dim, gather_dim)
+        ctx.scatter_sizes, ctx.gather_sizes = scatter_sizes, gather_sizes
+        return _all_to_all_dims(x, group, scatter_dim, gather_dim, scatter_sizes, gather_sizes)
 
     @staticmethod
     def backward(ctx, g):
-        return _all_to_all_dims(g.contiguous(), ctx.group, ctx.gd, ctx.sd), None, None, None
+        # the transpose exchange: no size negotiation needed, both size lists are known from forward
+        out = _all_to_all_dims(g.contiguous(), ctx.group, ctx.gd, ctx.sd, ctx.gather_sizes, ctx.scatter_sizes)
+        return out, None, None, None, None
 
 
-def dual_all_to_all(x: torch.Tensor, group=None, scatter_dim: int = 0, gather_dim: int = -1) -> torch.Tensor:
+def dual_all_to_all(x: torch.Tensor, group=None, scatter_dim: int = 0, gather_dim: int = -1,
+                    gather_sizes: Optional[List[int]] = None) -> torch.Tensor:
+    """forward scatters `scatter_dim`, gathers `gather_dim`; backward swaps the dims.
+    gather_sizes[p] = extent of peer p's tensor along gather_dim (None: exchanged with an all_gather)."""
     group = group if group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    if world == 1:
+        return x
     sd = scatter_dim % x.dim()
     gd = gather_dim % x.dim()
-    return _DualAllToAll.apply(x, group, sd, gd)
+    if gather_sizes is None:
+        t = torch.tensor([x.shape[gd]], dtype=torch.int64, device=x.device)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        gather_sizes = [int(o.item()) for o in out]
+    return _DualAllToAll.apply(x, group, sd, gd, list(gather_sizes))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -288,7 +304,7 @@ class RowwiseExchange:
         send = torch.stack([b[2] for b in buck], dim=1).contiguous()          # [W, P]
         recv = torch.empty_like(send)
         if W > 1:
-            dist.all_to_all_single(recv, send, group=self.group)
+            _a2a(recv, send, None, None, self.group)
         else:
             recv.copy_(send)
         send_h, recv_h = send.cpu(), recv.cpu()
@@ -299,7 +315,7 @@ class RowwiseExchange:
             rs = [int(v) for v in recv_h[:, b]]
             got = torch.empty(sum(rs), dtype=rows.dtype, device=rows.device)
             if W > 1:
-                dist.all_to_all_single(got, rows, rs, ss, group=self.group)
+                _a2a(got, rows, rs, ss, self.group)
             else:
                 got.copy_(rows)
             plans.append(BatchPlan(rows.numel(), perm, ss, rs, got))
@@ -315,14 +331,14 @@ class RowwiseExchange:
         if self.world == 1:
             return mine
         got = torch.empty(plan.n, self.ops.dim, dtype=mine.dtype, device=mine.device)
-        dist.all_to_all_single(got, mine, plan.send_splits, plan.recv_splits, group=self.group)
+        _a2a(got, mine, plan.send_splits, plan.recv_splits, self.group)
         return got
 
     def return_grads(self, plan: BatchPlan, grad_rows: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return grad_rows
         got = torch.empty(plan.recv_rows.numel(), self.ops.dim, dtype=grad_rows.dtype, device=grad_rows.device)
-        dist.all_to_all_single(got, grad_rows.contiguous(), plan.recv_splits, plan.send_splits, group=self.group)
+        _a2a(got, grad_rows.contiguous(), plan.recv_splits, plan.send_splits, self.group)
         return got
 
 
@@ -447,4 +463,8 @@ class ParallelCachedEmbeddingBag(CachedEmbeddingBag):
         out = super().forward(indices, offsets, per_sample_weights, shape_hook, hook_features=hook_features)
         if self.world_size == 1:
             return out
-        return dual_all_to_all(out, self.group, scatter_dim=scatter_dim, gather_dim=gather_dim)
+        sizes = None
+        if gather_dim in (-1, out.dim() - 1):      # column partition of every peer is known without talking
+            sizes = [hi - lo for lo, hi, _ in (get_partition(self.full_embedding_dim, p, self.world_size)
+                                               for p in range(self.world_size))]
+        return dual_all_to_all(out, self.group, scatter_dim=scatter_dim, gather_dim=gather_dim, gather_sizes=sizes)
