@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="cache op of window k+1 on a side stream")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
     ap.add_argument("--deterministic", action="store_true", help="sorted segmented SGD update instead of atomics")
+    ap.add_argument("--force_sharded", action="store_true", help="run the row-wise sharded code path even at N=1")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=1024)
@@ -72,9 +73,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import cachedembedding_amd as ce
     from cachedembedding_amd import synthetic
@@ -87,7 +89,7 @@ def main():
     N = sum(sizes)
     K, W = args.steps, args.warmup
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         return run_sharded(args, sizes, rank, world, dev)
 
     def note(msg):

@@ -39,6 +39,7 @@ struct BagParams {
   float alpha;              // bwd scale (1 or -lr)
   int32_t idx_bits;         // bits needed to tell two row indices apart (bwd duplicate matching)
   int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
+  uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
           for (int c = 0; c < NCH; ++c) {
             const int ch = gl + c * G;
             v[u][c] = vzero<VT>();
-            if (bi < nb && ch < rowlen) v[u][c] = W[(int64_t)ri * rowlen + ch];
+            if (bi < nb && ch < rowlen && (uint32_t)ri < p.num_rows) v[u][c] = W[(int64_t)ri * rowlen + ch];
           }
         }
 #pragma unroll
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
             for (int c = 0; c < NCH; ++c) {
               const int ch = gl + c * G;
               v[t][c] = vzero<VT>();
-              if (j + t < bhi && ch < rowlen) v[t][c] = W[(int64_t)r[t] * rowlen + ch];
+              if (j + t < bhi && ch < rowlen && (uint32_t)r[t] < p.num_rows) v[t][c] = W[(int64_t)r[t] * rowlen + ch];
             }
           }
 #pragma unroll
@@ -341,7 +342,8 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
               const int ch = gl + c * G;
-              if (ch < rowlen) atomic_add_vec(&DST[(int64_t)ri[u] * rowlen + ch], g[u][c] * p.alpha);
+              if (ch < rowlen && (uint32_t)ri[u] < p.num_rows)
+                atomic_add_vec(&DST[(int64_t)ri[u] * rowlen + ch], g[u][c] * p.alpha);
             }
           }
         }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
             const int ch = gl + c * G;
             if (ch < rowlen) {
               VT val = g[u][c] * s;
-              if (OP == 0) atomic_add_vec(&DST[r * rowlen + ch], val);
+              if (OP == 0) { if ((uint64_t)r < p.num_rows) atomic_add_vec(&DST[r * rowlen + ch], val); }
               else __builtin_nontemporal_store(val, &DST[r * rowlen + ch]);
             }
           }
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
             if (rw[t] != cur) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c) {
-                flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+                if (cur < p.num_rows) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
                 acc[c] = vzero<VT>();
               }
               cur = rw[t];
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+        if (cur < p.num_rows) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
       }
     }
     __syncthreads();
@@ -555,6 +557,7 @@ static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_
   p.hookB = hookF ? (int32_t)(num_bags / hookF) : 0;
   p.alpha = 1.f;
   p.idx_bits = 31;
+  p.num_rows = 0xffffffffu;
   return CE_OK;
 }
 
@@ -621,7 +624,6 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
                               int64_t nnz, const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                               int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                               int64_t hook_features, float* out, ce_stream_t stream) {
-  (void)num_rows;
   if (num_bags == 0) return CE_OK;
   CE_REQUIRE(weight && out && offsets && (indices || nnz == 0), CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -632,6 +634,8 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
   if (rc) return rc;
   p.weight = weight;
   p.dst = out;
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  p.num_rows = (uint32_t)num_rows;
   dim3 grid(bag_grid(num_bags)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define CE_FWD(VT, N) hipLaunchKernelGGL((k_bag_fwd<VT, N>), grid, block, 0, s, p)
@@ -663,6 +667,8 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
   p.alpha = 1.f;
   p.idx_bits = 1;
   while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  p.num_rows = (uint32_t)num_rows;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
 
@@ -683,6 +689,8 @@ extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
   p.alpha = -lr;
   p.idx_bits = 1;
   while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  p.num_rows = (uint32_t)num_rows;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
 

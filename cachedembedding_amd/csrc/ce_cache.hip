@@ -546,7 +546,10 @@ __global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, 
                                                const int32_t* __restrict__ idx_map,
                                                const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out,
                                                int64_t* freq, int slot_bits, const Ctl* ctl) {
-  if (ctl && ctl->status != CE_OK) return;
+  // a failed call (overflow / bad id) changes nothing but still hands back well-defined slots (-1):
+  // callers that skip the status check (strict=False) then gather zero rows instead of garbage
+  const bool failed = ctl && ctl->status != CE_OK;
+  if (failed) freq = nullptr;
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, 
     int64_t slot = -1;
     if (i < n) {
       const int64_t id = ids[i];
-      if ((unsigned long long)id < (unsigned long long)N) {
+      if (!failed && (unsigned long long)id < (unsigned long long)N) {
         const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
         slot = inverted[row];
       }

@@ -221,3 +221,21 @@ def test_window_prepare_then_cache_op_false_forwards():
     for ids, sl in zip(batches, torch.chunk(slots, P)):
         out = model(sl, off, shape_hook=lambda x: x.view(F, B, -1).transpose(0, 1))
         assert torch.equal(out.cpu(), w0[ids.cpu()].view(F, B, D).transpose(0, 1))
+
+
+def test_non_strict_overflow_yields_minus_one_slots_and_zero_rows():
+    """strict=False (no host sync in the pipeline): an overflowing call must stay harmless -- slots are -1,
+    the forward gathers zeros, the backward skips them, and the status is visible afterwards."""
+    ce = _ce()
+    w = torch.randn(1000, 16)
+    emb = ce.CachedEmbeddingBag(1000, 16, sparse=True, _weight=w, mode="sum", include_last_offset=True,
+                                cuda_row_num=20, strict=False)
+    emb.set_fused_sgd(0.1)
+    ids = torch.arange(100, 140, device="cuda")
+    off = torch.arange(41, dtype=torch.int32, device="cuda")
+    before = emb.cache_weight_mgr.cuda_cached_weight.detach().clone()
+    out = emb(ids, off)
+    assert torch.count_nonzero(out) == 0
+    out.backward(torch.ones_like(out))
+    assert torch.equal(before, emb.cache_weight_mgr.cuda_cached_weight.detach())
+    assert emb.cache_weight_mgr.sync_stats().status == 3     # CE_ERR_CAPACITY
