@@ -25,6 +25,8 @@
 // against oracle/cache_oracle.py.  Row payloads move either by zero-copy kernels that
 // address the mapped pinned host table directly over PCIe, or (CE_TRANSPORT_STAGED) through
 // pinned staging + hipMemcpyAsync with host worker threads doing the table gather/scatter.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
 }
 
 __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restrict__ keys, int64_t C, int pass,
-                                              uint32_t* hist, const Ctl* ctl) {
+                                              int top_pass, uint32_t* hist, const Ctl* ctl) {
   if (ctl->k_evict == 0) return;
   __shared__ uint32_t sh[256];
   sh[threadIdx.x] = 0;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restri
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
     const unsigned long long key = keys[s];
-    const bool match = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+    const bool match = (pass == top_pass) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
     if (match) atomicAdd(&sh[(key >> shift) & 255], 1u);
   }
   __syncthreads();
@@ -374,7 +376,8 @@ __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restri
 }
 
 // one block of 256: pick the digit holding the k-th smallest key, refine prefix/k, clear the histogram
-__global__ __launch_bounds__(256) void k_pick(uint32_t* hist, int pass, Ctl* ctl, ce_call_stats_t* ring_slot) {
+__global__ __launch_bounds__(256) void k_pick(uint32_t* hist, int pass, int top_pass, Ctl* ctl,
+                                              ce_call_stats_t* ring_slot) {
   if (ctl->k_evict == 0) return;
   __shared__ uint32_t sh[256];
   const uint32_t mine = hist[threadIdx.x];
@@ -383,8 +386,9 @@ __global__ __launch_bounds__(256) void k_pick(uint32_t* hist, int pass, Ctl* ctl
   __syncthreads();
   if (threadIdx.x == 0) {
     long long krem = ctl->sel_krem;
-    if (pass == 7) {
-      // bin 255 of the top byte holds exactly the ineligible (empty / protected) slots.  With
+    if (pass == top_pass) {
+      // bin 255 of the top byte holds exactly the ineligible (empty / protected) slots: eligible keys are
+      // < 2^63 (LFU) or < N < 2^31 (DATASET, whose top_pass is the highest byte N-1 can reach).  With
       // protect_depth > 0 the protected set can leave fewer than k candidates: that is the
       // capacity overflow of the overlapped pipeline (unique(window k u k+1) > cuda_row_num).
       long long eligible = 0;
@@ -440,10 +444,32 @@ __global__ __launch_bounds__(256) void k_evict(const int32_t* __restrict__ victi
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < k; i += gstride) {
-    const int32_t slot = victims[i];
-    const int32_t row = cached_idx_map[slot];
-    if (host) copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)row * rowlen, rowlen, gl, G);
+  if (!host) return;
+  // 4 rows in flight per lane group: the kernel is PCIe-latency bound, so it is launched on a SMALL grid
+  // (it must not occupy the wave slots of the training kernels it overlaps with) and gets its
+  // memory-level parallelism from unrolling instead
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * 4; i < k; i += gstride * 4) {
+    if (rowlen <= G) {
+      VT v[4];
+      int64_t dst[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dst[t] = -1;
+        if (i + t < k) {
+          const int32_t slot = victims[i + t];
+          dst[t] = cached_idx_map[slot];
+          if (gl < rowlen) v[t] = cache[(int64_t)slot * rowlen + gl];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (dst[t] >= 0 && gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
+    } else {
+      for (int t = 0; t < 4 && i + t < k; ++t) {
+        const int32_t slot = victims[i + t];
+        copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)cached_idx_map[slot] * rowlen, rowlen, gl, G);
+      }
+    }
   }
 }
 // map updates run after the payload pass (rows read cached_idx_map above)
@@ -517,10 +543,29 @@ __global__ __launch_bounds__(256) void k_admit(const int32_t* __restrict__ rows,
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride) {
-    const int64_t row = rows ? rows[i] : i;
-    const int64_t slot = slots ? slots[i] : i;
-    copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * 4; i < n; i += gstride * 4) {
+    if (rowlen <= G) {          // 4 host rows in flight per lane group (see k_evict)
+      VT v[4];
+      int64_t dst[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dst[t] = -1;
+        if (i + t < n) {
+          const int64_t row = rows ? rows[i + t] : i + t;
+          dst[t] = slots ? slots[i + t] : i + t;
+          if (gl < rowlen) v[t] = host[row * rowlen + gl];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (dst[t] >= 0 && gl < rowlen) cache[dst[t] * rowlen + gl] = v[t];
+    } else {
+      for (int t = 0; t < 4 && i + t < n; ++t) {
+        const int64_t row = rows ? rows[i + t] : i + t;
+        const int64_t slot = slots ? slots[i + t] : i + t;
+        copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
+      }
+    }
   }
 }
 
@@ -902,12 +947,12 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
   const int32_t epoch = (int32_t)(h->seq & 0x3fffffff);
   const int64_t groups_per_block = 256 >> h->g_log2;
   if (h->vec)
-    hipLaunchKernelGGL((k_admit<f32x4>), dim3(grid_for(n, (int)groups_per_block)), dim3(256), 0, s, rows,
+    hipLaunchKernelGGL((k_admit<f32x4>), dim3(grid_for(n, (int)groups_per_block * 4)), dim3(256), 0, s, rows,
                        (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
                        (const f32x4*)c.host_weight_dev, (f32x4*)c.cache_weight, h->rowlen, h->g_log2,
                        (const Ctl*)nullptr);
   else
-    hipLaunchKernelGGL((k_admit<float>), dim3(grid_for(n, (int)groups_per_block)), dim3(256), 0, s, rows,
+    hipLaunchKernelGGL((k_admit<float>), dim3(grid_for(n, (int)groups_per_block * 4)), dim3(256), 0, s, rows,
                        (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
                        (const float*)c.host_weight_dev, (float*)c.cache_weight, h->rowlen, h->g_log2,
                        (const Ctl*)nullptr);
@@ -979,13 +1024,21 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   ce_call_stats_t* slot = h->ring_dev + (h->seq % kRing);
   const int lfu = c.evict_strategy == CE_EVICT_LFU;
   const int gpb = 256 >> h->g_log2;
-  const int cap_groups = (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb)));
+  // swap kernels: small grid (default 2 workgroups per CU's worth of slots is left to training kernels)
+  static const int swap_blocks = [] {
+    const char* e = getenv("CE_SWAP_BLOCKS");
+    const int v = e ? atoi(e) : 32;
+    return v > 0 ? v : 32;
+  }();
+  const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb * 4)));
 
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
   {
-    const int hot_words = (int)std::min<int64_t>(L.bitmap_words, 8192);
+    static const int mark_hot = [] { const char* e = getenv("CE_MARK_HOT"); return e ? atoi(e) : 2048; }();
+    static const int mark_blocks = [] { const char* e = getenv("CE_MARK_BLOCKS"); return e ? atoi(e) : 256; }();
+    const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
     if (n > 0)
-      hipLaunchKernelGGL(k_mark, dim3(std::min(grid_for(n, 1024), 1024)), dim3(256), hot_words * 4, s, ids, n,
+      hipLaunchKernelGGL(k_mark, dim3(std::min(grid_for(n, 1024), mark_blocks)), dim3(256), hot_words * 4, s, ids, n,
                          c.idx_map, c.inverted_cached_idx, N, h->word_bits, hot_words, h->bitmap, h->ctl);
   }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
@@ -998,9 +1051,16 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   const int cgrid = grid_for(C, 256 * 4);
   hipLaunchKernelGGL(k_keys, dim3(cgrid), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
                      epoch, c.protect_depth, h->slot_bits, lfu, h->keys, h->hist, h->ctl);
-  for (int pass = 7; pass >= 0; --pass) {
-    hipLaunchKernelGGL(k_hist, dim3(cgrid), dim3(256), 0, s, h->keys, C, pass, h->hist, h->ctl);
-    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, h->hist, pass, h->ctl, slot);
+  // DATASET keys are < N: the bytes above the highest byte of N-1 are zero for every eligible slot, so the
+  // radix select starts there (4 passes at N = 178 M instead of 8)
+  int top_pass = 7;
+  if (!lfu) {
+    top_pass = 0;
+    while (top_pass < 3 && ((uint64_t)(N - 1) >> (8 * (top_pass + 1))) != 0) ++top_pass;
+  }
+  for (int pass = top_pass; pass >= 0; --pass) {
+    hipLaunchKernelGGL(k_hist, dim3(cgrid), dim3(256), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, h->hist, pass, top_pass, h->ctl, slot);
   }
   hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl);
   if (c.transport == CE_TRANSPORT_ZEROCOPY) {

@@ -1,7 +1,9 @@
 run() { echo "== $*"; timeout 600 python bench.py --no_cpu_baseline "$@" 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); print('  %.1f M lookups/s  step %.3f ms  hit %.3f rows_in %d rows_out %d | %s %.3f ms %.0f GB/s | %s %.3f ms %.0f GB/s' % (d['value']/1e6, d['ms_per_step'], d['cache']['unique_hit_rate'], d['cache']['rows_in'], d['cache']['rows_out'], d['roofline']['kernel'], d['roofline']['avg_ms'], d['roofline']['achieved'], d['roofline_other']['kernel'], d['roofline_other']['avg_ms'], d['roofline_other']['achieved']))"; }
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-run --use_lfu
+d=json.loads(sys.stdin.read()); print('  %.1f M lookups/s  step %.3f ms' % (d['value']/1e6, d['ms_per_step']))"; }
+timeout 600 python -m pytest tests/test_gpu_cache.py -m gpu -x -q 2>&1 | tail -2
+run
+for sb in 16 32; do echo "swap_blocks=$sb"; CE_SWAP_BLOCKS=$sb run --overlap; done
+for mh in 512 2048 8192; do for mb in 256 512 1024; do echo "mark_hot=$mh mark_blocks=$mb"; CE_MARK_HOT=$mh CE_MARK_BLOCKS=$mb run --overlap; done; done
+run
 run --overlap --use_lfu
-run --overlap
