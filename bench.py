@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no_overlap", action="store_true",
                     help="reference semantics: the window's cache op runs on the compute stream (default: the cache op "
                          "of window k+1 runs on a side HIP stream while window k trains, protect_depth=1)")
+    ap.add_argument("--cache_cus", type=int, default=0, help="CUs reserved for the side-stream cache op (0 = share all)")
+    ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
+                    "hipGraph of the window's P training steps")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
     ap.add_argument("--deterministic", action="store_true", help="sorted segmented SGD update instead of atomics")
     ap.add_argument("--force_sharded", action="store_true", help="run the row-wise sharded code path even at N=1")
@@ -123,16 +126,40 @@ def main():
     windows = [gen.next_values(P) for _ in range(n_windows)]          # each [P, F*B*L]
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
-    win = PrefetchWindow(embed, P, overlap=args.overlap)
+    win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus)
+    use_graph = (not args.no_graph) and W % P == 0 and K % P == 0
+
+    def train_step(slots_i, i):
+        out = embed(slots_i, offsets, hook_features=F)
+        out.backward(grad)
+
+    gw = None
+    if use_graph:
+        from cachedembedding_amd.pipeline import GraphedWindow
+        gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
+                           warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus)
+        note("hipGraph of the window's training steps captured")
+
+    def run_windows(first_w, count_w):
+        """graph mode: window w = cache op (side stream, one window ahead when overlapping) + one graph replay"""
+        if args.overlap:
+            gw.submit([windows[first_w][i] for i in range(P)], first_w % 2)
+        for w in range(first_w, first_w + count_w):
+            if args.overlap:
+                if w + 1 < n_windows:       # enqueued before graph w: overlaps with it
+                    gw.submit([windows[w + 1][i] for i in range(P)], (w + 1) % 2)
+            else:
+                gw.submit([windows[w][i] for i in range(P)], w % 2)
+            gw.run(w % 2)
 
     def run_steps(first, count, ev_pairs=None):
         slots = None
-        if args.overlap and win._pending is not None:
+        if win.overlap and win._pending is not None:
             win.collect()      # drop a window submitted by an earlier, non-contiguous call
         for step in range(first, first + count):
             wi, bi = divmod(step, P)
             if bi == 0 or slots is None:
-                if args.overlap:
+                if win.overlap:
                     if win._pending is None:
                         win.submit([windows[wi][i] for i in range(P)])
                     slots = win.collect()
@@ -156,11 +183,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(0, W)
+    if use_graph:
+        run_windows(0, W // P)
+    else:
+        run_steps(0, W)
     barrier()
     note("warmup done")
     t1 = time.perf_counter()
-    run_steps(W, K)
+    if use_graph:
+        run_windows(W // P, K // P)
+    else:
+        run_steps(W, K)
     enqueue_s = time.perf_counter() - t1
     barrier()
     elapsed = time.perf_counter() - t1
@@ -220,6 +253,7 @@ def main():
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
                    "transport": "staged" if args.async_copy else "zerocopy", "overlap": bool(args.overlap),
+                   "launch": "hipGraph per window" if use_graph else "python per step",
                    "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,

@@ -75,6 +75,8 @@ _BAG_COMMON = [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_int64]
 SIGNATURES = {
     "ce_version": (c_int, []),
     "ce_last_error": (c_char_p, []),
+    "ce_stream_create_cu_mask": (c_int, [c_void_p, c_int32, POINTER(c_void_p)]),
+    "ce_stream_destroy": (c_int, [c_void_p]),
     "ce_host_alloc": (c_int, [c_size_t, c_int, POINTER(c_void_p), POINTER(c_void_p)]),
     "ce_host_free": (c_int, [c_void_p]),
     "ce_host_register": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
@@ -92,7 +94,7 @@ SIGNATURES = {
     "ce_bag_backward_sgd_sorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                            c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,
                                            c_void_p, c_size_t, c_void_p]),
-    "ce_cache_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "ce_cache_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int32]),
     "ce_cache_create": (c_int, [POINTER(CeCacheConfig), c_void_p, POINTER(c_void_p)]),
     "ce_cache_destroy": (c_int, [c_void_p]),
     "ce_cache_preload": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

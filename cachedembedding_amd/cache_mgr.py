@@ -129,7 +129,7 @@ class CachedParamMgr(torch.nn.Module):
     # ------------------------------------------------------------------ handle plumbing
     def _create_handle(self):
         N, C = self.num_embeddings, self.cuda_row_num
-        ws_bytes = lib.ce_cache_workspace_bytes(N, C, self._max_ids)
+        ws_bytes = lib.ce_cache_workspace_bytes(N, C, self._max_ids, self.embedding_dim)
         self._workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=self.device)
         base = self._workspace.data_ptr()
         aligned = (base + 255) & ~255
@@ -209,14 +209,20 @@ class CachedParamMgr(torch.nn.Module):
 
     # ------------------------------------------------------------------ A.3
     @torch.no_grad()
-    def prepare_ids(self, ids: torch.Tensor) -> torch.Tensor:
+    def prepare_ids(self, ids: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`out` (int64, same numel, contiguous) lets a caller keep the slots in a static buffer, e.g. one
+        a captured hipGraph reads (pipeline.GraphedWindow)."""
         assert ids.is_cuda, "ids must live on the GPU (recsys/dlrm_main.py:250 moves the batch first)"
         shape = ids.shape
         flat = ids.reshape(-1)
         if flat.dtype != torch.int64:
             flat = flat.long()
         flat = flat.contiguous()
-        slots = torch.empty_like(flat)
+        if out is None:
+            slots = torch.empty_like(flat)
+        else:
+            assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == flat.numel()
+            slots = out.view(-1)
         with torch.cuda.device(self.device):
             check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
         if self.strict:

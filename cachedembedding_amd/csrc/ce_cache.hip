@@ -56,11 +56,13 @@ struct Ctl {                 // device control block (one per manager)
 
 struct Layout {              // byte offsets inside the caller-provided workspace
   size_t ctl, bitmap, blk_unique, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      total;
-  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words;
+      stage_idx, stage, total;
+  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
 
-static Layout make_layout(int64_t N, int64_t C, int64_t max_ids) {
+constexpr int64_t kStageRowsMax = 262144;   // write-back staging: 128 MB at D = 128
+
+static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   Layout L{};
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   L.n_chunks = cdiv(N, kChunkRows);
@@ -79,6 +81,9 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids) {
   L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
   L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
   L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
+  L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
+  L.stage_idx = o;  o = al(o + (size_t)L.stage_rows * 4);
+  L.stage = o;      o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
   L.total = o;
   return L;
 }
@@ -436,24 +441,28 @@ __device__ __forceinline__ void copy_row(const VT* __restrict__ src, VT* __restr
   for (int c = gl; c < rowlen; c += G) dst[c] = src[c];
 }
 
+constexpr int kSwapRows = 16;   // rows in flight per lane group in the PCIe swap kernels
+
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
                                                int32_t* inverted, const VT* __restrict__ cache, VT* host,
-                                               int rowlen, int g_log2, const Ctl* ctl) {
+                                               long long first, int rowlen, int g_log2, const Ctl* ctl) {
   const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  if (k <= first) return;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
   if (!host) return;
-  // 4 rows in flight per lane group: the kernel is PCIe-latency bound, so it is launched on a SMALL grid
+  // kSwapRows rows in flight per lane group: the kernel is PCIe-latency bound, so it is launched on a SMALL grid
   // (it must not occupy the wave slots of the training kernels it overlaps with) and gets its
   // memory-level parallelism from unrolling instead
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * 4; i < k; i += gstride * 4) {
+  for (int64_t i = first + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < k;
+       i += gstride * kSwapRows) {
     if (rowlen <= G) {
-      VT v[4];
-      int64_t dst[4];
+      VT v[kSwapRows];
+      int64_t dst[kSwapRows];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < kSwapRows; ++t) {
         dst[t] = -1;
         if (i + t < k) {
           const int32_t slot = victims[i + t];
@@ -462,16 +471,69 @@ __global__ __launch_bounds__(256) void k_evict(const int32_t* __restrict__ victi
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < kSwapRows; ++t)
         if (dst[t] >= 0 && gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
     } else {
-      for (int t = 0; t < 4 && i + t < k; ++t) {
+      for (int t = 0; t < kSwapRows && i + t < k; ++t) {
         const int32_t slot = victims[i + t];
         copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)cached_idx_map[slot] * rowlen, rowlen, gl, G);
       }
     }
   }
 }
+// Full-duplex swap: victims' rows are first copied cache -> HBM staging (fast), then written to the host
+// table from the staging buffer on an auxiliary stream while the admissions read the host table on the
+// main stream -- PCIe carries both directions at once.  Victims beyond the staging capacity (rare) are
+// written back directly by k_evict (`first` = staging capacity).
+template <typename VT>
+__global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
+                                                     const int32_t* __restrict__ cached_idx_map,
+                                                     const VT* __restrict__ cache, VT* stage, int32_t* stage_rows_idx,
+                                                     long long cap, int rowlen, int g_log2, const Ctl* ctl) {
+  long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  if (k > cap) k = cap;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < k; i += gstride) {
+    const int32_t slot = victims[i];
+    if (gl == 0) stage_rows_idx[i] = cached_idx_map[slot];
+    copy_row(cache + (int64_t)slot * rowlen, stage + i * rowlen, rowlen, gl, G);
+  }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_writeback(const int32_t* __restrict__ stage_rows_idx,
+                                                   const VT* __restrict__ stage, VT* host, long long cap, int rowlen,
+                                                   int g_log2, const Ctl* ctl) {
+  long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  if (k > cap) k = cap;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < k;
+       i += gstride * kSwapRows) {
+    if (rowlen <= G) {
+      VT v[kSwapRows];
+      int64_t dst[kSwapRows];
+#pragma unroll
+      for (int t = 0; t < kSwapRows; ++t) {
+        dst[t] = -1;
+        if (i + t < k) {
+          dst[t] = stage_rows_idx[i + t];
+          if (gl < rowlen) v[t] = stage[(i + t) * rowlen + gl];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kSwapRows; ++t)
+        if (dst[t] >= 0 && gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
+    } else {
+      for (int t = 0; t < kSwapRows && i + t < k; ++t)
+        copy_row(stage + (i + t) * rowlen, host + (int64_t)stage_rows_idx[i + t] * rowlen, rowlen, gl, G);
+    }
+  }
+}
+
 // map updates run after the payload pass (rows read cached_idx_map above)
 __global__ __launch_bounds__(256) void k_evict_maps(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
                                                     int32_t* inverted, int32_t* evicted_rows, const Ctl* ctl) {
@@ -543,12 +605,12 @@ __global__ __launch_bounds__(256) void k_admit(const int32_t* __restrict__ rows,
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * 4; i < n; i += gstride * 4) {
-    if (rowlen <= G) {          // 4 host rows in flight per lane group (see k_evict)
-      VT v[4];
-      int64_t dst[4];
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < n; i += gstride * kSwapRows) {
+    if (rowlen <= G) {          // kSwapRows host rows in flight per lane group (see k_evict)
+      VT v[kSwapRows];
+      int64_t dst[kSwapRows];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < kSwapRows; ++t) {
         dst[t] = -1;
         if (i + t < n) {
           const int64_t row = rows ? rows[i + t] : i + t;
@@ -557,10 +619,10 @@ __global__ __launch_bounds__(256) void k_admit(const int32_t* __restrict__ rows,
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < kSwapRows; ++t)
         if (dst[t] >= 0 && gl < rowlen) cache[dst[t] * rowlen + gl] = v[t];
     } else {
-      for (int t = 0; t < 4 && i + t < n; ++t) {
+      for (int t = 0; t < kSwapRows && i + t < n; ++t) {
         const int64_t row = rows ? rows[i + t] : i + t;
         const int64_t slot = slots ? slots[i + t] : i + t;
         copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
@@ -755,6 +817,10 @@ struct ce_cache {
   ce_call_stats_t* ring;       // pinned host
   ce_call_stats_t* ring_dev;   // device-visible alias
   hipEvent_t ev;
+  hipStream_t aux;             // write-back lane: evicted rows leave over PCIe while admissions come in
+  hipEvent_t ev_fork, ev_join;
+  float* stage;                // device staging for evicted rows (inside the workspace)
+  int32_t* stage_idx;          // host row of every staged victim
   long long seq;               // calls issued
   long long drained;           // calls whose stats were folded into history
   std::vector<ce_call_stats_t> history;
@@ -794,9 +860,10 @@ static int sync_and_drain(ce_cache* h) {
   return CE_OK;
 }
 
-extern "C" size_t ce_cache_workspace_bytes(int64_t num_embeddings, int64_t cuda_row_num, int64_t max_ids_per_call) {
-  if (num_embeddings <= 0 || cuda_row_num <= 0) return 0;
-  return make_layout(num_embeddings, cuda_row_num, max_ids_per_call).total;
+extern "C" size_t ce_cache_workspace_bytes(int64_t num_embeddings, int64_t cuda_row_num, int64_t max_ids_per_call,
+                                           int32_t embedding_dim) {
+  if (num_embeddings <= 0 || cuda_row_num <= 0 || embedding_dim <= 0) return 0;
+  return make_layout(num_embeddings, cuda_row_num, max_ids_per_call, embedding_dim).total;
 }
 
 extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream, ce_cache_t** out) {
@@ -816,7 +883,7 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
              CE_ERR_INVALID, "null device array");
   CE_REQUIRE(cfg->evict_strategy != CE_EVICT_LFU || cfg->freq_cnter, CE_ERR_INVALID, "LFU needs freq_cnter");
   CE_REQUIRE(cfg->host_weight && cfg->host_weight_dev, CE_ERR_INVALID, "null host table");
-  Layout L = make_layout(cfg->num_embeddings, cfg->cuda_row_num, cfg->max_ids_per_call);
+  Layout L = make_layout(cfg->num_embeddings, cfg->cuda_row_num, cfg->max_ids_per_call, cfg->embedding_dim);
   CE_REQUIRE(cfg->workspace_bytes >= L.total, CE_ERR_INVALID, "workspace too small: need %zu bytes", L.total);
   CE_REQUIRE((((uintptr_t)cfg->workspace) & 255) == 0, CE_ERR_INVALID, "workspace must be 256-byte aligned");
 
@@ -869,15 +936,20 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   void* ring_dev = nullptr;
   if (hipHostGetDevicePointer(&ring_dev, ring_host, 0) != hipSuccess) ring_dev = ring_host;
   h->ring_dev = (ce_call_stats_t*)ring_dev;
-  if (hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) {
+  h->stage = (float*)(h->ws + L.stage);
+  h->stage_idx = (int32_t*)(h->ws + L.stage_idx);
+  if (hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) {
     (void)hipHostFree(ring_host);
     delete h;
-    set_error("hipEventCreate failed");
+    set_error("hipEventCreate / hipStreamCreate failed");
     return CE_ERR_HIP;
   }
   // empty-cache state of A.1
   const int64_t N = cfg->num_embeddings, C = cfg->cuda_row_num;
-  (void)hipMemsetAsync(h->ws, 0, L.total, s);
+  (void)hipMemsetAsync(h->ws, 0, L.stage_idx, s);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(N, 256)), dim3(256), 0, s, cfg->inverted_cached_idx, N, -1);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, cfg->cached_idx_map, C, -1);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, h->slot_epoch, C, kEpochNever);
@@ -903,6 +975,10 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
 extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
   (void)hipEventSynchronize(h->ev);
+  (void)hipStreamSynchronize(h->aux);
+  (void)hipStreamDestroy(h->aux);
+  (void)hipEventDestroy(h->ev_fork);
+  (void)hipEventDestroy(h->ev_join);
   (void)hipEventDestroy(h->ev);
   (void)hipHostFree(h->ring);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
@@ -947,12 +1023,12 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
   const int32_t epoch = (int32_t)(h->seq & 0x3fffffff);
   const int64_t groups_per_block = 256 >> h->g_log2;
   if (h->vec)
-    hipLaunchKernelGGL((k_admit<f32x4>), dim3(grid_for(n, (int)groups_per_block * 4)), dim3(256), 0, s, rows,
+    hipLaunchKernelGGL((k_admit<f32x4>), dim3(grid_for(n, (int)groups_per_block * kSwapRows)), dim3(256), 0, s, rows,
                        (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
                        (const f32x4*)c.host_weight_dev, (f32x4*)c.cache_weight, h->rowlen, h->g_log2,
                        (const Ctl*)nullptr);
   else
-    hipLaunchKernelGGL((k_admit<float>), dim3(grid_for(n, (int)groups_per_block * 4)), dim3(256), 0, s, rows,
+    hipLaunchKernelGGL((k_admit<float>), dim3(grid_for(n, (int)groups_per_block * kSwapRows)), dim3(256), 0, s, rows,
                        (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
                        (const float*)c.host_weight_dev, (float*)c.cache_weight, h->rowlen, h->g_log2,
                        (const Ctl*)nullptr);
@@ -1025,12 +1101,14 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   const int lfu = c.evict_strategy == CE_EVICT_LFU;
   const int gpb = 256 >> h->g_log2;
   // swap kernels: small grid (default 2 workgroups per CU's worth of slots is left to training kernels)
-  static const int swap_blocks = [] {
+  // protect_depth > 0 means the call overlaps with training kernels on another stream: stay small (32
+  // workgroups measured best: 1.43 -> 1.82 G lookups/s); alone on the GPU a wider grid finishes sooner
+  static const int swap_blocks_env = [] {
     const char* e = getenv("CE_SWAP_BLOCKS");
-    const int v = e ? atoi(e) : 32;
-    return v > 0 ? v : 32;
+    return e ? atoi(e) : 0;
   }();
-  const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb * 4)));
+  const int swap_blocks = swap_blocks_env > 0 ? swap_blocks_env : (c.protect_depth > 0 ? 32 : 512);
+  const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb * kSwapRows)));
 
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
   {
@@ -1064,15 +1142,34 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl);
   if (c.transport == CE_TRANSPORT_ZEROCOPY) {
-    // ---- write-back + map clear, free-slot list, admit: all device-side
-    if (h->vec)
+    // ---- victims -> HBM staging (fast), then the PCIe write-back runs on the aux stream concurrently with
+    // the admissions below; map clear, free-slot list, admit stay on the caller's stream
+    const long long scap = (long long)L.stage_rows;
+    const int sgrid = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    if (h->vec) {
+      hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
+                         (const f32x4*)c.cache_weight, (f32x4*)h->stage, h->stage_idx, scap, h->rowlen, h->g_log2,
+                         h->ctl);
       hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, h->rowlen,
-                         h->g_log2, h->ctl);
-    else
+                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
+                         h->rowlen, h->g_log2, h->ctl);
+    } else {
+      hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
+                         (const float*)c.cache_weight, (float*)h->stage, h->stage_idx, scap, h->rowlen, h->g_log2,
+                         h->ctl);
       hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, h->rowlen,
-                         h->g_log2, h->ctl);
+                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
+                         h->rowlen, h->g_log2, h->ctl);
+    }
+    CE_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+    CE_HIP_CHECK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    if (h->vec)
+      hipLaunchKernelGGL((k_writeback<f32x4>), dim3(cap_groups), dim3(256), 0, h->aux, h->stage_idx,
+                         (const f32x4*)h->stage, (f32x4*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
+    else
+      hipLaunchKernelGGL((k_writeback<float>), dim3(cap_groups), dim3(256), 0, h->aux, h->stage_idx,
+                         (const float*)h->stage, (float*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
+    CE_HIP_CHECK(hipEventRecord(h->ev_join, h->aux));
     hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
                        c.cached_idx_map, c.inverted_cached_idx, (int32_t*)nullptr, h->ctl);
   } else {
@@ -1119,6 +1216,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                            (float*)c.cache_weight, h->rowlen, h->g_log2);
     }
   }
+  if (c.transport == CE_TRANSPORT_ZEROCOPY) CE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));   // write-back joined
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
                      (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
                      c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl);

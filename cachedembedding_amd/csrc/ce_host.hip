@@ -123,3 +123,21 @@ extern "C" int ce_host_fill_uniform(float* dst, int64_t n, float lo, float hi, u
   });
   return CE_OK;
 }
+
+extern "C" int ce_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words, ce_stream_t* out) {
+  CE_REQUIRE(out && words >= 0 && (words == 0 || cu_mask), CE_ERR_INVALID, "bad arguments");
+  hipStream_t s = nullptr;
+  if (words == 0) {
+    CE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  } else {
+    CE_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask));
+  }
+  *out = (ce_stream_t)s;
+  return CE_OK;
+}
+
+extern "C" int ce_stream_destroy(ce_stream_t stream) {
+  if (!stream) return CE_OK;
+  CE_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return CE_OK;
+}

@@ -57,6 +57,15 @@ int ce_version(void);
 const char* ce_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
+ * Side stream for the cache manager (the "Stream1" lane of pics/prefetch.png).  The cache op is
+ * PCIe/latency bound, the training kernels HBM bound; if both share all 256 CUs the cache op's
+ * resident waves take wave slots from training.  ce_stream_create_cu_mask returns a HIP stream
+ * restricted to the CUs whose bits are set in cu_mask (word w bit b = CU 32*w + b), so e.g. one XCD
+ * (32 CUs) serves the cache manager and 7 XCDs keep training.  words == 0: an ordinary stream. */
+int ce_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words, ce_stream_t* out);
+int ce_stream_destroy(ce_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Host table (the `weight` of CachedParamMgr, A.1; `pin_weight=True` at
  * benchmark/benchmark_fbgemm_uvm.py:98-105).  Pinned + device-mapped host memory.
  * ce_host_alloc pins `bytes` (first-touched by `threads` workers so a 91 GB table is
@@ -171,7 +180,8 @@ typedef struct ce_call_stats {
 #define CE_CALL_PRELOAD 1
 #define CE_CALL_FLUSH 2
 
-size_t ce_cache_workspace_bytes(int64_t num_embeddings, int64_t cuda_row_num, int64_t max_ids_per_call);
+size_t ce_cache_workspace_bytes(int64_t num_embeddings, int64_t cuda_row_num, int64_t max_ids_per_call,
+                                int32_t embedding_dim);
 
 /* Builds the manager over caller-owned arrays and initialises them to the empty-cache
  * state of A.1 (maps = -1, freq_cnter = INT64_MAX, cache rows untouched).  Blocks. */

@@ -1,9 +1,11 @@
-run() { echo "== $*"; timeout 600 python bench.py --no_cpu_baseline "$@" 2>/dev/null | python -c "
+run() { echo "== $*"; timeout 600 python bench.py --no_cpu_baseline "$@" 2>gpurun_out/err.txt | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); print('  %.1f M lookups/s  step %.3f ms' % (d['value']/1e6, d['ms_per_step']))"; }
-timeout 600 python -m pytest tests/test_gpu_cache.py -m gpu -x -q 2>&1 | tail -2
+try:
+    d=json.loads(sys.stdin.read()); print('  %.1f M lookups/s  step %.3f ms' % (d['value']/1e6, d['ms_per_step']))
+except Exception as e:
+    print('  FAILED', e)" ; grep -E "Error|error" gpurun_out/err.txt | tail -2; }
+timeout 600 python -m pytest tests/test_gpu_cache.py tests/test_gpu_parallel.py -m gpu -x -q 2>&1 | tail -2
 run
-for sb in 16 32; do echo "swap_blocks=$sb"; CE_SWAP_BLOCKS=$sb run --overlap; done
-for mh in 512 2048 8192; do for mb in 256 512 1024; do echo "mark_hot=$mh mark_blocks=$mb"; CE_MARK_HOT=$mh CE_MARK_BLOCKS=$mb run --overlap; done; done
-run
-run --overlap --use_lfu
+run --no_overlap
+run --use_lfu
+CE_SWAP_BLOCKS=64 run

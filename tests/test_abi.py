@@ -61,8 +61,8 @@ def test_argument_validation_without_gpu():
     """Pure host-side checks run before any HIP call, so they are testable here."""
     from cachedembedding_amd import _lib
     lib = _lib.lib
-    assert lib.ce_cache_workspace_bytes(0, 0, 0) == 0
-    assert lib.ce_cache_workspace_bytes(1000, 50, 64) > 0
+    assert lib.ce_cache_workspace_bytes(0, 0, 0, 8) == 0
+    assert lib.ce_cache_workspace_bytes(1000, 50, 64, 8) > 0
     assert lib.ce_bucketize_workspace(4096, 8) > 0
     rc = lib.ce_bag_forward(None, 10, 0, None, 0, None, 0, 4, 1, None, 0, 0, None, None)
     assert rc == _lib.CE_ERR_INVALID and "null pointer" in _lib.last_error()
