@@ -1,0 +1,194 @@
+"""GPU tests of the glue around the operator: side-stream data iterator, FusedSparseModules wiring,
+table-wise sharding, synthetic KJT generator, prefetch window (sequential, overlapped, graphed)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_finite_data_iter_side_stream():
+    from cachedembedding_amd.modules import CudaStreamDataIter, FiniteDataIter
+    batches = [dict(dense=torch.full((4, 3), float(i)).pin_memory(), sparse=[torch.arange(6) + i, torch.arange(7), 2])
+               for i in range(5)]
+    it = FiniteDataIter(batches)
+    seen = []
+    for b in it:
+        assert b["dense"].is_cuda and b["sparse"][0].is_cuda and b["sparse"][2] == 2
+        seen.append(int(b["dense"][0, 0].item()))
+        assert torch.equal(b["sparse"][0].cpu(), torch.arange(6) + seen[-1])
+    assert seen == [0, 1, 2, 3, 4]
+    inf = CudaStreamDataIter(batches)
+    got = [int(next(inf)["dense"][0, 0].item()) for _ in range(12)]
+    assert got == [0, 1, 2, 3, 4] * 2 + [0, 1]
+
+
+def test_synthetic_kjt_layout_and_generator():
+    from cachedembedding_amd import synthetic
+    sizes = [1000, 3, 50000, 17]
+    gen = synthetic.SyntheticKJT(sizes, 64, 1, "power_law", 0.25, seed=3, device="cuda")
+    b = gen.next_batch()
+    F, B = 4, 64
+    assert b.values.shape == (F * B,) and b.offsets.dtype == torch.int32 and b.stride == B
+    assert torch.equal(b.offsets.cpu(), torch.arange(F * B + 1, dtype=torch.int32))
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    v = b.values.view(F, B).cpu().numpy()                    # feature-major (criteo.py:127-134)
+    for f in range(F):
+        assert (v[f] >= off[f]).all() and (v[f] < off[f + 1]).all()
+    freq = gen.id_freq_map(8)
+    assert freq.shape == (sum(sizes),) and int(freq.sum()) == 8 * F * B
+    # long tail: the first id of a big table is by far the most frequent
+    assert freq[off[2]] > 20 * freq[off[2] + 100]
+
+
+def test_fused_sparse_modules_matches_reference_wiring():
+    from cachedembedding_amd.modules import FusedSparseModules
+    torch.manual_seed(0)
+    sizes, D, B = [50, 7, 300], 32, 16
+    m = FusedSparseModules(sizes, D, reduction_mode="sum", sparse=True, use_cache=True, cache_ratio=0.5,
+                           is_dist_dataloader=False)
+    table = m.embed.weight.clone()                           # host table before training
+    F = len(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ids = torch.stack([torch.randint(int(off[f]), int(off[f + 1]), (B,)) for f in range(F)]).view(-1)
+    offsets = torch.arange(F * B + 1, dtype=torch.int32)
+    out = m([ids.cuda(), offsets.cuda(), B], cache_op=True)
+    assert out.shape == (B, F, D)
+    exp = table[ids].view(F, B, D).transpose(0, 1)
+    assert torch.equal(out.cpu(), exp)
+    m2 = FusedSparseModules(sizes, D, reduction_mode="sum", sparse=True, use_cache=True, cache_ratio=0.5,
+                            is_dist_dataloader=False, fold_hook=True)
+    out2 = m2([ids.cuda(), offsets.cuda(), B])
+    assert out2.is_contiguous() and out2.shape == (B, F, D)
+    with pytest.raises(NotImplementedError):
+        FusedSparseModules(sizes, D, use_cache=False)
+    with pytest.raises(TypeError):
+        m(torch.zeros(3))
+
+
+def test_tablewise_arrangement_balances_rows():
+    from cachedembedding_amd import synthetic
+    from cachedembedding_amd.tablewise import get_tablewise_rank_arrange, prepare_tablewise_config
+    for sizes in (synthetic.CRITEO_KAGGLE, synthetic.CRITEO_1TB, synthetic.AVAZU):
+        for W in (1, 2, 4, 8):
+            arr = get_tablewise_rank_arrange(sizes, W)
+            loads = [sum(s for s, r in zip(sizes, arr) if r == k) for k in range(W)]
+            assert len(arr) == len(sizes) and max(loads) <= sum(sizes) / W + max(sizes)
+    cfg = prepare_tablewise_config([100, 100000], 0.01, None, "criteo_kaggle", 2)
+    assert [c.cuda_row_num for c in cfg] == [100, 3000] and {c.assigned_rank for c in cfg} == {0, 1}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tablewise(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cachedembedding_amd.tablewise import ParallelCachedEmbeddingBagTablewise, TablewiseEmbeddingBagConfig
+        torch.manual_seed(0)
+        sizes, D, B = [40, 300, 25, 120], 16, 8
+        tables = [torch.randn(n, D) for n in sizes]
+        arrange = [0, 1, 1, 0] if world == 2 else [0, 0, 0, 0]
+        cfgs = [TablewiseEmbeddingBagConfig(n, max(8, n // 4), arrange[i], initial_weight=tables[i])
+                for i, n in enumerate(sizes)]
+        m = ParallelCachedEmbeddingBagTablewise(cfgs, D, sparse=True, mode="sum", include_last_offset=True)
+        mine = [i for i, r in enumerate(arrange) if r == rank]
+        ids_per_table = [torch.randint(0, n, (B,)) for n in sizes]               # global batch, same on all ranks
+        loc_off = np.concatenate([[0], np.cumsum([sizes[i] for i in mine])])
+        values = torch.cat([ids_per_table[t] + int(loc_off[k]) for k, t in enumerate(mine)])
+        offsets = torch.arange(len(mine) * B + 1, dtype=torch.int32)
+        Fq = len(sizes)
+        out = m(values.cuda(), offsets.cuda(), shape_hook=lambda x: x.view(x.shape[0], Fq, -1))
+        order = [t for r in range(world) for t in range(Fq) if arrange[t] == r]    # rank-major table order
+        exp = torch.stack([tables[t][ids_per_table[t]] for t in order], dim=1)      # [B, F, D]
+        exp = torch.tensor_split(exp, world, dim=0)[rank]
+        torch.testing.assert_close(out.cpu(), exp, rtol=1e-6, atol=1e-6)
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_tablewise_parallel(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_tablewise, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    res = [q.get() for _ in range(world) if not q.empty()]
+    assert len(res) == world and all(r[1] == "ok" for r in res), res
+
+
+@pytest.mark.parametrize("mode", ["sequential", "overlap", "graph"])
+def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode):
+    """_train's window block in its three forms gives the same training trajectory as a plain full-table
+    EmbeddingBag with SGD (each window's unique rows fit the cache even when two windows are protected)."""
+    import cachedembedding_amd as ce
+    from cachedembedding_amd.pipeline import GraphedWindow, PrefetchWindow
+    torch.manual_seed(0)
+    N, D, F, B, P, lr, nwin = 20000, 64, 4, 64, 4, 0.5, 6
+    w0 = torch.randn(N, D)
+    emb = ce.CachedEmbeddingBag(N, D, sparse=True, _weight=w0.clone(), mode="sum", include_last_offset=True,
+                                cuda_row_num=4 * F * B * P, warmup_ratio=0.5, strict=False)
+    emb.set_fused_sgd(lr)
+    emb.set_cache_op(False)
+    off = torch.arange(F * B + 1, dtype=torch.int32, device="cuda")
+    grad = (torch.randn(B, F, D) * 0.1).cuda()
+    g = torch.Generator().manual_seed(5)
+    windows = [[(torch.rand(F * B, generator=g) ** 3 * N).long().clamp_(0, N - 1) for _ in range(P)] for _ in range(nwin)]
+    ref = w0.clone()
+
+    def step(slots, i):
+        out = emb(slots, off, hook_features=F)
+        out.backward(grad)
+
+    if mode == "graph":
+        gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=[v.cuda() for v in windows[0]])
+        # the capture warm-up trained on window 0 twice over (eager pass + nothing else): replay that on the ref
+        for v in windows[0]:
+            ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+        gw.submit([v.cuda() for v in windows[0]], 0)
+        for w in range(nwin):
+            if w + 1 < nwin:
+                gw.submit([v.cuda() for v in windows[w + 1]], (w + 1) % 2)
+            gw.run(w % 2)
+    else:
+        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"))
+        if mode == "overlap":
+            win.submit([v.cuda() for v in windows[0]])
+        for w in range(nwin):
+            if mode == "overlap":
+                slots = win.collect()
+                if w + 1 < nwin:
+                    win.submit([v.cuda() for v in windows[w + 1]])
+            else:
+                slots = win.prepare([v.cuda() for v in windows[w]])
+            for i in range(P):
+                step(slots[i], i)
+    for w in range(nwin):
+        for v in windows[w]:
+            ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+    torch.cuda.synchronize()
+    assert emb.cache_weight_mgr.sync_stats().status == 0
+    emb.flush()
+    torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
