@@ -266,7 +266,20 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(embed, gen, args, B, F, L, D)
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
+
+
+def emit(result):
+    """The JSON line must be the LAST thing on stdout: flush whatever C libraries (RCCL's version banner) still
+    hold in stdio buffers first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(result) + "\n")
+    sys.stdout.flush()
 
 
 def run_sharded(args, sizes, rank, world, dev):
@@ -349,9 +362,9 @@ def run_sharded(args, sizes, rank, world, dev):
                   "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "setup_s": setup_s},
         "roofline": None, "cpu_baseline": None,
     }
-    if rank == 0:
-        print(json.dumps(result))
     dist.destroy_process_group()
+    if rank == 0:
+        emit(result)
 
 
 def cpu_baseline(embed, gen, args, B, F, L, D):

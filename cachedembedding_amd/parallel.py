@@ -176,8 +176,15 @@ class ShardOps:
     rank: int
     dim: int
 
-    def bucketize(self, ids: torch.Tensor):                   # -> local_rows[n] (bucket order), perm[n], counts[W]
+    def bucketize(self, ids: torch.Tensor):
+        """-> (local_rows[n_u] of the batch's UNIQUE rows in owner-bucket order, pos[n]: lookup j -> position of
+        its row in that list, counts[W]).  Only unique rows travel: a Criteo-shaped batch of 425,984 lookups
+        holds ~40 k distinct rows, so the all-to-all payload shrinks ~10x and the requester expands locally."""
         raise NotImplementedError
+
+    def bucketize_many(self, ids_list: Sequence[torch.Tensor]):
+        """bucketize every batch of a window (implementations may batch their host syncs)."""
+        return [self.bucketize(ids) for ids in ids_list]
 
     def owner_prepare(self, local_rows: torch.Tensor):       # -> slots[n_recv]
         raise NotImplementedError
@@ -185,10 +192,11 @@ class ShardOps:
     def owner_gather(self, slots: torch.Tensor):             # -> rows fp32[n_recv, D]
         raise NotImplementedError
 
-    def pool(self, rows, perm, offsets, psw, mode, include_last, hook_features):   # -> pooled
+    def pool(self, rows, pos, offsets, psw, mode, include_last, hook_features):   # -> pooled
         raise NotImplementedError
 
-    def grad_rows(self, grad_out, perm, offsets, psw, mode, include_last, hook_features, n):  # -> fp32[n, D]
+    def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u):
+        """-> fp32[n_u, D]: gradient of every unique row (duplicates of the batch already summed)."""
         raise NotImplementedError
 
     def owner_update(self, slots, grad_rows, lr):            # cache rows -= lr * grad (duplicates summed)
@@ -198,27 +206,77 @@ class ShardOps:
 class HipShardOps(ShardOps):
     """ShardOps over libce_hip.so: ce_bucketize_rows, the local CachedParamMgr, ce_bag_* kernels."""
 
-    def __init__(self, mgr: CachedParamMgr, idx_map: Optional[torch.Tensor], world: int, rank: int):
+    def __init__(self, mgr: CachedParamMgr, idx_map: Optional[torch.Tensor], world: int, rank: int,
+                 num_global_rows: Optional[int] = None):
         _lib.require_gpu()
         self.mgr = mgr
         self.idx_map = idx_map            # GLOBAL id -> global rank row (replicated), None = identity
         self.world, self.rank = world, rank
         self.dim = mgr.embedding_dim
         self._ws = None
+        self.num_global_rows = num_global_rows
+        self._stamp = None                # ce_dedupe_rows state: int32[N] stamps + scratch, call tag
+        self._slot_of_row = None
+        self._tag = 0
+
+    def _bucketize_unique(self, uniq: torch.Tensor, n_u: int, inv: torch.Tensor):
+        dev = uniq.device
+        rows = torch.empty(n_u, dtype=torch.int64, device=dev)
+        perm_u = torch.empty(n_u, dtype=torch.int64, device=dev)
+        counts = torch.empty(self.world, dtype=torch.int64, device=dev)
+        need = lib.ce_bucketize_workspace(n_u, self.world)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+        check(lib.ce_bucketize_rows(ptr(uniq), n_u, None, self.world, ptr(rows), ptr(perm_u), ptr(counts),
+                                    ptr(self._ws), self._ws.numel(), stream_ptr()))
+        return rows, perm_u[inv], counts
+
+    def bucketize_many(self, ids_list):
+        """Window form: ce_dedupe_rows for every batch (no sync), ONE readback of the unique counts, then the
+        owner bucketing of each batch's unique rows."""
+        if self.num_global_rows is None:
+            return [self.bucketize(ids) for ids in ids_list]
+        dev = ids_list[0].device
+        N = self.num_global_rows
+        if self._stamp is None:
+            self._stamp = torch.zeros(N, dtype=torch.int32, device=dev)
+            self._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
+        P = len(ids_list)
+        n_unique = torch.empty(P, dtype=torch.int64, device=dev)
+        staged = []
+        for b, ids in enumerate(ids_list):
+            ids = ids.reshape(-1).long().contiguous()
+            n = ids.numel()
+            uniq = torch.empty(n, dtype=torch.int64, device=dev)
+            inv = torch.empty(n, dtype=torch.int64, device=dev)
+            self._tag += 1
+            if self._tag >= 2 ** 31 - 1:
+                self._stamp.zero_()
+                self._tag = 1
+            check(lib.ce_dedupe_rows(ptr(ids), n, ptr(self.idx_map), N, self._tag, ptr(self._stamp),
+                                     ptr(self._slot_of_row), ptr(uniq), ptr(inv), n_unique[b:].data_ptr(),
+                                     stream_ptr()))
+            staged.append((uniq, inv))
+        counts_h = n_unique.cpu().tolist()            # the only host sync of the dedupe phase
+        return [self._bucketize_unique(u[:c], int(c), inv) for (u, inv), c in zip(staged, counts_h)]
 
     def bucketize(self, ids):
         ids = ids.reshape(-1).long().contiguous()
-        n = ids.numel()
         dev = ids.device
-        rows = torch.empty(n, dtype=torch.int64, device=dev)
-        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        rows_all = self.idx_map[ids].long() if self.idx_map is not None else ids
+        # unique rows of the batch (torch.unique: plumbing for now; a device bitmap pass like the cache
+        # manager's would avoid its sort and its host sync)
+        uniq, inv = torch.unique(rows_all, return_inverse=True)
+        n_u = uniq.numel()
+        rows = torch.empty(n_u, dtype=torch.int64, device=dev)
+        perm_u = torch.empty(n_u, dtype=torch.int64, device=dev)
         counts = torch.empty(self.world, dtype=torch.int64, device=dev)
-        need = lib.ce_bucketize_workspace(n, self.world)
+        need = lib.ce_bucketize_workspace(n_u, self.world)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
-        check(lib.ce_bucketize_rows(ptr(ids), n, ptr(self.idx_map), self.world, ptr(rows), ptr(perm), ptr(counts),
+        check(lib.ce_bucketize_rows(ptr(uniq), n_u, None, self.world, ptr(rows), ptr(perm_u), ptr(counts),
                                     ptr(self._ws), self._ws.numel(), stream_ptr()))
-        return rows, perm, counts
+        return rows, perm_u[inv], counts
 
     def owner_prepare(self, local_rows):
         return self.mgr.prepare_ids(local_rows)
@@ -233,7 +291,8 @@ class HipShardOps(ShardOps):
                                      _lib.CE_MODE_SUM, 0, ptr(out), stream_ptr()))
         return out
 
-    def pool(self, rows, perm, offsets, psw, mode, include_last, hook_features):
+    def pool(self, rows, pos, offsets, psw, mode, include_last, hook_features):
+        perm = pos
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
         if hook_features:
             out = torch.empty(num_bags // hook_features, hook_features, self.dim, dtype=torch.float32,
@@ -245,12 +304,13 @@ class HipShardOps(ShardOps):
                                  _MODES[mode], hook_features, ptr(out), stream_ptr()))
         return out
 
-    def grad_rows(self, grad_out, perm, offsets, psw, mode, include_last, hook_features, n):
+    def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u):
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
-        g = torch.empty(n, self.dim, dtype=torch.float32, device=grad_out.device)
-        check(lib.ce_bag_backward_rows(ptr(g), ptr(perm), self.dim, n, ptr(offsets),
-                                       int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
-                                       _MODES[mode], hook_features, ptr(grad_out.contiguous()), stream_ptr()))
+        g = torch.zeros(n_u, self.dim, dtype=torch.float32, device=grad_out.device)
+        # tile-sorted accumulate: duplicates of a row inside the batch are summed here, before they travel
+        check(lib.ce_bag_backward_dense(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
+                                        int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
+                                        _MODES[mode], hook_features, ptr(grad_out.contiguous()), stream_ptr()))
         return g
 
     def owner_update(self, slots, grad_rows, lr):
@@ -277,8 +337,8 @@ def _arange_offsets(n: int, device) -> torch.Tensor:
 
 @dataclass
 class BatchPlan:
-    n: int
-    perm: torch.Tensor
+    n: int                      # unique rows of the batch (= rows exchanged)
+    perm: torch.Tensor          # int64[lookups]: lookup j -> position of its row in my bucket-ordered list
     send_splits: List[int]      # lookups I send to each peer (== rows each peer returns to me)
     recv_splits: List[int]      # lookups each peer sends me (rows I own)
     recv_rows: torch.Tensor     # local row ids I serve, peer-major
@@ -300,7 +360,7 @@ class RowwiseExchange:
         """Bucket every batch of the window by owner, exchange counts (one host sync per WINDOW) and
         ids, then run ONE owner-side cache op over all rows this rank serves in the window."""
         W, P = self.world, len(ids_list)
-        buck = [self.ops.bucketize(ids) for ids in ids_list]
+        buck = self.ops.bucketize_many(ids_list)
         send = torch.stack([b[2] for b in buck], dim=1).contiguous()          # [W, P]
         recv = torch.empty_like(send)
         if W > 1:
@@ -410,7 +470,7 @@ class RowwiseShardedEmbeddingBag(nn.Module):
         if ids_freq_mapping is not None and evict_strategy == EvictionStrategy.LFU:
             local_freq = torch.as_tensor(ids_freq_mapping).view(-1)[r::W]
         self.cache_weight_mgr.reorder(local_freq, warmup_ratio)
-        self.ops = HipShardOps(self.cache_weight_mgr, self.idx_map, W, r)
+        self.ops = HipShardOps(self.cache_weight_mgr, self.idx_map, W, r, num_global_rows=num_embeddings)
         self.exchange = RowwiseExchange(self.ops, self.group)
         self._lr = [None]
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)

@@ -1,11 +1,4 @@
-run() { echo "== $*"; timeout 600 python bench.py --no_cpu_baseline "$@" 2>gpurun_out/err.txt | python -c "
+timeout 900 python -m pytest tests/test_gpu_parallel.py -m gpu -x -q 2>&1 | tail -3
+timeout 600 python bench.py --force_sharded 2>gpurun_out/err.txt | tail -1 | python -c "
 import sys,json
-try:
-    d=json.loads(sys.stdin.read()); print('  %.1f M lookups/s  step %.3f ms' % (d['value']/1e6, d['ms_per_step']))
-except Exception as e:
-    print('  FAILED', e)" ; grep -E "Error|error" gpurun_out/err.txt | tail -2; }
-timeout 600 python -m pytest tests/test_gpu_cache.py tests/test_gpu_parallel.py -m gpu -x -q 2>&1 | tail -2
-run
-run --no_overlap
-run --use_lfu
-CE_SWAP_BLOCKS=64 run
+d=json.loads(sys.stdin.read()); print('sharded W=1: %.1f M lookups/s  step %.3f ms' % (d['value']/1e6, d['ms_per_step']))"; tail -2 gpurun_out/err.txt

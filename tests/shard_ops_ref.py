@@ -18,13 +18,14 @@ class TorchShardOps(ShardOps):
 
     def bucketize(self, ids):
         ids = ids.reshape(-1).long()
-        rows = self.idx_map[ids].long() if self.idx_map is not None else ids
+        rows_all = self.idx_map[ids].long() if self.idx_map is not None else ids
+        rows, inv = torch.unique(rows_all, return_inverse=True)       # only unique rows travel
         owner = rows % self.world
         order = torch.argsort(owner, stable=True)              # stable counting sort by owner
         perm = torch.empty_like(order)
-        perm[order] = torch.arange(ids.numel())
+        perm[order] = torch.arange(rows.numel())
         counts = torch.bincount(owner, minlength=self.world).long()
-        return (rows[order] // self.world).contiguous(), perm, counts
+        return (rows[order] // self.world).contiguous(), perm[inv], counts
 
     def owner_prepare(self, local_rows):
         return torch.from_numpy(self.mgr.prepare_ids(local_rows.numpy()))

@@ -74,7 +74,7 @@ def _rowwise(rank, world, mode, hook):
     plans = ex.plan_window(ids_list)
     ref_w = w_full.clone()                    # global table indexed by re-ranked row
     for ids, plan in zip(ids_list, plans):
-        assert sum(plan.send_splits) == ids.numel() and plan.recv_rows.numel() == sum(plan.recv_splits)
+        assert sum(plan.send_splits) == plan.n == len(torch.unique(ids)) and plan.recv_rows.numel() == sum(plan.recv_splits)
         rows = ex.fetch_rows(plan)
         out = ops.pool(rows, plan.perm, offsets, None, mode, True, F if hook else 0)
         # expected: plain EmbeddingBag over the full table (row = idx_map[id]); all ranks' updates of the

@@ -1,0 +1,137 @@
+"""Cache-manager checks that do not fit the small fixtures: oracle parity at medium size, size-independent
+properties at the FULL Criteo-1TB index size (N = 177,944,275 rows, C = 1,779,442 slots, 3.4 M ids per call;
+D = 4 keeps the host table at 2.8 GB -- the cache op does not depend on D), and hypothesis-driven random
+streams against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ce():
+    import cachedembedding_amd as ce
+    return ce
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+def test_medium_size_exact_vs_oracle(strategy):
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr, id_freq_map, power_law_ids
+    rng = np.random.default_rng(77)
+    N, C, D, n_ids = 2_000_003, 150_000, 8, 400_000
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    perm = rng.permutation(N)
+    freq = id_freq_map(perm[power_law_ids(rng, N, 2_000_000, 0.25)], N)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+    ora.reorder(freq, 0.7)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C,
+                            evict_strategy=ce.EvictionStrategy.LFU if strategy == "lfu" else ce.EvictionStrategy.DATASET)
+    mgr.reorder(freq, 0.7)
+    for c in range(5):
+        ids = perm[power_law_ids(rng, N, n_ids, 0.25)]
+        exp = ora.prepare_ids(ids)
+        got = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(got.cpu().numpy(), exp)
+        assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+        if strategy == "lfu":
+            assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+    assert mgr.num_miss_history == ora.num_miss_history and mgr.num_write_back_history == ora.num_write_back_history
+    assert sum(mgr.num_write_back_history) > 0, "the stream must exercise eviction"
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+def test_full_criteo1tb_index_size_properties(strategy):
+    ce = _ce()
+    from cachedembedding_amd import synthetic
+    sizes = synthetic.CRITEO_1TB
+    N, D, B, P = sum(sizes), 4, 16384, 8
+    C = int(N * 0.01)
+    assert N == 177_944_275 and C == 1_779_442
+    gen = synthetic.SyntheticKJT(sizes, B, 1, "power_law", 0.25, seed=11, device="cuda")
+    freq = gen.id_freq_map(16)
+    table = ce.HostTable.allocate(N, D)
+    # payload pattern: row r holds (r, r+1, r+2, r+3) mod 2^20 -- lets every admitted row be verified
+    t = table.tensor
+    chunk = 1 << 24
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        t[s:e] = ((torch.arange(s, e).unsqueeze(1) + torch.arange(D)) % (1 << 20)).float()
+    lfu = strategy == "lfu"
+    mgr = ce.CachedParamMgr(table, C, evict_strategy=ce.EvictionStrategy.LFU if lfu else ce.EvictionStrategy.DATASET)
+    mgr.reorder(freq, 0.7)
+    id2row = mgr.idx_map.long()
+    prev_resident = None
+    for call in range(12):
+        ids = gen.next_values(P).view(-1)                      # 3,407,872 ids
+        slots = mgr.prepare_ids(ids)
+        rows = id2row[ids]
+        cim = mgr.cached_idx_map.long()
+        inv = mgr.inverted_cached_idx.long()
+        assert int(slots.min()) >= 0 and int(slots.max()) < C
+        assert torch.equal(cim[slots], rows), "a lookup's slot must hold exactly the requested row"
+        occ = torch.nonzero(cim >= 0).view(-1)
+        assert torch.equal(inv[cim[occ]], occ), "cached_idx_map and inverted_cached_idx disagree"
+        assert int((inv >= 0).sum()) == occ.numel() == C - mgr.cuda_available_row_num
+        uniq = torch.unique(rows)
+        assert mgr.num_hits_history[-1] + mgr.num_miss_history[-1] == uniq.numel()
+        # payload: every resident row carries its own pattern (admit copied the right host row)
+        samp = occ[torch.randint(0, occ.numel(), (200_000,), device="cuda")]
+        exp = ((cim[samp].unsqueeze(1) + torch.arange(D, device="cuda")) % (1 << 20)).float()
+        assert torch.equal(mgr.cuda_cached_weight.detach()[samp], exp)
+        if prev_resident is not None and mgr.num_write_back_history[-1] > 0:
+            evicted = prev_resident[inv[prev_resident] < 0]
+            assert evicted.numel() == mgr.num_write_back_history[-1]
+            assert not torch.isin(evicted, uniq).any(), "a row of the current call was evicted"
+            if not lfu:
+                # DATASET evicts the coldest (largest re-ranked row) among unprotected residents
+                kept = prev_resident[inv[prev_resident] >= 0]
+                kept_unprot = kept[~torch.isin(kept, uniq)]
+                assert int(evicted.min()) > int(kept_unprot.max())
+        prev_resident = cim[occ].clone()
+    assert sum(mgr.num_write_back_history) > 0
+    mgr.flush()
+    assert mgr.cuda_available_row_num == C and int((mgr.inverted_cached_idx >= 0).sum()) == 0
+
+
+def test_hypothesis_random_streams_vs_oracle():
+    ce = _ce()
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+
+    @settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.integers(20, 400), st.integers(1, 40), st.sampled_from(["dataset", "lfu"]), st.booleans(),
+           st.integers(0, 1), st.floats(0.0, 1.0), st.integers(0, 2 ** 31 - 1))
+    def run(N, C, strategy, with_freq, depth, warm, seed):
+        C = min(C, N)
+        rng = np.random.default_rng(seed)
+        w = rng.standard_normal((N, 4)).astype(np.float32)
+        freq = rng.integers(0, 6, size=N) if with_freq else None
+        ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+        ora.protect_depth = depth
+        ora.reorder(freq, warm)
+        mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C, evict_strategy=ce.EvictionStrategy.LFU
+                                if strategy == "lfu" else ce.EvictionStrategy.DATASET)
+        mgr.reorder(freq, warm)
+        mgr.set_protect_depth(depth)
+        for _ in range(8):
+            n = int(rng.integers(0, 3 * C + 2))
+            ids = rng.integers(0, N, size=n)
+            try:
+                exp = ora.prepare_ids(ids)
+            except AssertionError:
+                with pytest.raises(AssertionError):
+                    mgr.prepare_ids(torch.from_numpy(ids).cuda())
+                if depth:          # after an overflow with a protected history the two may legitimately differ
+                    return
+                continue
+            got = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+            assert np.array_equal(got.cpu().numpy(), exp)
+            assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+            assert np.array_equal(mgr.inverted_cached_idx.cpu().numpy().astype(np.int64), ora.inverted_cached_idx)
+            if strategy == "lfu":
+                assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+            np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
+
+    run()
