@@ -56,9 +56,12 @@ __device__ __forceinline__ int64_t out_row(const BagParams& p, int g) {
   return (int64_t)b * p.hookF + f;
 }
 
+constexpr int kIdxStage = 2048;   // indices of one 64-bag tile staged in LDS (8 KB per wave)
+
 template <typename VT, int NCH>
 __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
   constexpr int U = (NCH == 1) ? 8 : (NCH == 2 ? 4 : 2);
+  __shared__ int lds_idx[4][kIdxStage];
   const int lane = threadIdx.x & 63;
   const int G = 1 << p.g_log2;
   const int gpw = 64 >> p.g_log2;
@@ -120,7 +123,18 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
         }
       }
     } else {
-      // ---- general tile: each lane group walks its bag, 4 rows in flight
+      // ---- general tile.  The 64 bags' indices are one contiguous range: stage it in LDS with coalesced
+      // loads (removes a dependent global round trip per step), then each lane group walks its bag with
+      // 8 rows in flight.
+      const int t_lo = __shfl(lo, 0);
+      const int t_hi = __shfl(hi, nb - 1);
+      const int t_n = t_hi - t_lo;
+      const bool staged = t_n <= kIdxStage;
+      int* sidx = &lds_idx[threadIdx.x >> 6][0];
+      if (staged) {
+        for (int k = lane; k < t_n; k += 64) sidx[k] = (int)p.indices[t_lo + k];
+      }
+      __builtin_amdgcn_wave_barrier();
       for (int base = 0; base < nb; base += gpw) {
         const int bi = base + grp;
         int blo = __shfl(lo, bi & 63);
@@ -129,30 +143,30 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
         VT acc[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
-        for (int j = blo; j < bhi; j += 4) {
-          int r[4];
-          float w[4];
+        for (int j = blo; j < bhi; j += 8) {
+          int r[8];
+          float w[8];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            r[t] = 0;
+          for (int t = 0; t < 8; ++t) {
+            r[t] = -1;
             w[t] = 1.f;
             if (j + t < bhi) {
-              r[t] = (int)p.indices[j + t];
+              r[t] = staged ? sidx[j + t - t_lo] : (int)p.indices[j + t];
               if (p.psw) w[t] = p.psw[j + t];
             }
           }
-          VT v[4][NCH];
+          VT v[8][NCH];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < 8; ++t) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
               const int ch = gl + c * G;
               v[t][c] = vzero<VT>();
-              if (j + t < bhi && ch < rowlen && (uint32_t)r[t] < p.num_rows) v[t][c] = W[(int64_t)r[t] * rowlen + ch];
+              if (ch < rowlen && (uint32_t)r[t] < p.num_rows) v[t][c] = W[(int64_t)r[t] * rowlen + ch];
             }
           }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < 8; ++t) {
             if (j + t < bhi) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c) acc[c] = p.psw ? acc[c] + v[t][c] * w[t] : acc[c] + v[t][c];
