@@ -41,7 +41,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="criteo_1tb", choices=["criteo_1tb", "criteo_kaggle", "avazu", "custom"])
     ap.add_argument("--batch_size", type=int, default=16384)
     ap.add_argument("--embedding_dim", type=int, default=128)
@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
     ap.add_argument("--deterministic", action="store_true", help="sorted segmented SGD update instead of atomics")
     ap.add_argument("--force_sharded", action="store_true", help="run the row-wise sharded code path even at N=1")
+    ap.add_argument("--no_prefill", action="store_true", help="skip the untimed cache-fill phase (cache ops on fresh "
+                    "windows until no slot is free, so the timed region is steady state incl. evictions whatever "
+                    "--warmup is)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=1024)
@@ -120,6 +123,12 @@ def main():
     setup_s = time.time() - t0
     note(f"host table {N * D * 4 / 1e9:.1f} GB pinned+initialised, cache C={C} rows warmed up")
 
+    prefill = 0
+    if not args.no_prefill:
+        while prefill < 64 and mgr.cuda_available_row_num > 0:
+            mgr.prepare_ids(gen.next_values(P).view(-1))
+            prefill += 1
+        note(f"cache filled by {prefill} untimed cache ops")
     total = W + K
     n_windows = (total + P - 1) // P
     # inputs resident in HBM before the timed region
@@ -127,7 +136,13 @@ def main():
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
     win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus)
-    use_graph = (not args.no_graph) and W % P == 0 and K % P == 0
+    use_graph = not args.no_graph
+    if use_graph and W % P:
+        W = (W // P + 1) * P          # graph mode trains whole windows: round the untimed warm-up up
+        total = W + K
+        n_windows = (total + P - 1) // P
+        while len(windows) < n_windows:
+            windows.append(gen.next_values(P))
 
     def train_step(slots_i, i):
         out = embed(slots_i, offsets, hook_features=F)
@@ -140,17 +155,19 @@ def main():
                            warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus)
         note("hipGraph of the window's training steps captured")
 
-    def run_windows(first_w, count_w):
-        """graph mode: window w = cache op (side stream, one window ahead when overlapping) + one graph replay"""
-        if args.overlap:
+    def run_windows(first_w, count_w, tail_steps=0):
+        """graph mode: window w = cache op (side stream, one window ahead when overlapping) + one graph replay;
+        tail_steps > 0 adds a trailing partial window of that many steps"""
+        last = first_w + count_w + (1 if tail_steps else 0)
+        if args.overlap and last > first_w:
             gw.submit([windows[first_w][i] for i in range(P)], first_w % 2)
-        for w in range(first_w, first_w + count_w):
+        for w in range(first_w, last):
             if args.overlap:
-                if w + 1 < n_windows:       # enqueued before graph w: overlaps with it
+                if w + 1 < last:            # enqueued before graph w: overlaps with it
                     gw.submit([windows[w + 1][i] for i in range(P)], (w + 1) % 2)
             else:
                 gw.submit([windows[w][i] for i in range(P)], w % 2)
-            gw.run(w % 2)
+            gw.run(w % 2, None if w < first_w + count_w else tail_steps)
 
     def run_steps(first, count, ev_pairs=None):
         slots = None
@@ -191,7 +208,7 @@ def main():
     note("warmup done")
     t1 = time.perf_counter()
     if use_graph:
-        run_windows(W // P, K // P)
+        run_windows(W // P, K // P, K % P)
     else:
         run_steps(W, K)
     enqueue_s = time.perf_counter() - t1
@@ -245,7 +262,8 @@ def main():
 
     result = {
         "metric": "embedding lookups/sec (cache op + EmbeddingBag fwd + bwd/SGD), Criteo-1TB table @1% cache",
-        "value": value, "unit": "lookups/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": value, "unit": "lookups/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "warmup_steps_run": W,
         "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
@@ -257,7 +275,7 @@ def main():
                    "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,
-                  "setup_s": setup_s},
+                  "prefill_cache_ops": prefill, "setup_s": setup_s},
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} |
                     {"kernel": dominant["kernel"], "avg_ms": dominant["avg_ms"], "bytes_per_launch": dominant["bytes_per_launch"]},
         "roofline_other": other,
@@ -312,6 +330,15 @@ def run_sharded(args, sizes, rank, world, dev):
     mgr = embed.cache_weight_mgr
     mgr.strict = False
     setup_s = time.time() - t0
+    prefill = 0
+    if not args.no_prefill:
+        while prefill < 64:
+            full = torch.tensor([int(mgr.cuda_available_row_num == 0)], device=dev)
+            dist.all_reduce(full, op=dist.ReduceOp.MIN)          # every rank runs the same number of windows
+            if int(full.item()):
+                break
+            embed.plan_window([v for v in gen.next_values(P)])
+            prefill += 1
     total = W + K
     n_windows = (total + P - 1) // P
     windows = [gen.next_values(P) for _ in range(n_windows)]
@@ -359,7 +386,7 @@ def run_sharded(args, sizes, rank, world, dev):
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB_per_gpu": mgr.num_embeddings * D * 4 / 1e9,
                    "sharding": f"row-wise x{world} (row % W), RCCL all-to-all-v", "update": "atomic", "lr": args.lr},
         "cache": {"rank0_unique_hit_rate": hits / max(1, hits + miss), "rank0_rows_in": tot["cpu_to_cuda_numel"] // D,
-                  "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "setup_s": setup_s},
+                  "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "prefill_cache_ops": prefill, "setup_s": setup_s},
         "roofline": None, "cpu_baseline": None,
     }
     dist.destroy_process_group()

@@ -444,7 +444,7 @@ __device__ __forceinline__ void copy_row(const VT* __restrict__ src, VT* __restr
 constexpr int kSwapRows = 16;   // rows in flight per lane group in the PCIe swap kernels
 
 template <typename VT>
-__global__ __launch_bounds__(256) void k_evict(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
+__global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
                                                int32_t* inverted, const VT* __restrict__ cache, VT* host,
                                                long long first, int rowlen, int g_log2, const Ctl* ctl) {
   const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
 }
 
 template <typename VT>
-__global__ __launch_bounds__(256) void k_writeback(const int32_t* __restrict__ stage_rows_idx,
+__global__ __launch_bounds__(1024) void k_writeback(const int32_t* __restrict__ stage_rows_idx,
                                                    const VT* __restrict__ stage, VT* host, long long cap, int rowlen,
                                                    int g_log2, const Ctl* ctl) {
   long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
 
 // rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i)
 template <typename VT>
-__global__ __launch_bounds__(256) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
+__global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                                const long long* n_ptr, long long n_imm,
                                                const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
                                                const Ctl* ctl) {
@@ -1108,7 +1108,13 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     return e ? atoi(e) : 0;
   }();
   const int swap_blocks = swap_blocks_env > 0 ? swap_blocks_env : (c.protect_depth > 0 ? 32 : 512);
-  const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, gpb * kSwapRows)));
+  static const int swap_threads = [] {
+    const char* e = getenv("CE_SWAP_THREADS");
+    const int v = e ? atoi(e) : 256;
+    return (v == 256 || v == 512 || v == 1024) ? v : 256;
+  }();
+  const dim3 swap_block(swap_threads);
+  const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, (swap_threads >> h->g_log2) * kSwapRows)));
 
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
   {
@@ -1150,24 +1156,24 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
       hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
                          (const f32x4*)c.cache_weight, (f32x4*)h->stage, h->stage_idx, scap, h->rowlen, h->g_log2,
                          h->ctl);
-      hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), dim3(256), 0, s, h->victims, c.cached_idx_map,
+      hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
                          (const float*)c.cache_weight, (float*)h->stage, h->stage_idx, scap, h->rowlen, h->g_log2,
                          h->ctl);
-      hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), dim3(256), 0, s, h->victims, c.cached_idx_map,
+      hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
     }
     CE_HIP_CHECK(hipEventRecord(h->ev_fork, s));
     CE_HIP_CHECK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
     if (h->vec)
-      hipLaunchKernelGGL((k_writeback<f32x4>), dim3(cap_groups), dim3(256), 0, h->aux, h->stage_idx,
+      hipLaunchKernelGGL((k_writeback<f32x4>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
                          (const f32x4*)h->stage, (f32x4*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
     else
-      hipLaunchKernelGGL((k_writeback<float>), dim3(cap_groups), dim3(256), 0, h->aux, h->stage_idx,
+      hipLaunchKernelGGL((k_writeback<float>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
                          (const float*)h->stage, (float*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
     CE_HIP_CHECK(hipEventRecord(h->ev_join, h->aux));
     hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
@@ -1183,11 +1189,11 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                      h->blk_free, h->free_list, h->ctl);
   if (c.transport == CE_TRANSPORT_ZEROCOPY) {
     if (h->vec)
-      hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), dim3(256), 0, s, h->miss_list, h->free_list,
+      hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
                          (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
                          (f32x4*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl);
     else
-      hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), dim3(256), 0, s, h->miss_list, h->free_list,
+      hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
                          (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
                          (float*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl);
   } else {

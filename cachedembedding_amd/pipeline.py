@@ -111,6 +111,7 @@ class GraphedWindow:
         self._bufs = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
         self._side = make_side_stream(dev, cache_cus) if overlap else None
         self._events = [None, None]
+        self._step_fn = step_fn
         if overlap:
             self.mgr.set_protect_depth(1)
             self.mgr.strict = False
@@ -153,9 +154,14 @@ class GraphedWindow:
             self.mgr.prepare_ids(cat, out=self._bufs[buf])
             self._events[buf] = None
 
-    def run(self, buf: int) -> None:
-        """Replay the P training steps on the slots in buffer `buf` (waits for its cache op)."""
+    def run(self, buf: int, steps: Optional[int] = None) -> None:
+        """Replay the P training steps on the slots in buffer `buf` (waits for its cache op).  steps < P runs
+        only the first `steps` batches, eagerly (a trailing partial window)."""
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
-        self._graphs[buf].replay()
+        if steps is None or steps >= self.P:
+            self._graphs[buf].replay()
+        else:
+            for i in range(steps):
+                self._step_fn(self._bufs[buf][i], i)
