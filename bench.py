@@ -170,6 +170,7 @@ def main():
             gw.run(w % 2, None if w < first_w + count_w else tail_steps)
 
     def run_steps(first, count, ev_pairs=None):
+        nonlocal win
         slots = None
         if win.overlap and win._pending is not None:
             win.collect()      # drop a window submitted by an earlier, non-contiguous call
@@ -225,7 +226,12 @@ def main():
     tot = mgr.totals()
 
     # ---- per-kernel launch duration with HIP events on the launch stream (separate pass, same data)
+    # (sequential window on the compute stream: no side-stream interference, which is also how rocprofv3 sees
+    # the kernels -- it serialises the streams -- so the two averages are comparable)
     evs = []
+    if win.overlap:
+        torch.cuda.synchronize()
+        win = PrefetchWindow(embed, P, overlap=False)
     run_steps(W, min(K, 4 * P), evs)
     torch.cuda.synchronize()
     fwd_ms = sorted(e0.elapsed_time(e1) for e0, e1, _ in evs)

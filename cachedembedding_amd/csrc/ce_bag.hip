@@ -40,6 +40,7 @@ struct BagParams {
   int32_t idx_bits;         // bits needed to tell two row indices apart (bwd duplicate matching)
   int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
   uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
+  int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -58,10 +59,11 @@ __device__ __forceinline__ int64_t out_row(const BagParams& p, int g) {
 
 constexpr int kIdxStage = 2048;   // indices of one 64-bag tile staged in LDS (8 KB per wave)
 
-template <typename VT, int NCH>
+// STAGE: tiles with multi-id bags stage their indices in LDS (32 KB per workgroup); the launcher picks the
+// LDS-free variant when nnz == num_bags (single-id batches) so occupancy is set by registers alone.
+template <typename VT, int NCH, bool STAGE, int U>
 __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
-  constexpr int U = (NCH == 1) ? 8 : (NCH == 2 ? 4 : 2);
-  __shared__ int lds_idx[4][kIdxStage];
+  __shared__ int lds_idx[STAGE ? 4 : 1][STAGE ? kIdxStage : 1];
   const int lane = threadIdx.x & 63;
   const int G = 1 << p.g_log2;
   const int gpw = 64 >> p.g_log2;
@@ -70,10 +72,12 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
   const int wpb = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * wpb;
-  const int ntiles = (p.num_bags + 63) >> 6;
   const VT* __restrict__ W = (const VT*)p.weight;
   VT* __restrict__ O = (VT*)p.dst;
   const int rowlen = p.rowlen;
+  // tiles are dealt round-robin to the waves of an oversubscribed grid (an even contiguous split over a
+  // resident-sized grid measured 15 % slower: 0.060 -> 0.069 ms)
+  const int ntiles = (p.num_bags + 63) >> 6;
 
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int b0 = (int)(tile << 6);
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
       const int t_lo = __shfl(lo, 0);
       const int t_hi = __shfl(hi, nb - 1);
       const int t_n = t_hi - t_lo;
-      const bool staged = t_n <= kIdxStage;
-      int* sidx = &lds_idx[threadIdx.x >> 6][0];
+      const bool staged = STAGE && t_n <= kIdxStage;
+      int* sidx = &lds_idx[STAGE ? (threadIdx.x >> 6) : 0][0];
       if (staged) {
         for (int k = lane; k < t_n; k += 64) sidx[k] = (int)p.indices[t_lo + k];
       }
@@ -423,9 +427,30 @@ __device__ __forceinline__ int find_bag(const BagParams& p, int j) {
   return lo;
 }
 
-template <typename VT, int NCH>
+// sort keys: (row, lookup-in-tile).  32-bit keys (row < 2^22, i.e. caches up to 4 M rows) halve the LDS traffic
+// of the bitonic network; wider tables fall back to 64-bit keys.
+template <typename KT> struct KeyOps;
+template <> struct KeyOps<uint32_t> {
+  static __device__ __forceinline__ uint32_t make(uint32_t row, int i) { return (row << 10) | (uint32_t)i; }
+  static __device__ __forceinline__ uint32_t row(uint32_t k) { return k >> 10; }
+  static __device__ __forceinline__ int idx(uint32_t k) { return (int)(k & 1023u); }
+  static __device__ __forceinline__ uint32_t invalid() { return 0xffffffffu; }
+  static __device__ __forceinline__ uint32_t row_invalid() { return 0x3fffffu; }
+};
+template <> struct KeyOps<unsigned long long> {
+  static __device__ __forceinline__ unsigned long long make(uint32_t row, int i) {
+    return ((unsigned long long)row << 32) | (uint32_t)i;
+  }
+  static __device__ __forceinline__ uint32_t row(unsigned long long k) { return (uint32_t)(k >> 32); }
+  static __device__ __forceinline__ int idx(unsigned long long k) { return (int)(uint32_t)k; }
+  static __device__ __forceinline__ unsigned long long invalid() { return ~0ull; }
+  static __device__ __forceinline__ uint32_t row_invalid() { return 0xffffffffu; }
+};
+
+template <typename VT, int NCH, typename KT, int R>
 __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
-  __shared__ unsigned long long keys[kBwdTile];
+  using K = KeyOps<KT>;
+  __shared__ KT keys[kBwdTile];
   __shared__ int bagl[kBwdTile];
   __shared__ float scl[kBwdTile];
 
@@ -437,14 +462,17 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   const int rowlen = p.rowlen;
   const int dim = rowlen * (int)(sizeof(VT) / 4);
   const VT* __restrict__ GO = (const VT*)p.grad_out;
-  const int ntiles = (int)((p.nnz + kBwdTile - 1) / kBwdTile);
+  // tile_len <= kBwdTile is chosen by the launcher so that the tile count is a multiple of the CU count
+  // (425,984 lookups -> 512 tiles of 832: two per CU, instead of 416 tiles = 1 or 2 per CU)
+  const int tile_len = p.tile_len;
+  const int ntiles = (int)((p.nnz + tile_len - 1) / tile_len);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int j0 = tile * kBwdTile;
-    const int nv = min(kBwdTile, (int)(p.nnz - j0));
-    // ---- a. keys, bag and scale of every lookup of the tile
+    const int j0 = tile * tile_len;
+    const int nv = min(tile_len, (int)(p.nnz - j0));
+    // ---- a. keys, bag and scale of every lookup of the tile (out-of-range rows become invalid keys)
     for (int i = tid; i < kBwdTile; i += 256) {
-      unsigned long long key = ~0ull;
+      KT key = K::invalid();
       if (i < nv) {
         const int j = j0 + i;
         const int bag = find_bag(p, j);
@@ -456,13 +484,14 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         }
         bagl[i] = bag;
         scl[i] = sc;
-        key = ((unsigned long long)(unsigned)p.indices[j] << 32) | (unsigned)i;
+        const int64_t r = p.indices[j];
+        if ((uint64_t)r < (uint64_t)p.num_rows) key = K::make((uint32_t)r, i);
       }
       keys[i] = key;
     }
     __syncthreads();
     if (p.debug == 3) continue;
-    // ---- b. bitonic sort (row major, lookup minor) -> runs are in lookup order
+    // ---- b. bitonic sort (row major, lookup minor) -> runs are in lookup order, invalid keys last
     for (int k = 2; k <= kBwdTile; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -470,7 +499,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
           const int c = tid + t * 256;
           const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
           const int l = i | j;
-          const unsigned long long a = keys[i], b = keys[l];
+          const KT a = keys[i], b = keys[l];
           const bool up = (i & k) == 0;
           if ((a > b) == up) {
             keys[i] = b;
@@ -480,9 +509,9 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         __syncthreads();
       }
     }
-    // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, 8 gradient rows in flight,
-    // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated R
-    // times in the tile costs R/kChunk+1 atomics instead of R.
+    // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, R gradient rows in flight,
+    // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated n
+    // times in the tile costs n/kChunk+1 atomics instead of n.
     constexpr int kChunk = 32;
     if (p.debug == 4) continue;
     const int nchunks = (nv + kChunk - 1) / kChunk;
@@ -491,17 +520,17 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       VT acc[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
-      unsigned cur = (unsigned)(keys[s0] >> 32);
-      for (int q = s0; q < s1; q += 8) {
-        VT v[8][NCH];
-        float sc[8];
-        unsigned rw[8];
+      uint32_t cur = K::row(keys[s0]);
+      for (int q = s0; q < s1; q += R) {
+        VT v[R][NCH];
+        float sc[R];
+        uint32_t rw[R];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const bool on = q + t < s1;
-          const unsigned long long key = on ? keys[q + t] : 0ull;
-          const int li = (int)(unsigned)key;
-          rw[t] = on ? (unsigned)(key >> 32) : 0xffffffffu;
+        for (int t = 0; t < R; ++t) {
+          const KT key = (q + t < s1) ? keys[q + t] : K::invalid();
+          const bool on = key != K::invalid();
+          const int li = on ? K::idx(key) : 0;
+          rw[t] = on ? K::row(key) : K::row_invalid();
           sc[t] = on ? scl[li] : 0.f;
           const int64_t orow = out_row(p, bagl[li]);
 #pragma unroll
@@ -512,12 +541,13 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
           }
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (rw[t] != 0xffffffffu) {          // group-uniform
+        for (int t = 0; t < R; ++t) {
+          if (rw[t] != K::row_invalid()) {          // group-uniform
             if (rw[t] != cur) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c) {
-                if (cur < p.num_rows) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+                if (cur != K::row_invalid())
+                  flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
                 acc[c] = vzero<VT>();
               }
               cur = rw[t];
@@ -529,7 +559,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (cur < p.num_rows) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+        if (cur != K::row_invalid()) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
       }
     }
     __syncthreads();
@@ -595,24 +625,22 @@ static int launch_bwd(const BagParams& p, bool vec, int nch, hipStream_t s) {
     const char* dbg = getenv("CE_BWD_DEBUG");
     BagParams q = p;
     q.debug = dbg ? atoi(dbg) : 0;
-    const char* sv = getenv("CE_BWD_SCALAR");
-    if (sv && atoi(sv) && vec) {       // experiment: dword-strided lanes (contiguous 256 B per atomic instr)
-      vec = false;
-      q.rowlen = p.rowlen * 4;
-      int g = 1, gl2 = 0;
-      while (g < q.rowlen && g < 64) { g <<= 1; ++gl2; }
-      q.g_log2 = gl2;
-      nch = 1;
-      while (nch * g < q.rowlen) nch <<= 1;
-      if (nch > 4) return CE_ERR_UNSUPPORTED;
-    }
-    const int ntiles = (int)cdiv(p.nnz, kBwdTile);
+    const int tile_len = kBwdTile;      // (a CU-multiple tile count, 512 x 832, measured no better: 0.105 -> 0.108 ms)
+    q.tile_len = tile_len;
+    const int ntiles = (int)cdiv(p.nnz, tile_len);
     dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
-#define CE_BWT(VT, N) hipLaunchKernelGGL((k_bag_bwd_tile<VT, N>), grid, block, 0, s, q)
+    const bool k32 = q.num_rows <= (1u << 22) - 2;
+    static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
+#define CE_BWT(VT, N, R)                                                                              \
+  do {                                                                                                \
+    if (k32) hipLaunchKernelGGL((k_bag_bwd_tile<VT, N, uint32_t, R>), grid, block, 0, s, q);          \
+    else hipLaunchKernelGGL((k_bag_bwd_tile<VT, N, unsigned long long, R>), grid, block, 0, s, q);    \
+  } while (0)
     if (vec) {
-      if (nch == 1) CE_BWT(f32x4, 1); else if (nch == 2) CE_BWT(f32x4, 2); else CE_BWT(f32x4, 4);
+      if (nch == 1) { if (r_env == 8) CE_BWT(f32x4, 1, 8); else CE_BWT(f32x4, 1, 16); }
+      else if (nch == 2) CE_BWT(f32x4, 2, 4); else CE_BWT(f32x4, 4, 2);
     } else {
-      if (nch == 1) CE_BWT(float, 1); else if (nch == 2) CE_BWT(float, 2); else CE_BWT(float, 4);
+      if (nch == 1) CE_BWT(float, 1, 8); else if (nch == 2) CE_BWT(float, 2, 4); else CE_BWT(float, 4, 2);
     }
 #undef CE_BWT
     CE_LAUNCH_CHECK();
@@ -652,11 +680,20 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
   p.num_rows = (uint32_t)num_rows;
   dim3 grid(bag_grid(num_bags)), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define CE_FWD(VT, N) hipLaunchKernelGGL((k_bag_fwd<VT, N>), grid, block, 0, s, p)
+  const bool stage = nnz != num_bags;      // multi-id bags possible
+  static const int u_env = [] { const char* e = getenv("CE_FWD_U"); return e ? atoi(e) : 16; }();
+#define CE_FWD(VT, N, U)                                                                   \
+  do {                                                                                     \
+    if (stage) hipLaunchKernelGGL((k_bag_fwd<VT, N, true, U>), grid, block, 0, s, p);      \
+    else hipLaunchKernelGGL((k_bag_fwd<VT, N, false, U>), grid, block, 0, s, p);           \
+  } while (0)
   if (vec) {
-    if (nch == 1) CE_FWD(f32x4, 1); else if (nch == 2) CE_FWD(f32x4, 2); else CE_FWD(f32x4, 4);
+    if (nch == 1) {
+      if (u_env == 4) CE_FWD(f32x4, 1, 4); else if (u_env == 8) CE_FWD(f32x4, 1, 8);
+      else if (u_env == 32) CE_FWD(f32x4, 1, 32); else CE_FWD(f32x4, 1, 16);
+    } else if (nch == 2) CE_FWD(f32x4, 2, 4); else CE_FWD(f32x4, 4, 2);
   } else {
-    if (nch == 1) CE_FWD(float, 1); else if (nch == 2) CE_FWD(float, 2); else CE_FWD(float, 4);
+    if (nch == 1) CE_FWD(float, 1, 8); else if (nch == 2) CE_FWD(float, 2, 4); else CE_FWD(float, 4, 2);
   }
 #undef CE_FWD
   CE_LAUNCH_CHECK();
