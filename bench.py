@@ -40,7 +40,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="criteo_1tb", choices=["criteo_1tb", "criteo_kaggle", "avazu", "custom"])
     ap.add_argument("--batch_size", type=int, default=16384)
@@ -159,6 +159,10 @@ def main():
         """graph mode: window w = cache op (side stream, one window ahead when overlapping) + one graph replay;
         tail_steps > 0 adds a trailing partial window of that many steps"""
         last = first_w + count_w + (1 if tail_steps else 0)
+        if os.environ.get("CE_BENCH_SKIP_CACHE_OP") and first_w > 0:      # diagnostic: training kernels only
+            for w in range(first_w, last):
+                gw.run(w % 2, None if w < first_w + count_w else tail_steps)
+            return
         if args.overlap and last > first_w:
             gw.submit([windows[first_w][i] for i in range(P)], first_w % 2)
         for w in range(first_w, last):
