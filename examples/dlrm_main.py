@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""DLRM trainer around the MI355X-native cached EmbeddingBag -- the counterpart of the reference's
+recsys/dlrm_main.py, with the reference's flag names for everything that touches the hot path
+(recsys/dlrm_main.py:23-173) and its training-loop structure (`_train`, :206-297):
+
+    every `--prefetch_num` iterations: pull P batches from the (side-stream) data iterator,
+    ONE cache_weight_mgr.prepare_ids over their concatenated ids, slots split back per batch;
+    every iteration: forward with cache_op=False, BCE-with-logits loss, backward, optimizer step.
+
+Only the embedding operator is this repository's product; the dense part (bottom MLP, pairwise-dot
+interaction, top MLP -- the standard DLRM arch the reference takes from torchrec) is stock torch.nn and the
+data is synthetic (Criteo/Avazu-shaped KJT batches; no dataset exists on the box).  One process per GPU:
+with WORLD_SIZE > 1 the embedding is column-sharded exactly like the reference's default
+(ParallelCachedEmbeddingBag + dual_all_to_all) and the dense part is DDP.
+
+  python examples/dlrm_main.py --dataset criteo_kaggle --use_cache --cache_ratio 0.05 --use_freq \
+      --batch_size 16384 --prefetch_num 8 --use_overlap --use_sparse_embed_grad --limit_train_batches 200
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import os
+import sys
+import time
+from pathlib import Path
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from cachedembedding_amd import synthetic  # noqa: E402
+from cachedembedding_amd.modules import FiniteDataIter, FusedSparseModules  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="DLRM on the cached EmbeddingBag (MI355X)")
+    p.add_argument("--dataset", default="criteo_kaggle", choices=list(synthetic.TABLES))
+    p.add_argument("--table_scale", type=float, default=1.0)
+    p.add_argument("--epochs", type=int, default=1)
+    p.add_argument("--limit_train_batches", type=int, default=200)
+    p.add_argument("--batch_size", type=int, default=16384)
+    p.add_argument("--num_dense_features", type=int, default=13)
+    p.add_argument("--embedding_dim", type=int, default=128)
+    p.add_argument("--dense_arch_layer_sizes", type=str, default="512,256,128")
+    p.add_argument("--over_arch_layer_sizes", type=str, default="1024,1024,512,256,1")
+    p.add_argument("--learning_rate", type=float, default=1.0)
+    p.add_argument("--seed", type=int, default=1024)
+    # hot-path flags, same names as recsys/dlrm_main.py:120-166
+    p.add_argument("--use_cache", action="store_true")
+    p.add_argument("--cache_ratio", type=float, default=0.01)
+    p.add_argument("--use_freq", action="store_true")
+    p.add_argument("--use_lfu", action="store_true")
+    p.add_argument("--warmup_ratio", type=float, default=0.7)
+    p.add_argument("--buffer_size", type=int, default=0)
+    p.add_argument("--prefetch_num", type=int, default=1)
+    p.add_argument("--use_cache_mgr_async_copy", action="store_true")
+    p.add_argument("--use_sparse_embed_grad", action="store_true")
+    p.add_argument("--use_tablewise", action="store_true")
+    p.add_argument("--use_distributed_dataloader", action="store_true")
+    p.add_argument("--use_overlap", action="store_true")
+    # additions of this build
+    p.add_argument("--fused_sgd", action="store_true", help="apply the embedding SGD inside backward")
+    p.add_argument("--fold_hook", action="store_true", help="write [B,F,D] from the gather kernel")
+    return p.parse_args(argv)
+
+
+def mlp(sizes: List[int], last_activation: bool) -> nn.Sequential:
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i + 2 < len(sizes) or last_activation:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class DenseModules(nn.Module):
+    """bottom MLP -> pairwise dots of the F+1 vectors (upper triangle) -> top MLP"""
+
+    def __init__(self, num_dense: int, num_sparse: int, dim: int, dense_sizes: List[int], over_sizes: List[int]):
+        super().__init__()
+        assert dense_sizes[-1] == dim
+        self.bottom = mlp([num_dense] + dense_sizes, last_activation=True)
+        n = num_sparse + 1
+        self.register_buffer("tri", torch.triu_indices(n, n, offset=1), persistent=False)
+        self.top = mlp([dim + n * (n - 1) // 2] + over_sizes, last_activation=False)
+
+    def forward(self, dense: torch.Tensor, sparse: torch.Tensor) -> torch.Tensor:
+        d = self.bottom(dense)                                   # [B, D]
+        z = torch.cat([d.unsqueeze(1), sparse], dim=1)           # [B, F+1, D]
+        inter = torch.bmm(z, z.transpose(1, 2))[:, self.tri[0], self.tri[1]]
+        return self.top(torch.cat([d, inter], dim=1))
+
+
+class HybridParallelDLRM(nn.Module):
+    """model-parallel sparse part + data-parallel dense part (recsys/models/dlrm.py:144-235)"""
+
+    def __init__(self, sizes, args, id_freq_map, device):
+        super().__init__()
+        self.sparse_modules = FusedSparseModules(
+            sizes, args.embedding_dim, reduction_mode="sum", sparse=args.use_sparse_embed_grad,
+            use_cache=args.use_cache, cache_ratio=args.cache_ratio, id_freq_map=id_freq_map,
+            warmup_ratio=args.warmup_ratio, buffer_size=args.buffer_size,
+            is_dist_dataloader=args.use_distributed_dataloader, use_lfu_eviction=args.use_lfu,
+            use_tablewise_parallel=args.use_tablewise, dataset=args.dataset, fold_hook=args.fold_hook)
+        dense = DenseModules(args.num_dense_features, len(sizes), args.embedding_dim,
+                             [int(x) for x in args.dense_arch_layer_sizes.split(",")],
+                             [int(x) for x in args.over_arch_layer_sizes.split(",")]).to(device)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dense = nn.parallel.DistributedDataParallel(dense, device_ids=[device.index], gradient_as_bucket_view=True,
+                                                        broadcast_buffers=False, static_graph=True)
+        self.dense_modules = dense
+        self.dense_device = self.sparse_device = device
+
+    def forward(self, dense, sparse, cache_op: bool = True):
+        emb = self.sparse_modules(sparse, cache_op=cache_op)     # [B(/W), F, D]
+        return self.dense_modules(dense, emb)
+
+
+class SyntheticLoader:
+    """In-memory loader like the reference's npy pipe (recsys/datasets/criteo.py:38-249): all batches are
+    materialised in pinned host memory up front -- dense fp32 [B, 13], KJT list [values, offsets, stride],
+    labels -- so an iteration only pays the host->HBM copy (overlapped by FiniteDataIter)."""
+
+    def __init__(self, sizes, batch_size, num_dense, n_batches, seed):
+        gen = synthetic.SyntheticKJT(sizes, batch_size, 1, "power_law", 0.25, seed=seed, device="cuda")
+        cpu_gen = torch.Generator().manual_seed(seed)
+        offsets = gen.offsets.cpu().pin_memory()
+        self.batches = []
+        done = 0
+        while done < n_batches:
+            k = min(16, n_batches - done)
+            vals = gen.next_values(k).cpu()
+            for i in range(k):
+                self.batches.append(dict(
+                    dense=torch.rand(batch_size, num_dense, generator=cpu_gen).pin_memory(),
+                    sparse=[vals[i].contiguous().pin_memory(), offsets, batch_size],
+                    labels=torch.randint(0, 2, (batch_size,), generator=cpu_gen).float().pin_memory()))
+            done += k
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def put_data_in_device(batch, device, is_dist, rank, world):
+    """recsys/dlrm_main.py:195-203: with the non-distributed loader every rank holds the global batch and
+    keeps its slice of dense/labels, the sparse part stays global"""
+    dense, labels = batch["dense"].to(device), batch["labels"].to(device)
+    sparse = [t.to(device) if torch.is_tensor(t) else t for t in batch["sparse"]]
+    if not is_dist and world > 1:
+        dense = torch.tensor_split(dense, world, dim=0)[rank]
+        labels = torch.tensor_split(labels, world, dim=0)[rank]
+    return dense, sparse, labels
+
+
+def train(model, optimizer, loader, args, device, rank, world):
+    criterion = nn.BCEWithLogitsLoss()
+    data_iter = FiniteDataIter(loader, device) if args.use_overlap else iter(loader)
+    P = args.prefetch_num
+    embed = model.sparse_modules.embed
+    dense_l, sparse_l, labels_l = [None] * P, [None] * P, [None] * P
+    elapsed, done = 0.0, 0
+    model.train()
+    for idx in itertools.count():
+        try:
+            start = time.time()
+            k = idx % P
+            if k == 0:
+                with torch.no_grad():
+                    for i in range(P):
+                        dense_l[i], sparse_l[i], labels_l[i] = put_data_in_device(
+                            next(data_iter), device, args.use_distributed_dataloader, rank, world)
+                    counts = [s[0].numel() for s in sparse_l]
+                    slots = embed.cache_weight_mgr.prepare_ids(torch.cat([s[0] for s in sparse_l]))
+                    for i, sl in enumerate(torch.split(slots, counts)):
+                        sparse_l[i][0] = sl
+            logits = model(dense_l[k], sparse_l[k], cache_op=False).squeeze(-1)
+            loss = criterion(logits, labels_l[k])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            elapsed += time.time() - start
+            done += 1
+        except StopIteration:
+            break
+    torch.cuda.synchronize()
+    return done, elapsed, float(loss.detach()) if done else float("nan")
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not args.use_cache:
+        raise NotImplementedError("Other EmbeddingBags are under development")   # recsys/models/dlrm.py:83-84
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    torch.manual_seed(args.seed)
+    sizes = synthetic.TABLES[args.dataset]
+    if args.table_scale != 1.0:
+        sizes = synthetic.scale_tables(sizes, args.table_scale)
+    freq = None
+    if args.use_freq:
+        freq = synthetic.SyntheticKJT(sizes, args.batch_size, 1, "power_law", 0.25, seed=args.seed + 1,
+                                      device=device).id_freq_map(32)
+    model = HybridParallelDLRM(sizes, args, freq, device)
+    embed = model.sparse_modules.embed
+    embed.set_cache_mgr_async_copy(args.use_cache_mgr_async_copy)
+    groups = [{"params": list(model.dense_modules.parameters()), "lr": args.learning_rate * world}]
+    if args.fused_sgd:
+        embed.set_fused_sgd(args.learning_rate)
+    else:
+        groups.insert(0, {"params": list(model.sparse_modules.parameters()), "lr": args.learning_rate})
+    optimizer = torch.optim.SGD(groups)
+    loader = SyntheticLoader(sizes, args.batch_size, args.num_dense_features, args.limit_train_batches,
+                             args.seed + 17)
+    for epoch in range(args.epochs):
+        done, elapsed, loss = train(model, optimizer, loader, args, device, rank, world)
+        if rank == 0:
+            lookups = done * args.batch_size * len(sizes)
+            print(f"epoch {epoch}: {done} iterations, average throughput: {done / max(elapsed, 1e-9):.2f} it/s, "
+                  f"{lookups / max(elapsed, 1e-9) / 1e6:.1f} M lookups/s, last loss {loss:.4f}")
+            embed.print_comm_stats_()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

