@@ -311,6 +311,7 @@ def emit(result):
 
 
 def run_sharded(args, sizes, rank, world, dev):
+    args.overlap = not args.no_overlap
     """N > 1: the table is row-sharded over the ranks (row r of the frequency ranking lives on rank r % W),
     every rank brings its own batch of B samples (weak scaling): ids are bucketed by owner and exchanged with
     RCCL all-to-all-v once per window, each owner runs its cache op, and per step the looked-up rows travel back
@@ -355,12 +356,20 @@ def run_sharded(args, sizes, rank, world, dev):
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3
 
+    from cachedembedding_amd.parallel import ShardedWindowPipeline
+    pipe = ShardedWindowPipeline(embed, overlap=args.overlap)
+
     def run_steps(first, count):
+        """window plans are built one window ahead on a side stream (submit before training the current one)"""
         plans = None
+        first_w, last_w = first // P, (first + count - 1) // P
+        pipe.submit([windows[first_w][i] for i in range(P)], wait_for_current=False)
         for step in range(first, first + count):
             wi, bi = divmod(step, P)
             if bi == 0 or plans is None:
-                plans = embed.plan_window([windows[wi][i] for i in range(P)])
+                if wi + 1 <= last_w:
+                    pipe.submit([windows[wi + 1][i] for i in range(P)], wait_for_current=False)
+                plans = pipe.collect()
             out = embed(plans[bi], offsets, hook_features=F)
             out.backward(grad)
 
@@ -394,7 +403,8 @@ def run_sharded(args, sizes, rank, world, dev):
                    "pooling": L, "cache_ratio": args.cache_ratio, "cuda_row_num_per_gpu": mgr.cuda_row_num,
                    "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB_per_gpu": mgr.num_embeddings * D * 4 / 1e9,
-                   "sharding": f"row-wise x{world} (row % W), RCCL all-to-all-v", "update": "atomic", "lr": args.lr},
+                   "sharding": f"row-wise x{world} (row % W), RCCL all-to-all-v of unique rows", "overlap": bool(args.overlap),
+                   "update": "atomic", "lr": args.lr},
         "cache": {"rank0_unique_hit_rate": hits / max(1, hits + miss), "rank0_rows_in": tot["cpu_to_cuda_numel"] // D,
                   "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "prefill_cache_ops": prefill, "setup_s": setup_s},
         "roofline": None, "cpu_baseline": None,

@@ -497,6 +497,53 @@ class RowwiseShardedEmbeddingBag(nn.Module):
         self.cache_weight_mgr.flush()
 
 
+class ShardedWindowPipeline:
+    """Prefetch window for the row-wise sharded module: the window plan (dedupe, owner bucketing, count/id
+    all-to-alls, owner-side cache op) of window k+1 is built on a side stream while window k trains.
+    The host syncs inside plan_window then only wait for that side stream, so the CPU can keep enqueueing
+    training steps; rows of window k stay protected while window k+1's victims are chosen (protect_depth 1).
+    Call order per window (identical on every rank, which keeps the collectives matched):
+        submit(ids of window k+1)  ->  collect()  ->  train on the returned plans of window k ..."""
+
+    def __init__(self, embed: "RowwiseShardedEmbeddingBag", overlap: bool = True):
+        self.embed = embed
+        self.overlap = overlap
+        self._pending = []
+        dev = embed.cache_weight_mgr.device
+        self._side = torch.cuda.Stream(device=dev) if overlap else None
+        if overlap:
+            embed.cache_weight_mgr.set_protect_depth(1)
+            embed.cache_weight_mgr.strict = False
+
+    def submit(self, ids_list: Sequence[torch.Tensor], wait_for_current: bool = True) -> None:
+        if not self.overlap:
+            # reference semantics: the cache op of a window must not run before the previous window finished
+            # training (its rows are not protected), so planning is deferred to collect()
+            self._pending.append((None, list(ids_list)))
+            return
+        dev = self.embed.cache_weight_mgr.device
+        if wait_for_current:          # ids produced on the current stream just now
+            self._side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._side):
+            plans = self.embed.plan_window(ids_list)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pending.append((ev, plans))
+
+    def collect(self) -> List[BatchPlan]:
+        ev, plans = self._pending.pop(0)
+        if not self.overlap:
+            return self.embed.plan_window(plans)
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
+            cur.wait_event(ev)
+            for p in plans:
+                for t in (p.perm, p.recv_rows, p.slots):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
+        return plans
+
+
 class ParallelCachedEmbeddingBag(CachedEmbeddingBag):
     """Column-wise parallel cached EmbeddingBag -- the class recsys/models/dlrm.py:70-81 builds.
     Every rank holds num_embeddings x (embedding_dim / W) and receives the GLOBAL batch; forward returns

@@ -54,9 +54,9 @@ def _spawn(fn, world, *args):
         assert r[1] == "ok", r
 
 
-def _rowwise(rank, world, strategy, with_freq):
+def _rowwise(rank, world, strategy, with_freq, overlap=False):
     import cachedembedding_amd as ce
-    from cachedembedding_amd.parallel import RowwiseShardedEmbeddingBag
+    from cachedembedding_amd.parallel import RowwiseShardedEmbeddingBag, ShardedWindowPipeline
     torch.manual_seed(0)
     N, D, F, B_loc, P, lr = 5003, 64, 4, 32, 3, 0.25
     w_full = torch.randn(N, D)
@@ -72,14 +72,20 @@ def _rowwise(rank, world, strategy, with_freq):
     shard = w_full[rank::world].contiguous()
     emb = RowwiseShardedEmbeddingBag(N, D, mode="sum", include_last_offset=True, ids_freq_mapping=freq,
                                      warmup_ratio=0.7, evict_strategy=strat, _weight_shard=shard,
-                                     cuda_row_num=600 * world)
+                                     cuda_row_num=(1000 if overlap else 600) * world)
     emb.set_fused_sgd(lr)
     g = torch.Generator().manual_seed(100 + rank)
     offsets = torch.arange(F * B_loc + 1, dtype=torch.int32, device="cuda")
     ref_w = w_full.clone()
-    for window in range(2):
-        ids_list = [torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)]
-        plans = emb.plan_window([i.cuda() for i in ids_list])
+    nwin = 4 if overlap else 2
+    all_ids = [[torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)] for _ in range(nwin)]
+    pipe = ShardedWindowPipeline(emb, overlap=overlap)
+    pipe.submit([i.cuda() for i in all_ids[0]])
+    for window in range(nwin):
+        ids_list = all_ids[window]
+        if window + 1 < nwin:
+            pipe.submit([i.cuda() for i in all_ids[window + 1]])
+        plans = pipe.collect()
         for ids, plan in zip(ids_list, plans):
             out = emb(plan, offsets, hook_features=F)
             exp = ref_w[id2row[ids]].view(F, B_loc, D).transpose(0, 1)
@@ -90,6 +96,7 @@ def _rowwise(rank, world, strategy, with_freq):
             dist.all_gather_object(packs, (ids, go))
             for pids, pgo in packs:
                 ref_w.index_add_(0, id2row[pids], pgo.transpose(0, 1).reshape(-1, D), alpha=-lr)
+    assert emb.cache_weight_mgr.sync_stats().status == 0
     emb.flush()
     torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
 
@@ -98,6 +105,12 @@ def _rowwise(rank, world, strategy, with_freq):
 @pytest.mark.parametrize("strategy,with_freq", [("dataset", True), ("lfu", False), ("lfu", True)])
 def test_rowwise_sharded_vs_full_table(world, strategy, with_freq):
     _spawn(_rowwise, world, strategy, with_freq)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_rowwise_sharded_overlapped_window_pipeline(world):
+    """window plans built one window ahead on a side stream (protect_depth 1) train identically"""
+    _spawn(_rowwise, world, "dataset", True, True)
 
 
 def _column(rank, world):
