@@ -1167,15 +1167,6 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
     }
-    CE_HIP_CHECK(hipEventRecord(h->ev_fork, s));
-    CE_HIP_CHECK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-    if (h->vec)
-      hipLaunchKernelGGL((k_writeback<f32x4>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
-                         (const f32x4*)h->stage, (f32x4*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
-    else
-      hipLaunchKernelGGL((k_writeback<float>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
-                         (const float*)h->stage, (float*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
-    CE_HIP_CHECK(hipEventRecord(h->ev_join, h->aux));
     hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
                        c.cached_idx_map, c.inverted_cached_idx, (int32_t*)nullptr, h->ctl);
   } else {
@@ -1187,6 +1178,20 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_free_scan, dim3(1), dim3(1024), 0, s, h->blk_free, L.n_slot_blocks, h->ctl);
   hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                      h->blk_free, h->free_list, h->ctl);
+  if (c.transport == CE_TRANSPORT_ZEROCOPY) {
+    // fork AFTER the free-slot list is built: PCIe write-back traffic slows every kernel that runs next to it
+    // (k_free_emit: 5 us alone, >300 us beside k_writeback), so only the admission overlaps with it
+    const long long scap = (long long)L.stage_rows;
+    CE_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+    CE_HIP_CHECK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    if (h->vec)
+      hipLaunchKernelGGL((k_writeback<f32x4>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
+                         (const f32x4*)h->stage, (f32x4*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
+    else
+      hipLaunchKernelGGL((k_writeback<float>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
+                         (const float*)h->stage, (float*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
+    CE_HIP_CHECK(hipEventRecord(h->ev_join, h->aux));
+  }
   if (c.transport == CE_TRANSPORT_ZEROCOPY) {
     if (h->vec)
       hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,

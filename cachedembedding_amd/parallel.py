@@ -369,16 +369,24 @@ class RowwiseExchange:
             recv.copy_(send)
         send_h, recv_h = send.cpu(), recv.cpu()
         plans: List[BatchPlan] = []
+        ss_all = [[int(v) for v in send_h[:, b]] for b in range(P)]
+        rs_all = [[int(v) for v in recv_h[:, b]] for b in range(P)]
+        if W > 1:
+            # ONE all-to-all-v for the ids of the whole window: the send buffer is peer-major, batch-minor
+            pieces = [torch.split(buck[b][0], ss_all[b]) for b in range(P)]
+            send_buf = torch.cat([pieces[b][p] for p in range(W) for b in range(P)])
+            in_splits = [sum(ss_all[b][p] for b in range(P)) for p in range(W)]
+            out_splits = [sum(rs_all[b][p] for b in range(P)) for p in range(W)]
+            got_all = torch.empty(sum(out_splits), dtype=send_buf.dtype, device=send_buf.device)
+            _a2a(got_all, send_buf, out_splits, in_splits, self.group)
+            segs = torch.split(got_all, [rs_all[b][p] for p in range(W) for b in range(P)])
         for b in range(P):
             rows, perm, _ = buck[b]
-            ss = [int(v) for v in send_h[:, b]]
-            rs = [int(v) for v in recv_h[:, b]]
-            got = torch.empty(sum(rs), dtype=rows.dtype, device=rows.device)
             if W > 1:
-                _a2a(got, rows, rs, ss, self.group)
+                got = torch.cat([segs[p * P + b] for p in range(W)])
             else:
-                got.copy_(rows)
-            plans.append(BatchPlan(rows.numel(), perm, ss, rs, got))
+                got = rows
+            plans.append(BatchPlan(rows.numel(), perm, ss_all[b], rs_all[b], got))
         all_rows = plans[0].recv_rows if P == 1 else torch.cat([p.recv_rows for p in plans])
         slots = self.ops.owner_prepare(all_rows)
         for p, s in zip(plans, torch.split(slots, [p.recv_rows.numel() for p in plans])):
