@@ -388,7 +388,11 @@ def run_sharded(args, sizes, rank, world, dev):
     barrier()
     t1 = time.perf_counter()
     run_steps(W, K)
+    enqueue_s = time.perf_counter() - t1
     barrier()
+    if rank == 0:
+        print(f"[bench] sharded timed region: host enqueue {enqueue_s:.3f}s of {time.perf_counter() - t1:.3f}s",
+              file=sys.stderr, flush=True)
     elapsed = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())

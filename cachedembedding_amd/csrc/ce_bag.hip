@@ -249,8 +249,10 @@ __device__ __forceinline__ void flush_chunk(float* row_base, float v, int gl, in
   else if (debug == 2) { if (v == 12345.678f) *dst = v; }
 }
 
-// OP 0: dst[indices[j]] += alpha*scale*psw[j]*grad_out[bag(j)]  (fp32 atomics)
-// OP 1: dst[j]           = alpha*scale*psw[j]*grad_out[bag(j)]  (COO values)
+// Per-lookup gradient rows (COO values of the sparse=True backward; dest_index redirects row j):
+// OP 1: dst[indices ? indices[j] : j] = alpha*scale*psw[j]*grad_out[bag(j)].
+// (OP 0 = atomic accumulation by row is compiled for completeness but the launcher always uses the
+// tile-sorted kernel below for it.)
 template <typename VT, int NCH, int OP>
 __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
   constexpr int U = (NCH == 1) ? 4 : (NCH == 2 ? 2 : 1);
@@ -274,99 +276,6 @@ __global__ __launch_bounds__(256) void k_bag_bwd(BagParams p) {
     if (lane < nb) {
       lo = ld_off(p, b0 + lane);
       hi = bag_end(p, b0 + lane);
-    }
-    if (OP == 0 && __all((hi - lo == 1) || (lane >= nb))) {
-      // ---- single-id tile (all Criteo/Avazu batches).  Small tables make most of the 64 lookups of a
-      // tile hit the same few rows, and fp32 atomics on one row serialise (~12 ns each), so duplicates
-      // are combined inside the wave first: 1 ballot per index bit gives every lane the mask of lanes
-      // with the same row; the lowest lane of each mask ("leader") sums its peers' gradient rows in
-      // lane order and issues ONE atomic row update.
-      int idx = -1 - lane;              // out-of-range lanes never match anything
-      float w = 1.f;
-      if (lane < nb) {
-        idx = (int)p.indices[lo];
-        if (p.psw) w = p.psw[lo];
-      }
-      unsigned long long peers = __ballot(lane < nb);
-      if (lane >= nb) peers = 0;
-      for (int b = 0; b < p.idx_bits; ++b) {
-        const unsigned long long m = __ballot((idx >> b) & 1);
-        peers &= ((idx >> b) & 1) ? m : ~m;
-      }
-      const unsigned plo = (unsigned)peers, phi = (unsigned)(peers >> 32);
-      for (int base = 0; base < nb; base += gpw * U) {
-        VT g[U][NCH];
-        unsigned long long rest[U];
-        int ri[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int bi = base + u * gpw + grp;
-          const int src = bi & 63;
-          const unsigned long long pm =
-              ((unsigned long long)(unsigned)__shfl((int)phi, src) << 32) | (unsigned)__shfl((int)plo, src);
-          ri[u] = __shfl(idx, src);
-          const float wi = __shfl(w, src);
-          const bool lead = (bi < nb) && ((__ffsll((long long)pm) - 1) == bi);
-          rest[u] = lead ? pm : 0ull;
-          const int64_t orow = out_row(p, b0 + min(bi, nb - 1));
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int ch = gl + c * G;
-            g[u][c] = vzero<VT>();
-            if (lead && ch < rowlen) g[u][c] = p.psw ? GO[orow * rowlen + ch] * wi : GO[orow * rowlen + ch];
-          }
-          rest[u] &= ~(1ull << src);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          unsigned long long r = rest[u];
-          while (r) {      // remaining peers, 4 gradient rows in flight
-            int pl[4];
-            VT t[4][NCH];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              pl[q] = r ? (__ffsll((long long)r) - 1) : -1;
-              if (r) r &= r - 1;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int64_t orow = out_row(p, b0 + max(pl[q], 0));
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const int ch = gl + c * G;
-                t[q][c] = vzero<VT>();
-                if (pl[q] >= 0 && ch < rowlen) t[q][c] = GO[orow * rowlen + ch];
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (pl[q] >= 0) {
-                // (no cross-lane op here: the two lane groups of a wave run different trip counts)
-                const float wq = p.psw ? p.psw[ld_off(p, b0 + pl[q])] : 1.f;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) g[u][c] = p.psw ? g[u][c] + t[q][c] * wq : g[u][c] + t[q][c];
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int bi = base + u * gpw + grp;
-          const int src = bi & 63;
-          const unsigned long long pm =
-              ((unsigned long long)(unsigned)__shfl((int)phi, src) << 32) | (unsigned)__shfl((int)plo, src);
-          const bool lead = (bi < nb) && ((__ffsll((long long)pm) - 1) == bi);
-          if (lead) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              const int ch = gl + c * G;
-              if (ch < rowlen && (uint32_t)ri[u] < p.num_rows)
-                atomic_add_vec(&DST[(int64_t)ri[u] * rowlen + ch], g[u][c] * p.alpha);
-            }
-          }
-        }
-      }
-      continue;
     }
     for (int base = 0; base < nb; base += gpw * U) {
       VT g[U][NCH];
@@ -610,18 +519,9 @@ static int bag_grid(int64_t num_bags) {
   return grid_for(tiles, 4);
 }
 
-static bool use_wave_bwd() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CE_BWD_IMPL");      // "wave": per-wave duplicate matching (A/B testing only)
-    v = (e && strcmp(e, "wave") == 0) ? 1 : 0;
-  }
-  return v == 1;
-}
-
 template <int OP>
 static int launch_bwd(const BagParams& p, bool vec, int nch, hipStream_t s) {
-  if (OP == 0 && !use_wave_bwd()) {
+  if (OP == 0) {
     const char* dbg = getenv("CE_BWD_DEBUG");
     BagParams q = p;
     q.debug = dbg ? atoi(dbg) : 0;

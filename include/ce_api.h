@@ -96,9 +96,10 @@ int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim,
                    int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                    int64_t hook_features, float* out, ce_stream_t stream);
 
-/* K13 (dense form): grad_weight[indices[j]] += psw[j]*scale*grad_out[bag(j)] accumulated
- * with fp32 atomics into a caller-zeroed [num_rows, dim] buffer -- the `sparse=False`
- * autograd backward of K12.  grad_out uses the same layout convention as `out` above. */
+/* K13 (dense form): grad_weight[indices[j]] += psw[j]*scale*grad_out[bag(j)] accumulated into a
+ * caller-zeroed [num_rows, dim] buffer -- the `sparse=False` autograd backward of K12.  Duplicates are
+ * folded per 1024-lookup tile (LDS sort) before one fp32 atomic row update per (row, chunk).
+ * grad_out uses the same layout convention as `out` above. */
 int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32_t dim,
                           const int64_t* indices, int64_t nnz,
                           const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
@@ -117,17 +118,18 @@ int ce_bag_backward_rows(float* grad_rows, const int64_t* dest_index, int32_t di
 
 /* K13+K14 fused: weight[indices[j]] -= lr * psw[j]*scale*grad_out[bag(j)] -- autograd
  * backward + torch.optim.SGD.step on the cache parameter (recsys/dlrm_main.py:274-279,
- * 455-461) in one pass, fp32 atomics (order of duplicate-row updates is not fixed). */
+ * 455-461) in one pass.  Same tile-sorted scatter as the dense form with alpha = -lr; the order in which
+ * DIFFERENT tiles update one row is not fixed (fp32 sums may differ in the last bits run to run). */
 int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
                         const int64_t* indices, int64_t nnz,
                         const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                         int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                         int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream);
 
-/* Deterministic variant of the fused update: lookups are bucketed by target row with a
- * stable counting pass (workspace from ce_bag_backward_sgd_sorted_workspace), each row's
- * gradients are summed in lookup order and applied once:  W[r] -= lr * sum.  Matches the
- * reference's coalesce-then-add order for sparse grads. */
+/* Deterministic variant of the fused update: lookups are stably radix-sorted by target row
+ * (workspace from ce_bag_backward_sgd_sorted_workspace), each row's gradients are summed in
+ * lookup order and applied once:  W[r] -= lr * sum.  Matches the reference's coalesce-then-add
+ * order for sparse grads; bit-reproducible, slower for very hot rows. */
 size_t ce_bag_backward_sgd_sorted_workspace(int64_t num_rows, int64_t nnz);
 int ce_bag_backward_sgd_sorted(float* weight, int64_t num_rows, int32_t dim,
                                const int64_t* indices, int64_t nnz,
