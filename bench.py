@@ -365,6 +365,7 @@ def run_sharded(args, sizes, rank, world, dev):
 
     from cachedembedding_amd.parallel import ShardedWindowPipeline
     pipe = ShardedWindowPipeline(embed, overlap=args.overlap)
+    pump_at = {max(0, P // 3 - 1), max(0, (2 * P) // 3 - 1)} if P >= 3 else set()
 
     def run_steps(first, count):
         """window plans are built one window ahead on a side stream (submit before training the current one)"""
@@ -379,6 +380,8 @@ def run_sharded(args, sizes, rank, world, dev):
                 plans = pipe.collect()
             out = embed(plans[bi], offsets, hook_features=F)
             out.backward(grad)
+            if bi in pump_at:        # next window's plan advances one phase; its counts have landed by now
+                pipe.pump()
 
     def barrier():
         dist.barrier()
@@ -387,7 +390,15 @@ def run_sharded(args, sizes, rank, world, dev):
     run_steps(0, W)
     barrier()
     t1 = time.perf_counter()
-    run_steps(W, K)
+    if os.environ.get("CE_BENCH_CPROFILE") and rank == 0:       # diagnostic: where does the host time go
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run_steps(W, K)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(30)
+    else:
+        run_steps(W, K)
     enqueue_s = time.perf_counter() - t1
     barrier()
     if rank == 0:

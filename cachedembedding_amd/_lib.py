@@ -154,7 +154,14 @@ def require_gpu() -> None:
                            "no CPU fallback for the product path")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~20x cheaper than
+    constructing a torch.cuda.Stream object, and this is called for every kernel launch)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

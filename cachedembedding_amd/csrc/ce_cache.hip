@@ -481,9 +481,9 @@ __global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ vict
     }
   }
 }
-// Full-duplex swap: victims' rows are first copied cache -> HBM staging (fast), then written to the host
-// table from the staging buffer on an auxiliary stream while the admissions read the host table on the
-// main stream -- PCIe carries both directions at once.  Victims beyond the staging capacity (rare) are
+// Full-duplex swap: victims' rows are first copied cache -> HBM staging (fast); k_swap then writes them to the
+// host table from the staging buffer while its other workgroups read the missed rows -- PCIe carries both
+// directions at once.  Victims beyond the staging capacity (rare) are
 // written back directly by k_evict (`first` = staging capacity).
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
@@ -503,15 +503,15 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
 }
 
 template <typename VT>
-__global__ __launch_bounds__(1024) void k_writeback(const int32_t* __restrict__ stage_rows_idx,
-                                                   const VT* __restrict__ stage, VT* host, long long cap, int rowlen,
-                                                   int g_log2, const Ctl* ctl) {
+__device__ __forceinline__ void writeback_rows(const int32_t* __restrict__ stage_rows_idx,
+                                               const VT* __restrict__ stage, VT* host, long long cap, int rowlen,
+                                               int g_log2, const Ctl* ctl, int block, int nblocks) {
   long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
   if (k > cap) k = cap;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < k;
+  const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
+  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < k;
        i += gstride * kSwapRows) {
     if (rowlen <= G) {
       VT v[kSwapRows];
@@ -596,16 +596,15 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
 
 // rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i)
 template <typename VT>
-__global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
-                                               const long long* n_ptr, long long n_imm,
-                                               const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
-                                               const Ctl* ctl) {
+__device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
+                                           const long long* n_ptr, long long n_imm, const VT* __restrict__ host,
+                                           VT* cache, int rowlen, int g_log2, const Ctl* ctl, int block, int nblocks) {
   if (ctl && ctl->status != CE_OK) return;
   const long long n = n_ptr ? *n_ptr : n_imm;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < n; i += gstride * kSwapRows) {
+  const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
+  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < n; i += gstride * kSwapRows) {
     if (rowlen <= G) {          // kSwapRows host rows in flight per lane group (see k_evict)
       VT v[kSwapRows];
       int64_t dst[kSwapRows];
@@ -629,6 +628,31 @@ __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows
       }
     }
   }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
+                                               const long long* n_ptr, long long n_imm,
+                                               const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
+                                               const Ctl* ctl) {
+  admit_rows(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Full-duplex swap in ONE launch: the first wb_blocks workgroups stream the staged victims to the host table,
+// the others read the missed rows from it.  (An earlier version ran the write-back on an auxiliary stream; HIP
+// multiplexes streams onto a few hardware queues and that stream could land on the TRAINING stream's queue,
+// stalling training for the whole write-back -- seen in a rocprofv3 timeline.  One kernel needs no extra stream.)
+template <typename VT>
+__global__ __launch_bounds__(1024) void k_swap(const int32_t* __restrict__ stage_rows_idx,
+                                              const VT* __restrict__ stage, long long cap, int wb_blocks,
+                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
+                                              const long long* n_ptr, VT* host, VT* cache, int rowlen, int g_log2,
+                                              const Ctl* ctl) {
+  if ((int)blockIdx.x < wb_blocks)
+    writeback_rows(stage_rows_idx, stage, host, cap, rowlen, g_log2, ctl, (int)blockIdx.x, wb_blocks);
+  else
+    admit_rows(rows, slots, n_ptr, 0ll, (const VT*)host, cache, rowlen, g_log2, ctl, (int)blockIdx.x - wb_blocks,
+               (int)gridDim.x - wb_blocks);
 }
 
 __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ rows,
@@ -817,8 +841,6 @@ struct ce_cache {
   ce_call_stats_t* ring;       // pinned host
   ce_call_stats_t* ring_dev;   // device-visible alias
   hipEvent_t ev;
-  hipStream_t aux;             // write-back lane: evicted rows leave over PCIe while admissions come in
-  hipEvent_t ev_fork, ev_join;
   float* stage;                // device staging for evicted rows (inside the workspace)
   int32_t* stage_idx;          // host row of every staged victim
   long long seq;               // calls issued
@@ -938,13 +960,10 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->ring_dev = (ce_call_stats_t*)ring_dev;
   h->stage = (float*)(h->ws + L.stage);
   h->stage_idx = (int32_t*)(h->ws + L.stage_idx);
-  if (hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) {
+  if (hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) {
     (void)hipHostFree(ring_host);
     delete h;
-    set_error("hipEventCreate / hipStreamCreate failed");
+    set_error("hipEventCreate failed");
     return CE_ERR_HIP;
   }
   // empty-cache state of A.1
@@ -975,10 +994,6 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
 extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
   (void)hipEventSynchronize(h->ev);
-  (void)hipStreamSynchronize(h->aux);
-  (void)hipStreamDestroy(h->aux);
-  (void)hipEventDestroy(h->ev_fork);
-  (void)hipEventDestroy(h->ev_join);
   (void)hipEventDestroy(h->ev);
   (void)hipHostFree(h->ring);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
@@ -1179,28 +1194,18 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                      h->blk_free, h->free_list, h->ctl);
   if (c.transport == CE_TRANSPORT_ZEROCOPY) {
-    // fork AFTER the free-slot list is built: PCIe write-back traffic slows every kernel that runs next to it
-    // (k_free_emit: 5 us alone, >300 us beside k_writeback), so only the admission overlaps with it
+    // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy
     const long long scap = (long long)L.stage_rows;
-    CE_HIP_CHECK(hipEventRecord(h->ev_fork, s));
-    CE_HIP_CHECK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
     if (h->vec)
-      hipLaunchKernelGGL((k_writeback<f32x4>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
-                         (const f32x4*)h->stage, (f32x4*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
+      hipLaunchKernelGGL((k_swap<f32x4>), dim3(2 * cap_groups), swap_block, 0, s, h->stage_idx,
+                         (const f32x4*)h->stage, scap, cap_groups, h->miss_list, h->free_list,
+                         (const long long*)&h->ctl->n_miss, (f32x4*)c.host_weight_dev, (f32x4*)c.cache_weight,
+                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
     else
-      hipLaunchKernelGGL((k_writeback<float>), dim3(cap_groups), swap_block, 0, h->aux, h->stage_idx,
-                         (const float*)h->stage, (float*)c.host_weight_dev, scap, h->rowlen, h->g_log2, h->ctl);
-    CE_HIP_CHECK(hipEventRecord(h->ev_join, h->aux));
-  }
-  if (c.transport == CE_TRANSPORT_ZEROCOPY) {
-    if (h->vec)
-      hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
-                         (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
-                         (f32x4*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl);
-    else
-      hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
-                         (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
-                         (float*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+      hipLaunchKernelGGL((k_swap<float>), dim3(2 * cap_groups), swap_block, 0, s, h->stage_idx,
+                         (const float*)h->stage, scap, cap_groups, h->miss_list, h->free_list,
+                         (const long long*)&h->ctl->n_miss, (float*)c.host_weight_dev, (float*)c.cache_weight,
+                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
   } else {
     // H2D: worker threads gather the missed rows out of the table into pinned staging
     const Ctl ctl = *h->ctl_host;   // filled by staged_swap
@@ -1227,7 +1232,6 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                            (float*)c.cache_weight, h->rowlen, h->g_log2);
     }
   }
-  if (c.transport == CE_TRANSPORT_ZEROCOPY) CE_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));   // write-back joined
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
                      (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
                      c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl);

@@ -184,7 +184,14 @@ class ShardOps:
 
     def bucketize_many(self, ids_list: Sequence[torch.Tensor]):
         """bucketize every batch of a window (implementations may batch their host syncs)."""
-        return [self.bucketize(ids) for ids in ids_list]
+        return self.bucketize_finish(self.bucketize_begin(ids_list))
+
+    def bucketize_begin(self, ids_list: Sequence[torch.Tensor]):
+        """launch whatever can run without host knowledge; returns a token for bucketize_finish"""
+        return list(ids_list)
+
+    def bucketize_finish(self, token):
+        return [self.bucketize(ids) for ids in token]
 
     def owner_prepare(self, local_rows: torch.Tensor):       # -> slots[n_recv]
         raise NotImplementedError
@@ -231,11 +238,11 @@ class HipShardOps(ShardOps):
                                     ptr(self._ws), self._ws.numel(), stream_ptr()))
         return rows, perm_u[inv], counts
 
-    def bucketize_many(self, ids_list):
-        """Window form: ce_dedupe_rows for every batch (no sync), ONE readback of the unique counts, then the
-        owner bucketing of each batch's unique rows."""
+    def bucketize_begin(self, ids_list):
+        """Window form, phase 1: ce_dedupe_rows for every batch (no sync) + an async copy of the unique counts
+        into pinned host memory; the event tells bucketize_finish when they have landed."""
         if self.num_global_rows is None:
-            return [self.bucketize(ids) for ids in ids_list]
+            return list(ids_list)
         dev = ids_list[0].device
         N = self.num_global_rows
         if self._stamp is None:
@@ -257,26 +264,19 @@ class HipShardOps(ShardOps):
                                      ptr(self._slot_of_row), ptr(uniq), ptr(inv), n_unique[b:].data_ptr(),
                                      stream_ptr()))
             staged.append((uniq, inv))
-        counts_h = n_unique.cpu().tolist()            # the only host sync of the dedupe phase
-        return [self._bucketize_unique(u[:c], int(c), inv) for (u, inv), c in zip(staged, counts_h)]
+        host = torch.empty(P, dtype=torch.int64, pin_memory=True)
+        host.copy_(n_unique, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ("dedupe", staged, host, ev, n_unique)
 
-    def bucketize(self, ids):
-        ids = ids.reshape(-1).long().contiguous()
-        dev = ids.device
-        rows_all = self.idx_map[ids].long() if self.idx_map is not None else ids
-        # unique rows of the batch (torch.unique: plumbing for now; a device bitmap pass like the cache
-        # manager's would avoid its sort and its host sync)
-        uniq, inv = torch.unique(rows_all, return_inverse=True)
-        n_u = uniq.numel()
-        rows = torch.empty(n_u, dtype=torch.int64, device=dev)
-        perm_u = torch.empty(n_u, dtype=torch.int64, device=dev)
-        counts = torch.empty(self.world, dtype=torch.int64, device=dev)
-        need = lib.ce_bucketize_workspace(n_u, self.world)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
-        check(lib.ce_bucketize_rows(ptr(uniq), n_u, None, self.world, ptr(rows), ptr(perm_u), ptr(counts),
-                                    ptr(self._ws), self._ws.numel(), stream_ptr()))
-        return rows, perm_u[inv], counts
+    def bucketize_finish(self, token):
+        if not (isinstance(token, tuple) and token and token[0] == "dedupe"):
+            return [self.bucketize(ids) for ids in token]
+        _, staged, host, ev, _keep = token
+        ev.synchronize()                              # the only host wait of the dedupe phase
+        counts_h = host.tolist()
+        return [self._bucketize_unique(u[:c], int(c), inv) for (u, inv), c in zip(staged, counts_h)]
 
     def owner_prepare(self, local_rows):
         return self.mgr.prepare_ids(local_rows)
@@ -357,17 +357,44 @@ class RowwiseExchange:
 
     @torch.no_grad()
     def plan_window(self, ids_list: Sequence[torch.Tensor]) -> List[BatchPlan]:
-        """Bucket every batch of the window by owner, exchange counts (one host sync per WINDOW) and
-        ids, then run ONE owner-side cache op over all rows this rank serves in the window."""
-        W, P = self.world, len(ids_list)
-        buck = self.ops.bucketize_many(ids_list)
+        """Bucket every batch of the window by owner, exchange counts and ids, then run ONE owner-side cache
+        op over all rows this rank serves in the window.  = plan_begin + plan_mid + plan_end back to back;
+        a pipeline calls the three phases with training steps enqueued in between so that neither of the two
+        host waits (unique counts, exchanged counts) stalls the launch thread."""
+        return self.plan_end(self.plan_mid(self.plan_begin(ids_list)))
+
+    @torch.no_grad()
+    def plan_begin(self, ids_list: Sequence[torch.Tensor]):
+        return {"phase": 1, "P": len(ids_list), "token": self.ops.bucketize_begin(ids_list)}
+
+    @torch.no_grad()
+    def plan_mid(self, st):
+        W = self.world
+        buck = self.ops.bucketize_finish(st["token"])                       # host wait #1 (unique counts)
         send = torch.stack([b[2] for b in buck], dim=1).contiguous()          # [W, P]
         recv = torch.empty_like(send)
         if W > 1:
             _a2a(recv, send, None, None, self.group)
         else:
             recv.copy_(send)
-        send_h, recv_h = send.cpu(), recv.cpu()
+        both = torch.stack([send, recv])
+        if both.is_cuda:
+            host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+            host.copy_(both, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = both, None
+        st.update(phase=2, buck=buck, counts_host=host, counts_event=ev, keep=both)
+        st.pop("token")
+        return st
+
+    @torch.no_grad()
+    def plan_end(self, st) -> List[BatchPlan]:
+        W, P, buck = self.world, st["P"], st["buck"]
+        if st["counts_event"] is not None:
+            st["counts_event"].synchronize()                                # host wait #2 (exchanged counts)
+        send_h, recv_h = st["counts_host"][0], st["counts_host"][1]
         plans: List[BatchPlan] = []
         ss_all = [[int(v) for v in send_h[:, b]] for b in range(P)]
         rs_all = [[int(v) for v in recv_h[:, b]] for b in range(P)]
@@ -524,31 +551,54 @@ class ShardedWindowPipeline:
             embed.cache_weight_mgr.strict = False
 
     def submit(self, ids_list: Sequence[torch.Tensor], wait_for_current: bool = True) -> None:
+        """Phase 1 of the next window's plan (dedupe kernels + async count readback) on the side stream."""
         if not self.overlap:
             # reference semantics: the cache op of a window must not run before the previous window finished
             # training (its rows are not protected), so planning is deferred to collect()
-            self._pending.append((None, list(ids_list)))
+            self._pending.append({"ids": list(ids_list)})
             return
         dev = self.embed.cache_weight_mgr.device
         if wait_for_current:          # ids produced on the current stream just now
             self._side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side):
-            plans = self.embed.plan_window(ids_list)
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-        self._pending.append((ev, plans))
+            st = self.embed.exchange.plan_begin(ids_list)
+        self._pending.append(st)
+
+    def pump(self) -> None:
+        """Advance the oldest unfinished plan by ONE phase (call it between training steps: by then the
+        counts the phase needs have landed in pinned memory and the host does not wait).  Every rank must
+        call submit/pump/collect in the same order -- the phases contain collectives."""
+        if not self.overlap:
+            return
+        for st in self._pending:
+            if st.get("phase") == 1:
+                with torch.cuda.stream(self._side):
+                    self.embed.exchange.plan_mid(st)
+                return
+            if st.get("phase") == 2:
+                with torch.cuda.stream(self._side):
+                    plans = self.embed.exchange.plan_end(st)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                st.clear()
+                st.update(phase=3, plans=plans, event=ev)
+                return
 
     def collect(self) -> List[BatchPlan]:
-        ev, plans = self._pending.pop(0)
+        st = self._pending.pop(0)
         if not self.overlap:
-            return self.embed.plan_window(plans)
-        if ev is not None:
-            cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
-            cur.wait_event(ev)
-            for p in plans:
-                for t in (p.perm, p.recv_rows, p.slots):
-                    if t is not None and t.is_cuda:
-                        t.record_stream(cur)
+            return self.embed.plan_window(st["ids"])
+        while st.get("phase") != 3:           # phases not pumped yet: finish them now
+            self._pending.insert(0, st)
+            self.pump()
+            st = self._pending.pop(0)
+        plans, ev = st["plans"], st["event"]
+        cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
+        cur.wait_event(ev)
+        for p in plans:
+            for t in (p.perm, p.recv_rows, p.slots):
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
         return plans
 
 

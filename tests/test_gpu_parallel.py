@@ -92,6 +92,7 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
             torch.testing.assert_close(out.cpu(), exp, rtol=1e-5, atol=1e-6)
             go = torch.randn(B_loc, F, D, generator=g)
             out.backward(go.cuda())
+            pipe.pump()                         # next window's plan advances one phase between steps
             packs = [None] * world
             dist.all_gather_object(packs, (ids, go))
             for pids, pgo in packs:
