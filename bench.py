@@ -28,8 +28,12 @@ import sys
 import time
 from pathlib import Path
 
-import torch
-import torch.distributed as dist
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the pipeline uses up to 4 streams
+# per process (training, cache op / planning x2, RCCL), and two streams that share a hardware queue serialise.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -365,7 +369,7 @@ def run_sharded(args, sizes, rank, world, dev):
 
     from cachedembedding_amd.parallel import ShardedWindowPipeline
     pipe = ShardedWindowPipeline(embed, overlap=args.overlap)
-    pump_at = {max(0, P // 3 - 1), max(0, (2 * P) // 3 - 1)} if P >= 3 else set()
+    pump_at = {0, max(1, P // 4)} if P >= 3 else set()     # early: the cache op of the next window needs the lead
 
     def run_steps(first, count):
         """window plans are built one window ahead on a side stream (submit before training the current one)"""

@@ -545,7 +545,10 @@ class ShardedWindowPipeline:
         self.overlap = overlap
         self._pending = []
         dev = embed.cache_weight_mgr.device
-        self._side = torch.cuda.Stream(device=dev) if overlap else None
+        # two side streams: dedupe + owner bucketing of window k+1 must not queue behind the (long) cache op
+        # of window k, so the cache-state-free phases get their own stream
+        self._side = torch.cuda.Stream(device=dev) if overlap else None       # phases 1-2
+        self._side2 = torch.cuda.Stream(device=dev) if overlap else None      # phase 3: id exchange + cache op
         if overlap:
             embed.cache_weight_mgr.set_protect_depth(1)
             embed.cache_weight_mgr.strict = False
@@ -576,10 +579,15 @@ class ShardedWindowPipeline:
                     self.embed.exchange.plan_mid(st)
                 return
             if st.get("phase") == 2:
-                with torch.cuda.stream(self._side):
+                self._side2.wait_stream(self._side)
+                for rows, perm, counts in st["buck"]:
+                    for t in (rows, perm, counts):
+                        if t.is_cuda:
+                            t.record_stream(self._side2)
+                with torch.cuda.stream(self._side2):
                     plans = self.embed.exchange.plan_end(st)
                     ev = torch.cuda.Event()
-                    ev.record(self._side)
+                    ev.record(self._side2)
                 st.clear()
                 st.update(phase=3, plans=plans, event=ev)
                 return

@@ -4,8 +4,6 @@ try:
     d=json.loads(sys.stdin.read()); print('  %s -> %.1f M lookups/s  step %.3f ms' % ('$*', d['value']/1e6, d['ms_per_step']))
 except Exception as e:
     print('  FAILED', e)" ; grep -E "Error|error|host enqueue" gpurun_out/err.txt | tail -2; }
-timeout 900 python -m pytest tests/test_gpu_cache.py tests/test_gpu_cache_scale.py tests/test_gpu_parallel.py -m gpu -x -q 2>&1 | tail -2
-run
-run --no_overlap
-run --use_lfu
+timeout 900 python -m pytest tests/test_gpu_parallel.py -m gpu -x -q 2>&1 | tail -2
+run --force_sharded
 run --force_sharded
