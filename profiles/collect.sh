@@ -1,3 +1,4 @@
+# Regenerates every artefact under profiles/ on an MI355X box (run from the repo root; writes to gpurun_out/).
 set -x
 R=$PWD
 timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/final_pytest.txt; cat gpurun_out/final_pytest.txt
