@@ -29,7 +29,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -810,21 +812,80 @@ static void parallel_rows(int64_t n, int threads, const std::function<void(int64
 
 namespace ce {
 
+// persistent worker pool for the staged transport's table gather/scatter (spawning 64 std::threads per call cost
+// more than the copies themselves)
+class RowPool {
+ public:
+  explicit RowPool(int n) {
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+  }
+  ~RowPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void parallel(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
+    const int t = (int)std::min<int64_t>((int64_t)workers_.size(), std::max<int64_t>(1, cdiv(n, 1024)));
+    if (t <= 1) {
+      fn(0, n);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> g(m_);
+      fn_ = &fn;
+      n_ = n;
+      parts_ = t;
+      pending_ = t;
+      ++gen_;
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void run(int id) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int64_t, int64_t)>* fn;
+      int64_t n;
+      int parts;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        fn = fn_;
+        n = n_;
+        parts = parts_;
+      }
+      if (id < parts) {
+        const int64_t per = cdiv(n, parts);
+        const int64_t lo = id * per, hi = std::min<int64_t>(n, lo + per);
+        if (lo < hi) (*fn)(lo, hi);
+        std::lock_guard<std::mutex> g(m_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
+  int64_t n_ = 0;
+  int parts_ = 0, pending_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
 static void parallel_rows(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
   if (n <= 0) return;
-  int t = (int)std::min<int64_t>(threads, cdiv(n, 2048));
-  if (t <= 1) {
-    fn(0, n);
-    return;
-  }
-  std::vector<std::thread> pool;
-  const int64_t per = cdiv(n, t);
-  for (int i = 0; i < t; ++i) {
-    const int64_t lo = i * per, hi = std::min<int64_t>(n, lo + per);
-    if (lo >= hi) break;
-    pool.emplace_back([=, &fn] { fn(lo, hi); });
-  }
-  for (auto& th : pool) th.join();
+  static RowPool pool(std::max(1, std::min(threads, 32)));
+  pool.parallel(n, fn);
 }
 
 }  // namespace ce
