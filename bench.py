@@ -233,10 +233,13 @@ def main():
     hits, miss = sum(mgr.num_hits_history), sum(mgr.num_miss_history)
     tot = mgr.totals()
 
-    # ---- per-kernel launch duration with HIP events on the launch stream (separate pass over the same data).
-    # Pass 1 runs in the SAME mode as the timed region (side-stream cache op overlapping when --overlap): these
-    # are the durations `rocprofv3 --kernel-trace --stats` reports for this very command.  Pass 2 repeats it with
-    # the cache op on the compute stream, i.e. the kernels with nothing else on the GPU ("isolated").
+    # ---- per-kernel launch duration with HIP events on the launch stream (separate passes over the same data).
+    # Pass A: cache op on the compute stream, i.e. each kernel has the GPU to itself -> `avg_ms`, the number the
+    #         roofline uses; `rocprofv3 --kernel-trace --stats -- python bench.py --no_overlap --no_graph` reports
+    #         the same averages (profiles/r01_kernel_stats_criteo1tb_seq.txt).
+    # Pass B (only when overlapping): the same launches while the side stream runs the next window's cache op ->
+    #         `avg_ms_in_pipeline`; event-bracketed, so it includes the time a kernel waits for CUs held by the
+    #         other stream (rocprofv3 of the default command shows 126 / 75 us of pure execution there).
     def event_pass():
         evs = []
         run_steps(W, min(K, 4 * P), evs)
@@ -245,11 +248,14 @@ def main():
         g = [e1.elapsed_time(e2) for _, e1, e2 in evs]
         return sum(f) / len(f), sum(g) / len(g)
 
+    torch.cuda.synchronize()
+    win = PrefetchWindow(embed, P, overlap=False)
     fwd_avg, bwd_avg = event_pass()
-    fwd_iso, bwd_iso = fwd_avg, bwd_avg
-    if win.overlap:
-        win = PrefetchWindow(embed, P, overlap=False)
-        fwd_iso, bwd_iso = event_pass()
+    fwd_pipe, bwd_pipe = fwd_avg, bwd_avg
+    if args.overlap:
+        win = PrefetchWindow(embed, P, overlap=True)
+        fwd_pipe, bwd_pipe = event_pass()
+        torch.cuda.synchronize()
     row_b = 4 * D
     fwd_bytes = B * F * (L * (row_b + 8) + 8 + row_b)            # 1040 B/lookup at D=128, L=1
     # backward: per bag read the gradient row (4D) + offset (8), per lookup the slot (8); per UNIQUE
@@ -264,11 +270,9 @@ def main():
     bwd_roof = dict(kernel="k_bag_bwd(sgd)", bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=bwd_avg, bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
-    fwd_roof["isolated_avg_ms"], bwd_roof["isolated_avg_ms"] = fwd_iso, bwd_iso
+    fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
     for r in (fwd_roof, bwd_roof):
         r["frac"] = r["achieved"] / r["peak"]
-        r["isolated_achieved"] = r["bytes_per_launch"] / r["isolated_avg_ms"] / 1e6
-        r["isolated_frac"] = r["isolated_achieved"] / r["peak"]
         r["traffic"] = None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():

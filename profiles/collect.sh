@@ -6,6 +6,8 @@ python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err;
 python bench.py --no_overlap > gpurun_out/bench_seq.json 2>/dev/null
 python bench.py --use_lfu --no_cpu_baseline > gpurun_out/bench_lfu.json 2>/dev/null
 python bench.py --force_sharded --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_sharded_w1.json
+python bench.py --async_copy --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_staged.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 64 --warmup 16 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_torchrun1.json
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ov -o r01 -- python $R/bench.py --no_cpu_baseline > $R/gpurun_out/prof_ov.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_seq -o r01 -- python $R/bench.py --no_cpu_baseline --no_overlap --no_graph > $R/gpurun_out/prof_seq.log 2>&1
