@@ -94,6 +94,56 @@ def test_full_criteo1tb_index_size_properties(strategy):
     assert mgr.cuda_available_row_num == C and int((mgr.inverted_cached_idx >= 0).sum()) == 0
 
 
+def test_eviction_larger_than_the_staging_buffer_vs_oracle():
+    """more victims in one call (> 262,144) than the HBM write-back staging holds: the overflow goes straight
+    from the cache rows to the host table; state and host table must still match the oracle exactly"""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    rng = np.random.default_rng(5)
+    N, C, D = 1_500_000, 400_000, 4
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 1.0)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C, evict_strategy=ce.EvictionStrategy.DATASET)
+    mgr.reorder(None, 1.0)
+    ora.cuda_cached_weight += np.float32(1.0)                 # "training" touched every resident row
+    with torch.no_grad():
+        mgr.cuda_cached_weight += 1.0
+    ids = rng.permutation(np.arange(C, N))[:350_000]           # 350 k fresh rows -> 350 k evictions
+    exp = ora.prepare_ids(ids)
+    got = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+    assert mgr.num_write_back_history[-1] == 350_000 == ora.num_write_back_history[-1]
+    assert np.array_equal(got.cpu().numpy(), exp)
+    assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)     # written-back payloads
+    np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
+
+
+@pytest.mark.parametrize("D", [7, 130])
+def test_rows_not_multiple_of_16_bytes(D):
+    ce = _ce()
+    from oracle.cache_oracle import LFU, OracleCachedParamMgr
+    rng = np.random.default_rng(D)
+    N, C = 3000, 200
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU)
+    ora.reorder(None, 0.7)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C, evict_strategy=ce.EvictionStrategy.LFU)
+    mgr.reorder(None, 0.7)
+    for _ in range(10):
+        ids = rng.integers(0, N, size=150)
+        exp = ora.prepare_ids(ids)
+        got = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(got.cpu().numpy(), exp)
+        ora.cuda_cached_weight[np.unique(exp)] += np.float32(0.25)
+        with torch.no_grad():
+            mgr.cuda_cached_weight[torch.unique(got)] += 0.25
+        np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
+    mgr.flush(); ora.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+
+
 def test_hypothesis_random_streams_vs_oracle():
     ce = _ce()
     hypothesis = pytest.importorskip("hypothesis")
