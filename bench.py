@@ -63,6 +63,9 @@ def parse():
                     help="reference semantics: the window's cache op runs on the compute stream (default: the cache op "
                          "of window k+1 runs on a side HIP stream while window k trains, protect_depth=1)")
     ap.add_argument("--cache_cus", type=int, default=0, help="CUs reserved for the side-stream cache op (0 = share all)")
+    ap.add_argument("--presort", action="store_true", help="sort the backward tiles once per window on the cache-op "
+                    "stream (ce_bag_presort) instead of inside every backward launch: backward 104 -> 94 us, but the "
+                    "extra side-stream work costs more than it saves when overlapping (1.92 -> 1.83 G lookups/s)")
     ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
                     "hipGraph of the window's P training steps")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
@@ -139,7 +142,8 @@ def main():
     windows = [gen.next_values(P) for _ in range(n_windows)]          # each [P, F*B*L]
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
-    win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus)
+    presort = args.presort and not args.deterministic
+    win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort)
     use_graph = not args.no_graph
     if use_graph and W % P:
         W = (W // P + 1) * P          # graph mode trains whole windows: round the untimed warm-up up
@@ -148,15 +152,15 @@ def main():
         while len(windows) < n_windows:
             windows.append(gen.next_values(P))
 
-    def train_step(slots_i, i):
-        out = embed(slots_i, offsets, hook_features=F)
+    def train_step(slots_i, i, keys_i=None):
+        out = embed(slots_i, offsets, hook_features=F, presorted=keys_i)
         out.backward(grad)
 
     gw = None
     if use_graph:
         from cachedembedding_amd.pipeline import GraphedWindow
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
-                           warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus)
+                           warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort)
         note("hipGraph of the window's training steps captured")
 
     def run_windows(first_w, count_w, tail_steps=0):
@@ -196,7 +200,7 @@ def main():
             if ev_pairs is not None:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
-            out = embed(slots[bi], offsets, hook_features=F)
+            out = embed(slots[bi], offsets, hook_features=F, presorted=win.keys[bi] if win.keys else None)
             if ev_pairs is not None:
                 e1.record()
             out.backward(grad)
@@ -249,11 +253,11 @@ def main():
         return sum(f) / len(f), sum(g) / len(g)
 
     torch.cuda.synchronize()
-    win = PrefetchWindow(embed, P, overlap=False)
+    win = PrefetchWindow(embed, P, overlap=False, presort=presort)
     fwd_avg, bwd_avg = event_pass()
     fwd_pipe, bwd_pipe = fwd_avg, bwd_avg
     if args.overlap:
-        win = PrefetchWindow(embed, P, overlap=True)
+        win = PrefetchWindow(embed, P, overlap=True, presort=presort)
         fwd_pipe, bwd_pipe = event_pass()
         torch.cuda.synchronize()
     row_b = 4 * D
@@ -297,6 +301,7 @@ def main():
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
                    "transport": "staged" if args.async_copy else "zerocopy", "overlap": bool(args.overlap),
                    "launch": "hipGraph per window" if use_graph else "python per step",
+                   "bwd_tile_sort": "per window on the cache-op stream" if presort else "inside every backward",
                    "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,

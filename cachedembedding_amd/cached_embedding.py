@@ -93,14 +93,14 @@ class CachedEmbeddingBag(nn.Module):
 
     def forward(self, input: torch.Tensor, offsets: Optional[torch.Tensor] = None,
                 per_sample_weights: Optional[torch.Tensor] = None, shape_hook: Optional[Callable] = None,
-                *, hook_features: int = 0) -> torch.Tensor:
+                *, hook_features: int = 0, presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.cache_op:
             with torch.no_grad():
                 input = self.cache_weight_mgr.prepare_ids(input)
         out = embedding_bag(input, self.cache_weight_mgr.cuda_cached_weight, offsets, self.max_norm,
                             self.norm_type, self.scale_grad_by_freq, self.mode, self.sparse, per_sample_weights,
                             self.include_last_offset, None, hook_features=hook_features,
-                            fused_sgd=self.fused_sgd)
+                            fused_sgd=self.fused_sgd, presorted=presorted)
         if shape_hook is not None:
             out = shape_hook(out)
         return out

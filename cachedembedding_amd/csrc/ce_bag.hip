@@ -41,6 +41,7 @@ struct BagParams {
   int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
   uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
   int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
+  const uint32_t* presorted; // optional: per-tile sorted 32-bit keys from ce_bag_presort (skips the LDS sort)
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -356,6 +357,50 @@ template <> struct KeyOps<unsigned long long> {
   static __device__ __forceinline__ uint32_t row_invalid() { return 0xffffffffu; }
 };
 
+// The (row, lookup) sort of every 1024-lookup tile does not depend on the gradient, only on the slots the
+// cache op returns -- so it can run once per window on the cache-op stream (ce_bag_presort) instead of inside
+// every backward launch.  Output: for each tile the 1024 sorted 32-bit keys (row << 10 | lookup-in-tile),
+// invalid (out-of-range row / padding) = 0xffffffff, sorted last.
+__global__ __launch_bounds__(256) void k_bag_presort(const int64_t* __restrict__ indices, int64_t nnz, uint32_t num_rows,
+                                                     uint32_t* __restrict__ keys_out) {
+  using K = KeyOps<uint32_t>;
+  __shared__ uint32_t keys[kBwdTile];
+  const int tid = threadIdx.x;
+  const int ntiles = (int)((nnz + kBwdTile - 1) / kBwdTile);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t j0 = (int64_t)tile * kBwdTile;
+    for (int i = tid; i < kBwdTile; i += 256) {
+      uint32_t key = K::invalid();
+      if (j0 + i < nnz) {
+        const int64_t r = indices[j0 + i];
+        if ((uint64_t)r < (uint64_t)num_rows) key = K::make((uint32_t)r, i);
+      }
+      keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= kBwdTile; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int c = tid + t * 256;
+          const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+          const int l = i | j;
+          const uint32_t a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < kBwdTile; i += 256)
+      if (j0 + i < nnz) keys_out[j0 + i] = keys[i];
+    __syncthreads();
+  }
+}
+
 template <typename VT, int NCH, typename KT, int R>
 __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   using K = KeyOps<KT>;
@@ -393,14 +438,20 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         }
         bagl[i] = bag;
         scl[i] = sc;
-        const int64_t r = p.indices[j];
-        if ((uint64_t)r < (uint64_t)p.num_rows) key = K::make((uint32_t)r, i);
+        if (sizeof(KT) == 4 && p.presorted) {
+          key = (KT)p.presorted[j];                          // sorted position i of this tile, not lookup i
+        } else {
+          const int64_t r = p.indices[j];
+          if ((uint64_t)r < (uint64_t)p.num_rows) key = K::make((uint32_t)r, i);
+        }
       }
       keys[i] = key;
     }
     __syncthreads();
     if (p.debug == 3) continue;
     // ---- b. bitonic sort (row major, lookup minor) -> runs are in lookup order, invalid keys last
+    //         (skipped when the cache op already sorted this tile: ce_bag_presort)
+    if (!(sizeof(KT) == 4 && p.presorted))
     for (int k = 2; k <= kBwdTile; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
@@ -623,10 +674,11 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
 
-extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
-                                   int64_t nnz, const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
-                                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
-                                   int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream) {
+static int backward_sgd_impl(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
+                             const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                             int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                             int64_t hook_features, const float* grad_out, float lr, const uint32_t* presorted,
+                             ce_stream_t stream) {
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -642,7 +694,43 @@ extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
   while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
   p.num_rows = (uint32_t)num_rows;
+  CE_REQUIRE(!presorted || num_rows <= (1ll << 22) - 2, CE_ERR_UNSUPPORTED,
+             "presorted keys are 32-bit: the table must have fewer than 2^22 rows");
+  p.presorted = presorted;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                                   int64_t nnz, const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                                   int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream) {
+  return backward_sgd_impl(weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
+                           include_last_offset, per_sample_weights, mode, hook_features, grad_out, lr, nullptr, stream);
+}
+
+extern "C" int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                                             int64_t nnz, const void* offsets, int32_t offsets_are_i64,
+                                             int64_t num_bags, int32_t include_last_offset,
+                                             const float* per_sample_weights, int32_t mode, int64_t hook_features,
+                                             const float* grad_out, float lr, const uint32_t* presorted_keys,
+                                             ce_stream_t stream) {
+  CE_REQUIRE(presorted_keys, CE_ERR_INVALID, "null presorted_keys");
+  return backward_sgd_impl(weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
+                           include_last_offset, per_sample_weights, mode, hook_features, grad_out, lr,
+                           presorted_keys, stream);
+}
+
+extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint32_t* keys_out,
+                              ce_stream_t stream) {
+  if (nnz == 0) return CE_OK;
+  CE_REQUIRE(indices && keys_out && nnz > 0 && nnz < (int64_t)INT32_MAX, CE_ERR_INVALID, "bad arguments");
+  CE_REQUIRE(num_rows > 0 && num_rows <= (1ll << 22) - 2, CE_ERR_UNSUPPORTED,
+             "presorted keys are 32-bit: the table must have fewer than 2^22 rows");
+  const int ntiles = (int)cdiv(nnz, kBwdTile);
+  hipLaunchKernelGGL(k_bag_presort, dim3(std::min(ntiles, kMaxBlocks * 4)), dim3(256), 0, (hipStream_t)stream, indices,
+                     nnz, (uint32_t)num_rows, keys_out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
 }
 
 extern "C" int ce_bag_backward_rows(float* grad_rows, const int64_t* dest_index, int32_t dim, int64_t nnz,

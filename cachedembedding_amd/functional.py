@@ -48,7 +48,7 @@ def _prep(indices: torch.Tensor, offsets: Optional[torch.Tensor], include_last_o
 
 class _BagFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, indices, offsets, psw, mode, include_last, hook_features, sparse, fused):
+    def forward(ctx, weight, indices, offsets, psw, mode, include_last, hook_features, sparse, fused, presorted):
         _lib.require_gpu()
         assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
@@ -64,6 +64,7 @@ class _BagFn(torch.autograd.Function):
         ctx.save_for_backward(indices, offsets, psw)
         ctx.weight = weight
         ctx.args = (mode, include_last, hook_features, sparse, fused, num_bags)
+        ctx.presorted = presorted
         return out
 
     @staticmethod
@@ -85,6 +86,11 @@ class _BagFn(torch.autograd.Function):
                                                          ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
                                                          mode, hook_features, ptr(grad_out), float(fused.lr),
                                                          ptr(ws), ws.numel(), stream_ptr()))
+                elif ctx.presorted is not None:
+                    check(lib.ce_bag_backward_sgd_presorted(ptr(weight), weight.shape[0], dim, ptr(indices), nnz,
+                                                            ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
+                                                            mode, hook_features, ptr(grad_out), float(fused.lr),
+                                                            ptr(ctx.presorted), stream_ptr()))
                 else:
                     check(lib.ce_bag_backward_sgd(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets),
                                                   off64, num_bags, int(include_last), ptr(psw), mode, hook_features,
@@ -99,7 +105,7 @@ class _BagFn(torch.autograd.Function):
             check(lib.ce_bag_backward_dense(ptr(gw), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
                                             num_bags, int(include_last), ptr(psw), mode, hook_features,
                                             ptr(grad_out), stream_ptr()))
-        return gw, None, None, None, None, None, None, None, None
+        return gw, None, None, None, None, None, None, None, None, None
 
 
 class FusedSGD:
@@ -124,7 +130,8 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   max_norm: Optional[float] = None, norm_type: float = 2.0, scale_grad_by_freq: bool = False,
                   mode: str = "mean", sparse: bool = False, per_sample_weights: Optional[torch.Tensor] = None,
                   include_last_offset: bool = False, padding_idx: Optional[int] = None, *,
-                  hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None) -> torch.Tensor:
+                  hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None,
+                  presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
     if max_norm is not None:
         raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
     if scale_grad_by_freq:
@@ -143,5 +150,17 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
         raise ValueError("per_sample_weights must have the same number of elements as input")
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
+    if presorted is not None:
+        assert presorted.is_cuda and presorted.dtype == torch.int32 and presorted.numel() == indices.numel()
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
-                        int(hook_features), bool(sparse), fused_sgd)
+                        int(hook_features), bool(sparse), fused_sgd, presorted)
+
+
+def presort_slots(slots: torch.Tensor, num_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-tile sorted keys for the fused backward (ce_bag_presort); int32 tensor with the bits of uint32 keys.
+    Run it once per prefetch window on the cache-op stream, then pass slices to embedding_bag(presorted=...)."""
+    flat = slots.reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty(flat.numel(), dtype=torch.int32, device=flat.device)
+    check(lib.ce_bag_presort(ptr(flat), flat.numel(), int(num_rows), ptr(out), stream_ptr()))
+    return out

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 from .cached_embedding import CachedEmbeddingBag
+from .functional import presort_slots
 
 
 def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.cuda.Stream:
@@ -38,8 +39,13 @@ def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.
 
 
 class PrefetchWindow:
-    def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0):
+    def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
+                 presort: bool = False):
         assert prefetch_num >= 1
+        # presort=True: the cache op also sorts every backward tile of the window's slots (ce_bag_presort), so the
+        # fused backward skips its LDS sort; the keys of the last prepared/collected window are in `self.keys`
+        self.presort = presort and embed.cache_weight_mgr.cuda_row_num <= (1 << 22) - 2
+        self.keys: Optional[List[torch.Tensor]] = None
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
         self.P = prefetch_num
@@ -57,12 +63,22 @@ class PrefetchWindow:
         cat = values[0] if len(values) == 1 else torch.cat(list(values))
         slots = self.mgr.prepare_ids(cat)
         # split by per-batch id counts (torch.chunk in the reference is only right for equal sizes, B#13)
-        return list(torch.split(slots, counts))
+        parts = list(torch.split(slots, counts))
+        self._keys_tmp = None
+        if self.presort:
+            C = self.mgr.cuda_row_num
+            if all(c % 1024 == 0 for c in counts):
+                self._keys_tmp = list(torch.split(presort_slots(slots, C), counts))
+            else:
+                self._keys_tmp = [presort_slots(p, C) for p in parts]
+        return parts
 
     def prepare(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Synchronous window op on the current stream (reference behaviour)."""
         assert 1 <= len(values) <= self.P
-        return self._cache_op(values)
+        slots = self._cache_op(values)
+        self.keys = self._keys_tmp
+        return slots
 
     def submit(self, values: Sequence[torch.Tensor]) -> None:
         """Start the cache op for the NEXT window on the side stream (overlap=True)."""
@@ -71,21 +87,25 @@ class PrefetchWindow:
         self._side.wait_stream(cur)          # ids were produced on the current stream
         with torch.cuda.stream(self._side):
             slots = self._cache_op(values)
+            keys = self._keys_tmp
             ev = torch.cuda.Event()
             ev.record(self._side)
         for v in values:
             v.record_stream(self._side)
-        self._pending = (ev, slots)
+        self._pending = (ev, slots, keys)
 
     def collect(self) -> List[torch.Tensor]:
         """Slots of the submitted window; the current stream waits for the side stream."""
         assert self._pending is not None
-        ev, slots = self._pending
+        ev, slots, keys = self._pending
         self._pending = None
         cur = torch.cuda.current_stream(self.mgr.device)
         cur.wait_event(ev)
         for s in slots:
             s.record_stream(cur)
+        for k in keys or []:
+            k.record_stream(cur)
+        self.keys = keys
         return slots
 
 
@@ -101,7 +121,7 @@ class GraphedWindow:
     All tensors it reads besides `slots_i` must be static (offsets, upstream gradient / dense inputs)."""
 
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
-                 warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0):
+                 warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False):
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
         self.P = prefetch_num
@@ -109,6 +129,11 @@ class GraphedWindow:
         self.overlap = overlap
         dev = self.mgr.device
         self._bufs = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
+        # presort=True: step_fn(slots_i, i, keys_i); the per-tile sorted keys of the window (ce_bag_presort) are
+        # produced by the cache op into a static buffer next to the slots
+        self.presort = presort and self.mgr.cuda_row_num <= (1 << 22) - 2
+        self._keys = [torch.full((self.P, self.n), -1, dtype=torch.int32, device=dev) for _ in range(2)] \
+            if self.presort else None
         self._side = make_side_stream(dev, cache_cus) if overlap else None
         self._events = [None, None]
         self._step_fn = step_fn
@@ -119,11 +144,14 @@ class GraphedWindow:
         if warmup_values is not None:
             self.mgr.prepare_ids(torch.cat(list(warmup_values)), out=self._bufs[0])
             self._bufs[1].copy_(self._bufs[0])
+            if self.presort:
+                self._presort(0)
+                self._keys[1].copy_(self._keys[0])
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for i in range(self.P):
-                step_fn(self._bufs[0][i], i)
+                self._call(step_fn, 0, i)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self._graphs = []
@@ -131,8 +159,22 @@ class GraphedWindow:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for i in range(self.P):
-                    step_fn(self._bufs[b][i], i)
+                    self._call(step_fn, b, i)
             self._graphs.append(g)
+
+    def _call(self, step_fn, buf: int, i: int) -> None:
+        if self.presort:
+            step_fn(self._bufs[buf][i], i, self._keys[buf][i])
+        else:
+            step_fn(self._bufs[buf][i], i)
+
+    def _presort(self, buf: int) -> None:
+        C = self.mgr.cuda_row_num
+        if self.n % 1024 == 0:
+            presort_slots(self._bufs[buf], C, out=self._keys[buf].view(-1))
+        else:
+            for i in range(self.P):
+                presort_slots(self._bufs[buf][i], C, out=self._keys[buf][i])
 
     @torch.no_grad()
     def submit(self, values: Sequence[torch.Tensor], buf: int) -> None:
@@ -146,12 +188,16 @@ class GraphedWindow:
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 self.mgr.prepare_ids(cat, out=self._bufs[buf])
+                if self.presort:
+                    self._presort(buf)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             cat.record_stream(self._side)
             self._events[buf] = ev
         else:
             self.mgr.prepare_ids(cat, out=self._bufs[buf])
+            if self.presort:
+                self._presort(buf)
             self._events[buf] = None
 
     def run(self, buf: int, steps: Optional[int] = None) -> None:
@@ -164,4 +210,4 @@ class GraphedWindow:
             self._graphs[buf].replay()
         else:
             for i in range(steps):
-                self._step_fn(self._bufs[buf][i], i)
+                self._call(self._step_fn, buf, i)

@@ -171,3 +171,32 @@ def test_full_size_batch_properties():
     f, b = pick // B, pick % B
     assert torch.equal(out[b, f], w[idx[pick]])
     assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))
+
+
+@pytest.mark.parametrize("nb,F", [(4096, 4), (5000, 1), (1023, 1), (1, 1)])
+def test_presorted_backward_matches_in_kernel_sort(nb, F):
+    """ce_bag_presort + ce_bag_backward_sgd_presorted == ce_bag_backward_sgd (same tile sort, hoisted)"""
+    ce = _ce()
+    from cachedembedding_amd.functional import presort_slots
+    g = torch.Generator().manual_seed(nb)
+    C, D = 3000, 128
+    w = torch.randn(C, D, generator=g)
+    idx = (torch.rand(nb, generator=g) ** 3 * C).long().clamp_(0, C - 1)
+    idx[::17] = C + 5                       # out-of-range slots must be ignored by both paths
+    off = torch.arange(nb + 1, dtype=torch.int32)
+    go = torch.randn(nb // F, F, D, generator=g) * 0.01 if nb % F == 0 and F > 1 else torch.randn(nb, D, generator=g) * 0.01
+    hook = F if go.dim() == 3 else 0
+    outs = []
+    for use_keys in (False, True):
+        wc = w.cuda().requires_grad_(True)
+        keys = presort_slots(idx.cuda(), C) if use_keys else None
+        out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
+                               hook_features=hook, fused_sgd=ce.FusedSGD(0.5), presorted=keys)
+        out.backward(go.cuda())
+        outs.append(wc.detach().cpu())
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+    valid = idx < C
+    ref = w.clone()
+    gflat = go.transpose(0, 1).reshape(-1, D) if hook else go
+    ref.index_add_(0, idx[valid], gflat[valid], alpha=-0.5)
+    torch.testing.assert_close(outs[1], ref, rtol=1e-4, atol=1e-5)
