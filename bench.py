@@ -378,7 +378,9 @@ def run_sharded(args, sizes, rank, world, dev):
 
     from cachedembedding_amd.parallel import ShardedWindowPipeline
     pipe = ShardedWindowPipeline(embed, overlap=args.overlap)
-    pump_at = {0, max(1, P // 4)} if P >= 3 else set()     # early: the cache op of the next window needs the lead
+    # finish the next window's plan after a few steps: its dedupe kernels (~0.1 ms per batch on the side stream)
+    # have run by then, so the host does not wait, and the cache op still gets most of the window as lead
+    pump_at = {int(os.environ.get("CE_BENCH_PUMP_AT", min(2, P - 1)))} if P >= 2 else set()
 
     def run_steps(first, count):
         """window plans are built one window ahead on a side stream (submit before training the current one)"""
@@ -391,9 +393,8 @@ def run_sharded(args, sizes, rank, world, dev):
                 if wi + 1 <= last_w:
                     pipe.submit([windows[wi + 1][i] for i in range(P)], wait_for_current=False)
                 plans = pipe.collect()
-            out = embed(plans[bi], offsets, hook_features=F)
-            out.backward(grad)
-            if bi in pump_at:        # next window's plan advances one phase; its counts have landed by now
+            embed.forward_backward(plans[bi], offsets, grad, hook_features=F)
+            if bi in pump_at:        # finish the next window's plan; its bucket sizes have landed by now
                 pipe.pump()
 
     def barrier():

@@ -117,6 +117,9 @@ SIGNATURES = {
     "ce_bucketize_workspace": (c_size_t, [c_int64, c_int32]),
     "ce_bucketize_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
+    "ce_dedupe_bucket_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ce_rows_axpy": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
 }
 
 

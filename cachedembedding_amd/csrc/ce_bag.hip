@@ -526,6 +526,51 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   }
 }
 
+// dst[index[i]] += alpha * src[i] for whole rows (the owner-side SGD of the row-wise exchange: `src` holds one
+// already-folded gradient row per requested row, so there is nothing to sort or fold; rows requested by several
+// peers repeat, hence atomics).  Lane group per row, U rows in flight, lane-block transposed atomics as above.
+template <typename VT, int NCH>
+__global__ __launch_bounds__(256) void k_rows_axpy(float* __restrict__ dst, uint32_t num_rows,
+                                                   const int64_t* __restrict__ index, int64_t n,
+                                                   const VT* __restrict__ src, int rowlen, int g_log2, int dim,
+                                                   float alpha) {
+  constexpr int U = (NCH == 1) ? 8 : (NCH == 2 ? 4 : 2);
+  const int lane = threadIdx.x & 63;
+  const int G = 1 << g_log2;
+  const int gpw = 64 >> g_log2;
+  const int grp = lane >> g_log2;
+  const int gl = lane & (G - 1);
+  const int wpb = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  const int64_t per_wave = (int64_t)gpw * U;
+  for (int64_t r0 = wave * per_wave; r0 < n; r0 += nwaves * per_wave) {
+    VT v[U][NCH];
+    int64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = r0 + u * gpw + grp;
+      row[u] = -1;
+      if (i < n) {
+        row[u] = index[i];
+        if ((unsigned long long)row[u] >= (unsigned long long)num_rows) row[u] = -1;
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = gl + c * G;
+        v[u][c] = vzero<VT>();
+        if (row[u] >= 0 && ch < rowlen) v[u][c] = __builtin_nontemporal_load(&src[i * rowlen + ch]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (row[u] < 0) continue;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) flush_chunk(dst + row[u] * dim, v[u][c] * alpha, gl, G, c, rowlen, 0);
+    }
+  }
+}
+
 static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_t nnz, const void* offsets,
                        int32_t off64, int64_t num_bags, int32_t include_last, const float* psw, int32_t mode,
                        int64_t hookF, bool* vec, int* nch, const void* a0, const void* a1, const void* a2) {
@@ -729,6 +774,38 @@ extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_r
   const int ntiles = (int)cdiv(nnz, kBwdTile);
   hipLaunchKernelGGL(k_bag_presort, dim3(std::min(ntiles, kMaxBlocks * 4)), dim3(256), 0, (hipStream_t)stream, indices,
                      nnz, (uint32_t)num_rows, keys_out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_rows_axpy(float* weight, int64_t num_rows, int32_t dim, const int64_t* index, int64_t n,
+                            const float* src_rows, float alpha, ce_stream_t stream) {
+  if (n == 0) return CE_OK;
+  CE_REQUIRE(weight && index && src_rows, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(dim > 0 && n > 0 && n < (int64_t)INT32_MAX, CE_ERR_INVALID, "bad sizes");
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  const bool vec = (dim % 4 == 0) && al16(weight) && al16(src_rows);
+  const int rowlen = vec ? dim / 4 : dim;
+  int g = 1, gl2 = 0;
+  while (g < rowlen && g < 64) { g <<= 1; ++gl2; }
+  const int need = (rowlen + g - 1) / g;
+  int nch = 1;
+  while (nch < need) nch <<= 1;
+  CE_REQUIRE(nch <= 4, CE_ERR_UNSUPPORTED, "embedding dim %d too large for this build", dim);
+  const int u = nch == 1 ? 8 : (nch == 2 ? 4 : 2);
+  const int64_t per_block = (int64_t)(64 / g) * u * 4;
+  dim3 grid(grid_for(n, (int)per_block)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define CE_AXPY(VT, N)                                                                                      \
+  hipLaunchKernelGGL((k_rows_axpy<VT, N>), grid, block, 0, s, weight, (uint32_t)num_rows, index, n,         \
+                     (const VT*)src_rows, rowlen, gl2, dim, alpha)
+  if (vec) {
+    if (nch == 1) CE_AXPY(f32x4, 1); else if (nch == 2) CE_AXPY(f32x4, 2); else CE_AXPY(f32x4, 4);
+  } else {
+    if (nch == 1) CE_AXPY(float, 1); else if (nch == 2) CE_AXPY(float, 2); else CE_AXPY(float, 4);
+  }
+#undef CE_AXPY
   CE_LAUNCH_CHECK();
   return CE_OK;
 }

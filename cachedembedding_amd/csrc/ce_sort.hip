@@ -8,6 +8,8 @@
 // One split pass = histogram per 4096-lookup tile (digit-major), one-block exclusive scan,
 // stable scatter.  Ranks inside a tile come from wave64 ballots (8 ballots give each lane
 // the mask of lanes holding the same digit) plus per-wave digit counters in LDS.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ce_common.h"
@@ -285,6 +287,128 @@ __global__ __launch_bounds__(256) void k_dedupe_index(const int64_t* __restrict_
   }
 }
 
+// ---- fused dedupe + owner bucketing (row-wise exchange, requester side).  Three passes, no sort, no histogram /
+// scan chain, no host sync and NO returning atomics (a random device-scope atomic with return costs a
+// ~2 us round trip to the memory side and a CU keeps only a few dozen in flight: 426 k of them took 90 us):
+//   mark:   stamp[row] = lookup index, plain stores (any ONE of the racing lookups of a row survives -- which
+//           one does not matter); equal rows of a wave are merged first so hot rows cost one store per wave;
+//   claim:  the lookup whose index survived owns the row: it numbers the row WITHIN ITS OWNER'S BUCKET
+//           (wave ballots -> one counter bump per owner per workgroup);
+//   finish: (owner, index in bucket) -> position in the owner-major list once the bucket sizes are final.
+__global__ __launch_bounds__(256) void k_dedupe_mark_w(const int64_t* __restrict__ ids, int64_t n,
+                                                       const int32_t* __restrict__ idx_map, int64_t num_rows,
+                                                       int row_bits, int32_t* __restrict__ stamp,
+                                                       int32_t* __restrict__ rows32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // wave-uniform trip count (ballots inside)
+  for (int64_t b0 = (int64_t)blockIdx.x * blockDim.x; b0 < n; b0 += stride) {
+    const int64_t i = b0 + threadIdx.x;
+    bool on = i < n;
+    int32_t row = -1;
+    if (on) {
+      const int64_t id = ids[i];
+      on = (unsigned long long)id < (unsigned long long)num_rows;
+      if (on) row = idx_map ? idx_map[id] : (int32_t)id;
+      rows32[i] = row;
+    }
+    unsigned long long pm = __ballot(on);
+    if (!on) pm = 0;
+    for (int b = 0; b < row_bits; ++b) {
+      const unsigned long long m = __ballot((row >> b) & 1);
+      pm &= ((row >> b) & 1) ? m : ~m;
+    }
+    if (on && (__ffsll((long long)pm) - 1) == lane) stamp[row] = (int32_t)i;
+  }
+}
+
+template <int IT>
+__global__ __launch_bounds__(256) void k_dedupe_claim_w(const int32_t* __restrict__ rows32, int64_t n,
+                                                        int32_t world, const int32_t* __restrict__ stamp,
+                                                        int32_t* __restrict__ slot_of_row,
+                                                        int32_t* __restrict__ bucket_rows,
+                                                        unsigned long long* counts) {
+  __shared__ int wave_cnt[4][64];
+  __shared__ unsigned long long blk_base[64];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t per_block = 256 * IT;
+  for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
+    int32_t row[IT];
+    bool claim[IT];
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      const int64_t i = b0 + t * 256 + threadIdx.x;
+      row[t] = (i < n) ? rows32[i] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      const int64_t i = b0 + t * 256 + threadIdx.x;
+      claim[t] = row[t] >= 0 && stamp[row[t]] == (int32_t)i;
+    }
+    // rank of every claimed row inside (wave, owner); lane o carries the wave's running count for owner o
+    int own[IT], rank[IT];
+    int mycnt = 0;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      own[t] = claim[t] ? row[t] % world : 0;
+      rank[t] = 0;
+      for (int o = 0; o < world; ++o) {
+        const bool mine = claim[t] && own[t] == o;
+        const unsigned long long m = __ballot(mine);
+        const int prev = __shfl(mycnt, o);
+        if (mine) rank[t] = prev + __popcll(m & lt);
+        if (lane == o) mycnt += __popcll(m);
+      }
+    }
+    wave_cnt[wv][lane] = mycnt;
+    __syncthreads();
+    if (threadIdx.x < world) {
+      const int tot = wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] +
+                      wave_cnt[3][threadIdx.x];
+      blk_base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x], (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      if (claim[t]) {
+        unsigned long long p = blk_base[own[t]] + rank[t];
+        for (int k = 0; k < wv; ++k) p += wave_cnt[k][own[t]];
+        bucket_rows[(int64_t)own[t] * n + p] = row[t] / world;
+        slot_of_row[row[t]] = (int32_t)p;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dedupe_finish_w(const int32_t* __restrict__ rows32, int64_t n, int32_t world,
+                                                         const int32_t* __restrict__ slot_of_row,
+                                                         const int32_t* __restrict__ bucket_rows,
+                                                         const unsigned long long* __restrict__ counts,
+                                                         int64_t* __restrict__ local_rows_out,
+                                                         int64_t* __restrict__ pos_out) {
+  __shared__ long long pre[65];
+  if (threadIdx.x == 0) {
+    long long acc = 0;
+    for (int o = 0; o < world; ++o) { pre[o] = acc; acc += (long long)counts[o]; }
+    pre[world] = acc;
+  }
+  __syncthreads();
+  const long long n_u = pre[world];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t row = rows32[i];
+    pos_out[i] = row >= 0 ? pre[row % world] + slot_of_row[row] : -1;
+    if (i < n_u) {                       // owner-major compaction of the bucket lists
+      int o = 0;
+      while (o + 1 < world && pre[o + 1] <= i) ++o;
+      local_rows_out[i] = bucket_rows[(int64_t)o * n + (i - pre[o])];
+    }
+  }
+}
+
 struct SortWs {
   int32_t *keys[2], *vals[2], *bag_of, *hist, *total;
   size_t bytes;
@@ -364,6 +488,43 @@ extern "C" int ce_dedupe_rows(const int64_t* ids, int64_t n, const int32_t* idx_
                      stamp, slot_of_row, uniq_rows_out, (unsigned long long*)n_unique_out);
   hipLaunchKernelGGL(k_dedupe_index, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows,
                      (const int32_t*)slot_of_row, inv_out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_dedupe_bucket_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
+                                     int32_t world, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
+                                     int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out,
+                                     ce_stream_t stream) {
+  CE_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX && num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID,
+             "bad sizes");
+  CE_REQUIRE(world >= 1 && world <= 64, CE_ERR_UNSUPPORTED, "world size must be in [1, 64]");
+  CE_REQUIRE(stamp && slot_of_row && counts_out, CE_ERR_INVALID, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  CE_HIP_CHECK(hipMemsetAsync(counts_out, 0, sizeof(int64_t) * world, s));
+  if (n == 0) return CE_OK;
+  CE_REQUIRE(ids && scratch && local_rows_out && pos_out, CE_ERR_INVALID, "null pointer");
+  int bits = 1;
+  while ((1ll << bits) < num_rows && bits < 31) ++bits;
+  int32_t* rows32 = scratch;                 // int32[n]
+  int32_t* bucket_rows = scratch + n;        // int32[world][n]
+  unsigned long long* counts = (unsigned long long*)counts_out;
+  hipLaunchKernelGGL(k_dedupe_mark_w, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows, bits,
+                     stamp, rows32);
+  const char* it_e = getenv("CE_DEDUPE_IT");      // 1 / 2 / 4 lookups per thread in the claim pass (default 4)
+  const int it_env = it_e ? atoi(it_e) : 4;
+  if (it_env == 1)
+    hipLaunchKernelGGL((k_dedupe_claim_w<1>), dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n,
+                       world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+  else if (it_env == 2)
+    hipLaunchKernelGGL((k_dedupe_claim_w<2>), dim3(grid_for(n, 512)), dim3(256), 0, s, (const int32_t*)rows32, n,
+                       world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+  else
+    hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024)), dim3(256), 0, s, (const int32_t*)rows32, n,
+                       world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+  hipLaunchKernelGGL(k_dedupe_finish_w, dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n, world,
+                     (const int32_t*)slot_of_row, (const int32_t*)bucket_rows, (const unsigned long long*)counts,
+                     local_rows_out, pos_out);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }

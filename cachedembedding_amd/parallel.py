@@ -182,16 +182,26 @@ class ShardOps:
         holds ~40 k distinct rows, so the all-to-all payload shrinks ~10x and the requester expands locally."""
         raise NotImplementedError
 
+    # Window form.  The three calls let an implementation run the whole bucketing of a window without a host
+    # wait: launch -> device-side counts (fixed-size message, all-to-all'ed by the caller) -> results once the
+    # caller has read the counts back.  The defaults wrap the synchronous single-batch `bucketize`.
+    def bucketize_launch(self, ids_list: Sequence[torch.Tensor]):
+        return [self.bucketize(ids) for ids in ids_list]
+
+    def bucketize_counts(self, token) -> torch.Tensor:
+        """int64[P, W]: unique rows of batch b owned by rank w"""
+        return torch.stack([t[2] for t in token])
+
+    def bucketize_results(self, token, counts_host: Sequence[Sequence[int]]):
+        """-> [(local_rows[n_u], pos[n], counts)] per batch; counts_host = bucketize_counts on the host"""
+        return list(token)
+
+    def token_tensors(self, token) -> List[torch.Tensor]:
+        return [x for t in token for x in t if torch.is_tensor(x)]
+
     def bucketize_many(self, ids_list: Sequence[torch.Tensor]):
-        """bucketize every batch of a window (implementations may batch their host syncs)."""
-        return self.bucketize_finish(self.bucketize_begin(ids_list))
-
-    def bucketize_begin(self, ids_list: Sequence[torch.Tensor]):
-        """launch whatever can run without host knowledge; returns a token for bucketize_finish"""
-        return list(ids_list)
-
-    def bucketize_finish(self, token):
-        return [self.bucketize(ids) for ids in token]
+        token = self.bucketize_launch(ids_list)
+        return self.bucketize_results(token, self.bucketize_counts(token).tolist())
 
     def owner_prepare(self, local_rows: torch.Tensor):       # -> slots[n_recv]
         raise NotImplementedError
@@ -222,61 +232,48 @@ class HipShardOps(ShardOps):
         self.dim = mgr.embedding_dim
         self._ws = None
         self.num_global_rows = num_global_rows
-        self._stamp = None                # ce_dedupe_rows state: int32[N] stamps + scratch, call tag
+        self._stamp = None                # ce_dedupe_bucket_rows scratch: int32[N] x 2
         self._slot_of_row = None
-        self._tag = 0
 
-    def _bucketize_unique(self, uniq: torch.Tensor, n_u: int, inv: torch.Tensor):
-        dev = uniq.device
-        rows = torch.empty(n_u, dtype=torch.int64, device=dev)
-        perm_u = torch.empty(n_u, dtype=torch.int64, device=dev)
-        counts = torch.empty(self.world, dtype=torch.int64, device=dev)
-        need = lib.ce_bucketize_workspace(n_u, self.world)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
-        check(lib.ce_bucketize_rows(ptr(uniq), n_u, None, self.world, ptr(rows), ptr(perm_u), ptr(counts),
-                                    ptr(self._ws), self._ws.numel(), stream_ptr()))
-        return rows, perm_u[inv], counts
-
-    def bucketize_begin(self, ids_list):
-        """Window form, phase 1: ce_dedupe_rows for every batch (no sync) + an async copy of the unique counts
-        into pinned host memory; the event tells bucketize_finish when they have landed."""
-        if self.num_global_rows is None:
-            return list(ids_list)
+    def bucketize_launch(self, ids_list):
+        """ce_dedupe_bucket_rows per batch (2 launches each, no sync); the bucket sizes stay on the device."""
         dev = ids_list[0].device
-        N = self.num_global_rows
-        if self._stamp is None:
-            self._stamp = torch.zeros(N, dtype=torch.int32, device=dev)
+        N, W = self.num_global_rows, self.world
+        if W > 64:
+            raise NotImplementedError("row-wise sharding over more than 64 ranks")
+        if self._stamp is None:             # scratch of the dedupe passes; contents carry nothing across calls
+            self._stamp = torch.empty(N, dtype=torch.int32, device=dev)
             self._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
         P = len(ids_list)
-        n_unique = torch.empty(P, dtype=torch.int64, device=dev)
+        counts = torch.empty(P, W, dtype=torch.int64, device=dev)
+        n_max = max(int(ids.numel()) for ids in ids_list)
+        if self._ws is None or self._ws.numel() < (W + 1) * n_max:
+            self._ws = torch.empty(max((W + 1) * n_max, 1 << 16), dtype=torch.int32, device=dev)
         staged = []
+        sp = stream_ptr()
         for b, ids in enumerate(ids_list):
             ids = ids.reshape(-1).long().contiguous()
             n = ids.numel()
-            uniq = torch.empty(n, dtype=torch.int64, device=dev)
-            inv = torch.empty(n, dtype=torch.int64, device=dev)
-            self._tag += 1
-            if self._tag >= 2 ** 31 - 1:
-                self._stamp.zero_()
-                self._tag = 1
-            check(lib.ce_dedupe_rows(ptr(ids), n, ptr(self.idx_map), N, self._tag, ptr(self._stamp),
-                                     ptr(self._slot_of_row), ptr(uniq), ptr(inv), n_unique[b:].data_ptr(),
-                                     stream_ptr()))
-            staged.append((uniq, inv))
-        host = torch.empty(P, dtype=torch.int64, pin_memory=True)
-        host.copy_(n_unique, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        return ("dedupe", staged, host, ev, n_unique)
+            rows = torch.empty(n, dtype=torch.int64, device=dev)
+            pos = torch.empty(n, dtype=torch.int64, device=dev)
+            check(lib.ce_dedupe_bucket_rows(ptr(ids), n, ptr(self.idx_map), N, W, ptr(self._stamp),
+                                            ptr(self._slot_of_row), ptr(self._ws), ptr(rows), ptr(pos),
+                                            counts[b].data_ptr(), sp))
+            staged.append((rows, pos))
+        return ("hip", staged, counts)
 
-    def bucketize_finish(self, token):
-        if not (isinstance(token, tuple) and token and token[0] == "dedupe"):
-            return [self.bucketize(ids) for ids in token]
-        _, staged, host, ev, _keep = token
-        ev.synchronize()                              # the only host wait of the dedupe phase
-        counts_h = host.tolist()
-        return [self._bucketize_unique(u[:c], int(c), inv) for (u, inv), c in zip(staged, counts_h)]
+    def bucketize_counts(self, token):
+        return token[2]
+
+    def bucketize_results(self, token, counts_host):
+        _, staged, _counts = token
+        return [(rows[:sum(c)], pos, list(c)) for (rows, pos), c in zip(staged, counts_host)]
+
+    def token_tensors(self, token):
+        return [t for pair in token[1] for t in pair] + [token[2]]
+
+    def bucketize(self, ids):
+        return self.bucketize_many([ids])[0]
 
     def owner_prepare(self, local_rows):
         return self.mgr.prepare_ids(local_rows)
@@ -318,9 +315,9 @@ class HipShardOps(ShardOps):
         if n == 0:
             return
         w = self.mgr.cuda_cached_weight
-        off = _arange_offsets(n, w.device)
-        check(lib.ce_bag_backward_sgd(ptr(w), w.shape[0], self.dim, ptr(slots), n, ptr(off), 0, n, 1, None,
-                                      _lib.CE_MODE_SUM, 0, ptr(grad_rows), float(lr), stream_ptr()))
+        # one folded gradient row per requested row: plain row axpy (atomic: peers may request the same row)
+        check(lib.ce_rows_axpy(ptr(w), w.shape[0], self.dim, ptr(slots), n, ptr(grad_rows.contiguous()),
+                               -float(lr), stream_ptr()))
 
 
 _ARANGE = {}
@@ -358,21 +355,19 @@ class RowwiseExchange:
     @torch.no_grad()
     def plan_window(self, ids_list: Sequence[torch.Tensor]) -> List[BatchPlan]:
         """Bucket every batch of the window by owner, exchange counts and ids, then run ONE owner-side cache
-        op over all rows this rank serves in the window.  = plan_begin + plan_mid + plan_end back to back;
-        a pipeline calls the three phases with training steps enqueued in between so that neither of the two
-        host waits (unique counts, exchanged counts) stalls the launch thread."""
-        return self.plan_end(self.plan_mid(self.plan_begin(ids_list)))
+        op over all rows this rank serves in the window.  = plan_begin + plan_end back to back; a pipeline
+        enqueues training steps between the two so that the single host wait of a window (the exchanged
+        bucket sizes) never stalls the launch thread."""
+        return self.plan_end(self.plan_begin(ids_list))
 
     @torch.no_grad()
     def plan_begin(self, ids_list: Sequence[torch.Tensor]):
-        return {"phase": 1, "P": len(ids_list), "token": self.ops.bucketize_begin(ids_list)}
-
-    @torch.no_grad()
-    def plan_mid(self, st):
+        """Everything that needs no host knowledge: dedupe + owner bucketing of the P batches, the all-to-all
+        of the bucket sizes (a fixed-size [W, P] message) and the async readback of both size matrices."""
         W = self.world
-        buck = self.ops.bucketize_finish(st["token"])                       # host wait #1 (unique counts)
-        send = torch.stack([b[2] for b in buck], dim=1).contiguous()          # [W, P]
-        recv = torch.empty_like(send)
+        token = self.ops.bucketize_launch(ids_list)
+        send = self.ops.bucketize_counts(token).t().contiguous()            # [W, P]: rows I request from w
+        recv = torch.empty_like(send)                                       # [W, P]: rows w requests from me
         if W > 1:
             _a2a(recv, send, None, None, self.group)
         else:
@@ -385,19 +380,23 @@ class RowwiseExchange:
             ev.record()
         else:
             host, ev = both, None
-        st.update(phase=2, buck=buck, counts_host=host, counts_event=ev, keep=both)
-        st.pop("token")
+        return {"phase": 2, "P": len(ids_list), "token": token, "counts_host": host, "counts_event": ev,
+                "keep": both}
+
+    def plan_mid(self, st):
+        """kept for callers of the three-phase form; the size exchange now happens in plan_begin"""
         return st
 
     @torch.no_grad()
     def plan_end(self, st) -> List[BatchPlan]:
-        W, P, buck = self.world, st["P"], st["buck"]
+        W, P = self.world, st["P"]
         if st["counts_event"] is not None:
-            st["counts_event"].synchronize()                                # host wait #2 (exchanged counts)
-        send_h, recv_h = st["counts_host"][0], st["counts_host"][1]
+            st["counts_event"].synchronize()                                # the window's host wait
+        send_h, recv_h = st["counts_host"][0].tolist(), st["counts_host"][1].tolist()      # [W][P]
+        ss_all = [[send_h[p][b] for p in range(W)] for b in range(P)]
+        rs_all = [[recv_h[p][b] for p in range(W)] for b in range(P)]
+        buck = self.ops.bucketize_results(st["token"], ss_all)
         plans: List[BatchPlan] = []
-        ss_all = [[int(v) for v in send_h[:, b]] for b in range(P)]
-        rs_all = [[int(v) for v in recv_h[:, b]] for b in range(P)]
         if W > 1:
             # ONE all-to-all-v for the ids of the whole window: the send buffer is peer-major, batch-minor
             pieces = [torch.split(buck[b][0], ss_all[b]) for b in range(P)]
@@ -528,6 +527,22 @@ class RowwiseShardedEmbeddingBag(nn.Module):
                                self.include_last_offset, int(hook_features), self._lr)
         return shape_hook(out) if shape_hook is not None else out
 
+    @torch.no_grad()
+    def forward_backward(self, plan: BatchPlan, offsets: torch.Tensor, grad_out: torch.Tensor,
+                         per_sample_weights=None, *, hook_features: int = 0) -> torch.Tensor:
+        """One training step of the operator without the autograd engine (what `forward` + `.backward(grad_out)`
+        run, as straight-line launches): rows in, pooled output, folded gradient rows back, owner-side SGD."""
+        ex, lr = self.exchange, self._lr[0]
+        if lr is None:
+            raise RuntimeError("row-wise sharded embedding needs set_fused_sgd(lr)")
+        rows = ex.fetch_rows(plan)
+        out = ex.ops.pool(rows, plan.perm, offsets, per_sample_weights, self.mode, self.include_last_offset,
+                          int(hook_features))
+        g = ex.ops.grad_rows(grad_out, plan.perm, offsets, per_sample_weights, self.mode,
+                             self.include_last_offset, int(hook_features), plan.n)
+        ex.ops.owner_update(plan.slots, ex.return_grads(plan, g), lr)
+        return out
+
     def flush(self):
         self.cache_weight_mgr.flush()
 
@@ -568,22 +583,17 @@ class ShardedWindowPipeline:
         self._pending.append(st)
 
     def pump(self) -> None:
-        """Advance the oldest unfinished plan by ONE phase (call it between training steps: by then the
-        counts the phase needs have landed in pinned memory and the host does not wait).  Every rank must
-        call submit/pump/collect in the same order -- the phases contain collectives."""
+        """Finish the oldest unfinished plan (call it between training steps: by then the bucket sizes have
+        landed in pinned memory and the host does not wait).  Every rank must call submit/pump/collect in
+        the same order -- the phases contain collectives."""
         if not self.overlap:
             return
         for st in self._pending:
-            if st.get("phase") == 1:
-                with torch.cuda.stream(self._side):
-                    self.embed.exchange.plan_mid(st)
-                return
             if st.get("phase") == 2:
                 self._side2.wait_stream(self._side)
-                for rows, perm, counts in st["buck"]:
-                    for t in (rows, perm, counts):
-                        if t.is_cuda:
-                            t.record_stream(self._side2)
+                for t in self.embed.ops.token_tensors(st["token"]):
+                    if t.is_cuda:
+                        t.record_stream(self._side2)
                 with torch.cuda.stream(self._side2):
                     plans = self.embed.exchange.plan_end(st)
                     ev = torch.cuda.Event()

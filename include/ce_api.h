@@ -259,6 +259,23 @@ int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int
                       int64_t* local_rows_out, int64_t* perm_out, int64_t* counts_out,
                       void* workspace, size_t workspace_bytes, ce_stream_t stream);
 
+/* ce_dedupe_bucket_rows: what the row-wise exchange uses instead of ce_dedupe_rows + ce_bucketize_rows: the
+ * batch's unique rows, grouped by owner (row % world, any order inside a bucket), as local rows
+ * (row / world) in local_rows_out[0 .. sum(counts)), pos_out[j] = position of lookup j's row in that list
+ * (-1 for an id outside [0, num_rows)), counts_out[w] = unique rows owned by w (device int64[world]).
+ * stamp, slot_of_row: device int32[num_rows] scratch owned by the caller (no initialisation needed, contents
+ * are meaningless between calls); scratch: device int32[(world + 1) * n].  world <= 64.
+ * No host sync: the bucket sizes stay on the device (the caller all-to-alls them as a fixed-size message). */
+int ce_dedupe_bucket_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
+                          int32_t world, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
+                          int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out, ce_stream_t stream);
+
+/* weight[index[i]] += alpha * src_rows[i] for i < n (whole rows of `dim` floats; repeated / out-of-range
+ * index entries are summed / skipped).  Owner-side update of the row-wise exchange: the requester has
+ * already folded a batch's duplicates, so each received gradient row is applied as is (alpha = -lr). */
+int ce_rows_axpy(float* weight, int64_t num_rows, int32_t dim, const int64_t* index, int64_t n,
+                 const float* src_rows, float alpha, ce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

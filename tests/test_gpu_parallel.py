@@ -159,3 +159,66 @@ def test_bucketize_rows_stable_and_counts():
         exp_perm = torch.empty_like(order)
         exp_perm[order] = torch.arange(n, device="cuda")
         assert torch.equal(perm, exp_perm)
+
+
+@pytest.mark.parametrize("it", ["1", "4"])
+def test_dedupe_bucket_rows_properties(it, monkeypatch):
+    monkeypatch.setenv("CE_DEDUPE_IT", it)
+    """ce_dedupe_bucket_rows: the unique rows of the batch, grouped by owner; pos maps every lookup to its row
+    (the order inside a bucket is not specified, so the check is on the properties the exchange relies on)."""
+    from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
+    torch.manual_seed(2)
+    for n, W, N, skew in [(1, 2, 10, False), (4097, 8, 100000, True), (50000, 3, 977, False),
+                          (8192, 64, 10**6, True), (425984, 8, 3_000_000, True), (1000, 1, 5000, False)]:
+        if skew:   # long-tail ids: many duplicates inside a wave
+            ids = (torch.rand(n, device="cuda").pow(6) * N).long().clamp_(0, N - 1)
+        else:
+            ids = torch.randint(0, N, (n,), device="cuda")
+        if n > 10:
+            ids[3] = -1          # out-of-range ids are skipped: pos = -1
+            ids[7] = N
+        idx_map = torch.randperm(N, device="cuda").int()
+        stamp = torch.randint(0, 2**31 - 1, (N,), dtype=torch.int32, device="cuda")   # garbage is fine
+        slot = torch.empty(N, dtype=torch.int32, device="cuda")
+        scratch = torch.empty((W + 1) * n, dtype=torch.int32, device="cuda")
+        for _rep in (1, 2):      # second call reuses the scratch arrays
+            rows = torch.full((n,), -7, dtype=torch.int64, device="cuda")
+            pos = torch.empty(n, dtype=torch.int64, device="cuda")
+            counts = torch.empty(W, dtype=torch.int64, device="cuda")
+            check(lib.ce_dedupe_bucket_rows(ptr(ids), n, ptr(idx_map), N, W, ptr(stamp), ptr(slot),
+                                            ptr(scratch), ptr(rows), ptr(pos), ptr(counts), stream_ptr()))
+            ok = (ids >= 0) & (ids < N)
+            r = idx_map[ids[ok]].long()
+            uniq = torch.unique(r)
+            assert torch.equal(counts, torch.bincount(uniq % W, minlength=W))
+            n_u = int(counts.sum())
+            assert n_u == uniq.numel()
+            assert bool((pos[~ok] == -1).all())
+            # bucket w holds exactly the local rows of owner w, each once
+            off = 0
+            for w, c in enumerate(counts.tolist()):
+                seg = rows[off:off + c]
+                assert torch.equal(torch.sort(seg).values, torch.sort(uniq[uniq % W == w] // W).values)
+                off += c
+            # every lookup points at its own row: global row = local * W + owner(position)
+            owner_of_pos = torch.repeat_interleave(torch.arange(W, device="cuda"), counts)
+            p = pos[ok]
+            assert bool(((p >= 0) & (p < n_u)).all())
+            assert torch.equal(rows[p] * W + owner_of_pos[p], r)
+
+
+def test_rows_axpy_matches_index_add():
+    from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
+    torch.manual_seed(3)
+    for R, D, n in [(1000, 128, 5000), (64, 32, 1), (5000, 64, 4097), (300, 100, 999), (300, 7, 50), (200, 256, 333),
+                    (100, 512, 77)]:
+        w = torch.randn(R, D, device="cuda")
+        idx = torch.randint(0, R, (n,), device="cuda")
+        if n > 4:
+            idx[2] = -1
+            idx[4] = R
+        src = torch.randn(n, D, device="cuda")
+        ok = (idx >= 0) & (idx < R)
+        exp = w.clone().index_add_(0, idx[ok], src[ok], alpha=-0.5)
+        check(lib.ce_rows_axpy(ptr(w), R, D, ptr(idx), n, ptr(src), -0.5, stream_ptr()))
+        torch.testing.assert_close(w, exp, rtol=1e-5, atol=1e-5)   # fp32 sums, atomic order differs
