@@ -9,7 +9,8 @@ recsys/dlrm_main.py, with the reference's flag names for everything that touches
 
 Only the embedding operator is this repository's product; the dense part (bottom MLP, pairwise-dot
 interaction, top MLP -- the standard DLRM arch the reference takes from torchrec) is stock torch.nn and the
-data is synthetic (Criteo/Avazu-shaped KJT batches; no dataset exists on the box).  One process per GPU:
+data is synthetic by default (Criteo/Avazu-shaped KJT batches; no dataset exists on the box) or, with
+`--dataset_dir`, the binary npy Criteo files the reference reads (cachedembedding_amd/datasets.py).  One process per GPU:
 with WORLD_SIZE > 1 the embedding is column-sharded exactly like the reference's default
 (ParallelCachedEmbeddingBag + dual_all_to_all) and the dense part is DDP.
 
@@ -39,6 +40,11 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description="DLRM on the cached EmbeddingBag (MI355X)")
     p.add_argument("--dataset", default="criteo_kaggle", choices=list(synthetic.TABLES))
     p.add_argument("--table_scale", type=float, default=1.0)
+    # real data: directory of day_*_{dense,sparse,labels}.npy files (recsys/dlrm_main.py:81-101 flag names)
+    p.add_argument("--dataset_dir", type=str, default=None)
+    p.add_argument("--num_embeddings_per_feature", type=str, default=None)
+    p.add_argument("--mmap_mode", action="store_true")
+    p.add_argument("--shuffle_batches", action="store_true")
     p.add_argument("--epochs", type=int, default=1)
     p.add_argument("--limit_train_batches", type=int, default=200)
     p.add_argument("--batch_size", type=int, default=16384)
@@ -147,10 +153,23 @@ class SyntheticLoader:
         return iter(self.batches)
 
 
+class _Limit:
+    """first n batches of a loader (--limit_train_batches)"""
+
+    def __init__(self, loader, n):
+        self.loader, self.n = loader, n
+
+    def __len__(self):
+        return min(self.n, len(self.loader))
+
+    def __iter__(self):
+        return itertools.islice(iter(self.loader), self.n)
+
+
 def put_data_in_device(batch, device, is_dist, rank, world):
     """recsys/dlrm_main.py:195-203: with the non-distributed loader every rank holds the global batch and
     keeps its slice of dense/labels, the sparse part stays global"""
-    dense, labels = batch["dense"].to(device), batch["labels"].to(device)
+    dense, labels = batch["dense"].to(device), batch["labels"].to(device).float()
     sparse = [t.to(device) if torch.is_tensor(t) else t for t in batch["sparse"]]
     if not is_dist and world > 1:
         dense = torch.tensor_split(dense, world, dim=0)[rank]
@@ -206,10 +225,24 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=device)
     torch.manual_seed(args.seed)
     sizes = synthetic.TABLES[args.dataset]
+    if args.num_embeddings_per_feature:
+        sizes = [int(x) for x in args.num_embeddings_per_feature.split(",")]
     if args.table_scale != 1.0:
         sizes = synthetic.scale_tables(sizes, args.table_scale)
     freq = None
-    if args.use_freq:
+    loader = None
+    if args.dataset_dir:
+        from cachedembedding_amd.datasets import BinaryCriteoNpy, criteo_files, get_id_freq_map
+        if args.use_tablewise:
+            raise NotImplementedError("--dataset_dir with --use_tablewise: pass assigned_tables per rank")
+        dense_f, sparse_f, labels_f = criteo_files(args.dataset_dir, "train")
+        dist_loader = args.use_distributed_dataloader
+        loader = BinaryCriteoNpy(dense_f, sparse_f, labels_f, args.batch_size, rank if dist_loader else 0,
+                                 world if dist_loader else 1, shuffle_batches=args.shuffle_batches,
+                                 mmap_mode=args.mmap_mode, hashes=sizes, seed=args.seed)
+        if args.use_freq:
+            freq = get_id_freq_map(sparse_f, sizes, os.path.join(args.dataset_dir, "id_freq_map.pt"))
+    elif args.use_freq:
         freq = synthetic.SyntheticKJT(sizes, args.batch_size, 1, "power_law", 0.25, seed=args.seed + 1,
                                       device=device).id_freq_map(32)
     model = HybridParallelDLRM(sizes, args, freq, device)
@@ -221,8 +254,11 @@ def main(argv=None):
     else:
         groups.insert(0, {"params": list(model.sparse_modules.parameters()), "lr": args.learning_rate})
     optimizer = torch.optim.SGD(groups)
-    loader = SyntheticLoader(sizes, args.batch_size, args.num_dense_features, args.limit_train_batches,
-                             args.seed + 17)
+    if loader is None:
+        loader = SyntheticLoader(sizes, args.batch_size, args.num_dense_features, args.limit_train_batches,
+                                 args.seed + 17)
+    elif args.limit_train_batches:
+        loader = _Limit(loader, args.limit_train_batches)
     for epoch in range(args.epochs):
         done, elapsed, loss = train(model, optimizer, loader, args, device, rank, world)
         if rank == 0:

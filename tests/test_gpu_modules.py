@@ -208,3 +208,27 @@ def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):
     dm.main(args)
     out = capsys.readouterr().out
     assert "24 iterations" in out and "it/s" in out and "CUDA->CPU" in out
+
+
+def test_dlrm_trainer_reads_binary_criteo_npy(tmp_path, capsys):
+    """--dataset_dir: day_*_{dense,sparse,labels}.npy -> BinaryCriteoNpy -> FiniteDataIter -> prefetch window"""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "examples"))
+    import importlib
+    dm = importlib.import_module("dlrm_main")
+    rng = np.random.default_rng(0)
+    sizes = [50 + 37 * i for i in range(26)]
+    for d, n in enumerate([900, 700, 300]):                 # day_6 is held out (val/test)
+        day = d if d < 2 else 6
+        np.save(tmp_path / f"day_{day}_dense.npy", rng.random((n, 13), dtype=np.float32))
+        np.save(tmp_path / f"day_{day}_sparse.npy", rng.integers(0, 1 << 30, (n, 26)).astype(np.int32))
+        np.save(tmp_path / f"day_{day}_labels.npy", rng.integers(0, 2, (n, 1)).astype(np.int32))
+    args = ["--dataset_dir", str(tmp_path), "--num_embeddings_per_feature", ",".join(map(str, sizes)),
+            "--batch_size", "128", "--embedding_dim", "32", "--dense_arch_layer_sizes", "64,32",
+            "--over_arch_layer_sizes", "64,1", "--use_cache", "--cache_ratio", "0.9", "--use_freq", "--prefetch_num", "3",
+            "--use_overlap", "--use_sparse_embed_grad", "--limit_train_batches", "0", "--learning_rate", "0.05",
+            "--shuffle_batches"]
+    dm.main(args)
+    out = capsys.readouterr().out
+    assert f"{(900 + 700) // 128} iterations" in out and "it/s" in out
+    assert (tmp_path / "id_freq_map.pt").exists()
