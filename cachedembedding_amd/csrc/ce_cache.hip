@@ -678,39 +678,79 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, int64_t n,
                                                const int32_t* __restrict__ idx_map,
                                                const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out,
-                                               int64_t* freq, int slot_bits, const Ctl* ctl) {
+                                               const Ctl* ctl) {
   // a failed call (overflow / bad id) changes nothing but still hands back well-defined slots (-1):
   // callers that skip the status check (strict=False) then gather zero rows instead of garbage
   const bool failed = ctl && ctl->status != CE_OK;
-  if (failed) freq = nullptr;
-  const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
-    const int64_t i = i0 + lane;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t id = ids[i];
     int64_t slot = -1;
-    if (i < n) {
-      const int64_t id = ids[i];
-      if (!failed && (unsigned long long)id < (unsigned long long)N) {
-        const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
-        slot = inverted[row];
-      }
-      slots_out[i] = slot;
+    if (!failed && (unsigned long long)id < (unsigned long long)N) {
+      const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
+      slot = inverted[row];
     }
-    if (freq) {
-      // LFU [A.3-7]: counter += multiplicity.  A hot slot collects >100k lookups per window, so equal
-      // slots of a wave are merged first (ballot match) and the lowest lane adds the whole count.
-      const bool on = slot >= 0;
-      const int sl = (int)slot;
-      unsigned long long pm = __ballot(on);
-      if (!on) pm = 0;
-      for (int b = 0; b < slot_bits; ++b) {
-        const unsigned long long m = __ballot((sl >> b) & 1);
-        pm &= ((sl >> b) & 1) ? m : ~m;
+    slots_out[i] = slot;
+  }
+}
+
+// LFU form of k_slots: slots + `freq[slot] += multiplicity` [A.3-7].  A hot slot collects >100 k lookups per
+// window and same-address device atomics serialise at the memory side (~7 ns each): with one merged atomic per
+// WAVE the hottest counter alone still took 53 k of them (k_slots 381 us per window).  Here every workgroup owns
+// a contiguous range of lookups and counts them in an LDS hash table (slot -> count, open addressing); only the
+// table's entries go to memory, so a counter sees at most one atomic per workgroup.  Four lookups per thread are
+// in flight to cover the two dependent random loads (idx_map, inverted).
+constexpr int kSlotsHashBits = 13;
+constexpr int kSlotsHash = 1 << kSlotsHashBits;
+__global__ __launch_bounds__(1024) void k_slots_lfu(const int64_t* __restrict__ ids, int64_t n,
+                                                    const int32_t* __restrict__ idx_map,
+                                                    const int32_t* __restrict__ inverted, int64_t N,
+                                                    int64_t* slots_out, int64_t* freq, const Ctl* ctl) {
+  __shared__ int hkey[kSlotsHash];
+  __shared__ int hcnt[kSlotsHash];
+  for (int i = threadIdx.x; i < kSlotsHash; i += blockDim.x) { hkey[i] = -1; hcnt[i] = 0; }
+  __syncthreads();
+  const bool failed = ctl->status != CE_OK;
+  const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = lo + per_block < n ? lo + per_block : n;
+  constexpr int U = 4;
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)blockDim.x * U) {
+    int32_t row[U];
+    int slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      row[u] = -1;
+      if (i < hi && !failed) {
+        const int64_t id = ids[i];
+        if ((unsigned long long)id < (unsigned long long)N) row[u] = idx_map ? idx_map[id] : (int32_t)id;
       }
-      if (on && (__ffsll((long long)pm) - 1) == lane)
-        atomicAdd((unsigned long long*)&freq[slot], (unsigned long long)__popcll(pm));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) slot[u] = row[u] >= 0 ? inverted[row[u]] : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i < hi) slots_out[i] = slot[u];
+      if (slot[u] < 0) continue;
+      unsigned h = ((unsigned)slot[u] * 2654435761u) >> (32 - kSlotsHashBits);
+      bool done = false;
+      for (int p = 0; p < 16 && !done; ++p) {
+        const int old = atomicCAS(&hkey[h], -1, slot[u]);
+        if (old == -1 || old == slot[u]) {
+          atomicAdd(&hcnt[h], 1);
+          done = true;
+        } else {
+          h = (h + 1) & (kSlotsHash - 1);
+        }
+      }
+      if (!done) atomicAdd((unsigned long long*)&freq[slot[u]], 1ull);      // table crowded: count directly
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSlotsHash; i += blockDim.x)
+    if (hkey[i] >= 0) atomicAdd((unsigned long long*)&freq[hkey[i]], (unsigned long long)hcnt[i]);
 }
 
 template <typename VT>
@@ -1296,9 +1336,14 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
                      (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
                      c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl);
-  if (n > 0)
+  if (n > 0 && lfu) {
+    // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
+    hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, ids, n, c.idx_map,
+                       c.inverted_cached_idx, N, slots_out, c.freq_cnter, (const Ctl*)h->ctl);
+  } else if (n > 0) {
     hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map, c.inverted_cached_idx,
-                       N, slots_out, lfu ? c.freq_cnter : (int64_t*)nullptr, h->slot_bits, (const Ctl*)h->ctl);
+                       N, slots_out, (const Ctl*)h->ctl);
+  }
   CE_LAUNCH_CHECK();
   CE_HIP_CHECK(hipEventRecord(h->ev, s));
   return CE_OK;
@@ -1354,8 +1399,7 @@ extern "C" int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t 
   CE_REQUIRE(ids && slots_out && n > 0, CE_ERR_INVALID, "null ids/slots");
   const ce_cache_config_t& c = h->cfg;
   hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, c.idx_map,
-                     c.inverted_cached_idx, c.num_embeddings, slots_out, (int64_t*)nullptr, h->slot_bits,
-                     (const Ctl*)nullptr);
+                     c.inverted_cached_idx, c.num_embeddings, slots_out, (const Ctl*)nullptr);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }
