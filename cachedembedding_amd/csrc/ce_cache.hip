@@ -143,10 +143,11 @@ __global__ void k_begin(Ctl* ctl) {
 // merges its 64 ids: ballots over the word-index bits give every lane the mask of lanes aiming at the
 // same word, 32 more ballots OR their bits together, and only the lowest lane of each mask issues
 // ONE atomicOr -- and only if a plain load did not already show the bits set.
-__global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, int64_t n,
-                                              const int32_t* __restrict__ idx_map,
-                                              const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                              int hot_words, uint32_t* bitmap, Ctl* ctl) {
+template <bool MERGE>
+__global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
+                                               const int32_t* __restrict__ idx_map,
+                                               const int32_t* __restrict__ inverted, int64_t N, int word_bits,
+                                               int hot_words, uint32_t* bitmap, Ctl* ctl) {
   // Under DATASET ordering the frequency re-rank packs the hot rows of ALL tables into the lowest
   // row indices, i.e. into a handful of bitmap words every wave wants.  Those words are staged in an
   // LDS window per workgroup and flushed once, so a hot word sees one global atomic per workgroup.
@@ -178,7 +179,9 @@ __global__ __launch_bounds__(256) void k_mark(const int64_t* __restrict__ ids, i
       if (word < hot_words) atomicOr(&hot[word], 1u << bidx);
       else need = ((*(volatile uint32_t*)(bitmap + word)) & (1u << bidx)) == 0;
     }
-    if (__any(need)) {
+    if (!MERGE) {
+      if (need) atomicOr(bitmap + word, 1u << bidx);
+    } else if (__any(need)) {
       unsigned long long pm = __ballot(need);
       if (!need) pm = 0;
       for (int b = 0; b < word_bits; ++b) {
@@ -1247,12 +1250,28 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
 
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
   {
-    static const int mark_hot = [] { const char* e = getenv("CE_MARK_HOT"); return e ? atoi(e) : 2048; }();
+    // Two shapes (rocprofv3, 3.4 M ids per call).  Rows in frequency order (idx_map present): the hot rows sit in
+    // the lowest bitmap words, the LDS window absorbs them, and cold lookups issue their atomicOr directly --
+    // 512 threads x 256 workgroups, 8192-word window: 75 us.  Rows in id order (no idx_map): hot rows are
+    // scattered, every wave would hammer their words (421 us), so equal words of a wave are merged first (135 us).
+    const bool ranked = c.idx_map != nullptr;
+    static const int mark_hot_env = [] { const char* e = getenv("CE_MARK_HOT"); return e ? atoi(e) : 0; }();
     static const int mark_blocks = [] { const char* e = getenv("CE_MARK_BLOCKS"); return e ? atoi(e) : 256; }();
+    static const int mark_threads_env = [] { const char* e = getenv("CE_MARK_THREADS"); return e ? atoi(e) : 0; }();
+    static const int mark_merge_env = [] { const char* e = getenv("CE_MARK_MERGE"); return e ? atoi(e) : -1; }();
+    const int mark_hot = mark_hot_env > 0 ? mark_hot_env : (ranked ? 8192 : 2048);
+    const int mark_threads = mark_threads_env > 0 ? mark_threads_env : (ranked ? 512 : 256);
+    const bool mark_merge = mark_merge_env >= 0 ? mark_merge_env != 0 : !ranked;
     const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
-    if (n > 0)
-      hipLaunchKernelGGL(k_mark, dim3(std::min(grid_for(n, 1024), mark_blocks)), dim3(256), hot_words * 4, s, ids, n,
-                         c.idx_map, c.inverted_cached_idx, N, h->word_bits, hot_words, h->bitmap, h->ctl);
+    if (n > 0) {
+      const dim3 mg(std::min(grid_for(n, 1024), mark_blocks)), mb(mark_threads);
+      if (mark_merge)
+        hipLaunchKernelGGL((k_mark<true>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,
+                           h->word_bits, hot_words, h->bitmap, h->ctl);
+      else
+        hipLaunchKernelGGL((k_mark<false>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,
+                           h->word_bits, hot_words, h->bitmap, h->ctl);
+    }
   }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
