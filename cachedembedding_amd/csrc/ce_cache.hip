@@ -206,6 +206,34 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
   }
 }
 
+// Bits of one bitmap word (32 consecutive rows from row0) whose row is not resident.  The frequency ranking packs
+// the hot rows into the lowest words, where nearly every bit is set: a lookup per set bit would be up to 128
+// dependent-latency loads in one thread (the tail of k_count / k_emit), so dense words fetch the 32 map entries
+// as eight 16-byte loads instead.
+__device__ __forceinline__ bool dense_word(uint32_t bits, int64_t row0, int64_t N) {
+  return __popc(bits) >= 6 && row0 + 32 <= N;
+}
+__device__ __forceinline__ uint32_t miss_mask(const int32_t* __restrict__ inverted, int64_t row0, uint32_t bits,
+                                              int64_t N) {
+  uint32_t mm = 0;
+  if (dense_word(bits, row0, N)) {
+    const int4* p = (const int4*)(inverted + row0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int4 x = p[j];
+      mm |= ((uint32_t)(x.x < 0) | ((uint32_t)(x.y < 0) << 1) | ((uint32_t)(x.z < 0) << 2) |
+             ((uint32_t)(x.w < 0) << 3)) << (4 * j);
+    }
+    return mm & bits;
+  }
+  while (bits) {
+    const int b = __ffs(bits) - 1;
+    bits &= bits - 1;
+    if (inverted[row0 + b] < 0) mm |= 1u << b;
+  }
+  return mm;
+}
+
 // one uint4 (128 rows) per thread
 __global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4,
                                                const int32_t* __restrict__ inverted, int64_t N,
@@ -216,14 +244,9 @@ __global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4
   int u = 0, m = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    uint32_t bits = wds[k];
-    u += __popc(bits);
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const int64_t row = v * 128 + k * 32 + b;
-      m += (inverted[row] < 0);
-    }
+    if (!wds[k]) continue;
+    u += __popc(wds[k]);
+    m += __popc(miss_mask(inverted, v * 128 + k * 32, wds[k], N));
   }
   __shared__ int su[4], sm[4];
   u = wave_sum(u);
@@ -301,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
   }
 }
 
-__global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted,
+__global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
                                               const int32_t* __restrict__ blk_miss_off, int32_t* miss_list,
                                               int32_t* slot_epoch, int32_t epoch, const Ctl* ctl) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -311,14 +334,8 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
   int m = 0;
   if (ok) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t bits = wds[k];
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        m += (inverted[v * 128 + k * 32 + b] < 0);
-      }
-    }
+    for (int k = 0; k < 4; ++k)
+      if (wds[k]) m += __popc(miss_mask(inverted, v * 128 + k * 32, wds[k], N));
   }
   int tot;
   int pos = block_excl_scan_256(m, &tot) + blk_miss_off[blockIdx.x];
@@ -326,10 +343,27 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       uint32_t bits = wds[k];
+      if (!bits) continue;
+      const int64_t row0 = v * 128 + k * 32;
+      if (dense_word(bits, row0, N)) {
+        const int4* p = (const int4*)(inverted + row0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int4 x = p[j];
+          const int32_t sl[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (!((bits >> (4 * j + c)) & 1)) continue;
+            if (sl[c] < 0) miss_list[pos++] = (int32_t)(row0 + 4 * j + c);
+            else slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
+          }
+        }
+        continue;
+      }
       while (bits) {
         const int b = __ffs(bits) - 1;
         bits &= bits - 1;
-        const int64_t row = v * 128 + k * 32 + b;
+        const int64_t row = row0 + b;
         const int32_t slot = inverted[row];
         if (slot < 0) miss_list[pos++] = (int32_t)row;
         else slot_epoch[slot] = epoch;        // evict_backlist membership [A.3-3]
@@ -1020,6 +1054,8 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
              "unknown eviction strategy");
   CE_REQUIRE(cfg->cache_weight && cfg->inverted_cached_idx && cfg->cached_idx_map && cfg->workspace,
              CE_ERR_INVALID, "null device array");
+  CE_REQUIRE((((uintptr_t)cfg->inverted_cached_idx) & 15) == 0, CE_ERR_INVALID,
+             "inverted_cached_idx must be 16-byte aligned");
   CE_REQUIRE(cfg->evict_strategy != CE_EVICT_LFU || cfg->freq_cnter, CE_ERR_INVALID, "LFU needs freq_cnter");
   CE_REQUIRE(cfg->host_weight && cfg->host_weight_dev, CE_ERR_INVALID, "null host table");
   Layout L = make_layout(cfg->num_embeddings, cfg->cuda_row_num, cfg->max_ids_per_call, cfg->embedding_dim);
@@ -1278,7 +1314,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n,
                      (long long)h->seq, h->ctl, slot);
   hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap,
-                     c.inverted_cached_idx, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl);
+                     c.inverted_cached_idx, N, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl);
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
   hipLaunchKernelGGL(k_keys, dim3(cgrid), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,

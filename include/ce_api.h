@@ -169,7 +169,7 @@ typedef struct ce_cache_config {
   float* host_weight_dev;        /* same memory, DEVICE-visible address (ce_host_*)        */
   float* cache_weight;           /* device [C, D]  cuda_cached_weight                      */
   int32_t* idx_map;              /* device int32[N] id -> cpu_row_idx, NULL = identity     */
-  int32_t* inverted_cached_idx;  /* device int32[N] cpu_row_idx -> slot, -1 = absent       */
+  int32_t* inverted_cached_idx;  /* device int32[N] cpu_row_idx -> slot, -1 = absent (16-B aligned) */
   int32_t* cached_idx_map;       /* device int32[C] slot -> cpu_row_idx, -1 = empty        */
   int64_t* freq_cnter;           /* device int64[C] (LFU) or NULL                          */
   void* workspace;               /* device scratch, ce_cache_workspace_bytes() bytes       */
