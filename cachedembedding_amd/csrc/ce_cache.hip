@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
   }
 }
 
-template <typename VT>
+template <typename VT, int R>
 __device__ __forceinline__ void writeback_rows(const int32_t* __restrict__ stage_rows_idx,
                                                const VT* __restrict__ stage, VT* host, long long cap, int rowlen,
                                                int g_log2, const Ctl* ctl, int block, int nblocks) {
@@ -563,13 +563,13 @@ __device__ __forceinline__ void writeback_rows(const int32_t* __restrict__ stage
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < k;
-       i += gstride * kSwapRows) {
+  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * R; i < k;
+       i += gstride * R) {
     if (rowlen <= G) {
-      VT v[kSwapRows];
-      int64_t dst[kSwapRows];
+      VT v[R];
+      int64_t dst[R];
 #pragma unroll
-      for (int t = 0; t < kSwapRows; ++t) {
+      for (int t = 0; t < R; ++t) {
         dst[t] = -1;
         if (i + t < k) {
           dst[t] = stage_rows_idx[i + t];
@@ -577,10 +577,10 @@ __device__ __forceinline__ void writeback_rows(const int32_t* __restrict__ stage
         }
       }
 #pragma unroll
-      for (int t = 0; t < kSwapRows; ++t)
+      for (int t = 0; t < R; ++t)
         if (dst[t] >= 0 && gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
     } else {
-      for (int t = 0; t < kSwapRows && i + t < k; ++t)
+      for (int t = 0; t < R && i + t < k; ++t)
         copy_row(stage + (i + t) * rowlen, host + (int64_t)stage_rows_idx[i + t] * rowlen, rowlen, gl, G);
     }
   }
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
 }
 
 // rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i)
-template <typename VT>
+template <typename VT, int R>
 __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                            const long long* n_ptr, long long n_imm, const VT* __restrict__ host,
                                            VT* cache, int rowlen, int g_log2, const Ctl* ctl, int block, int nblocks) {
@@ -656,12 +656,12 @@ __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, con
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < n; i += gstride * kSwapRows) {
-    if (rowlen <= G) {          // kSwapRows host rows in flight per lane group (see k_evict)
-      VT v[kSwapRows];
-      int64_t dst[kSwapRows];
+  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
+    if (rowlen <= G) {          // R host rows in flight per lane group (see k_evict)
+      VT v[R];
+      int64_t dst[R];
 #pragma unroll
-      for (int t = 0; t < kSwapRows; ++t) {
+      for (int t = 0; t < R; ++t) {
         dst[t] = -1;
         if (i + t < n) {
           const int64_t row = rows ? rows[i + t] : i + t;
@@ -670,10 +670,10 @@ __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, con
         }
       }
 #pragma unroll
-      for (int t = 0; t < kSwapRows; ++t)
+      for (int t = 0; t < R; ++t)
         if (dst[t] >= 0 && gl < rowlen) cache[dst[t] * rowlen + gl] = v[t];
     } else {
-      for (int t = 0; t < kSwapRows && i + t < n; ++t) {
+      for (int t = 0; t < R && i + t < n; ++t) {
         const int64_t row = rows ? rows[i + t] : i + t;
         const int64_t slot = slots ? slots[i + t] : i + t;
         copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
@@ -687,24 +687,25 @@ __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows
                                                const long long* n_ptr, long long n_imm,
                                                const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
                                                const Ctl* ctl) {
-  admit_rows(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x, (int)gridDim.x);
+  admit_rows<VT, kSwapRows>(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x,
+                            (int)gridDim.x);
 }
 
 // Full-duplex swap in ONE launch: the first wb_blocks workgroups stream the staged victims to the host table,
 // the others read the missed rows from it.  (An earlier version ran the write-back on an auxiliary stream; HIP
 // multiplexes streams onto a few hardware queues and that stream could land on the TRAINING stream's queue,
 // stalling training for the whole write-back -- seen in a rocprofv3 timeline.  One kernel needs no extra stream.)
-template <typename VT>
+template <typename VT, int R>
 __global__ __launch_bounds__(1024) void k_swap(const int32_t* __restrict__ stage_rows_idx,
                                               const VT* __restrict__ stage, long long cap, int wb_blocks,
                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                               const long long* n_ptr, VT* host, VT* cache, int rowlen, int g_log2,
                                               const Ctl* ctl) {
   if ((int)blockIdx.x < wb_blocks)
-    writeback_rows(stage_rows_idx, stage, host, cap, rowlen, g_log2, ctl, (int)blockIdx.x, wb_blocks);
+    writeback_rows<VT, R>(stage_rows_idx, stage, host, cap, rowlen, g_log2, ctl, (int)blockIdx.x, wb_blocks);
   else
-    admit_rows(rows, slots, n_ptr, 0ll, (const VT*)host, cache, rowlen, g_log2, ctl, (int)blockIdx.x - wb_blocks,
-               (int)gridDim.x - wb_blocks);
+    admit_rows<VT, R>(rows, slots, n_ptr, 0ll, (const VT*)host, cache, rowlen, g_log2, ctl,
+                      (int)blockIdx.x - wb_blocks, (int)gridDim.x - wb_blocks);
 }
 
 __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ rows,
@@ -1366,16 +1367,18 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   if (c.transport == CE_TRANSPORT_ZEROCOPY) {
     // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy
     const long long scap = (long long)L.stage_rows;
-    if (h->vec)
-      hipLaunchKernelGGL((k_swap<f32x4>), dim3(2 * cap_groups), swap_block, 0, s, h->stage_idx,
-                         (const f32x4*)h->stage, scap, cap_groups, h->miss_list, h->free_list,
-                         (const long long*)&h->ctl->n_miss, (f32x4*)c.host_weight_dev, (f32x4*)c.cache_weight,
-                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
-    else
-      hipLaunchKernelGGL((k_swap<float>), dim3(2 * cap_groups), swap_block, 0, s, h->stage_idx,
-                         (const float*)h->stage, scap, cap_groups, h->miss_list, h->free_list,
-                         (const long long*)&h->ctl->n_miss, (float*)c.host_weight_dev, (float*)c.cache_weight,
-                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+    static const int swap_rows = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : kSwapRows; }();
+#define CE_SWAP(VT, R)                                                                                          \
+  hipLaunchKernelGGL((k_swap<VT, R>), dim3(2 * cap_groups), swap_block, 0, s, h->stage_idx, (const VT*)h->stage, \
+                     scap, cap_groups, h->miss_list, h->free_list, (const long long*)&h->ctl->n_miss,           \
+                     (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl)
+    if (h->vec) {
+      if (swap_rows == 2) CE_SWAP(f32x4, 2); else if (swap_rows == 4) CE_SWAP(f32x4, 4);
+      else if (swap_rows == 8) CE_SWAP(f32x4, 8); else CE_SWAP(f32x4, 16);
+    } else {
+      CE_SWAP(float, 16);
+    }
+#undef CE_SWAP
   } else {
     // H2D: worker threads gather the missed rows out of the table into pinned staging
     const Ctl ctl = *h->ctl_host;   // filled by staged_swap
