@@ -1,0 +1,20 @@
+run() { timeout 600 python bench.py --no_cpu_baseline "$@" 2>gpurun_out/err.txt | tail -1 | python -c "
+import sys,json
+try:
+    d=json.loads(sys.stdin.read()); c=d['cache']; print('| \`%s\` | %.0f M | %.3f | %.0f | %.3f | %d / %d |' % ('$*', d['value']/1e6, d['ms_per_step'], d['it_per_s'], c['unique_hit_rate'], c['rows_in'], c['rows_out']))
+except Exception as e:
+    print('  FAILED $*', e)" ; grep -E "Error|error" gpurun_out/err.txt | tail -2; }
+echo "| bench.py flags | lookups/s | ms/step | it/s | unique-row hit rate | rows in / out (timed+warmup) |"
+echo "|---|---|---|---|---|---|"
+run --workload criteo_kaggle --cache_ratio 0.05 --prefetch_num 1
+run --workload criteo_kaggle --cache_ratio 0.05 --prefetch_num 1 --use_lfu
+run --workload criteo_kaggle --cache_ratio 0.05 --prefetch_num 8
+run
+run --use_lfu
+run --no_overlap
+run --workload avazu --cache_ratio 0.01
+run --workload avazu --cache_ratio 0.01 --use_lfu
+run --workload avazu --cache_ratio 0.01 --use_lfu --batch_size 2048 --embedding_dim 32 --prefetch_num 1
+run --workload custom --cache_ratio 0.01 --pooling 2
+run --workload custom --cache_ratio 0.01 --pooling 8 --batch_size 4096
+run --dist uniform --batch_size 4096 --prefetch_num 4
