@@ -185,3 +185,27 @@ def test_hypothesis_random_streams_vs_oracle():
             np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
 
     run()
+
+
+def test_lfu_counters_when_every_lookup_is_a_different_row():
+    """k_slots_lfu counts in an 8192-entry LDS hash table per workgroup; 8192 distinct slots per workgroup fill it
+    completely, so this stream drives the crowded-table path (direct atomics) as well as the table flush."""
+    ce = _ce()
+    from oracle.cache_oracle import LFU, OracleCachedParamMgr
+    rng = np.random.default_rng(5)
+    N, C, D, n_ids = 400_000, 200_000, 4, 120_000
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU)
+    ora.reorder(None, 0.0)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C, evict_strategy=ce.EvictionStrategy.LFU)
+    mgr.reorder(None, 0.0)
+    for c in range(4):
+        ids = rng.permutation(N)[:n_ids]                     # all distinct
+        if c == 3:
+            ids = np.concatenate([ids[:60_000], ids[:60_000]])   # every row twice, far apart
+        exp = ora.prepare_ids(ids)
+        got = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(got.cpu().numpy(), exp)
+        assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+        assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+    assert sum(mgr.num_write_back_history) > 0
