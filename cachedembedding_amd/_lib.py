@@ -111,6 +111,7 @@ SIGNATURES = {
     "ce_cache_flush": (c_int, [c_void_p, c_void_p]),
     "ce_cache_set_protect_depth": (c_int, [c_void_p, c_int32]),
     "ce_cache_set_transport": (c_int, [c_void_p, c_int32]),
+    "ce_cache_set_buffer_rows": (c_int, [c_void_p, c_int64]),
     "ce_cache_free_rows": (c_int, [c_void_p, POINTER(c_int64)]),
     "ce_dedupe_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p]),

@@ -81,8 +81,9 @@ class CachedParamMgr(torch.nn.Module):
     """Manages a [cuda_row_num, D] HBM cache of rows of a host-resident [N, D] table.
 
     Args mirror upstream: weight (CPU fp32 [N, D], or a HostTable), cuda_row_num,
-    buffer_size (accepted; the zero-copy / staged transports make LimitBuffIndexCopyer
-    unnecessary), pin_weight (the table is always pinned + mapped here), evict_strategy,
+    buffer_size (rows of staging the async_copy transport may use at a time -- upstream's
+    LimitBuffIndexCopyer; 0 = stage a whole swap at once; the default zero-copy transport has no staging),
+    pin_weight (the table is always pinned + mapped here), evict_strategy,
     async_copy (maps to the staged hipMemcpyAsync transport when True)."""
 
     def __init__(self, weight, cuda_row_num: int = 0, buffer_size: int = 0, pin_weight: bool = True,
@@ -155,6 +156,8 @@ class CachedParamMgr(torch.nn.Module):
             check(lib.ce_cache_create(ctypes.byref(cfg), stream_ptr(), ctypes.byref(h)))
         self._handle = h
         self._fin = weakref.finalize(self, lib.ce_cache_destroy, h)
+        if self.buffer_size and self.buffer_size > 0:
+            check(lib.ce_cache_set_buffer_rows(h, int(self.buffer_size)))
 
     @property
     def idx_map(self) -> torch.Tensor:

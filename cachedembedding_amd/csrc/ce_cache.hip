@@ -1008,6 +1008,8 @@ struct ce_cache {
   int32_t* list_host;          // pinned host copy of row/slot lists
   ce::Ctl* ctl_host;           // pinned host copy of the control block
   int64_t stage_rows;
+  int64_t list_rows;           // capacity of list_host
+  int64_t buffer_rows;         // > 0: staged transfers go through at most this many staging rows at a time
 };
 
 using namespace ce;
@@ -1099,6 +1101,8 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->list_host = nullptr;
   h->ctl_host = nullptr;
   h->stage_rows = 0;
+  h->list_rows = 0;
+  h->buffer_rows = 0;
 
   hipStream_t s = (hipStream_t)stream;
   void* ring_host = nullptr;
@@ -1165,18 +1169,31 @@ static int before_call(ce_cache* h) {
   return CE_OK;
 }
 
-static int ensure_staging(ce_cache* h, int64_t rows) {
-  if (rows <= h->stage_rows) return CE_OK;
-  if (h->stage_dev) (void)hipFree(h->stage_dev);
-  if (h->stage_host) (void)hipHostFree(h->stage_host);
-  if (h->list_host) (void)hipHostFree(h->list_host);
-  h->stage_dev = nullptr; h->stage_host = nullptr; h->list_host = nullptr;
-  const size_t bytes = (size_t)rows * h->cfg.embedding_dim * sizeof(float);
-  CE_HIP_CHECK(hipMalloc((void**)&h->stage_dev, bytes));
-  CE_HIP_CHECK(hipHostMalloc((void**)&h->stage_host, bytes, hipHostMallocDefault));
-  CE_HIP_CHECK(hipHostMalloc((void**)&h->list_host, (size_t)rows * 2 * sizeof(int32_t), hipHostMallocDefault));
-  h->stage_rows = rows;
+static int ensure_staging(ce_cache* h, int64_t rows, int64_t list_rows) {
+  if (rows > h->stage_rows) {
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
+    h->stage_dev = nullptr; h->stage_host = nullptr;
+    h->stage_rows = 0;
+    const size_t bytes = (size_t)rows * h->cfg.embedding_dim * sizeof(float);
+    CE_HIP_CHECK(hipMalloc((void**)&h->stage_dev, bytes));
+    CE_HIP_CHECK(hipHostMalloc((void**)&h->stage_host, bytes, hipHostMallocDefault));
+    h->stage_rows = rows;
+  }
+  if (list_rows > h->list_rows) {
+    if (h->list_host) (void)hipHostFree(h->list_host);
+    h->list_host = nullptr;
+    h->list_rows = 0;
+    CE_HIP_CHECK(hipHostMalloc((void**)&h->list_host, (size_t)list_rows * sizeof(int32_t), hipHostMallocDefault));
+    h->list_rows = list_rows;
+  }
   return CE_OK;
+}
+
+// rows moved per staged transfer: everything at once, or `buffer_rows` at a time (upstream's buffer_size /
+// LimitBuffIndexCopyer: a bounded staging buffer walked in chunks)
+static int64_t staged_chunk(const ce_cache* h, int64_t rows) {
+  return (h->buffer_rows > 0 && h->buffer_rows < rows) ? h->buffer_rows : rows;
 }
 
 extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_vals, int64_t n,
@@ -1225,7 +1242,8 @@ static int staged_swap(ce_cache* h, hipStream_t s) {
   const Ctl ctl = *h->ctl_host;
   if (ctl.status != CE_OK) return CE_OK;
   const int64_t k = ctl.k_evict, m = ctl.n_miss;
-  int rc = ensure_staging(h, std::max<int64_t>(std::max(k, m), 1));
+  const int64_t big = std::max<int64_t>(std::max(k, m), 1);
+  int rc = ensure_staging(h, staged_chunk(h, big), big);
   if (rc) return rc;
   const int gpb = 256 >> h->g_log2;
   if (k > 0) {
@@ -1233,21 +1251,27 @@ static int staged_swap(ce_cache* h, hipStream_t s) {
     int32_t* evicted_rows_dev = h->free_list;   // free_list is not live yet: reuse as the row list
     hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(k, 256)), dim3(256), 0, s, h->victims, c.cached_idx_map,
                        c.inverted_cached_idx, evicted_rows_dev, h->ctl);
-    if (h->vec)
-      hipLaunchKernelGGL((k_pack_rows<f32x4>), dim3(grid_for(k, gpb)), dim3(256), 0, s, (const int32_t*)h->victims,
-                         (long long)k, (const f32x4*)c.cache_weight, (f32x4*)h->stage_dev, h->rowlen, h->g_log2);
-    else
-      hipLaunchKernelGGL((k_pack_rows<float>), dim3(grid_for(k, gpb)), dim3(256), 0, s, (const int32_t*)h->victims,
-                         (long long)k, (const float*)c.cache_weight, (float*)h->stage_dev, h->rowlen, h->g_log2);
-    CE_HIP_CHECK(hipMemcpyAsync(h->stage_host, h->stage_dev, (size_t)k * rowbytes, hipMemcpyDeviceToHost, s));
     CE_HIP_CHECK(hipMemcpyAsync(h->list_host, evicted_rows_dev, (size_t)k * 4, hipMemcpyDeviceToHost, s));
-    CE_HIP_CHECK(hipStreamSynchronize(s));
-    float* table = c.host_weight;
-    const float* st = h->stage_host;
-    const int32_t* rows = h->list_host;
-    parallel_rows(k, h->host_threads, [=](int64_t lo, int64_t hi) {
-      for (int64_t i = lo; i < hi; ++i) memcpy(table + (size_t)rows[i] * D, st + (size_t)i * D, rowbytes);
-    });
+    const int64_t chunk = staged_chunk(h, k);
+    for (int64_t off = 0; off < k; off += chunk) {
+      const int64_t cnt = std::min(chunk, k - off);
+      if (h->vec)
+        hipLaunchKernelGGL((k_pack_rows<f32x4>), dim3(grid_for(cnt, gpb)), dim3(256), 0, s,
+                           (const int32_t*)h->victims + off, (long long)cnt, (const f32x4*)c.cache_weight,
+                           (f32x4*)h->stage_dev, h->rowlen, h->g_log2);
+      else
+        hipLaunchKernelGGL((k_pack_rows<float>), dim3(grid_for(cnt, gpb)), dim3(256), 0, s,
+                           (const int32_t*)h->victims + off, (long long)cnt, (const float*)c.cache_weight,
+                           (float*)h->stage_dev, h->rowlen, h->g_log2);
+      CE_HIP_CHECK(hipMemcpyAsync(h->stage_host, h->stage_dev, (size_t)cnt * rowbytes, hipMemcpyDeviceToHost, s));
+      CE_HIP_CHECK(hipStreamSynchronize(s));
+      float* table = c.host_weight;
+      const float* st = h->stage_host;
+      const int32_t* rows = h->list_host + off;
+      parallel_rows(cnt, h->host_threads, [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) memcpy(table + (size_t)rows[i] * D, st + (size_t)i * D, rowbytes);
+      });
+    }
   }
   return CE_OK;
 }
@@ -1390,19 +1414,24 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
       CE_HIP_CHECK(hipStreamSynchronize(s));
       const float* table = c.host_weight;
       float* st = h->stage_host;
-      const int32_t* rows = h->list_host;
-      parallel_rows(m, h->host_threads, [=](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) memcpy(st + (size_t)i * D, table + (size_t)rows[i] * D, rowbytes);
-      });
-      CE_HIP_CHECK(hipMemcpyAsync(h->stage_dev, h->stage_host, (size_t)m * rowbytes, hipMemcpyHostToDevice, s));
-      if (h->vec)
-        hipLaunchKernelGGL((k_unpack_rows<f32x4>), dim3(grid_for(m, gpb)), dim3(256), 0, s,
-                           (const int32_t*)h->free_list, (long long)m, (const f32x4*)h->stage_dev,
-                           (f32x4*)c.cache_weight, h->rowlen, h->g_log2);
-      else
-        hipLaunchKernelGGL((k_unpack_rows<float>), dim3(grid_for(m, gpb)), dim3(256), 0, s,
-                           (const int32_t*)h->free_list, (long long)m, (const float*)h->stage_dev,
-                           (float*)c.cache_weight, h->rowlen, h->g_log2);
+      const int64_t chunk = staged_chunk(h, m);
+      for (int64_t off = 0; off < m; off += chunk) {
+        const int64_t cnt = std::min(chunk, m - off);
+        if (off > 0) CE_HIP_CHECK(hipStreamSynchronize(s));      // the staging buffer is reused
+        const int32_t* rows = h->list_host + off;
+        parallel_rows(cnt, h->host_threads, [=](int64_t lo, int64_t hi) {
+          for (int64_t i = lo; i < hi; ++i) memcpy(st + (size_t)i * D, table + (size_t)rows[i] * D, rowbytes);
+        });
+        CE_HIP_CHECK(hipMemcpyAsync(h->stage_dev, h->stage_host, (size_t)cnt * rowbytes, hipMemcpyHostToDevice, s));
+        if (h->vec)
+          hipLaunchKernelGGL((k_unpack_rows<f32x4>), dim3(grid_for(cnt, gpb)), dim3(256), 0, s,
+                             (const int32_t*)h->free_list + off, (long long)cnt, (const f32x4*)h->stage_dev,
+                             (f32x4*)c.cache_weight, h->rowlen, h->g_log2);
+        else
+          hipLaunchKernelGGL((k_unpack_rows<float>), dim3(grid_for(cnt, gpb)), dim3(256), 0, s,
+                             (const int32_t*)h->free_list + off, (long long)cnt, (const float*)h->stage_dev,
+                             (float*)c.cache_weight, h->rowlen, h->g_log2);
+      }
     }
   }
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
@@ -1504,6 +1533,12 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
 extern "C" int ce_cache_set_protect_depth(ce_cache_t* h, int32_t depth) {
   CE_REQUIRE(h && depth >= 0 && depth < 1024, CE_ERR_INVALID, "bad protect depth");
   h->cfg.protect_depth = depth;
+  return CE_OK;
+}
+
+extern "C" int ce_cache_set_buffer_rows(ce_cache_t* h, int64_t rows) {
+  CE_REQUIRE(h && rows >= 0, CE_ERR_INVALID, "bad buffer_rows");
+  h->buffer_rows = rows;
   return CE_OK;
 }
 

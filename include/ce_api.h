@@ -235,6 +235,9 @@ int ce_cache_flush(ce_cache_t* h, ce_stream_t stream);
 
 int ce_cache_set_protect_depth(ce_cache_t* h, int32_t depth);
 int ce_cache_set_transport(ce_cache_t* h, int32_t transport);
+/* upstream buffer_size / LimitBuffIndexCopyer: rows > 0 bounds the pinned + device staging of the STAGED
+ * transport to `rows` rows; larger swaps walk it in chunks.  0 (default) = stage a whole swap at once. */
+int ce_cache_set_buffer_rows(ce_cache_t* h, int64_t rows);
 /* number of free slots as of the last finished call (blocks like ce_cache_last_stats) */
 int ce_cache_free_rows(ce_cache_t* h, int64_t* out);
 

@@ -20,9 +20,10 @@ def _strat(ce, s):
     return ce.EvictionStrategy.LFU if s == "lfu" else ce.EvictionStrategy.DATASET
 
 
-def _mk(ce, w, C, strategy, freq, warmup, async_copy=False):
+def _mk(ce, w, C, strategy, freq, warmup, async_copy=False, buffer_size=0):
     table = torch.from_numpy(w.copy())
-    mgr = ce.CachedParamMgr(table, C, evict_strategy=_strat(ce, strategy), async_copy=async_copy)
+    mgr = ce.CachedParamMgr(table, C, buffer_size=buffer_size, evict_strategy=_strat(ce, strategy),
+                            async_copy=async_copy)
     mgr.reorder(freq, warmup)
     return mgr
 
@@ -55,13 +56,14 @@ def test_lfu_known_answer(init_freq):
 
 @pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"),
                                            ("cache_lfu_freq", "lfu"), ("cache_lfu_nofreq", "lfu")])
-@pytest.mark.parametrize("async_copy", [False, True])
-def test_golden_streams(name, strategy, async_copy):
+@pytest.mark.parametrize("async_copy,buffer_size", [(False, 0), (True, 0), (True, 3), (True, 50_000)])
+def test_golden_streams(name, strategy, async_copy, buffer_size):
+    """buffer_size > 0 (upstream LimitBuffIndexCopyer): the staged transport walks a 3-row staging buffer"""
     ce = _ce()
     z = np.load(GOLD / f"{name}.npz")
     N, C, D, n_ids, calls, warm = (int(v) for v in z["meta"])
     freq = z["freq"] if z["freq"].size else None
-    mgr = _mk(ce, z["weight"], C, strategy, freq, warm / 1000.0, async_copy)
+    mgr = _mk(ce, z["weight"], C, strategy, freq, warm / 1000.0, async_copy, buffer_size)
     assert np.array_equal(mgr.idx_map.cpu().numpy().astype(np.int64), z["idx_map"])
     assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), z["cached_idx_map_0"])
     for c in range(calls):
