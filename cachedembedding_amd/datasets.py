@@ -1,4 +1,5 @@
-"""Binary (npy) Criteo reader: the data format on the input side of the path.
+"""Criteo readers (binary npy day files, and the 1TB set's parquet parts below): the data formats on the input side
+of the path.
 
 What the reference feeds `_train` from for Criteo-Kaggle (recsys/datasets/criteo.py:38-249
 `InMemoryBinaryCriteoIterDataPipe`, :377-413 file selection, :461-486 + recsys/datasets/feature_counter.py:12-31 for
@@ -176,3 +177,99 @@ class BinaryCriteoNpy:
         self._epoch += 1
         for i in range(self.num_batches):
             yield self._batch(i, rng)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Parquet form of the Criteo-1TB set (NVTabular-preprocessed: `part_*.parquet` with columns int_0..int_12,
+# cat_0..cat_25, label; categorical ids already folded into [0, hash_size)), recsys/datasets/criteo.py:252-376
+# (`PetastormDataReader`) and :416-445 (split directories train / validation / test).
+INT_NAMES = [f"int_{i}" for i in range(INT_FEATURE_COUNT)]
+CAT_NAMES = [f"cat_{i}" for i in range(CAT_FEATURE_COUNT)]
+LABEL_NAME = "label"
+
+
+def parquet_files(dataset_dir: str, stage: str) -> List[str]:
+    split = {"train": "train", "val": "validation", "test": "test"}[stage.lower()]
+    d = os.path.join(dataset_dir, split)
+    n = len([f for f in os.listdir(d) if f.endswith(".parquet")])
+    return [os.path.join(d, f"part_{i}.parquet") for i in range(n)]
+
+
+class ParquetCriteo:
+    """Row groups are read one at a time with pyarrow (in file order, or in a per-epoch seeded order with
+    shuffle_row_groups) and cut into batches of `batch_size` rows that may span row groups and files; ids get the
+    offset of their table in the loader's concatenated table (no modulo: the files hold folded ids).  Batches have
+    the same dict form as BinaryCriteoNpy.  Single reader per process (the reference raises for world_size > 1
+    as well); `rank` / `world_size` split the FILE list round-robin when given."""
+
+    def __init__(self, paths: Sequence[str], batch_size: int, rank: Optional[int] = None,
+                 world_size: Optional[int] = None, shuffle_batches: bool = False,
+                 hashes: Optional[Sequence[int]] = None, seed: int = 1024, drop_last: bool = True,
+                 assigned_tables: Optional[Sequence[int]] = None, shuffle_row_groups: bool = False):
+        import pyarrow.parquet as pq
+        self._pq = pq
+        self.paths = list(paths)
+        if world_size is not None and world_size > 1:
+            self.paths = self.paths[(rank or 0)::world_size]
+        self.batch_size, self.shuffle_batches, self.seed, self.drop_last = int(batch_size), shuffle_batches, seed, drop_last
+        self.shuffle_row_groups = shuffle_row_groups
+        self.assigned_tables = np.arange(CAT_FEATURE_COUNT) if assigned_tables is None else np.asarray(assigned_tables)
+        F = len(self.assigned_tables)
+        self.keys = [CAT_NAMES[t] for t in self.assigned_tables]
+        if hashes is not None:
+            h = np.asarray([hashes[t] for t in self.assigned_tables], dtype=np.int64)
+            self.sparse_offsets = np.concatenate([[0], np.cumsum(h)[:-1]]).astype(np.int64).reshape(F, 1)
+        else:
+            self.sparse_offsets = None
+        self._groups = []                                   # (path, row group index, rows)
+        for p in self.paths:
+            md = pq.ParquetFile(p).metadata
+            self._groups += [(p, g, md.row_group(g).num_rows) for g in range(md.num_row_groups)]
+        rows = sum(g[2] for g in self._groups)
+        self.num_batches = rows // self.batch_size if drop_last else (rows + self.batch_size - 1) // self.batch_size
+        self.offsets = torch.arange(0, F * self.batch_size + 1, dtype=torch.int32)
+        self.stride = self.batch_size
+        self.epoch = 0
+
+    def __len__(self) -> int:
+        return self.num_batches
+
+    def _emit(self, dense, sparse, labels, rng):
+        n = dense.shape[0]
+        if self.shuffle_batches:
+            perm = rng.permutation(n)
+            dense, sparse, labels = dense[perm], sparse[:, perm], labels[perm]
+        offsets = self.offsets if n == self.batch_size else torch.arange(0, sparse.shape[0] * n + 1, dtype=torch.int32)
+        return {"dense": torch.from_numpy(np.ascontiguousarray(dense)),
+                "sparse": [torch.from_numpy(np.ascontiguousarray(sparse).reshape(-1)), offsets, n],
+                "labels": torch.from_numpy(np.ascontiguousarray(labels))}
+
+    def __iter__(self) -> Iterator[dict]:
+        rng = np.random.default_rng(self.seed + self.epoch)
+        self.epoch += 1
+        order = rng.permutation(len(self._groups)) if self.shuffle_row_groups else range(len(self._groups))
+        B = self.batch_size
+        buf = None                                          # < B rows carried over from the previous row group
+        files = {}
+        cols = INT_NAMES + self.keys + [LABEL_NAME]
+        for gi in order:
+            path, g, _ = self._groups[gi]
+            if path not in files:
+                files[path] = self._pq.ParquetFile(path)
+            t = files[path].read_row_group(g, columns=cols)
+            dense = np.stack([t.column(c).to_numpy().astype(np.float32, copy=False) for c in INT_NAMES], axis=1)
+            sparse = np.stack([t.column(c).to_numpy().astype(np.int64, copy=False) for c in self.keys], axis=0)
+            if self.sparse_offsets is not None:
+                sparse = sparse + self.sparse_offsets
+            labels = t.column(LABEL_NAME).to_numpy().astype(np.int32, copy=False).reshape(-1)
+            if buf is not None:
+                dense = np.concatenate([buf[0], dense], axis=0)
+                sparse = np.concatenate([buf[1], sparse], axis=1)
+                labels = np.concatenate([buf[2], labels], axis=0)
+            n, s = dense.shape[0], 0
+            while n - s >= B:
+                yield self._emit(dense[s:s + B], sparse[:, s:s + B], labels[s:s + B], rng)
+                s += B
+            buf = (dense[s:], sparse[:, s:], labels[s:]) if s < n else None
+        if buf is not None and not self.drop_last:
+            yield self._emit(*buf, rng)

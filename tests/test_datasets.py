@@ -116,3 +116,52 @@ def test_id_freq_map(criteo_dir, tmp_path):
     np.testing.assert_array_equal(freq.numpy(), np.bincount(allrows.reshape(-1), minlength=h.sum()))
     assert freq.numel() == sum(HASHES) and int(freq.sum()) == allrows.size
     assert torch.equal(get_id_freq_map([], HASHES, cache_path=cache), freq)        # served from the cache file
+
+
+def _write_parquet(root, rows_per_file, hashes, rg):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    rng = np.random.default_rng(1)
+    (root / "train").mkdir()
+    allcols = []
+    for i, n in enumerate(rows_per_file):
+        cols = {f"int_{k}": rng.random(n).astype(np.float32) for k in range(13)}
+        cols.update({f"cat_{k}": rng.integers(0, hashes[k], n).astype(np.int64) for k in range(26)})
+        cols["label"] = rng.integers(0, 2, n).astype(np.int32)
+        pq.write_table(pa.table(cols), root / "train" / f"part_{i}.parquet", row_group_size=rg)
+        allcols.append(cols)
+    return {k: np.concatenate([c[k] for c in allcols]) for k in allcols[0]}
+
+
+@pytest.mark.parametrize("drop_last", [True, False])
+def test_parquet_reader_batches_span_row_groups_and_files(tmp_path, drop_last):
+    from cachedembedding_amd.datasets import ParquetCriteo, parquet_files
+    cols = _write_parquet(tmp_path, [130, 75, 201], HASHES, rg=48)
+    files = parquet_files(str(tmp_path), "train")
+    assert [f.rsplit("/", 1)[1] for f in files] == ["part_0.parquet", "part_1.parquet", "part_2.parquet"]
+    B, tables = 64, [0, 3, 9, 25]
+    ds = ParquetCriteo(files, B, hashes=HASHES, drop_last=drop_last, assigned_tables=tables)
+    total = 130 + 75 + 201
+    assert len(ds) == (total // B if drop_last else -(-total // B))
+    h = np.array([HASHES[t] for t in tables])
+    off = np.concatenate([[0], np.cumsum(h)[:-1]])
+    got = list(ds)
+    assert len(got) == len(ds)
+    for i, b in enumerate(got):
+        lo, hi = i * B, min(total, (i + 1) * B)
+        n = hi - lo
+        exp_sparse = np.stack([cols[f"cat_{t}"][lo:hi] + off[j] for j, t in enumerate(tables)]).reshape(-1)
+        vals, offs, stride = b["sparse"]
+        assert stride == n and offs.numel() == len(tables) * n + 1
+        np.testing.assert_array_equal(vals.numpy(), exp_sparse)
+        np.testing.assert_array_equal(b["dense"].numpy(), np.stack([cols[f"int_{k}"][lo:hi] for k in range(13)], 1))
+        np.testing.assert_array_equal(b["labels"].numpy(), cols["label"][lo:hi])
+    # seeded row-group shuffle: same multiset of rows, different order, reproducible per (seed, epoch)
+    a = ParquetCriteo(files, B, hashes=HASHES, shuffle_row_groups=True, seed=7)
+    b2 = ParquetCriteo(files, B, hashes=HASHES, shuffle_row_groups=True, seed=7)
+    la, lb = list(a), list(b2)
+    assert all(torch.equal(x["sparse"][0], y["sparse"][0]) for x, y in zip(la, lb))
+    plain = torch.cat([x["labels"] for x in ParquetCriteo(files, B, hashes=HASHES, drop_last=False)])
+    shuf = torch.cat([x["labels"] for x in ParquetCriteo(files, B, hashes=HASHES, drop_last=False,
+                                                          shuffle_row_groups=True, seed=7)])
+    assert plain.numel() == shuf.numel() == total and int(plain.sum()) == int(shuf.sum())
