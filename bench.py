@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
     ap.add_argument("--deterministic", action="store_true", help="sorted segmented SGD update instead of atomics")
     ap.add_argument("--force_sharded", action="store_true", help="run the row-wise sharded code path even at N=1")
+    ap.add_argument("--share_gpu", action="store_true",
+                    help="diagnostic: every rank uses cuda:0 and the collectives run over gloo (staged through host "
+                         "memory), so the multi-rank code path can be exercised at full size on a one-GPU box; "
+                         "the throughput printed this way is NOT a benchmark result")
     ap.add_argument("--no_prefill", action="store_true", help="skip the untimed cache-fill phase (cache ops on fresh "
                     "windows until no slot is free, so the timed region is steady state incl. evictions whatever "
                     "--warmup is)")
@@ -87,12 +91,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import cachedembedding_amd as ce
     from cachedembedding_amd import synthetic
@@ -330,6 +339,29 @@ def emit(result):
     sys.stdout.flush()
 
 
+def _host_staged(t):
+    """gloo (--share_gpu diagnostic) only moves CPU buffers"""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def bcast(t, src=0):
+    if _host_staged(t):
+        c = t.cpu()
+        dist.broadcast(c, src=src)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, src=src)
+
+
+def allreduce(t, op=dist.ReduceOp.SUM):
+    if _host_staged(t):
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def run_sharded(args, sizes, rank, world, dev):
     args.overlap = not args.no_overlap
     """N > 1: the table is row-sharded over the ranks (row r of the frequency ranking lives on rank r % W),
@@ -350,7 +382,7 @@ def run_sharded(args, sizes, rank, world, dev):
     if not args.no_freq:
         fgen = synthetic.SyntheticKJT(sizes, B, L, args.dist, args.skew, seed=args.seed, device=dev)
         freq = fgen.id_freq_map(sample_batches=4 * P)
-        dist.broadcast(freq, src=0)
+        bcast(freq, src=0)
         del fgen
     strategy = ce.EvictionStrategy.LFU if args.use_lfu else ce.EvictionStrategy.DATASET
     embed = RowwiseShardedEmbeddingBag(N, D, mode="sum", include_last_offset=True, cache_ratio=args.cache_ratio,
@@ -361,11 +393,37 @@ def run_sharded(args, sizes, rank, world, dev):
     mgr = embed.cache_weight_mgr
     mgr.strict = False
     setup_s = time.time() - t0
+    # Window size.  A shard serves the rows ALL ranks ask for, and the global batch grows with N (weak scaling), so
+    # the unique rows of a window of P batches grow with N while the per-GPU cache (C/N slots) shrinks: the
+    # reference's own constraint unique(window) <= cuda_row_num (x2 when the next window's cache op overlaps this
+    # window's training: protect_depth 1) can fail at the P the 1-GPU line uses.  SURVEY 8(d)-3: "else lower B or P
+    # and report it" -- P is lowered until the busiest shard fits, identically on every rank.
+    depth = 1 if args.overlap else 0
+    P_req = P
+    while True:
+        embed.plan_window([v for v in gen.next_values(P)])
+        need = torch.tensor([mgr.sync_stats().n_unique], dtype=torch.int64, device=dev)
+        allreduce(need, op=dist.ReduceOp.MAX)
+        need = int(need.item())
+        if (1 + depth) * need <= 0.9 * mgr.cuda_row_num:
+            break
+        if P == 1 and depth == 1 and need <= 0.9 * mgr.cuda_row_num:
+            depth, args.overlap = 0, False          # one window fits, two do not: plan on the compute stream
+            if rank == 0:
+                print("[bench] shard cache holds one window but not two: overlap disabled", file=sys.stderr, flush=True)
+            break
+        if P == 1:
+            raise AssertionError(f"one batch needs {need} rows of a {mgr.cuda_row_num}-row shard cache "
+                                 f"(x{1 + depth} with overlap): lower --batch_size or raise --cache_ratio")
+        P = max(1, min(P - 1, int(P * 0.9 * mgr.cuda_row_num / ((1 + depth) * need))))
+    if rank == 0 and P != P_req:
+        print(f"[bench] prefetch_num lowered {P_req} -> {P}: a window of {P_req} global batches needs more unique "
+              f"rows per shard than the {mgr.cuda_row_num}-slot shard cache holds", file=sys.stderr, flush=True)
     prefill = 0
     if not args.no_prefill:
         while prefill < 64:
             full = torch.tensor([int(mgr.cuda_available_row_num == 0)], device=dev)
-            dist.all_reduce(full, op=dist.ReduceOp.MIN)          # every rank runs the same number of windows
+            allreduce(full, op=dist.ReduceOp.MIN)          # every rank runs the same number of windows
             if int(full.item()):
                 break
             embed.plan_window([v for v in gen.next_values(P)])
@@ -419,11 +477,11 @@ def run_sharded(args, sizes, rank, world, dev):
         print(f"[bench] sharded timed region: host enqueue {enqueue_s:.3f}s of {time.perf_counter() - t1:.3f}s",
               file=sys.stderr, flush=True)
     elapsed = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    allreduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     st = mgr.sync_stats()
     bad = torch.tensor([int(st.status != 0)], device=dev)
-    dist.all_reduce(bad)
+    allreduce(bad)
     if int(bad.item()):
         raise AssertionError("a shard's cache op overflowed cuda_row_num")
     hits, miss = sum(mgr.num_hits_history), sum(mgr.num_miss_history)
@@ -437,7 +495,7 @@ def run_sharded(args, sizes, rank, world, dev):
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
                    "embedding_dim": D, "features": F, "batch_size_per_gpu": B, "global_batch": B * world,
                    "pooling": L, "cache_ratio": args.cache_ratio, "cuda_row_num_per_gpu": mgr.cuda_row_num,
-                   "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
+                   "prefetch_num": P, "prefetch_num_requested": P_req, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB_per_gpu": mgr.num_embeddings * D * 4 / 1e9,
                    "sharding": f"row-wise x{world} (row % W), RCCL all-to-all-v of unique rows", "overlap": bool(args.overlap),
                    "update": "atomic", "lr": args.lr},
