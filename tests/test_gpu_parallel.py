@@ -172,8 +172,12 @@ def test_dedupe_bucket_rows_properties(it, monkeypatch):
     from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
     torch.manual_seed(2)
     for n, W, N, skew in [(1, 2, 10, False), (4097, 8, 100000, True), (50000, 3, 977, False),
-                          (8192, 64, 10**6, True), (425984, 8, 3_000_000, True), (1000, 1, 5000, False)]:
-        if skew:   # long-tail ids: many duplicates inside a wave
+                          (8192, 64, 10**6, True), (425984, 8, 3_000_000, True), (1000, 1, 5000, False),
+                          (255, 5, 300, False), (257, 7, 64, True), (1023, 2, 2000, False), (1025, 16, 40, True),
+                          (70000, 8, 1, False), (3000, 4, 5000, None)]:
+        if skew is None:   # one row carries every lookup
+            ids = torch.full((n,), 1234, device="cuda", dtype=torch.long)
+        elif skew:   # long-tail ids: many duplicates inside a wave
             ids = (torch.rand(n, device="cuda").pow(6) * N).long().clamp_(0, N - 1)
         else:
             ids = torch.randint(0, N, (n,), device="cuda")
