@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
           for (int c = 0; c < NCH; ++c) {
             const int ch = gl + c * G;
             v[t][c] = vzero<VT>();
-            if (on && ch < rowlen) v[t][c] = GO[orow * rowlen + ch];
+            if (on && ch < rowlen) v[t][c] = __builtin_nontemporal_load(&GO[orow * rowlen + ch]);
           }
         }
 #pragma unroll
