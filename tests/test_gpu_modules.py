@@ -232,3 +232,16 @@ def test_dlrm_trainer_reads_binary_criteo_npy(tmp_path, capsys):
     out = capsys.readouterr().out
     assert f"{(900 + 700) // 128} iterations" in out and "it/s" in out
     assert (tmp_path / "id_freq_map.pt").exists()
+
+
+@pytest.mark.parametrize("use_lfu", [False, True])
+def test_benchmark_cache_counterpart_runs(use_lfu, capsys):
+    """benchmarks/benchmark_cache.py (benchmark/benchmark_cache.py:21-75): cache_op=True forward + backward loop"""
+    sys.path.insert(0, str(ROOT / "benchmarks"))
+    import importlib
+    from cachedembedding_amd import synthetic
+    bc = importlib.import_module("benchmark_cache")
+    g = synthetic.SyntheticKJT(synthetic.TABLES["avazu"], 512, 1, "power_law", 0.25, seed=7, device="cuda")
+    rate = bc.benchmark_cache_embedding(512, 32, 0.02, g.id_freq_map(8), 0.7, use_lfu, "avazu", iters=6)
+    out = capsys.readouterr().out
+    assert rate > 0 and "it/s" in out and "unique-row hit rate" in out and "CUDA->CPU" in out
