@@ -357,6 +357,63 @@ template <> struct KeyOps<unsigned long long> {
   static __device__ __forceinline__ uint32_t row_invalid() { return 0xffffffffu; }
 };
 
+// Bitonic sort of the tile's 1024 keys, four per thread (thread t holds positions 4t..4t+3).  Compare-exchange
+// distances 1-2 stay inside a thread, 4-128 inside a wave (__shfl_xor, no LDS, no barrier); only the three stages
+// with distance 256 / 512 cross waves and go through LDS.  (The all-LDS network paid a barrier on each of its 55
+// stages: 13 us per tile; this one 3.)  Ends with the sorted keys in lds[0..1023] and a barrier.
+template <typename KT>
+__device__ __forceinline__ KT shfl_xor_key(KT v, int m) { return __shfl_xor(v, m); }
+template <>
+__device__ __forceinline__ unsigned long long shfl_xor_key<unsigned long long>(unsigned long long v, int m) {
+  const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename KT>
+__device__ __forceinline__ void tile_sort_1024(KT (&key)[4], KT* lds, int tid) {
+  for (int k = 2; k <= kBwdTile; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 256) {                                  // partner lives in another wave
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[tid * 4 + r] = key[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = tid * 4 + r;
+          const KT other = lds[i ^ j];
+          const bool lower = (i & j) == 0, up = (i & k) == 0;
+          const KT lo = key[r] < other ? key[r] : other, hi = key[r] < other ? other : key[r];
+          key[r] = (lower == up) ? lo : hi;
+        }
+        __syncthreads();
+      } else if (j >= 4) {                             // partner lane = lane ^ (j / 4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = tid * 4 + r;
+          const KT other = shfl_xor_key<KT>(key[r], j >> 2);
+          const bool lower = (i & j) == 0, up = (i & k) == 0;
+          const KT lo = key[r] < other ? key[r] : other, hi = key[r] < other ? other : key[r];
+          key[r] = (lower == up) ? lo : hi;
+        }
+      } else {                                         // j = 1, 2: both elements in this thread
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r & j) continue;
+          const bool up = ((tid * 4 + r) & k) == 0;
+          const KT a = key[r], b = key[r | j];
+          if ((a > b) == up) {
+            key[r] = b;
+            key[r | j] = a;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lds[tid * 4 + r] = key[r];
+  __syncthreads();
+}
+
 // The (row, lookup) sort of every 1024-lookup tile does not depend on the gradient, only on the slots the
 // cache op returns -- so it can run once per window on the cache-op stream (ce_bag_presort) instead of inside
 // every backward launch.  Output: for each tile the 1024 sorted 32-bit keys (row << 10 | lookup-in-tile),
@@ -369,32 +426,17 @@ __global__ __launch_bounds__(256) void k_bag_presort(const int64_t* __restrict__
   const int ntiles = (int)((nnz + kBwdTile - 1) / kBwdTile);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t j0 = (int64_t)tile * kBwdTile;
-    for (int i = tid; i < kBwdTile; i += 256) {
-      uint32_t key = K::invalid();
-      if (j0 + i < nnz) {
-        const int64_t r = indices[j0 + i];
-        if ((uint64_t)r < (uint64_t)num_rows) key = K::make((uint32_t)r, i);
-      }
-      keys[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= kBwdTile; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
+    uint32_t kr[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int c = tid + t * 256;
-          const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
-          const int l = i | j;
-          const uint32_t a = keys[i], b = keys[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            keys[i] = b;
-            keys[l] = a;
-          }
-        }
-        __syncthreads();
+    for (int r = 0; r < 4; ++r) {
+      const int i = tid * 4 + r;
+      kr[r] = K::invalid();
+      if (j0 + i < nnz) {
+        const int64_t row = indices[j0 + i];
+        if ((uint64_t)row < (uint64_t)num_rows) kr[r] = K::make((uint32_t)row, i);
       }
     }
+    tile_sort_1024<uint32_t>(kr, keys, tid);
     for (int i = tid; i < kBwdTile; i += 256)
       if (j0 + i < nnz) keys_out[j0 + i] = keys[i];
     __syncthreads();
@@ -424,9 +466,14 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int j0 = tile * tile_len;
     const int nv = min(tile_len, (int)(p.nnz - j0));
-    // ---- a. keys, bag and scale of every lookup of the tile (out-of-range rows become invalid keys)
-    for (int i = tid; i < kBwdTile; i += 256) {
-      KT key = K::invalid();
+    // ---- a. keys, bag and scale of every lookup of the tile (out-of-range rows become invalid keys);
+    //         thread t owns lookups 4t..4t+3 of the tile
+    const bool presorted = sizeof(KT) == 4 && p.presorted;
+    KT kr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = tid * 4 + r;
+      kr[r] = K::invalid();
       if (i < nv) {
         const int j = j0 + i;
         const int bag = find_bag(p, j);
@@ -438,36 +485,23 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         }
         bagl[i] = bag;
         scl[i] = sc;
-        if (sizeof(KT) == 4 && p.presorted) {
-          key = (KT)p.presorted[j];                          // sorted position i of this tile, not lookup i
+        if (presorted) {
+          kr[r] = (KT)p.presorted[j];                        // sorted position i of this tile, not lookup i
         } else {
-          const int64_t r = p.indices[j];
-          if ((uint64_t)r < (uint64_t)p.num_rows) key = K::make((uint32_t)r, i);
+          const int64_t row = p.indices[j];
+          if ((uint64_t)row < (uint64_t)p.num_rows) kr[r] = K::make((uint32_t)row, i);
         }
       }
-      keys[i] = key;
     }
-    __syncthreads();
-    if (p.debug == 3) continue;
-    // ---- b. bitonic sort (row major, lookup minor) -> runs are in lookup order, invalid keys last
+    if (p.debug == 3) { __syncthreads(); continue; }
+    // ---- b. sort (row major, lookup minor) -> runs are in lookup order, invalid keys last
     //         (skipped when the cache op already sorted this tile: ce_bag_presort)
-    if (!(sizeof(KT) == 4 && p.presorted))
-    for (int k = 2; k <= kBwdTile; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
+    if (presorted) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int c = tid + t * 256;
-          const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
-          const int l = i | j;
-          const KT a = keys[i], b = keys[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            keys[i] = b;
-            keys[l] = a;
-          }
-        }
-        __syncthreads();
-      }
+      for (int r = 0; r < 4; ++r) keys[tid * 4 + r] = kr[r];
+      __syncthreads();
+    } else {
+      tile_sort_1024<KT>(kr, keys, tid);
     }
     // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, R gradient rows in flight,
     // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated n
