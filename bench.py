@@ -63,9 +63,9 @@ def parse():
                     help="reference semantics: the window's cache op runs on the compute stream (default: the cache op "
                          "of window k+1 runs on a side HIP stream while window k trains, protect_depth=1)")
     ap.add_argument("--cache_cus", type=int, default=0, help="CUs reserved for the side-stream cache op (0 = share all)")
-    ap.add_argument("--presort", action="store_true", help="sort the backward tiles once per window on the cache-op "
-                    "stream (ce_bag_presort) instead of inside every backward launch: backward 104 -> 94 us, but the "
-                    "extra side-stream work costs more than it saves when overlapping (1.92 -> 1.83 G lookups/s)")
+    ap.add_argument("--no_presort", action="store_true", help="sort 1024-lookup tiles inside every backward launch "
+                    "instead of grouping the window's slots by row once per window on the cache-op stream "
+                    "(ce_bag_presort, 16384-lookup segments: about half the atomic row updates)")
     ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
                     "hipGraph of the window's P training steps")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
@@ -151,7 +151,7 @@ def main():
     windows = [gen.next_values(P) for _ in range(n_windows)]          # each [P, F*B*L]
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
-    presort = args.presort and not args.deterministic
+    presort = not args.no_presort and not args.deterministic
     win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort)
     use_graph = not args.no_graph
     if use_graph and W % P:
@@ -310,7 +310,8 @@ def main():
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
                    "transport": "staged" if args.async_copy else "zerocopy", "overlap": bool(args.overlap),
                    "launch": "hipGraph per window" if use_graph else "python per step",
-                   "bwd_tile_sort": "per window on the cache-op stream" if presort else "inside every backward",
+                   "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window (ce_bag_presort)"
+                   if presort else "1024-lookup tiles sorted inside every backward",
                    "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,

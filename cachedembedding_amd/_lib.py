@@ -90,6 +90,7 @@ SIGNATURES = {
                                      c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
                                     c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float, c_void_p]),
+    "ce_bag_presort_len": (c_int64, [c_int64]),
     "ce_bag_presort": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd_presorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                               c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,

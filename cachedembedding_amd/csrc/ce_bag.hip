@@ -41,7 +41,7 @@ struct BagParams {
   int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
   uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
   int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
-  const uint32_t* presorted; // optional: per-tile sorted 32-bit keys from ce_bag_presort (skips the LDS sort)
+  const unsigned long long* presorted;   // optional: segment-sorted keys from ce_bag_presort (no sort in the kernel)
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -414,31 +414,83 @@ __device__ __forceinline__ void tile_sort_1024(KT (&key)[4], KT* lds, int tid) {
   __syncthreads();
 }
 
-// The (row, lookup) sort of every 1024-lookup tile does not depend on the gradient, only on the slots the
-// cache op returns -- so it can run once per window on the cache-op stream (ce_bag_presort) instead of inside
-// every backward launch.  Output: for each tile the 1024 sorted 32-bit keys (row << 10 | lookup-in-tile),
-// invalid (out-of-range row / padding) = 0xffffffff, sorted last.
-__global__ __launch_bounds__(256) void k_bag_presort(const int64_t* __restrict__ indices, int64_t nnz, uint32_t num_rows,
-                                                     uint32_t* __restrict__ keys_out) {
-  using K = KeyOps<uint32_t>;
-  __shared__ uint32_t keys[kBwdTile];
-  const int tid = threadIdx.x;
-  const int ntiles = (int)((nnz + kBwdTile - 1) / kBwdTile);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t j0 = (int64_t)tile * kBwdTile;
-    uint32_t kr[4];
+// The order the backward folds duplicates in does not depend on the gradient, only on the slots the cache op
+// returns -- so it can be computed once per window on the cache-op stream (ce_bag_presort), and over a much wider
+// scope than a workgroup can sort inside the backward: SEGMENTS of 16384 consecutive lookups (one Criteo feature
+// at B = 16384).  The scope matters because the memory side retires fp32 atomics at only ~1.5 TB/s (one 64-byte
+// line-op per ~5 ns and channel): 1024-lookup tiles leave 109 k row updates per batch, 16384-lookup segments ~55 k.
+// The backward only needs EQUAL ROWS TO BE ADJACENT, not a total order, so the segment is not sorted (a 16 k
+// bitonic network in registers / shuffles / LDS took 170 us per window, as much as it saved) but GROUPED with one
+// counting pass: bucket = row & 4095; the lanes of a wave that hold the same bucket are matched with ballots and
+// their leader reserves their places with ONE returning LDS atomic; a scan of the 4096 counters turns
+// (bucket, place) into the output position.  ~4 keys share a bucket, so a hot row's lookups end up contiguous
+// apart from the odd cold row of the same bucket.  One workgroup of 1024 threads per segment, 16 keys per thread.
+// Key = row << 32 | lookup-in-segment; ignored lookups (out-of-range row) and padding = all ones, placed last.
+constexpr int kSegLen = 16384;
+constexpr int kSegKeys = 16;          // per thread
+constexpr int kSegBuckets = 4096;
+__global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz,
+                                                         uint32_t num_rows, unsigned long long* __restrict__ keys_out) {
+  __shared__ int cnt[kSegBuckets + 1];                  // [kSegBuckets] = ignored lookups
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t nseg = (nnz + kSegLen - 1) / kSegLen;
+  for (int64_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int64_t base = seg * kSegLen;
+    for (int i = tid; i <= kSegBuckets; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    unsigned long long key[kSegKeys];
+    int place[kSegKeys], bkt[kSegKeys];                  // place inside the bucket (a bucket can hold the whole segment)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = tid * 4 + r;
-      kr[r] = K::invalid();
-      if (j0 + i < nnz) {
-        const int64_t row = indices[j0 + i];
-        if ((uint64_t)row < (uint64_t)num_rows) kr[r] = K::make((uint32_t)row, i);
+    for (int r = 0; r < kSegKeys; ++r) {
+      // lane-interleaved ownership: lookup e = r * 1024 + tid (coalesced loads; the order inside a row's group
+      // follows the lookup order up to the atomic race between waves)
+      const int e = r * 1024 + tid;
+      key[r] = ~0ull;
+      bkt[r] = kSegBuckets;
+      if (base + e < nnz) {
+        const int64_t row = indices[base + e];
+        if ((uint64_t)row < (uint64_t)num_rows) {
+          key[r] = ((unsigned long long)row << 32) | (unsigned)e;
+          bkt[r] = (int)(row & (kSegBuckets - 1));
+        }
       }
+      // wave match on the 13-bit bucket id, leader reserves popcount places
+      unsigned long long pm = ~0ull;
+#pragma unroll
+      for (int b = 0; b < 13; ++b) {
+        const unsigned long long m = __ballot((bkt[r] >> b) & 1);
+        pm &= ((bkt[r] >> b) & 1) ? m : ~m;
+      }
+      const int leader = __ffsll((long long)pm) - 1;
+      int first = 0;
+      if (lane == leader) first = atomicAdd(&cnt[bkt[r]], __popcll(pm));
+      place[r] = __shfl(first, leader) + __popcll(pm & lt);
     }
-    tile_sort_1024<uint32_t>(kr, keys, tid);
-    for (int i = tid; i < kBwdTile; i += 256)
-      if (j0 + i < nnz) keys_out[j0 + i] = keys[i];
+    __syncthreads();
+    // exclusive scan of the 4097 counters (thread t owns 4t..4t+3; the ignored bucket follows everything)
+    int c4[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c4[q] = cnt[tid * 4 + q]; sum += c4[q]; }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int pre = inc - sum;
+    for (int k = 0; k < wv; ++k) pre += wsum[k];
+    int total = 0;
+    for (int k = 0; k < 16; ++k) total += wsum[k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cnt[tid * 4 + q] = pre; pre += c4[q]; }
+    if (tid == 0) cnt[kSegBuckets] = total;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSegKeys; ++r) keys_out[base + cnt[bkt[r]] + place[r]] = key[r];
     __syncthreads();
   }
 }
@@ -461,21 +513,37 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   // tile_len <= kBwdTile is chosen by the launcher so that the tile count is a multiple of the CU count
   // (425,984 lookups -> 512 tiles of 832: two per CU, instead of 416 tiles = 1 or 2 per CU)
   const int tile_len = p.tile_len;
-  const int ntiles = (int)((p.nnz + tile_len - 1) / tile_len);
+  // presorted: the tiles are 1024 consecutive SORTED positions of the segment-padded key array
+  const int ntiles = p.presorted ? (int)(((p.nnz + kSegLen - 1) / kSegLen) * (kSegLen / kBwdTile))
+                                 : (int)((p.nnz + tile_len - 1) / tile_len);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int j0 = tile * tile_len;
-    const int nv = min(tile_len, (int)(p.nnz - j0));
+    const int nv = p.presorted ? kBwdTile : min(tile_len, (int)(p.nnz - j0));
     // ---- a. keys, bag and scale of every lookup of the tile (out-of-range rows become invalid keys);
     //         thread t owns lookups 4t..4t+3 of the tile
-    const bool presorted = sizeof(KT) == 4 && p.presorted;
+    const bool presorted = p.presorted != nullptr;
     KT kr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = tid * 4 + r;
       kr[r] = K::invalid();
-      if (i < nv) {
-        const int j = j0 + i;
+      int j = j0 + i;                                          // the lookup behind position i
+      uint32_t row = 0xffffffffu;
+      if (presorted) {
+        const unsigned long long sk = p.presorted[(int64_t)tile * kBwdTile + i];
+        j = -1;
+        if (sk != ~0ull) {
+          row = (uint32_t)(sk >> 32);
+          j = (int)(((int64_t)tile * kBwdTile / kSegLen) * kSegLen) + (int)(uint32_t)sk;
+        }
+      } else if (i < nv) {
+        const int64_t r64 = p.indices[j];
+        if ((uint64_t)r64 < (uint64_t)p.num_rows) row = (uint32_t)r64;
+      } else {
+        j = -1;
+      }
+      if (j >= 0) {
         const int bag = find_bag(p, j);
         float sc = p.alpha;
         if (p.psw) sc *= p.psw[j];
@@ -485,12 +553,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         }
         bagl[i] = bag;
         scl[i] = sc;
-        if (presorted) {
-          kr[r] = (KT)p.presorted[j];                        // sorted position i of this tile, not lookup i
-        } else {
-          const int64_t row = p.indices[j];
-          if ((uint64_t)row < (uint64_t)p.num_rows) kr[r] = K::make((uint32_t)row, i);
-        }
+        if (row != 0xffffffffu) kr[r] = K::make(row, i);
       }
     }
     if (p.debug == 3) { __syncthreads(); continue; }
@@ -657,7 +720,7 @@ static int launch_bwd(const BagParams& p, bool vec, int nch, hipStream_t s) {
     q.debug = dbg ? atoi(dbg) : 0;
     const int tile_len = kBwdTile;      // (a CU-multiple tile count, 512 x 832, measured no better: 0.105 -> 0.108 ms)
     q.tile_len = tile_len;
-    const int ntiles = (int)cdiv(p.nnz, tile_len);
+    const int ntiles = p.presorted ? (int)(cdiv(p.nnz, kSegLen) * (kSegLen / kBwdTile)) : (int)cdiv(p.nnz, tile_len);
     dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
     const bool k32 = q.num_rows <= (1u << 22) - 2;
     static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
@@ -756,7 +819,8 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
 static int backward_sgd_impl(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
                              const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                              int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
-                             int64_t hook_features, const float* grad_out, float lr, const uint32_t* presorted,
+                             int64_t hook_features, const float* grad_out, float lr,
+                             const unsigned long long* presorted,
                              ce_stream_t stream) {
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
@@ -773,8 +837,6 @@ static int backward_sgd_impl(float* weight, int64_t num_rows, int32_t dim, const
   while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
   p.num_rows = (uint32_t)num_rows;
-  CE_REQUIRE(!presorted || num_rows <= (1ll << 22) - 2, CE_ERR_UNSUPPORTED,
-             "presorted keys are 32-bit: the table must have fewer than 2^22 rows");
   p.presorted = presorted;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
 }
@@ -791,23 +853,24 @@ extern "C" int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, in
                                              int64_t nnz, const void* offsets, int32_t offsets_are_i64,
                                              int64_t num_bags, int32_t include_last_offset,
                                              const float* per_sample_weights, int32_t mode, int64_t hook_features,
-                                             const float* grad_out, float lr, const uint32_t* presorted_keys,
+                                             const float* grad_out, float lr, const uint64_t* presorted_keys,
                                              ce_stream_t stream) {
   CE_REQUIRE(presorted_keys, CE_ERR_INVALID, "null presorted_keys");
   return backward_sgd_impl(weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
                            include_last_offset, per_sample_weights, mode, hook_features, grad_out, lr,
-                           presorted_keys, stream);
+                           (const unsigned long long*)presorted_keys, stream);
 }
 
-extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint32_t* keys_out,
+extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }
+
+extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out,
                               ce_stream_t stream) {
   if (nnz == 0) return CE_OK;
-  CE_REQUIRE(indices && keys_out && nnz > 0 && nnz < (int64_t)INT32_MAX, CE_ERR_INVALID, "bad arguments");
-  CE_REQUIRE(num_rows > 0 && num_rows <= (1ll << 22) - 2, CE_ERR_UNSUPPORTED,
-             "presorted keys are 32-bit: the table must have fewer than 2^22 rows");
-  const int ntiles = (int)cdiv(nnz, kBwdTile);
-  hipLaunchKernelGGL(k_bag_presort, dim3(std::min(ntiles, kMaxBlocks * 4)), dim3(256), 0, (hipStream_t)stream, indices,
-                     nnz, (uint32_t)num_rows, keys_out);
+  CE_REQUIRE(indices && keys_out && nnz > 0 && nnz < (int64_t)INT32_MAX - kSegLen, CE_ERR_INVALID, "bad arguments");
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  const int nseg = (int)cdiv(nnz, kSegLen);
+  hipLaunchKernelGGL(k_bag_presort_seg, dim3(std::min(nseg, kMaxBlocks)), dim3(1024), 0, (hipStream_t)stream,
+                     indices, nnz, (uint32_t)num_rows, (unsigned long long*)keys_out);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }

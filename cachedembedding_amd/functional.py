@@ -151,16 +151,24 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
     if presorted is not None:
-        assert presorted.is_cuda and presorted.dtype == torch.int32 and presorted.numel() == indices.numel()
+        assert presorted.is_cuda and presorted.dtype == torch.int64 and \
+            presorted.numel() == lib.ce_bag_presort_len(indices.numel()), "presorted must come from presort_slots"
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
                         int(hook_features), bool(sparse), fused_sgd, presorted)
 
 
+def presort_len(n: int) -> int:
+    """elements of the key tensor presort_slots writes for n lookups (n rounded up to whole 16384-lookup segments)"""
+    return int(lib.ce_bag_presort_len(int(n)))
+
+
 def presort_slots(slots: torch.Tensor, num_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-tile sorted keys for the fused backward (ce_bag_presort); int32 tensor with the bits of uint32 keys.
-    Run it once per prefetch window on the cache-op stream, then pass slices to embedding_bag(presorted=...)."""
+    """Segment-sorted keys of one batch's slots for the fused backward (ce_bag_presort): int64 tensor holding the
+    bits of uint64 keys, presort_len(n) long.  Run it once per prefetch window on the cache-op stream, then pass
+    the batch's keys to embedding_bag(presorted=...)."""
     flat = slots.reshape(-1).contiguous()
     if out is None:
-        out = torch.empty(flat.numel(), dtype=torch.int32, device=flat.device)
+        out = torch.empty(presort_len(flat.numel()), dtype=torch.int64, device=flat.device)
+    assert out.dtype == torch.int64 and out.numel() == presort_len(flat.numel()) and out.is_contiguous()
     check(lib.ce_bag_presort(ptr(flat), flat.numel(), int(num_rows), ptr(out), stream_ptr()))
     return out

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .cached_embedding import CachedEmbeddingBag
-from .functional import presort_slots
+from .functional import presort_len, presort_slots
 
 
 def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.cuda.Stream:
@@ -42,9 +42,10 @@ class PrefetchWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
                  presort: bool = False):
         assert prefetch_num >= 1
-        # presort=True: the cache op also sorts every backward tile of the window's slots (ce_bag_presort), so the
-        # fused backward skips its LDS sort; the keys of the last prepared/collected window are in `self.keys`
-        self.presort = presort and embed.cache_weight_mgr.cuda_row_num <= (1 << 22) - 2
+        # presort=True: the cache op also sorts the window's slots in 16384-lookup segments (ce_bag_presort), so the
+        # fused backward neither sorts nor issues as many row updates; the keys of the last prepared/collected window
+        # are in `self.keys`
+        self.presort = presort
         self.keys: Optional[List[torch.Tensor]] = None
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
@@ -67,7 +68,7 @@ class PrefetchWindow:
         self._keys_tmp = None
         if self.presort:
             C = self.mgr.cuda_row_num
-            if all(c % 1024 == 0 for c in counts):
+            if all(c == presort_len(c) for c in counts):       # whole segments: one launch for the window
                 self._keys_tmp = list(torch.split(presort_slots(slots, C), counts))
             else:
                 self._keys_tmp = [presort_slots(p, C) for p in parts]
@@ -129,10 +130,11 @@ class GraphedWindow:
         self.overlap = overlap
         dev = self.mgr.device
         self._bufs = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
-        # presort=True: step_fn(slots_i, i, keys_i); the per-tile sorted keys of the window (ce_bag_presort) are
+        # presort=True: step_fn(slots_i, i, keys_i); the segment-sorted keys of the window (ce_bag_presort) are
         # produced by the cache op into a static buffer next to the slots
-        self.presort = presort and self.mgr.cuda_row_num <= (1 << 22) - 2
-        self._keys = [torch.full((self.P, self.n), -1, dtype=torch.int32, device=dev) for _ in range(2)] \
+        self.presort = presort
+        self._klen = presort_len(self.n)
+        self._keys = [torch.full((self.P, self._klen), -1, dtype=torch.int64, device=dev) for _ in range(2)] \
             if self.presort else None
         self._side = make_side_stream(dev, cache_cus) if overlap else None
         self._events = [None, None]
@@ -170,7 +172,7 @@ class GraphedWindow:
 
     def _presort(self, buf: int) -> None:
         C = self.mgr.cuda_row_num
-        if self.n % 1024 == 0:
+        if self.n == self._klen:                                # whole segments: one launch for the window
             presort_slots(self._bufs[buf], C, out=self._keys[buf].view(-1))
         else:
             for i in range(self.P):

@@ -126,17 +126,20 @@ int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
                         int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                         int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream);
 
-/* The (row, lookup) sort of each 1024-lookup tile depends only on the slots, so it can be hoisted out of the
- * backward: ce_bag_presort writes the sorted 32-bit keys of every tile of `indices` (device uint32[nnz]; needs
- * num_rows < 2^22) -- typically once per prefetch window, on the cache-op stream, right after
- * ce_cache_prepare_ids -- and ce_bag_backward_sgd_presorted consumes them (same result as ce_bag_backward_sgd). */
-int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint32_t* keys_out, ce_stream_t stream);
+/* The (row, lookup) order the backward folds duplicates in depends only on the slots, so it can be computed ahead
+ * of the backward, once per prefetch window on the cache-op stream right after ce_cache_prepare_ids, and over a
+ * wider scope than a workgroup can sort on the fly: ce_bag_presort sorts every SEGMENT of 16384 consecutive lookups
+ * of `indices` and writes keys (row << 32 | lookup-in-segment, all-ones = ignored / padding) to keys_out, device
+ * uint64[ce_bag_presort_len(nnz)] (nnz rounded up to whole segments).  ce_bag_backward_sgd_presorted consumes
+ * them: same result as ce_bag_backward_sgd up to fp32 summation order, about half the row updates. */
+int64_t ce_bag_presort_len(int64_t nnz);
+int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out, ce_stream_t stream);
 int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, int32_t dim,
                                   const int64_t* indices, int64_t nnz,
                                   const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                   int64_t hook_features, const float* grad_out, float lr,
-                                  const uint32_t* presorted_keys, ce_stream_t stream);
+                                  const uint64_t* presorted_keys, ce_stream_t stream);
 
 /* Deterministic variant of the fused update: lookups are stably radix-sorted by target row
  * (workspace from ce_bag_backward_sgd_sorted_workspace), each row's gradients are summed in

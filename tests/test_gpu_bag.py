@@ -173,13 +173,15 @@ def test_full_size_batch_properties():
     assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))
 
 
-@pytest.mark.parametrize("nb,F", [(4096, 4), (5000, 1), (1023, 1), (1, 1)])
-def test_presorted_backward_matches_in_kernel_sort(nb, F):
-    """ce_bag_presort + ce_bag_backward_sgd_presorted == ce_bag_backward_sgd (same tile sort, hoisted)"""
+@pytest.mark.parametrize("nb,F,C,D", [(4096, 4, 3000, 128), (5000, 1, 3000, 128), (1023, 1, 3000, 128), (1, 1, 3000, 128),
+                                      (16384, 4, 3000, 64), (16385, 1, 500, 32), (50000, 2, 40000, 128),
+                                      (425984, 26, 200000, 32), (70000, 1, 5_000_000, 8)])
+def test_presorted_backward_matches_in_kernel_sort(nb, F, C, D):
+    """ce_bag_presort (16384-lookup segments) + ce_bag_backward_sgd_presorted == ce_bag_backward_sgd up to fp32
+    summation order; the last case has more than 2^22 rows (64-bit tile keys)"""
     ce = _ce()
-    from cachedembedding_amd.functional import presort_slots
+    from cachedembedding_amd.functional import presort_len, presort_slots
     g = torch.Generator().manual_seed(nb)
-    C, D = 3000, 128
     w = torch.randn(C, D, generator=g)
     idx = (torch.rand(nb, generator=g) ** 3 * C).long().clamp_(0, C - 1)
     idx[::17] = C + 5                       # out-of-range slots must be ignored by both paths
@@ -190,13 +192,52 @@ def test_presorted_backward_matches_in_kernel_sort(nb, F):
     for use_keys in (False, True):
         wc = w.cuda().requires_grad_(True)
         keys = presort_slots(idx.cuda(), C) if use_keys else None
+        if use_keys:
+            k = keys.cpu().numpy().view("uint64")
+            assert k.size == presort_len(nb) and k.size % 16384 == 0
+            for s0 in range(0, k.size, 16384):              # every segment: its valid lookups, equal rows adjacent
+                seg = k[s0:s0 + 16384]
+                real = seg[seg != 0xFFFFFFFFFFFFFFFF]
+                assert (seg[real.size:] == 0xFFFFFFFFFFFFFFFF).all(), "ignored lookups / padding come last"
+                lo = idx[s0:min(nb, s0 + 16384)]
+                assert real.size == int((lo < C).sum())
+                pos = (real & 0xFFFFFFFF).astype("int64")
+                assert np.array_equal(np.sort(pos), np.nonzero((lo < C).numpy())[0])       # each lookup once
+                rows = (real >> 32).astype("int64")
+                assert torch.equal(torch.from_numpy(rows), lo[pos])
+                runs = 1 + int((rows[1:] != rows[:-1]).sum()) if rows.size else 0
+                assert runs <= 1.35 * np.unique(rows).size + 8, "grouping leaves too many broken runs"
         out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
                                hook_features=hook, fused_sgd=ce.FusedSGD(0.5), presorted=keys)
         out.backward(go.cuda())
         outs.append(wc.detach().cpu())
-    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=1e-5)
     valid = idx < C
     ref = w.clone()
     gflat = go.transpose(0, 1).reshape(-1, D) if hook else go
     ref.index_add_(0, idx[valid], gflat[valid], alpha=-0.5)
     torch.testing.assert_close(outs[1], ref, rtol=1e-4, atol=1e-5)
+
+
+def test_presorted_backward_multi_id_bags_mean_and_weights():
+    """presorted keys with bags of several ids: mean scaling and per-sample weights follow the lookup, not the slot"""
+    ce = _ce()
+    from cachedembedding_amd.functional import presort_slots
+    g = torch.Generator().manual_seed(9)
+    C, D, nb = 700, 64, 9000
+    lens = torch.randint(0, 6, (nb,), generator=g)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
+    nnz = int(off[-1])
+    idx = (torch.rand(nnz, generator=g) ** 2 * C).long().clamp_(0, C - 1)
+    w = torch.randn(C, D, generator=g)
+    go = torch.randn(nb, D, generator=g) * 0.01
+    for mode, psw in (("mean", None), ("sum", torch.rand(nnz, generator=g))):
+        wc = w.cuda().requires_grad_(True)
+        out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode=mode, include_last_offset=True, sparse=True,
+                               per_sample_weights=None if psw is None else psw.cuda(), fused_sgd=ce.FusedSGD(0.25),
+                               presorted=presort_slots(idx.cuda(), C))
+        out.backward(go.cuda())
+        ref = w.clone().requires_grad_(True)
+        torch.nn.functional.embedding_bag(idx, ref, off, mode=mode, per_sample_weights=psw,
+                                          include_last_offset=True).backward(go)
+        torch.testing.assert_close(wc.detach().cpu(), w - 0.25 * ref.grad, rtol=1e-4, atol=1e-5)
