@@ -421,14 +421,17 @@ __device__ __forceinline__ void tile_sort_1024(KT (&key)[4], KT* lds, int tid) {
 // line-op per ~5 ns and channel): 1024-lookup tiles leave 109 k row updates per batch, 16384-lookup segments ~55 k.
 // The backward only needs EQUAL ROWS TO BE ADJACENT, not a total order, so the segment is not sorted (a 16 k
 // bitonic network in registers / shuffles / LDS took 170 us per window, as much as it saved) but GROUPED with one
-// counting pass: bucket = row & 4095; the lanes of a wave that hold the same bucket are matched with ballots and
-// their leader reserves their places with ONE returning LDS atomic; a scan of the 4096 counters turns
-// (bucket, place) into the output position.  ~4 keys share a bucket, so a hot row's lookups end up contiguous
+// counting pass: bucket = row & 8191; the lanes of a wave that hold the same bucket are matched with ballots and
+// their leader reserves their places with ONE returning LDS atomic; a scan of the 8192 counters turns
+// (bucket, place) into the output position.  ~2 keys share a bucket, so a hot row's lookups end up contiguous
 // apart from the odd cold row of the same bucket.  One workgroup of 1024 threads per segment, 16 keys per thread.
 // Key = row << 32 | lookup-in-segment; ignored lookups (out-of-range row) and padding = all ones, placed last.
 constexpr int kSegLen = 16384;
 constexpr int kSegKeys = 16;          // per thread
-constexpr int kSegBuckets = 4096;
+#ifndef CE_SEG_BUCKETS
+#define CE_SEG_BUCKETS 8192
+#endif
+constexpr int kSegBuckets = CE_SEG_BUCKETS;
 __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz,
                                                          uint32_t num_rows, unsigned long long* __restrict__ keys_out) {
   __shared__ int cnt[kSegBuckets + 1];                  // [kSegBuckets] = ignored lookups
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
       // wave match on the 13-bit bucket id, leader reserves popcount places
       unsigned long long pm = ~0ull;
 #pragma unroll
-      for (int b = 0; b < 13; ++b) {
+      for (int b = 0; (1 << b) <= kSegBuckets; ++b) {
         const unsigned long long m = __ballot((bkt[r] >> b) & 1);
         pm &= ((bkt[r] >> b) & 1) ? m : ~m;
       }
@@ -470,9 +473,10 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     }
     __syncthreads();
     // exclusive scan of the 4097 counters (thread t owns 4t..4t+3; the ignored bucket follows everything)
-    int c4[4], sum = 0;
+    constexpr int kPer = kSegBuckets / 1024;
+    int c4[kPer], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { c4[q] = cnt[tid * 4 + q]; sum += c4[q]; }
+    for (int q = 0; q < kPer; ++q) { c4[q] = cnt[tid * kPer + q]; sum += c4[q]; }
     int inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     int total = 0;
     for (int k = 0; k < 16; ++k) total += wsum[k];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { cnt[tid * 4 + q] = pre; pre += c4[q]; }
+    for (int q = 0; q < kPer; ++q) { cnt[tid * kPer + q] = pre; pre += c4[q]; }
     if (tid == 0) cnt[kSegBuckets] = total;
     __syncthreads();
 #pragma unroll
