@@ -86,6 +86,8 @@ SIGNATURES = {
                                c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_dense": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
                                       c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "ce_bag_backward_dense_presorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
+                                      c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "ce_bag_backward_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                      c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,

@@ -797,11 +797,11 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
   return CE_OK;
 }
 
-extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32_t dim, const int64_t* indices,
-                                     int64_t nnz, const void* offsets, int32_t offsets_are_i64,
-                                     int64_t num_bags, int32_t include_last_offset,
-                                     const float* per_sample_weights, int32_t mode, int64_t hook_features,
-                                     const float* grad_out, ce_stream_t stream) {
+static int backward_dense_impl(float* grad_weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
+                               const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                               int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                               int64_t hook_features, const float* grad_out, const unsigned long long* presorted,
+                               ce_stream_t stream) {
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(grad_weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -817,7 +817,29 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
   while ((1ll << p.idx_bits) < num_rows && p.idx_bits < 31) ++p.idx_bits;
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
   p.num_rows = (uint32_t)num_rows;
+  p.presorted = presorted;
   return launch_bwd<0>(p, vec, nch, (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32_t dim, const int64_t* indices,
+                                     int64_t nnz, const void* offsets, int32_t offsets_are_i64,
+                                     int64_t num_bags, int32_t include_last_offset,
+                                     const float* per_sample_weights, int32_t mode, int64_t hook_features,
+                                     const float* grad_out, ce_stream_t stream) {
+  return backward_dense_impl(grad_weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
+                             include_last_offset, per_sample_weights, mode, hook_features, grad_out, nullptr, stream);
+}
+
+extern "C" int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_t dim,
+                                               const int64_t* indices, int64_t nnz, const void* offsets,
+                                               int32_t offsets_are_i64, int64_t num_bags,
+                                               int32_t include_last_offset, const float* per_sample_weights,
+                                               int32_t mode, int64_t hook_features, const float* grad_out,
+                                               const uint64_t* presorted_keys, ce_stream_t stream) {
+  CE_REQUIRE(presorted_keys, CE_ERR_INVALID, "null presorted_keys");
+  return backward_dense_impl(grad_weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
+                             include_last_offset, per_sample_weights, mode, hook_features, grad_out,
+                             (const unsigned long long*)presorted_keys, stream);
 }
 
 static int backward_sgd_impl(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,

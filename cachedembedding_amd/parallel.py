@@ -212,8 +212,9 @@ class ShardOps:
     def pool(self, rows, pos, offsets, psw, mode, include_last, hook_features):   # -> pooled
         raise NotImplementedError
 
-    def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u):
-        """-> fp32[n_u, D]: gradient of every unique row (duplicates of the batch already summed)."""
+    def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u, keys=None):
+        """-> fp32[n_u, D]: gradient of every unique row (duplicates of the batch already summed).  `keys`: what
+        the implementation's bucketize returned as 4th element (grouping of the lookups by pos), if anything."""
         raise NotImplementedError
 
     def owner_update(self, slots, grad_rows, lr):            # cache rows -= lr * grad (duplicates summed)
@@ -259,7 +260,11 @@ class HipShardOps(ShardOps):
             check(lib.ce_dedupe_bucket_rows(ptr(ids), n, ptr(self.idx_map), N, W, ptr(self._stamp),
                                             ptr(self._slot_of_row), ptr(self._ws), ptr(rows), ptr(pos),
                                             counts[b].data_ptr(), sp))
-            staged.append((rows, pos))
+            # the fold of the batch's gradients (grad_rows) groups lookups by `pos`: do the grouping here, once,
+            # on the planning stream (any pos < n is a valid row of the [n_u, D] gradient buffer)
+            keys = torch.empty(lib.ce_bag_presort_len(n), dtype=torch.int64, device=dev)
+            check(lib.ce_bag_presort(ptr(pos), n, max(n, 1), ptr(keys), sp))
+            staged.append((rows, pos, keys))
         return ("hip", staged, counts)
 
     def bucketize_counts(self, token):
@@ -267,10 +272,10 @@ class HipShardOps(ShardOps):
 
     def bucketize_results(self, token, counts_host):
         _, staged, _counts = token
-        return [(rows[:sum(c)], pos, list(c)) for (rows, pos), c in zip(staged, counts_host)]
+        return [(rows[:sum(c)], pos, list(c), keys) for (rows, pos, keys), c in zip(staged, counts_host)]
 
     def token_tensors(self, token):
-        return [t for pair in token[1] for t in pair] + [token[2]]
+        return [t for tup in token[1] for t in tup] + [token[2]]
 
     def bucketize(self, ids):
         return self.bucketize_many([ids])[0]
@@ -301,13 +306,19 @@ class HipShardOps(ShardOps):
                                  _MODES[mode], hook_features, ptr(out), stream_ptr()))
         return out
 
-    def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u):
+    def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u, keys=None):
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
         g = torch.zeros(n_u, self.dim, dtype=torch.float32, device=grad_out.device)
-        # tile-sorted accumulate: duplicates of a row inside the batch are summed here, before they travel
-        check(lib.ce_bag_backward_dense(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
-                                        int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
-                                        _MODES[mode], hook_features, ptr(grad_out.contiguous()), stream_ptr()))
+        # duplicates of a row inside the batch are summed here, before they travel
+        if keys is not None:
+            check(lib.ce_bag_backward_dense_presorted(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
+                                                      int(offsets.dtype == torch.int64), num_bags, int(include_last),
+                                                      ptr(psw), _MODES[mode], hook_features,
+                                                      ptr(grad_out.contiguous()), ptr(keys), stream_ptr()))
+        else:
+            check(lib.ce_bag_backward_dense(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
+                                            int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
+                                            _MODES[mode], hook_features, ptr(grad_out.contiguous()), stream_ptr()))
         return g
 
     def owner_update(self, slots, grad_rows, lr):
@@ -340,6 +351,7 @@ class BatchPlan:
     recv_splits: List[int]      # lookups each peer sends me (rows I own)
     recv_rows: torch.Tensor     # local row ids I serve, peer-major
     slots: Optional[torch.Tensor] = None
+    keys: Optional[torch.Tensor] = None     # grouping of the batch's lookups by perm (ShardOps-specific), or None
 
 
 class RowwiseExchange:
@@ -407,12 +419,13 @@ class RowwiseExchange:
             _a2a(got_all, send_buf, out_splits, in_splits, self.group)
             segs = torch.split(got_all, [rs_all[b][p] for p in range(W) for b in range(P)])
         for b in range(P):
-            rows, perm, _ = buck[b]
+            rows, perm = buck[b][0], buck[b][1]
             if W > 1:
                 got = torch.cat([segs[p * P + b] for p in range(W)])
             else:
                 got = rows
-            plans.append(BatchPlan(rows.numel(), perm, ss_all[b], rs_all[b], got))
+            plans.append(BatchPlan(rows.numel(), perm, ss_all[b], rs_all[b], got,
+                                   keys=buck[b][3] if len(buck[b]) > 3 else None))
         all_rows = plans[0].recv_rows if P == 1 else torch.cat([p.recv_rows for p in plans])
         slots = self.ops.owner_prepare(all_rows)
         for p, s in zip(plans, torch.split(slots, [p.recv_rows.numel() for p in plans])):
@@ -452,7 +465,7 @@ class _RowwiseFn(torch.autograd.Function):
         ex, plan = ctx.ex, ctx.plan
         offsets, psw, mode, include_last, hook = ctx.args
         with torch.no_grad():
-            g = ex.ops.grad_rows(grad_out, plan.perm, offsets, psw, mode, include_last, hook, plan.n)
+            g = ex.ops.grad_rows(grad_out, plan.perm, offsets, psw, mode, include_last, hook, plan.n, plan.keys)
             g_own = ex.return_grads(plan, g)
             lr = ctx.lr_box[0]
             if lr is None:
@@ -539,7 +552,7 @@ class RowwiseShardedEmbeddingBag(nn.Module):
         out = ex.ops.pool(rows, plan.perm, offsets, per_sample_weights, self.mode, self.include_last_offset,
                           int(hook_features))
         g = ex.ops.grad_rows(grad_out, plan.perm, offsets, per_sample_weights, self.mode,
-                             self.include_last_offset, int(hook_features), plan.n)
+                             self.include_last_offset, int(hook_features), plan.n, plan.keys)
         ex.ops.owner_update(plan.slots, ex.return_grads(plan, g), lr)
         return out
 
@@ -614,7 +627,7 @@ class ShardedWindowPipeline:
         cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
         cur.wait_event(ev)
         for p in plans:
-            for t in (p.perm, p.recv_rows, p.slots):
+            for t in (p.perm, p.recv_rows, p.slots, p.keys):
                 if t is not None and t.is_cuda:
                     t.record_stream(cur)
         return plans

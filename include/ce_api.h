@@ -140,6 +140,13 @@ int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, int32_t dim,
                                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                   int64_t hook_features, const float* grad_out, float lr,
                                   const uint64_t* presorted_keys, ce_stream_t stream);
+/* the same for the plain accumulation (ce_bag_backward_dense): grad_weight += folded gradients */
+int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_t dim,
+                                    const int64_t* indices, int64_t nnz,
+                                    const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
+                                    int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
+                                    int64_t hook_features, const float* grad_out,
+                                    const uint64_t* presorted_keys, ce_stream_t stream);
 
 /* Deterministic variant of the fused update: lookups are stably radix-sorted by target row
  * (workspace from ce_bag_backward_sgd_sorted_workspace), each row's gradients are summed in

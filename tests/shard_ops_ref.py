@@ -40,7 +40,7 @@ class TorchShardOps(ShardOps):
             out = out.view(hook_features, -1, self.dim).transpose(0, 1).contiguous()
         return out
 
-    def grad_rows(self, grad_out, perm, offsets, psw, mode, include_last, hook_features, n):
+    def grad_rows(self, grad_out, perm, offsets, psw, mode, include_last, hook_features, n, keys=None):
         if hook_features:
             grad_out = grad_out.transpose(0, 1).reshape(-1, self.dim)
         rows = torch.zeros(n, self.dim, requires_grad=True)
