@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
     // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, R gradient rows in flight,
     // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated n
     // times in the tile costs n/kChunk+1 atomics instead of n.
-    constexpr int kChunk = 32;
+    constexpr int kChunk = 64;
     if (p.debug == 4) continue;
     const int nchunks = (nv + kChunk - 1) / kChunk;
     for (int ck = grp; ck < nchunks; ck += ngroups) {
