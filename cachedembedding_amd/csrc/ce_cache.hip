@@ -1392,9 +1392,16 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy
     const long long scap = (long long)L.stage_rows;
     static const int swap_rows = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : kSwapRows; }();
+    // workgroups of the write-back part: as many as admit when the call has the GPU to itself; half as many when it
+    // overlaps with training (protect_depth > 0) -- PCIe writes are what slows the kernels next to them, and fewer
+    // rows leave than enter (32 + 16 workgroups: 2.11 -> 2.22 G lookups/s; 32 + 8 makes the write-back the bottleneck)
+    static const int wb_env = [] { const char* e = getenv("CE_SWAP_WB_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int wb_groups = wb_env > 0 ? std::min(wb_env, cap_groups)
+                                     : (c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups);
 #define CE_SWAP(VT, R)                                                                                          \
-  hipLaunchKernelGGL((k_swap<VT, R>), dim3(2 * cap_groups), swap_block, 0, s, h->stage_idx, (const VT*)h->stage, \
-                     scap, cap_groups, h->miss_list, h->free_list, (const long long*)&h->ctl->n_miss,           \
+  hipLaunchKernelGGL((k_swap<VT, R>), dim3(wb_groups + cap_groups), swap_block, 0, s, h->stage_idx,             \
+                     (const VT*)h->stage, scap, wb_groups, h->miss_list, h->free_list,                           \
+                     (const long long*)&h->ctl->n_miss,                                                          \
                      (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl)
     if (h->vec) {
       if (swap_rows == 2) CE_SWAP(f32x4, 2); else if (swap_rows == 4) CE_SWAP(f32x4, 4);
