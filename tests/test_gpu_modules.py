@@ -139,8 +139,9 @@ def test_tablewise_parallel(world):
     assert len(res) == world and all(r[1] == "ok" for r in res), res
 
 
+@pytest.mark.parametrize("presort", [False, True])
 @pytest.mark.parametrize("mode", ["sequential", "overlap", "graph"])
-def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode):
+def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, presort):
     """_train's window block in its three forms gives the same training trajectory as a plain full-table
     EmbeddingBag with SGD (each window's unique rows fit the cache even when two windows are protected)."""
     import cachedembedding_amd as ce
@@ -158,12 +159,13 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode):
     windows = [[(torch.rand(F * B, generator=g) ** 3 * N).long().clamp_(0, N - 1) for _ in range(P)] for _ in range(nwin)]
     ref = w0.clone()
 
-    def step(slots, i):
-        out = emb(slots, off, hook_features=F)
+    def step(slots, i, keys=None):
+        out = emb(slots, off, hook_features=F, presorted=keys)
         out.backward(grad)
 
     if mode == "graph":
-        gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=[v.cuda() for v in windows[0]])
+        gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=[v.cuda() for v in windows[0]],
+                           presort=presort)
         # the capture warm-up trained on window 0 twice over (eager pass + nothing else): replay that on the ref
         for v in windows[0]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
@@ -173,7 +175,7 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode):
                 gw.submit([v.cuda() for v in windows[w + 1]], (w + 1) % 2)
             gw.run(w % 2)
     else:
-        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"))
+        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"), presort=presort)
         if mode == "overlap":
             win.submit([v.cuda() for v in windows[0]])
         for w in range(nwin):
@@ -184,7 +186,7 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode):
             else:
                 slots = win.prepare([v.cuda() for v in windows[w]])
             for i in range(P):
-                step(slots[i], i)
+                step(slots[i], i, win.keys[i] if presort else None)
     for w in range(nwin):
         for v in windows[w]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
