@@ -209,3 +209,41 @@ def test_lfu_counters_when_every_lookup_is_a_different_row():
         assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
         assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
     assert sum(mgr.num_write_back_history) > 0
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+@pytest.mark.parametrize("workload,ratio,P,calls", [("criteo_kaggle", 0.05, 1, 40), ("avazu", 0.01, 1, 40),
+                                                    ("criteo_1tb", 0.01, 8, 12)])
+def test_baseline_configs_at_real_index_sizes_exact_vs_oracle(workload, ratio, P, calls, strategy):
+    """BASELINE.json configs[1], [2], [4] (Criteo-Kaggle 5 % P=1, Criteo-1TB 1 % P=8, Avazu 1 % P=1) at their real
+    table and cache sizes: slots, cached_idx_map, LFU counters and the hit / miss / write-back histories are identical
+    to the oracle's, call by call."""
+    ce = _ce()
+    from cachedembedding_amd import synthetic
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+    sizes = synthetic.TABLES[workload]
+    N, D, B = sum(sizes), 4, 16384
+    C = int(N * ratio)
+    assert (N, C) in ((33_762_577, 1_688_128), (9_445_823, 94_458), (177_944_275, 1_779_442))
+    gen = synthetic.SyntheticKJT(sizes, B, 1, "power_law", 0.25, seed=3, device="cuda")
+    freq = gen.id_freq_map(8).cpu().numpy()
+    w = (np.arange(N, dtype=np.float32) % 4099).reshape(N, 1).repeat(D, axis=1)
+    lfu = strategy == "lfu"
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if lfu else DATASET)
+    ora.reorder(freq, 0.98)         # nearly full after warm-up: evictions start within a few iterations
+    mgr = ce.CachedParamMgr(torch.from_numpy(w), C,
+                            evict_strategy=ce.EvictionStrategy.LFU if lfu else ce.EvictionStrategy.DATASET)
+    mgr.reorder(freq, 0.98)
+    assert np.array_equal(mgr.idx_map.cpu().numpy().astype(np.int64), ora.idx_map)
+    for call in range(calls):
+        ids = gen.next_values(P).view(-1)                      # P iterations' ids = one cache op
+        got = mgr.prepare_ids(ids)
+        exp = ora.prepare_ids(ids.cpu().numpy())
+        assert np.array_equal(got.cpu().numpy(), exp)
+        if call % 8 == 7 or call < 2 or call == calls - 1:
+            assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+            if lfu:
+                assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+    assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
+    assert mgr.num_write_back_history == ora.num_write_back_history
+    assert sum(ora.num_write_back_history) > 0, "the stream must reach eviction"
