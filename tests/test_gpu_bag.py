@@ -173,6 +173,40 @@ def test_full_size_batch_properties():
     assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))
 
 
+@pytest.mark.parametrize("presort", [False, True])
+def test_full_size_step_vs_torch_cpu(presort):
+    """BASELINE config [2] step at its real shape -- cache of C = 1,779,442 rows x 128, B = 16384, F = 26, long-tail
+    slots -- against the calls the reference makes on the CPU (F.embedding_bag, then SGD on the summed gradient):
+    forward bit-exact (L = 1 is a copy), updated cache rows within 1e-5 relative (fp32 sums in another order)."""
+    ce = _ce()
+    from cachedembedding_amd.functional import presort_slots
+    B, F, D, C, lr = 16384, 26, 128, 1_779_442, 0.5
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(C, D, generator=g)
+    idx = (torch.rand(B * F, generator=g) ** 6 * C).long().clamp_(0, C - 1)      # hot rows repeat thousands of times
+    off = torch.arange(B * F + 1, dtype=torch.int32)
+    go = torch.randn(B, F, D, generator=g) * 0.01
+    wc = w.cuda().requires_grad_(True)
+    keys = presort_slots(idx.cuda(), C) if presort else None
+    out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
+                           hook_features=F, fused_sgd=ce.FusedSGD(lr), presorted=keys)
+    ref_out = torch.nn.functional.embedding_bag(idx, w, off.long(), mode="sum", include_last_offset=True)
+    assert torch.equal(out.detach().cpu(), ref_out.view(F, B, D).transpose(0, 1))
+    out.backward(go.cuda())
+    gflat = go.transpose(0, 1).reshape(-1, D)
+    ref32 = w.clone().index_add_(0, idx, gflat, alpha=-lr)                       # what the reference computes
+    ref64 = w.double().index_add_(0, idx, gflat.double(), alpha=-lr)             # what it means
+    got = wc.detach().cpu()
+    # 1e-5 relative, plus the fp32 accumulation noise of a row that sums n gradients (the hottest row here sums
+    # ~100 k of them; torch's own fp32 result is held to the same bound)
+    n = torch.bincount(idx, minlength=C).double().unsqueeze(1)
+    bound = 1e-5 * ref64.abs() + 2e-6 + 3e-7 * n.sqrt()
+    assert bool(((got.double() - ref64).abs() <= bound).all())
+    assert bool(((ref32.double() - ref64).abs() <= bound).all())
+    cold = (n <= 4).expand(-1, D)
+    torch.testing.assert_close(got[cold], ref32[cold], rtol=1e-5, atol=2e-6)    # the bulk: 1e-5 against torch fp32
+
+
 @pytest.mark.parametrize("nb,F,C,D", [(4096, 4, 3000, 128), (5000, 1, 3000, 128), (1023, 1, 3000, 128), (1, 1, 3000, 128),
                                       (16384, 4, 3000, 64), (16385, 1, 500, 32), (50000, 2, 40000, 128),
                                       (425984, 26, 200000, 32), (70000, 1, 5_000_000, 8)])
