@@ -68,7 +68,15 @@ def parse():
                     "(ce_bag_presort, 16384-lookup segments: about half the atomic row updates)")
     ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
                     "hipGraph of the window's P training steps")
-    ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport instead of zero-copy")
+    ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport (= --transport staged)")
+    ap.add_argument("--transport", default=None, choices=["worker", "zerocopy", "staged"],
+                    help="how rows move between the host table and the cache.  worker (default when the cache op "
+                         "overlaps training): admissions by zero-copy reads, evictions by ONE pinned hipMemcpyAsync "
+                         "+ a worker thread in libce_hip; zerocopy (default with --no_overlap): one kernel moves "
+                         "both directions over the mapped host table; staged: upstream's async_copy")
+    ap.add_argument("--min_time", type=float, default=0.5, help="the K-step block is repeated until the timed "
+                    "region is at least this long (seconds); the median block is reported")
+    ap.add_argument("--max_reps", type=int, default=400)
     ap.add_argument("--deterministic", action="store_true", help="sorted segmented SGD update instead of atomics")
     ap.add_argument("--force_sharded", action="store_true", help="run the row-wise sharded code path even at N=1")
     ap.add_argument("--share_gpu", action="store_true",
@@ -130,8 +138,8 @@ def main():
                                   cache_ratio=args.cache_ratio, ids_freq_mapping=freq, warmup_ratio=args.warmup_ratio,
                                   pin_weight=True, evict_strategy=strategy, init_seed=args.seed, strict=False)
     del freq
-    if args.async_copy:
-        embed.set_cache_mgr_async_copy(True)
+    transport = args.transport or ("staged" if args.async_copy else ("worker" if args.overlap else "zerocopy"))
+    embed.cache_weight_mgr.set_transport(transport)
     embed.set_fused_sgd(args.lr, deterministic=args.deterministic)
     embed.set_cache_op(False)
     mgr = embed.cache_weight_mgr
@@ -145,21 +153,24 @@ def main():
             mgr.prepare_ids(gen.next_values(P).view(-1))
             prefill += 1
         note(f"cache filled by {prefill} untimed cache ops")
-    total = W + K
-    n_windows = (total + P - 1) // P
-    # inputs resident in HBM before the timed region
-    windows = [gen.next_values(P) for _ in range(n_windows)]          # each [P, F*B*L]
+    use_graph = not args.no_graph
+    if W % P:
+        W = (W // P + 1) * P          # whole windows of untimed warm-up (the timed blocks then start on a window)
+    # inputs resident in HBM before they are used; windows are generated on demand OUTSIDE the timed blocks
+    windows = []
+
+    def need_windows(n_steps, first_step=0):
+        while len(windows) * P < n_steps + P:          # + one look-ahead window for the overlapped cache op
+            windows.append(gen.next_values(P))          # each [P, F*B*L]
+        for w in range(max(0, first_step // P - 2)):   # windows long done: give the HBM back
+            windows[w] = None
+
+    need_windows(W + K)
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
     presort = not args.no_presort and not args.deterministic
-    win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort)
-    use_graph = not args.no_graph
-    if use_graph and W % P:
-        W = (W // P + 1) * P          # graph mode trains whole windows: round the untimed warm-up up
-        total = W + K
-        n_windows = (total + P - 1) // P
-        while len(windows) < n_windows:
-            windows.append(gen.next_values(P))
+    win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort,
+                         transport=None)
 
     def train_step(slots_i, i, keys_i=None):
         out = embed(slots_i, offsets, hook_features=F, presorted=keys_i)
@@ -169,28 +180,52 @@ def main():
     if use_graph:
         from cachedembedding_amd.pipeline import GraphedWindow
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
-                           warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort)
+                           warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort,
+                           transport=None)
         note("hipGraph of the window's training steps captured")
 
-    def run_windows(first_w, count_w, tail_steps=0):
-        """graph mode: window w = cache op (side stream, one window ahead when overlapping) + one graph replay;
-        tail_steps > 0 adds a trailing partial window of that many steps"""
-        last = first_w + count_w + (1 if tail_steps else 0)
-        if os.environ.get("CE_BENCH_SKIP_CACHE_OP") and first_w > 0:      # diagnostic: training kernels only
-            for w in range(first_w, last):
-                gw.run(w % 2, None if w < first_w + count_w else tail_steps)
-            return
-        if args.overlap and last > first_w:
-            gw.submit([windows[first_w][i] for i in range(P)], first_w % 2)
-        for w in range(first_w, last):
-            if args.overlap:
-                if w + 1 < last:            # enqueued before graph w: overlaps with it
-                    gw.submit([windows[w + 1][i] for i in range(P)], (w + 1) % 2)
+    skip_cache_op = bool(os.environ.get("CE_BENCH_SKIP_CACHE_OP"))      # diagnostic: training kernels only
+    state = {"submitted": -1, "slots": None}
+
+    def run_range(g0, g1):
+        """Steps [g0, g1) of one continuous stream of steps; window w = steps [w*P, (w+1)*P).  Entering window w
+        first enqueues the cache op of window w+1 on the side stream (overlap) -- it belongs to the block that
+        enqueued it, so every cache op is inside exactly one timed block -- then trains window w: one hipGraph
+        replay when the whole window lies inside [g0, g1), step by step otherwise."""
+        g = g0
+        while g < g1:
+            w, i = divmod(g, P)
+            if use_graph:
+                if i == 0 and not (skip_cache_op and g0 >= W):
+                    if args.overlap:
+                        if state["submitted"] < w:
+                            gw.submit([windows[w][j] for j in range(P)], w % 2)
+                        gw.submit([windows[w + 1][j] for j in range(P)], (w + 1) % 2)
+                        state["submitted"] = w + 1
+                    else:
+                        gw.submit([windows[w][j] for j in range(P)], w % 2)
+                n = min(P - i, g1 - g)
+                if i == 0 and n == P:
+                    gw.run(w % 2)
+                else:
+                    gw.run_steps(w % 2, i, i + n)
+                g += n
             else:
-                gw.submit([windows[w][i] for i in range(P)], w % 2)
-            gw.run(w % 2, None if w < first_w + count_w else tail_steps)
+                if i == 0 or state["slots"] is None:
+                    if win.overlap:
+                        if win._pending is None:
+                            win.submit([windows[w][j] for j in range(P)])
+                        state["slots"] = win.collect()
+                        win.submit([windows[w + 1][j] for j in range(P)])
+                    else:
+                        state["slots"] = win.prepare([windows[w][j] for j in range(P)])
+                out = embed(state["slots"][i], offsets, hook_features=F,
+                            presorted=win.keys[i] if win.keys else None)
+                out.backward(grad)
+                g += 1
 
     def run_steps(first, count, ev_pairs=None):
+        """eager, event-bracketed steps for the per-kernel pass below (its own PrefetchWindow)"""
         nonlocal win
         slots = None
         if win.overlap and win._pending is not None:
@@ -202,7 +237,7 @@ def main():
                     if win._pending is None:
                         win.submit([windows[wi][i] for i in range(P)])
                     slots = win.collect()
-                    if wi + 1 < n_windows:
+                    if wi + 1 < len(windows):
                         win.submit([windows[wi + 1][i] for i in range(P)])
                 else:
                     slots = win.prepare([windows[wi][i] for i in range(P)])
@@ -222,21 +257,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_graph:
-        run_windows(0, W // P)
-    else:
-        run_steps(0, W)
     barrier()
-    note("warmup done")
-    t1 = time.perf_counter()
-    if use_graph:
-        run_windows(W // P, K // P, K % P)
-    else:
-        run_steps(W, K)
-    enqueue_s = time.perf_counter() - t1
+    tw = time.perf_counter()
+    run_range(0, W)
     barrier()
-    elapsed = time.perf_counter() - t1
-    note(f"timed region done: {elapsed:.3f}s for {K} steps (host enqueue took {enqueue_s:.3f}s)")
+    warm_s = time.perf_counter() - tw
+    note(f"warmup done ({W} steps, {1e3 * warm_s / max(W, 1):.3f} ms/step incl. pipeline fill)")
+    # ---- timed region: blocks of EXACTLY K steps, each bracketed by barrier + synchronize; the block is repeated
+    # until the region is >= --min_time long and the MEDIAN block is reported.  A 20-step block is 4 ms: one block
+    # alone measures the pipeline fill, not the pipeline.
+    mgr.set_profiling(True)
+    mgr.phase_times(reset=True)
+    tot0 = mgr.totals()
+    blocks = []
+    enqueue_s = 0.0
+    g = W
+    while True:
+        need_windows(g + K, g)
+        barrier()
+        t1 = time.perf_counter()
+        run_range(g, g + K)
+        enqueue_s += time.perf_counter() - t1
+        barrier()
+        blocks.append(time.perf_counter() - t1)
+        g += K
+        if (sum(blocks) >= args.min_time and len(blocks) >= 3) or len(blocks) >= args.max_reps:
+            break
+    reps = len(blocks)
+    elapsed = sorted(blocks)[reps // 2]
+    phases = mgr.phase_times()
+    mgr.set_profiling(False)
+    note(f"timed region done: {reps} blocks of {K} steps, {sum(blocks):.3f}s in total, median block "
+         f"{1e3 * elapsed:.3f} ms (min {1e3 * min(blocks):.3f}, max {1e3 * max(blocks):.3f}); host enqueue "
+         f"{enqueue_s:.3f}s")
     st = mgr.sync_stats()
     if st.status != 0:
         raise AssertionError(f"cache op failed with status {st.status}: unique rows of a window exceed cuda_row_num={C}")
@@ -253,28 +306,32 @@ def main():
     # Pass B (only when overlapping): the same launches while the side stream runs the next window's cache op ->
     #         `avg_ms_in_pipeline`; event-bracketed, so it includes the time a kernel waits for CUs held by the
     #         other stream (rocprofv3 of the default command shows 126 / 75 us of pure execution there).
-    def event_pass():
+    ev_first = ((g + P - 1) // P + 1) * P          # fresh windows after the timed blocks
+    need_windows(ev_first + 8 * P)
+
+    def event_pass(first):
         evs = []
-        run_steps(W, min(K, 4 * P), evs)
+        run_steps(first, 4 * P, evs)
         torch.cuda.synchronize()
         f = [e0.elapsed_time(e1) for e0, e1, _ in evs]
         g = [e1.elapsed_time(e2) for _, e1, e2 in evs]
         return sum(f) / len(f), sum(g) / len(g)
 
     torch.cuda.synchronize()
-    win = PrefetchWindow(embed, P, overlap=False, presort=presort)
-    fwd_avg, bwd_avg = event_pass()
+    win = PrefetchWindow(embed, P, overlap=False, presort=presort, transport=None)
+    mgr.set_protect_depth(0)
+    fwd_avg, bwd_avg = event_pass(ev_first)
     fwd_pipe, bwd_pipe = fwd_avg, bwd_avg
     if args.overlap:
-        win = PrefetchWindow(embed, P, overlap=True, presort=presort)
-        fwd_pipe, bwd_pipe = event_pass()
+        win = PrefetchWindow(embed, P, overlap=True, presort=presort, transport=None)
+        fwd_pipe, bwd_pipe = event_pass(ev_first + 4 * P)
         torch.cuda.synchronize()
     row_b = 4 * D
     fwd_bytes = B * F * (L * (row_b + 8) + 8 + row_b)            # 1040 B/lookup at D=128, L=1
     # backward: per bag read the gradient row (4D) + offset (8), per lookup the slot (8); per UNIQUE
     # target row of the batch a read-modify-write (2 * 4D).  Unique rows counted on the measured batches.
     with torch.no_grad():
-        wi0 = W // P
+        wi0 = ev_first // P + 3          # a window of the event pass: its rows are still resident
         uniq = [int(torch.unique(mgr._id_to_cached_cuda_id(windows[wi0][i])).numel()) for i in range(P)]
     uniq_avg = sum(uniq) / len(uniq)
     bwd_bytes = B * F * (row_b + 8) + B * F * L * 8 + uniq_avg * 2 * row_b
@@ -294,28 +351,66 @@ def main():
             key = f"{args.workload}:B{B}:D{D}"
             for r in (fwd_roof, bwd_roof):
                 r["traffic"] = tj.get(key, {}).get(r["kernel"])
+            for r in (fwd_roof, bwd_roof):
+                if r["traffic"] is not None:
+                    r["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "an earlier run of this command (profiles/collect.sh), not this run")
         except Exception:
             pass
-    dominant, other = (fwd_roof, bwd_roof) if fwd_avg >= bwd_avg else (bwd_roof, fwd_roof)
+    # the PCIe row swap of the cache op (k_swap), timed inside the timed blocks by the library's phase events
+    # (side stream, i.e. while training kernels run beside it).  Bytes: rows admitted (+ rows written back when the
+    # kernel carries both directions) x 4D; peak: PCIe Gen5 x16, ~63 GB/s per direction.
+    calls_t = max(1, phases.get("calls", 0))
+    rows_in_t = (tot["cpu_to_cuda_numel"] - tot0["cpu_to_cuda_numel"]) // D
+    rows_out_t = (tot["cuda_to_cpu_numel"] - tot0["cuda_to_cpu_numel"]) // D
+    swap_ms = phases.get("admit_swap", 0.0) / calls_t
+    both = transport == "zerocopy"
+    swap_bytes = (rows_in_t + (rows_out_t if both else 0)) * row_b / calls_t
+    swap_peak = 63.0 * (2 if both else 1)
+    swap_roof = dict(kernel="k_swap (admit%s)" % (" + write-back" if both else ""), bound="pcie",
+                     achieved=swap_bytes / max(swap_ms, 1e-9) / 1e6, peak=swap_peak, unit="GB/s",
+                     avg_ms=swap_ms, bytes_per_launch=swap_bytes, launches_per_step=1.0 / P,
+                     rows_in_per_launch=rows_in_t / calls_t, rows_out_per_launch=rows_out_t / calls_t, traffic=None,
+                     note="timed in the pipeline (side stream) by hipEvents around the phase")
+    swap_roof["frac"] = swap_roof["achieved"] / swap_roof["peak"]
+    wbs = mgr.writeback_stats()
+    if wbs["jobs"]:
+        moved = wbs["rows"] * row_b
+        swap_roof["writeback_worker"] = dict(jobs=wbs["jobs"], rows=wbs["rows"],
+                                             copy_GBps=moved / max(wbs["copy_s"], 1e-9) / 1e9,
+                                             scatter_GBps=moved / max(wbs["scatter_s"], 1e-9) / 1e9,
+                                             copy_ms_per_job=1e3 * wbs["copy_s"] / wbs["jobs"],
+                                             scatter_ms_per_job=1e3 * wbs["scatter_s"] / wbs["jobs"])
+    # `roofline` = the kernel with the largest share of a step's GPU time (a step = 1 fwd + 1 bwd + 1/P swap)
+    for r, per_step in ((fwd_roof, 1.0), (bwd_roof, 1.0), (swap_roof, 1.0 / P)):
+        r["ms_per_step_share"] = r["avg_ms"] * per_step
+    ranked = sorted((fwd_roof, bwd_roof, swap_roof), key=lambda r: -r["ms_per_step_share"])
+    dominant, other = ranked[0], ranked[1:]
+    cache_phases = {k: v / calls_t for k, v in phases.items() if k != "calls"}
 
     result = {
         "metric": "embedding lookups/sec (cache op + EmbeddingBag fwd + bwd/SGD), Criteo-1TB table @1% cache",
         "value": value, "unit": "lookups/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "warmup_steps_run": W,
+        "warmup_steps_run": W, "reps": reps,
+        "timing": "median of `reps` consecutive blocks of `steps` steps, each bracketed by barrier + synchronize; "
+                  "every cache op is enqueued inside one block",
+        "block_ms": {"median": 1e3 * elapsed, "min": 1e3 * min(blocks), "max": 1e3 * max(blocks),
+                     "first": 1e3 * blocks[0]},
         "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
                    "embedding_dim": D, "features": F, "batch_size": B, "pooling": L, "cache_ratio": args.cache_ratio,
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
-                   "transport": "staged" if args.async_copy else "zerocopy", "overlap": bool(args.overlap),
+                   "transport": transport, "overlap": bool(args.overlap),
                    "launch": "hipGraph per window" if use_graph else "python per step",
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window (ce_bag_presort)"
                    if presort else "1024-lookup tiles sorted inside every backward",
                    "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,
-                  "prefill_cache_ops": prefill, "setup_s": setup_s},
+                  "prefill_cache_ops": prefill, "setup_s": setup_s,
+                  "cache_op_ms_by_phase": cache_phases, "cache_ops_timed": phases.get("calls", 0)},
         "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} |
                     {k: dominant[k] for k in dominant if k not in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
         "roofline_other": other,
@@ -511,33 +606,48 @@ def run_sharded(args, sizes, rank, world, dev):
 
 def cpu_baseline(embed, gen, args, B, F, L, D):
     """The repo's pure-PyTorch CPU EmbeddingBag path (cache_ratio=1.0 == whole table in RAM):
-    F.embedding_bag fwd + sparse backward + SGD.step over the SAME pinned host table, timed on the host's own
-    cores.  Runs last: it updates the table in place."""
+    F.embedding_bag fwd + sparse backward + SGD.step over the SAME pinned host table (the Criteo-1TB table of the
+    bench workload, not config[0]'s Kaggle table), timed on the host's own cores.  torch's intra-op thread count
+    is swept (64 / all physical cores / all hardware threads) and the best is reported with its count.
+    Runs last: it updates the table in place."""
     from oracle import bag_oracle
     torch.cuda.synchronize()
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    hw = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or hw
+    except Exception:
+        phys = hw
+    cand = sorted({min(hw, 64), min(hw, phys), hw})
     table = embed.weight                      # CPU view of the pinned [N, D] host table
     w = torch.nn.Parameter(table)             # shares memory, no 91 GB clone
     opt = torch.optim.SGD([w], lr=args.lr)
     offsets = gen.offsets.cpu().long()
     grad = (torch.randn(B * F, D) * 1e-3)
     batches = gen.next_values(8).cpu()
-    times = []
-    t_end = time.perf_counter() + args.cpu_seconds
-    i = 0
-    while (time.perf_counter() < t_end or len(times) < 3) and len(times) < 200:
-        ids = batches[i % batches.shape[0]]
-        t0 = time.perf_counter()
-        bag_oracle.cpu_train_step_inplace(w, opt, ids, offsets, grad)
-        times.append(time.perf_counter() - t0)
-        i += 1
-    times = times[1:] if len(times) > 3 else times
-    med = sorted(times)[len(times) // 2]
-    return {"value": B * F * L / med, "unit": "lookups/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} iterations of torch-CPU F.embedding_bag fwd+bwd(sparse)+SGD.step, B={B} F={F} L={L} "
-                      f"D={D} over the full {table.shape[0]}-row host table, median; host has {cores} hw threads",
+    sweep = {}
+    n_timed = 0
+    for threads in cand:
+        torch.set_num_threads(threads)
+        times = []
+        t_end = time.perf_counter() + args.cpu_seconds / len(cand)
+        i = 0
+        while (time.perf_counter() < t_end or len(times) < 4) and len(times) < 200:
+            ids = batches[i % batches.shape[0]]
+            t0 = time.perf_counter()
+            bag_oracle.cpu_train_step_inplace(w, opt, ids, offsets, grad)
+            times.append(time.perf_counter() - t0)
+            i += 1
+        times = times[1:]
+        n_timed += len(times)
+        sweep[threads] = sorted(times)[len(times) // 2]
+    best = min(sweep, key=sweep.get)
+    med = sweep[best]
+    return {"value": B * F * L / med, "unit": "lookups/s", "cores": best, "kind": "port",
+            "sample": f"{n_timed} iterations of torch-CPU F.embedding_bag fwd+bwd(sparse)+SGD.step, B={B} F={F} L={L} "
+                      f"D={D} over the full {table.shape[0]}-row host table (the bench workload's table), median per "
+                      f"thread count; host has {phys} physical cores / {hw} hw threads",
+            "threads_swept": {str(k): B * F * L / v for k, v in sweep.items()},
             "it_per_s": 1.0 / med}
 
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 from pathlib import Path
 
 import torch  # noqa: F401  (must precede the CDLL below)
@@ -30,6 +30,7 @@ CE_MODE_SUM = 0
 CE_MODE_MEAN = 1
 CE_TRANSPORT_ZEROCOPY = 0
 CE_TRANSPORT_STAGED = 1
+CE_TRANSPORT_WORKER = 2
 CE_CALL_PREPARE = 0
 CE_CALL_PRELOAD = 1
 CE_CALL_FLUSH = 2
@@ -115,6 +116,14 @@ SIGNATURES = {
     "ce_cache_set_protect_depth": (c_int, [c_void_p, c_int32]),
     "ce_cache_set_transport": (c_int, [c_void_p, c_int32]),
     "ce_cache_set_buffer_rows": (c_int, [c_void_p, c_int64]),
+    "ce_cache_set_profiling": (c_int, [c_void_p, c_int32]),
+    "ce_cache_phase_count": (c_int32, []),
+    "ce_cache_phase_name": (c_char_p, [c_int32]),
+    "ce_cache_phase_times": (c_int, [c_void_p, POINTER(c_double), c_int32, POINTER(c_int64), c_int32]),
+    "ce_cache_writeback_wait": (c_int, [c_void_p]),
+    "ce_cache_writeback_stats": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double),
+                                         POINTER(c_int64), POINTER(c_int64)]),
+    "ce_cache_failures": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64)]),
     "ce_cache_free_rows": (c_int, [c_void_p, POINTER(c_int64)]),
     "ce_dedupe_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p]),

@@ -28,21 +28,33 @@ class EvictionStrategy(Enum):
     DATASET = 2
 
 
+class _PinnedBlock:
+    """Owner of one ce_host_alloc block; freed when the last tensor over it is gone."""
+
+    def __init__(self, host_ptr: int):
+        self._fin = weakref.finalize(self, _PinnedBlock._free, host_ptr)
+
+    @staticmethod
+    def _free(host_ptr: int):
+        try:
+            lib.ce_host_free(ctypes.c_void_p(host_ptr))
+        except Exception:
+            pass
+
+
 class HostTable:
     """[N, D] fp32 table in pinned, device-mapped host DRAM (CachedParamMgr.weight, A.1)."""
 
-    def __init__(self, tensor: torch.Tensor, host_ptr: int, dev_ptr: int, owned: bool, registered: bool):
+    def __init__(self, tensor: torch.Tensor, host_ptr: int, dev_ptr: int, registered: bool):
         self.tensor = tensor
         self.host_ptr = host_ptr
         self.dev_ptr = dev_ptr
-        self._fin = weakref.finalize(self, HostTable._release, host_ptr, owned, registered)
+        self._fin = weakref.finalize(self, HostTable._release, host_ptr, registered)
 
     @staticmethod
-    def _release(host_ptr: int, owned: bool, registered: bool):
+    def _release(host_ptr: int, registered: bool):
         try:
-            if owned:
-                lib.ce_host_free(ctypes.c_void_p(host_ptr))
-            elif registered:
+            if registered:
                 lib.ce_host_unregister(ctypes.c_void_p(host_ptr))
         except Exception:
             pass
@@ -53,9 +65,12 @@ class HostTable:
         nbytes = num_embeddings * dim * 4
         hp, dp = ctypes.c_void_p(), ctypes.c_void_p()
         check(lib.ce_host_alloc(nbytes, threads or _default_threads(), ctypes.byref(hp), ctypes.byref(dp)))
-        arr = np.ctypeslib.as_array((ctypes.c_float * (num_embeddings * dim)).from_address(hp.value))
-        t = torch.from_numpy(arr).view(num_embeddings, dim)
-        return cls(t, hp.value, dp.value, owned=True, registered=False)
+        carr = (ctypes.c_float * (num_embeddings * dim)).from_address(hp.value)
+        # the pinned block lives exactly as long as the tensors over it: tensor -> numpy array -> ctypes array ->
+        # block owner (a `.weight` view that outlives the module keeps the memory instead of dangling)
+        carr._ce_block = _PinnedBlock(hp.value)
+        t = torch.from_numpy(np.ctypeslib.as_array(carr)).view(num_embeddings, dim)
+        return cls(t, hp.value, dp.value, registered=False)
 
     @classmethod
     def wrap(cls, weight: torch.Tensor) -> "HostTable":
@@ -64,7 +79,7 @@ class HostTable:
         assert weight.device.type == "cpu" and weight.dtype == torch.float32 and weight.is_contiguous()
         dp = ctypes.c_void_p()
         check(lib.ce_host_register(ctypes.c_void_p(weight.data_ptr()), weight.numel() * 4, ctypes.byref(dp)))
-        return cls(weight, weight.data_ptr(), dp.value, owned=False, registered=True)
+        return cls(weight, weight.data_ptr(), dp.value, registered=True)
 
     def fill_uniform_(self, lo: float, hi: float, seed: int, threads: int = 0):
         check(lib.ce_host_fill_uniform(ctypes.c_void_p(self.host_ptr), self.tensor.numel(), lo, hi, seed,
@@ -94,8 +109,8 @@ class CachedParamMgr(torch.nn.Module):
         if cuda_row_num == 0:
             raise NotImplementedError("cuda_row_num == 0 (no cache) is not implemented")
         self._table = weight if isinstance(weight, HostTable) else HostTable.wrap(weight)
-        self.weight = self._table.tensor
-        self.num_embeddings, self.embedding_dim = self.weight.shape
+        self._weight = self._table.tensor
+        self.num_embeddings, self.embedding_dim = self._weight.shape
         self.cuda_row_num = int(cuda_row_num)
         self.buffer_size = buffer_size
         self.pin_weight = pin_weight
@@ -123,6 +138,7 @@ class CachedParamMgr(torch.nn.Module):
         self._workspace = None
         self._create_handle()
         self._hist_seen = 0
+        self._failures_seen = 0
         self.num_hits_history: List[int] = []
         self.num_miss_history: List[int] = []
         self.num_write_back_history: List[int] = []
@@ -139,7 +155,8 @@ class CachedParamMgr(torch.nn.Module):
         cfg.cuda_row_num = C
         cfg.embedding_dim = self.embedding_dim
         cfg.evict_strategy = _lib.CE_EVICT_LFU if self._evict_strategy == EvictionStrategy.LFU else _lib.CE_EVICT_DATASET
-        cfg.transport = _lib.CE_TRANSPORT_STAGED if self._async_copy else _lib.CE_TRANSPORT_ZEROCOPY
+        cfg.transport = getattr(self, "_transport", None) or (
+            _lib.CE_TRANSPORT_STAGED if self._async_copy else _lib.CE_TRANSPORT_ZEROCOPY)
         cfg.protect_depth = 0
         cfg.max_ids_per_call = self._max_ids
         cfg.host_weight = self._table.host_ptr
@@ -158,6 +175,14 @@ class CachedParamMgr(torch.nn.Module):
         self._fin = weakref.finalize(self, lib.ce_cache_destroy, h)
         if self.buffer_size and self.buffer_size > 0:
             check(lib.ce_cache_set_buffer_rows(h, int(self.buffer_size)))
+
+    @property
+    def weight(self) -> torch.Tensor:
+        """The host table (upstream `CachedParamMgr.weight`).  With the worker transport evicted rows reach it
+        asynchronously: reading it first waits for the write-backs queued so far (no-op otherwise)."""
+        if self._handle is not None:
+            check(lib.ce_cache_writeback_wait(self._handle))
+        return self._weight
 
     @property
     def idx_map(self) -> torch.Tensor:
@@ -209,6 +234,7 @@ class CachedParamMgr(torch.nn.Module):
         lib.ce_cache_destroy(self._handle)
         self._create_handle()
         self._hist_seen = 0
+        self._failures_seen = 0
 
     # ------------------------------------------------------------------ A.3
     @torch.no_grad()
@@ -232,6 +258,8 @@ class CachedParamMgr(torch.nn.Module):
             st = CeCallStats()
             rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))
             self._pull_history()
+            if rc != _lib.CE_OK:
+                self._failures_seen += 1
             if rc == _lib.CE_ERR_CAPACITY:
                 raise AssertionError(_lib.last_error())
             if rc == _lib.CE_ERR_RANGE:
@@ -294,6 +322,12 @@ class CachedParamMgr(torch.nn.Module):
         msg = (f"CUDA->CPU {t['cuda_to_cpu_numel'] * esz / 1e6:.2f} MB, CPU->CUDA "
                f"{t['cpu_to_cuda_numel'] * esz / 1e6:.2f} MB, cache miss {t['cache_miss']} / {t['total_cache']} "
                f"lookups ({100.0 * t['cache_miss'] / max(1, t['total_cache']):.2f} %)")
+        wb = self.writeback_stats()
+        if wb["jobs"]:
+            moved = wb["rows"] * self.embedding_dim * esz
+            msg += (f"; write-back worker: {wb['jobs']} jobs, {moved / 1e6:.2f} MB, copy "
+                    f"{moved / max(wb['copy_s'], 1e-9) / 1e9:.1f} GB/s, scatter "
+                    f"{moved / max(wb['scatter_s'], 1e-9) / 1e9:.1f} GB/s")
         print(msg)
         return msg
 
@@ -302,8 +336,61 @@ class CachedParamMgr(torch.nn.Module):
 
     def set_async_copy(self, flag: bool):
         self._async_copy = bool(flag)
-        check(lib.ce_cache_set_transport(self._handle,
-                                         _lib.CE_TRANSPORT_STAGED if flag else _lib.CE_TRANSPORT_ZEROCOPY))
+        self.set_transport("staged" if flag else "zerocopy")
+
+    _TRANSPORTS = {"zerocopy": _lib.CE_TRANSPORT_ZEROCOPY, "staged": _lib.CE_TRANSPORT_STAGED,
+                   "worker": _lib.CE_TRANSPORT_WORKER}
+
+    def set_transport(self, name: str):
+        """'zerocopy' (swap kernels address the mapped host table), 'staged' (upstream async_copy: pinned staging +
+        hipMemcpyAsync + host gather/scatter on the calling thread) or 'worker' (admissions zero-copy, evictions
+        through one SDMA copy + a worker thread inside the library; the host table lags until writeback_wait /
+        flush / a read of `.weight`)."""
+        self._transport = self._TRANSPORTS[name]
+        with torch.cuda.device(self.device):
+            check(lib.ce_cache_set_transport(self._handle, self._transport))
+
+    def set_profiling(self, on: bool = True):
+        """hipEvent timers around the phases of prepare_ids (read them with phase_times())."""
+        check(lib.ce_cache_set_profiling(self._handle, int(bool(on))))
+
+    def phase_times(self, reset: bool = False) -> dict:
+        """{phase name: accumulated ms} over the finished calls since profiling was switched on, plus 'calls'.
+        Blocks until the calls issued so far have finished."""
+        n = lib.ce_cache_phase_count()
+        buf = (ctypes.c_double * n)()
+        calls = ctypes.c_int64()
+        check(lib.ce_cache_phase_times(self._handle, buf, n, ctypes.byref(calls), int(reset)))
+        out = {lib.ce_cache_phase_name(i).decode(): buf[i] for i in range(n)}
+        out["calls"] = calls.value
+        return out
+
+    def writeback_wait(self):
+        check(lib.ce_cache_writeback_wait(self._handle))
+
+    def writeback_stats(self) -> dict:
+        a, b, c = (ctypes.c_double() for _ in range(3))
+        r, j = ctypes.c_int64(), ctypes.c_int64()
+        check(lib.ce_cache_writeback_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
+                                           ctypes.byref(r), ctypes.byref(j)))
+        return dict(wait_s=a.value, copy_s=b.value, scatter_s=c.value, rows=r.value, jobs=j.value)
+
+    def raise_on_failed_calls(self):
+        """Non-blocking check used by the pipelines that run prepare_ids with strict=False: raises the reference's
+        AssertionError (capacity) / IndexError (bad id) if any call that has FINISHED so far failed -- such a call
+        returned slots of -1 and the bag kernels skipped those lookups."""
+        n, st, sq = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+        check(lib.ce_cache_failures(self._handle, ctypes.byref(n), ctypes.byref(st), ctypes.byref(sq)))
+        if n.value > self._failures_seen:
+            self._failures_seen = n.value
+            if st.value == _lib.CE_ERR_CAPACITY:
+                raise AssertionError(
+                    f"cache op #{sq.value} needed more unique rows than the {self.cuda_row_num} rows available on "
+                    "CUDA (with an overlapped window: unique(window k U window k+1)). Please increase cuda_row_num "
+                    "or decrease the training batch size.")
+            if st.value == _lib.CE_ERR_RANGE:
+                raise IndexError(f"cache op #{sq.value}: an id is outside [0, {self.num_embeddings})")
+            raise _lib.CeError(st.value, f"cache op #{sq.value} failed")
 
     def cuda_weight_data(self, slot: int) -> torch.Tensor:
         return self.cuda_cached_weight.data[slot]

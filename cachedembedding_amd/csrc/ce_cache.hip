@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -43,6 +44,7 @@ constexpr int kChunkRows = 32768;     // rows covered by one 256-thread block of
 constexpr int kSlotsPerBlock = 1024;  // slots covered by one block of the slot-space scans (4/thread)
 constexpr int kRing = 1024;           // pinned host ring of per-call stats
 constexpr int32_t kEpochNever = -(1 << 30);
+constexpr int64_t kHistoryKeep = 1 << 16;   // per-call records kept on the host side
 
 struct Ctl {                 // device control block (one per manager)
   long long n_free;          // persistent: free slots
@@ -52,14 +54,15 @@ struct Ctl {                 // device control block (one per manager)
   long long miss_lookups;
   unsigned long long sel_prefix;   // radix-select state
   long long sel_krem;
+  long long n_eligible;      // slots that may be evicted in this call (resident and not protected)
   int victims_count;
   int status;
 };
 
 struct Layout {              // byte offsets inside the caller-provided workspace
   size_t ctl, bitmap, blk_unique, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      stage_idx, stage, total;
-  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
+      stage_idx, stage, stage_idx2, stage2, pend_hash[2], total;
+  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows, hash_entries;
 };
 
 constexpr int64_t kStageRowsMax = 262144;   // write-back staging: 128 MB at D = 128
@@ -86,6 +89,15 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
   L.stage_idx = o;  o = al(o + (size_t)L.stage_rows * 4);
   L.stage = o;      o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
+  // worker write-back (CE_TRANSPORT_WORKER): the staging is double-buffered -- the victims of call w stay in HBM
+  // until the host worker has copied them out, while call w+1 stages into the other buffer -- and every staged
+  // row is findable by row id (open-addressing table, row << 32 | position) so that a row re-admitted before its
+  // write-back reached the host table is taken from the staging buffer instead of the (stale) host row
+  L.stage_idx2 = o; o = al(o + (size_t)L.stage_rows * 4);
+  L.stage2 = o;     o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
+  L.hash_entries = 64;
+  while (L.hash_entries < 2 * L.stage_rows) L.hash_entries <<= 1;
+  for (int b = 0; b < 2; ++b) { L.pend_hash[b] = o; o = al(o + (size_t)L.hash_entries * 8); }
   L.total = o;
   return L;
 }
@@ -134,6 +146,7 @@ __global__ void k_begin(Ctl* ctl) {
   ctl->miss_lookups = 0;
   ctl->sel_prefix = 0;
   ctl->sel_krem = 0;
+  ctl->n_eligible = 0;
   ctl->victims_count = 0;
   ctl->status = CE_OK;
 }
@@ -292,7 +305,7 @@ __device__ void scan_inplace_1024(int32_t* a, int64_t n, long long* total_out) {
 }
 
 __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk_miss, int64_t n_chunks,
-                                               int64_t C, int64_t n_ids, long long seq, Ctl* ctl,
+                                               int64_t C, int64_t n_ids, Ctl* ctl,
                                                ce_call_stats_t* ring_slot) {
   long long tu, tm;
   scan_inplace_1024(blk_unique, n_chunks, &tu);
@@ -319,8 +332,8 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
     ring_slot->n_free_after = ctl->n_free;
     ring_slot->status = status;
     ring_slot->kind = CE_CALL_PREPARE;
-    __threadfence_system();
-    ring_slot->seq = seq;   // written last: a slot whose seq matches is complete
+    // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
+    // record (k_pick can turn it into a capacity failure): k_admit_maps
   }
 }
 
@@ -378,11 +391,12 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
                                               const int64_t* __restrict__ freq,
                                               const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
                                               int32_t epoch, int32_t depth, int slot_bits, int lfu,
-                                              unsigned long long* keys, uint32_t* hist, const Ctl* ctl) {
+                                              unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
   if (ctl->k_evict == 0) return;
   if (blockIdx.x == 0) hist[threadIdx.x] = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const unsigned long long fmax = (1ull << (63 - slot_bits)) - 1;
+  int elig = 0;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
     const int32_t row = cached_idx_map[s];
     const bool prot = (epoch - slot_epoch[s]) <= depth;
@@ -396,9 +410,14 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
       } else {
         key = (unsigned long long)(N - 1 - row);
       }
+      ++elig;
     }
     keys[s] = key;
   }
+  // evictable slots are counted here, not read off the top-digit histogram: a DATASET key N-1-row can share its
+  // top byte (0xff when N-1 has it, e.g. N = 256, 65536, 2^24) with the all-ones key of an ineligible slot
+  elig = wave_sum(elig);
+  if ((threadIdx.x & 63) == 0 && elig) atomicAdd((unsigned long long*)&ctl->n_eligible, (unsigned long long)elig);
 }
 
 // Few, fat workgroups: every workgroup ends with one device atomic per non-empty bin and same-address atomics
@@ -444,12 +463,9 @@ __global__ __launch_bounds__(256) void k_pick(uint32_t* hist, int pass, int top_
   if (threadIdx.x == 0) {
     long long krem = ctl->sel_krem;
     if (pass == top_pass) {
-      // bin 255 of the top byte holds exactly the ineligible (empty / protected) slots: eligible keys are
-      // < 2^63 (LFU) or < N < 2^31 (DATASET, whose top_pass is the highest byte N-1 can reach).  With
-      // protect_depth > 0 the protected set can leave fewer than k candidates: that is the
+      // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the
       // capacity overflow of the overlapped pipeline (unique(window k u k+1) > cuda_row_num).
-      long long eligible = 0;
-      for (int d = 0; d < 255; ++d) eligible += sh[d];
+      const long long eligible = ctl->n_eligible;      // counted by k_keys
       if (eligible < krem) {
         ctl->n_free = ctl->n_free - ctl->k_evict + ctl->n_miss;
         ctl->k_evict = 0;
@@ -537,19 +553,41 @@ __global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ vict
 // host table from the staging buffer while its other workgroups read the missed rows -- PCIe carries both
 // directions at once.  Victims beyond the staging capacity (rare) are
 // written back directly by k_evict (`first` = staging capacity).
+// pending-row table of the worker write-back: open addressing, entry = row << 32 | staging position, empty = ~0
+__device__ __forceinline__ uint32_t pend_slot(uint32_t row, uint32_t mask) { return (row * 2654435761u) & mask; }
+
+struct WbMail {              // pinned host mailbox, one per staging buffer: what the worker copies out
+  long long job;
+  long long count;
+};
+
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
                                                      const int32_t* __restrict__ cached_idx_map,
                                                      const VT* __restrict__ cache, VT* stage, int32_t* stage_rows_idx,
-                                                     long long cap, int rowlen, int g_log2, const Ctl* ctl) {
+                                                     long long cap, int rowlen, int g_log2, const Ctl* ctl,
+                                                     unsigned long long* pend_hash, uint32_t pend_mask, WbMail* mail,
+                                                     long long job) {
   long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
   if (k > cap) k = cap;
+  if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // read by the worker after this kernel's event
+    mail->count = k;
+    mail->job = job;
+  }
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < k; i += gstride) {
     const int32_t slot = victims[i];
-    if (gl == 0) stage_rows_idx[i] = cached_idx_map[slot];
+    if (gl == 0) {
+      const int32_t row = cached_idx_map[slot];
+      stage_rows_idx[i] = row;
+      if (pend_hash) {
+        const unsigned long long e = ((unsigned long long)(uint32_t)row << 32) | (unsigned long long)i;
+        uint32_t hs = pend_slot((uint32_t)row, pend_mask);
+        while (atomicCAS(&pend_hash[hs], ~0ull, e) != ~0ull) hs = (hs + 1) & pend_mask;   // table is < half full
+      }
+    }
     copy_row(cache + (int64_t)slot * rowlen, stage + i * rowlen, rowlen, gl, G);
   }
 }
@@ -646,11 +684,31 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
   }
 }
 
-// rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i)
+// rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i).  pend_hash != nullptr (worker
+// write-back): a missed row that the PREVIOUS call evicted may not have reached the host table yet -- it is
+// then read from that call's HBM staging buffer, where the table above finds it.
+template <typename VT>
+__device__ __forceinline__ const VT* admit_src(int64_t row, const VT* __restrict__ host, int rowlen,
+                                               const unsigned long long* __restrict__ pend_hash, uint32_t pend_mask,
+                                               const VT* __restrict__ pend_stage) {
+  if (pend_hash) {
+    uint32_t hs = pend_slot((uint32_t)row, pend_mask);
+    for (;;) {
+      const unsigned long long e = pend_hash[hs];
+      if (e == ~0ull) break;
+      if ((uint32_t)(e >> 32) == (uint32_t)row) return pend_stage + (int64_t)(uint32_t)e * rowlen;
+      hs = (hs + 1) & pend_mask;
+    }
+  }
+  return host + row * rowlen;
+}
+
 template <typename VT, int R>
 __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                            const long long* n_ptr, long long n_imm, const VT* __restrict__ host,
-                                           VT* cache, int rowlen, int g_log2, const Ctl* ctl, int block, int nblocks) {
+                                           VT* cache, int rowlen, int g_log2, const Ctl* ctl, int block, int nblocks,
+                                           const unsigned long long* __restrict__ pend_hash = nullptr,
+                                           uint32_t pend_mask = 0, const VT* __restrict__ pend_stage = nullptr) {
   if (ctl && ctl->status != CE_OK) return;
   const long long n = n_ptr ? *n_ptr : n_imm;
   const int G = 1 << g_log2;
@@ -660,15 +718,20 @@ __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, con
     if (rowlen <= G) {          // R host rows in flight per lane group (see k_evict)
       VT v[R];
       int64_t dst[R];
+      const VT* src[R];
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         dst[t] = -1;
+        src[t] = host;
         if (i + t < n) {
           const int64_t row = rows ? rows[i + t] : i + t;
           dst[t] = slots ? slots[i + t] : i + t;
-          if (gl < rowlen) v[t] = host[row * rowlen + gl];
+          src[t] = admit_src<VT>(row, host, rowlen, pend_hash, pend_mask, pend_stage);
         }
       }
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if (dst[t] >= 0 && gl < rowlen) v[t] = src[t][gl];
 #pragma unroll
       for (int t = 0; t < R; ++t)
         if (dst[t] >= 0 && gl < rowlen) cache[dst[t] * rowlen + gl] = v[t];
@@ -676,7 +739,8 @@ __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, con
       for (int t = 0; t < R && i + t < n; ++t) {
         const int64_t row = rows ? rows[i + t] : i + t;
         const int64_t slot = slots ? slots[i + t] : i + t;
-        copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
+        copy_row(admit_src<VT>(row, host, rowlen, pend_hash, pend_mask, pend_stage), cache + slot * rowlen, rowlen,
+                 gl, G);
       }
     }
   }
@@ -700,19 +764,26 @@ __global__ __launch_bounds__(1024) void k_swap(const int32_t* __restrict__ stage
                                               const VT* __restrict__ stage, long long cap, int wb_blocks,
                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                               const long long* n_ptr, VT* host, VT* cache, int rowlen, int g_log2,
-                                              const Ctl* ctl) {
+                                              const Ctl* ctl, const unsigned long long* pend_hash,
+                                              uint32_t pend_mask, const VT* pend_stage) {
   if ((int)blockIdx.x < wb_blocks)
     writeback_rows<VT, R>(stage_rows_idx, stage, host, cap, rowlen, g_log2, ctl, (int)blockIdx.x, wb_blocks);
   else
     admit_rows<VT, R>(rows, slots, n_ptr, 0ll, (const VT*)host, cache, rowlen, g_log2, ctl,
-                      (int)blockIdx.x - wb_blocks, (int)gridDim.x - wb_blocks);
+                      (int)blockIdx.x - wb_blocks, (int)gridDim.x - wb_blocks, pend_hash, pend_mask, pend_stage);
 }
 
 __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ rows,
                                                     const int32_t* __restrict__ slots, const long long* n_ptr,
                                                     long long n_imm, int32_t* cached_idx_map, int32_t* inverted,
                                                     int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
-                                                    int32_t epoch, const Ctl* ctl) {
+                                                    int32_t epoch, const Ctl* ctl, ce_call_stats_t* ring_slot,
+                                                    long long seq) {
+  // last kernel of prepare_ids that can change the call's record: publish it (a slot whose seq matches is complete)
+  if (ring_slot && blockIdx.x == 0 && threadIdx.x == 0) {
+    __threadfence_system();
+    *(volatile long long*)&ring_slot->seq = seq;
+  }
   if (ctl && ctl->status != CE_OK) return;
   const long long n = n_ptr ? *n_ptr : n_imm;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -894,9 +965,6 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const int32_t* __restrict__
     copy_row(staging + i * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
 }
 
-// host-side row gather/scatter for the staged transport: `threads` workers over contiguous ranges
-static void parallel_rows(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn);
-
 }  // namespace ce
 
 // ----------------------------------------------------------------------------- handle
@@ -973,11 +1041,168 @@ class RowPool {
   bool stop_ = false;
 };
 
-static void parallel_rows(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
-  if (n <= 0) return;
-  static RowPool pool(std::max(1, std::min(threads, 32)));
-  pool.parallel(n, fn);
-}
+// Per-phase timers of prepare_ids (the reference brackets the same phases with its Timer / record_function
+// ranges: recsys/dlrm_main.py:258, upstream CachedParamMgr._elapsed_dict printed by print_comm_stats :294).
+// hipEvents on the call's own stream, read back lazily: no host sync is added to the call.
+constexpr int kPhases = 6;
+constexpr int kProfDepth = 8;
+static const char* const kPhaseNames[kPhases] = {"unique_and_miss", "find_evict_ids", "evict_stage",
+                                                  "free_slots", "admit_swap", "ids_to_slots"};
+struct PhaseProf {
+  hipEvent_t ev[kProfDepth][kPhases + 1];
+  bool pending[kProfDepth];
+  double ms[kPhases];
+  long long calls;
+  PhaseProf() : calls(0) {
+    for (int i = 0; i < kProfDepth; ++i) {
+      pending[i] = false;
+      for (int j = 0; j <= kPhases; ++j) (void)hipEventCreate(&ev[i][j]);
+    }
+    for (int j = 0; j < kPhases; ++j) ms[j] = 0;
+  }
+  ~PhaseProf() {
+    for (int i = 0; i < kProfDepth; ++i)
+      for (int j = 0; j <= kPhases; ++j) (void)hipEventDestroy(ev[i][j]);
+  }
+  void collect(int i) {              // blocks until call slot i has finished
+    if (!pending[i]) return;
+    if (hipEventSynchronize(ev[i][kPhases]) == hipSuccess) {
+      for (int j = 0; j < kPhases; ++j) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, ev[i][j], ev[i][j + 1]) == hipSuccess) ms[j] += t;
+      }
+      calls += 1;
+    }
+    pending[i] = false;
+  }
+};
+
+// Worker write-back (CE_TRANSPORT_WORKER).  The cache op leaves the victims of call w packed in an HBM staging
+// buffer (k_evict_stage) and returns; this object's thread waits for that kernel's event ON ITS OWN THREAD, copies
+// the block out with ONE pinned hipMemcpyAsync on a private stream (SDMA: no CU, no posted PCIe writes issued by
+// waves that share the memory pipeline with training) and scatters the rows into the host table with a few helper
+// threads.  Two staging buffers alternate; the launch thread only waits when the worker is two calls behind.
+struct Writeback {
+  int device = 0;
+  int64_t D = 0, stage_rows = 0;
+  float* table = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  const float* stage_dev[2] = {nullptr, nullptr};
+  const int32_t* idx_dev[2] = {nullptr, nullptr};
+  float* rows_host[2] = {nullptr, nullptr};      // pinned
+  int32_t* idx_host[2] = {nullptr, nullptr};     // pinned
+  WbMail* mail = nullptr;                        // pinned + mapped, [2]
+  WbMail* mail_dev = nullptr;
+  std::thread worker;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  long long issued = 0, done = 0;                // jobs pushed / finished
+  bool stop = false;
+  int err = 0;
+  char errmsg[256] = {0};
+  RowPool* pool = nullptr;
+  // statistics (what upstream's swap_out_bandwidth reports)
+  double copy_s = 0, scatter_s = 0, wait_s = 0;
+  long long rows = 0, jobs = 0;
+
+  void fail(const char* what, hipError_t e) {
+    std::lock_guard<std::mutex> g(m);
+    if (!err) {
+      err = CE_ERR_HIP;
+      snprintf(errmsg, sizeof errmsg, "write-back worker: %s failed: %s", what, hipGetErrorString(e));
+    }
+  }
+
+  void run() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      long long job;
+      {
+        std::unique_lock<std::mutex> g(m);
+        cv_job.wait(g, [&] { return stop || done < issued; });
+        if (done >= issued) return;      // stop requested and nothing left
+        job = done + 1;
+      }
+      const int b = (int)(job & 1);
+      const auto t0 = std::chrono::steady_clock::now();
+      hipError_t e = hipEventSynchronize(ev[b]);
+      if (e != hipSuccess) fail("hipEventSynchronize", e);
+      const auto t1 = std::chrono::steady_clock::now();
+      long long k = mail[b].count;
+      if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record copies nothing
+      double cs = 0, ss = 0;
+      if (k > 0 && !err) {
+        e = hipMemcpyAsync(idx_host[b], idx_dev[b], (size_t)k * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(rows_host[b], stage_dev[b], (size_t)k * D * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        const auto t2 = std::chrono::steady_clock::now();
+        cs = std::chrono::duration<double>(t2 - t1).count();
+        if (e != hipSuccess) {
+          fail("hipMemcpyAsync(D2H)", e);
+        } else {
+          float* tb = table;
+          const float* st = rows_host[b];
+          const int32_t* ri = idx_host[b];
+          const int64_t d = D;
+          pool->parallel(k, [=](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) memcpy(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d * 4);
+          });
+          ss = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+        }
+      }
+      {
+        std::lock_guard<std::mutex> g(m);
+        done = job;
+        wait_s += std::chrono::duration<double>(t1 - t0).count();
+        copy_s += cs;
+        scatter_s += ss;
+        rows += k;
+        jobs += 1;
+      }
+      cv_done.notify_all();
+    }
+  }
+
+  // blocks until job `upto` has reached the host table
+  int wait(long long upto) {
+    std::unique_lock<std::mutex> g(m);
+    cv_done.wait(g, [&] { return done >= upto || done >= issued; });
+    if (err) {
+      set_error("%s", errmsg);
+      return err;
+    }
+    return CE_OK;
+  }
+
+  void push() {
+    {
+      std::lock_guard<std::mutex> g(m);
+      ++issued;
+    }
+    cv_job.notify_one();
+  }
+
+  ~Writeback() {
+    if (worker.joinable()) {
+      {
+        std::lock_guard<std::mutex> g(m);
+        stop = true;
+      }
+      cv_job.notify_all();
+      worker.join();
+    }
+    delete pool;
+    for (int b = 0; b < 2; ++b) {
+      if (ev[b]) (void)hipEventDestroy(ev[b]);
+      if (rows_host[b]) (void)hipHostFree(rows_host[b]);
+      if (idx_host[b]) (void)hipHostFree(idx_host[b]);
+    }
+    if (mail) (void)hipHostFree(mail);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
 
 }  // namespace ce
 
@@ -1010,16 +1235,38 @@ struct ce_cache {
   int64_t stage_rows;
   int64_t list_rows;           // capacity of list_host
   int64_t buffer_rows;         // > 0: staged transfers go through at most this many staging rows at a time
+  ce::RowPool* pool;           // host threads of the staged transport (created on first use)
+  ce::Writeback* wb;           // CE_TRANSPORT_WORKER state (created on first use)
+  float* stage2;               // second device staging buffer + row list + the two pending-row tables (workspace)
+  int32_t* stage_idx2;
+  unsigned long long* pend_hash[2];
+  long long hist_base;         // seq of history[0]
+  ce::PhaseProf* prof;         // optional per-phase hipEvent timers (ce_cache_set_profiling)
+  long long n_failed;          // finished prepare_ids calls whose status was not CE_OK
+  int last_fail_status;
+  long long last_fail_seq;
 };
 
 using namespace ce;
+
+static int ensure_writeback(ce_cache* h);
 
 static void drain(ce_cache* h) {
   while (h->drained < h->seq) {
     const long long s = h->drained + 1;
     const ce_call_stats_t& r = h->ring[s % kRing];
     if (r.seq != s) break;
+    if (h->history.empty()) h->hist_base = s;
     h->history.push_back(r);
+    if (h->history.size() > (size_t)2 * kHistoryKeep) {      // bounded: keep the most recent records
+      h->history.erase(h->history.begin(), h->history.end() - kHistoryKeep);
+      h->hist_base = h->history.front().seq;
+    }
+    if (r.status != CE_OK) {
+      h->n_failed += 1;
+      h->last_fail_status = r.status;
+      h->last_fail_seq = s;
+    }
     if (r.status == CE_OK && r.kind != CE_CALL_PRELOAD) {   // warm-up preload is not counted upstream either
       h->cpu_to_cuda_numel += r.n_miss * h->cfg.embedding_dim;
       h->cuda_to_cpu_numel += r.n_evict * h->cfg.embedding_dim;
@@ -1103,6 +1350,16 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->stage_rows = 0;
   h->list_rows = 0;
   h->buffer_rows = 0;
+  h->pool = nullptr;
+  h->wb = nullptr;
+  h->hist_base = 1;
+  h->prof = nullptr;
+  h->n_failed = 0;
+  h->last_fail_status = CE_OK;
+  h->last_fail_seq = 0;
+  h->stage2 = (float*)(h->ws + L.stage2);
+  h->stage_idx2 = (int32_t*)(h->ws + L.stage_idx2);
+  for (int b = 0; b < 2; ++b) h->pend_hash[b] = (unsigned long long*)(h->ws + L.pend_hash[b]);
 
   hipStream_t s = (hipStream_t)stream;
   void* ring_host = nullptr;
@@ -1127,6 +1384,7 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   // empty-cache state of A.1
   const int64_t N = cfg->num_embeddings, C = cfg->cuda_row_num;
   (void)hipMemsetAsync(h->ws, 0, L.stage_idx, s);
+  for (int b = 0; b < 2; ++b) (void)hipMemsetAsync(h->pend_hash[b], 0xff, (size_t)L.hash_entries * 8, s);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(N, 256)), dim3(256), 0, s, cfg->inverted_cached_idx, N, -1);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, cfg->cached_idx_map, C, -1);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, h->slot_epoch, C, kEpochNever);
@@ -1145,6 +1403,15 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
     return CE_ERR_HIP;
   }
   (void)hipEventRecord(h->ev, s);
+  if (cfg->transport == CE_TRANSPORT_WORKER) {
+    int rc = ensure_writeback(h);
+    if (rc) {
+      (void)hipEventDestroy(h->ev);
+      (void)hipHostFree(ring_host);
+      delete h;
+      return rc;
+    }
+  }
   *out = h;
   return CE_OK;
 }
@@ -1152,6 +1419,9 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
 extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
   (void)hipEventSynchronize(h->ev);
+  delete h->wb;          // finishes the queued write-backs, joins the worker
+  delete h->pool;
+  delete h->prof;
   (void)hipEventDestroy(h->ev);
   (void)hipHostFree(h->ring);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
@@ -1190,6 +1460,55 @@ static int ensure_staging(ce_cache* h, int64_t rows, int64_t list_rows) {
   return CE_OK;
 }
 
+static RowPool* host_pool(ce_cache* h) {
+  if (!h->pool) h->pool = new RowPool(std::max(1, std::min(h->host_threads, 32)));
+  return h->pool;
+}
+
+// CE_TRANSPORT_WORKER state: pinned landing buffers for both staging buffers, the copy stream, the worker thread
+static int ensure_writeback(ce_cache* h) {
+  if (h->wb) return CE_OK;
+  const Layout& L = h->L;
+  Writeback* w = new Writeback();
+  int rc = CE_OK;
+  do {
+    if (hipGetDevice(&w->device) != hipSuccess) { rc = CE_ERR_HIP; break; }
+    w->D = h->cfg.embedding_dim;
+    w->stage_rows = L.stage_rows;
+    w->table = h->cfg.host_weight;
+    w->stage_dev[0] = h->stage;
+    w->stage_dev[1] = h->stage2;
+    w->idx_dev[0] = h->stage_idx;
+    w->idx_dev[1] = h->stage_idx2;
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { rc = CE_ERR_HIP; break; }
+    void* mail = nullptr;
+    if (hipHostMalloc(&mail, sizeof(WbMail) * 2, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_HIP; break; }
+    memset(mail, 0, sizeof(WbMail) * 2);
+    w->mail = (WbMail*)mail;
+    void* md = nullptr;
+    if (hipHostGetDevicePointer(&md, mail, 0) != hipSuccess) md = mail;
+    w->mail_dev = (WbMail*)md;
+    for (int b = 0; b < 2 && rc == CE_OK; ++b) {
+      if (hipEventCreateWithFlags(&w->ev[b], hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
+      else if (hipHostMalloc((void**)&w->rows_host[b], (size_t)L.stage_rows * w->D * 4, hipHostMallocDefault) !=
+               hipSuccess) rc = CE_ERR_NOMEM;
+      else if (hipHostMalloc((void**)&w->idx_host[b], (size_t)L.stage_rows * 4, hipHostMallocDefault) != hipSuccess)
+        rc = CE_ERR_NOMEM;
+    }
+    if (rc) break;
+    static const int wb_threads = [] { const char* e = getenv("CE_WB_THREADS"); return e ? atoi(e) : 8; }();
+    w->pool = new RowPool(std::max(1, std::min(wb_threads, 64)));
+    w->worker = std::thread([w] { w->run(); });
+  } while (0);
+  if (rc) {
+    delete w;
+    set_error("write-back worker setup failed (pinned landing buffers / stream / events)");
+    return rc;
+  }
+  h->wb = w;
+  return CE_OK;
+}
+
 // rows moved per staged transfer: everything at once, or `buffer_rows` at a time (upstream's buffer_size /
 // LimitBuffIndexCopyer: a bounded staging buffer walked in chunks)
 static int64_t staged_chunk(const ce_cache* h, int64_t rows) {
@@ -1221,7 +1540,8 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
   // preloaded rows must not look "protected" to the first prepare_ids: stamp them as never used
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(n, 256)), dim3(256), 0, s, rows, (const int32_t*)nullptr,
                      (const long long*)nullptr, (long long)n, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, freq_vals, h->slot_epoch, kEpochNever, (const Ctl*)nullptr);
+                     c.freq_cnter, freq_vals, h->slot_epoch, kEpochNever, (const Ctl*)nullptr,
+                     (ce_call_stats_t*)nullptr, 0ll);
   (void)epoch;
   hipLaunchKernelGGL(k_preload_end, dim3(1), dim3(1), 0, s, (long long)n, h->ctl, h->ring_dev + (h->seq % kRing),
                      h->seq);
@@ -1268,7 +1588,7 @@ static int staged_swap(ce_cache* h, hipStream_t s) {
       float* table = c.host_weight;
       const float* st = h->stage_host;
       const int32_t* rows = h->list_host + off;
-      parallel_rows(cnt, h->host_threads, [=](int64_t lo, int64_t hi) {
+      host_pool(h)->parallel(cnt, [=](int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; ++i) memcpy(table + (size_t)rows[i] * D, st + (size_t)i * D, rowbytes);
       });
     }
@@ -1309,6 +1629,12 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   const dim3 swap_block(swap_threads);
   const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, (swap_threads >> h->g_log2) * kSwapRows)));
 
+  PhaseProf* const prof = h->prof;
+  const int pslot = (int)(h->seq % kProfDepth);
+  int pmark = 0;
+  if (prof) prof->collect(pslot);
+#define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
+  CE_PHASE();
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
   {
     // Two shapes (rocprofv3, 3.4 M ids per call).  Rows in frequency order (idx_map present): the hot rows sit in
@@ -1336,10 +1662,10 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n,
-                     (long long)h->seq, h->ctl, slot);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n, h->ctl, slot);
   hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl);
+  CE_PHASE();
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
   hipLaunchKernelGGL(k_keys, dim3(cgrid), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
@@ -1357,25 +1683,50 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, h->hist, pass, top_pass, h->ctl, slot);
   }
   hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl);
-  if (c.transport == CE_TRANSPORT_ZEROCOPY) {
-    // ---- victims -> HBM staging (fast), then the PCIe write-back runs on the aux stream concurrently with
-    // the admissions below; map clear, free-slot list, admit stay on the caller's stream
+  CE_PHASE();
+  const bool worker = c.transport == CE_TRANSPORT_WORKER;
+  // worker write-back: staging buffer / pending table of this call (alternating), and of the previous one
+  int wbuf = 0;
+  if (worker) {
+    rc = ensure_writeback(h);
+    if (rc) return rc;
+    const long long job = h->wb->issued + 1;
+    wbuf = (int)(job & 1);
+    rc = h->wb->wait(job - 2);        // the buffers of job-2 are about to be reused: only blocks a launch thread
+    if (rc) return rc;                //   that runs two cache ops ahead of the worker
+    CE_HIP_CHECK(hipMemsetAsync(h->pend_hash[wbuf], 0xff, (size_t)L.hash_entries * 8, s));
+  }
+  float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
+  int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
+  if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
+    // ---- victims -> HBM staging (fast); rows beyond the staging capacity (rare) are written back directly
+    // by k_evict; map clear, free-slot list, admit stay on the caller's stream
     const long long scap = (long long)L.stage_rows;
     const int sgrid = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    unsigned long long* const ph = worker ? h->pend_hash[wbuf] : nullptr;
+    const uint32_t pmask = (uint32_t)(L.hash_entries - 1);
+    WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
+    const long long job = worker ? h->wb->issued + 1 : 0;
     if (h->vec) {
       hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         (const f32x4*)c.cache_weight, (f32x4*)h->stage, h->stage_idx, scap, h->rowlen, h->g_log2,
-                         h->ctl);
+                         (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
+                         h->ctl, ph, pmask, mail, job);
       hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         (const float*)c.cache_weight, (float*)h->stage, h->stage_idx, scap, h->rowlen, h->g_log2,
-                         h->ctl);
+                         (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
+                         h->ctl, ph, pmask, mail, job);
       hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
+    }
+    if (worker) {
+      // the worker thread takes it from here: D2H of the packed block + scatter into the table, while this
+      // stream goes on with the admissions
+      CE_HIP_CHECK(hipEventRecord(h->wb->ev[wbuf], s));
+      h->wb->push();
     }
     hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
                        c.cached_idx_map, c.inverted_cached_idx, (int32_t*)nullptr, h->ctl);
@@ -1383,26 +1734,35 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     rc = staged_swap(h, s);
     if (rc) return rc;
   }
+  CE_PHASE();
   hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                      h->blk_free, h->ctl);
   hipLaunchKernelGGL(k_free_scan, dim3(1), dim3(1024), 0, s, h->blk_free, L.n_slot_blocks, h->ctl);
   hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                      h->blk_free, h->free_list, h->ctl);
-  if (c.transport == CE_TRANSPORT_ZEROCOPY) {
-    // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy
+  CE_PHASE();
+  if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
+    // zero-copy: write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions
+    // busy.  worker: admission only (the write-back left through the SDMA copy above); a missed row that the
+    // previous call evicted is read from that call's staging buffer (pending-row table).
     const long long scap = (long long)L.stage_rows;
     static const int swap_rows = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : kSwapRows; }();
     // workgroups of the write-back part: as many as admit when the call has the GPU to itself; half as many when it
     // overlaps with training (protect_depth > 0) -- PCIe writes are what slows the kernels next to them, and fewer
     // rows leave than enter (32 + 16 workgroups: 2.11 -> 2.22 G lookups/s; 32 + 8 makes the write-back the bottleneck)
     static const int wb_env = [] { const char* e = getenv("CE_SWAP_WB_BLOCKS"); return e ? atoi(e) : 0; }();
-    const int wb_groups = wb_env > 0 ? std::min(wb_env, cap_groups)
-                                     : (c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups);
+    const int wb_groups = worker ? 0
+                                 : (wb_env > 0 ? std::min(wb_env, cap_groups)
+                                               : (c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups));
+    const unsigned long long* const ph = worker ? h->pend_hash[wbuf ^ 1] : nullptr;
+    const uint32_t pmask = (uint32_t)(L.hash_entries - 1);
+    const float* const pstage = (wbuf ^ 1) ? h->stage2 : h->stage;
 #define CE_SWAP(VT, R)                                                                                          \
   hipLaunchKernelGGL((k_swap<VT, R>), dim3(wb_groups + cap_groups), swap_block, 0, s, h->stage_idx,             \
                      (const VT*)h->stage, scap, wb_groups, h->miss_list, h->free_list,                           \
                      (const long long*)&h->ctl->n_miss,                                                          \
-                     (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl)
+                     (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl, ph,  \
+                     pmask, (const VT*)pstage)
     if (h->vec) {
       if (swap_rows == 2) CE_SWAP(f32x4, 2); else if (swap_rows == 4) CE_SWAP(f32x4, 4);
       else if (swap_rows == 8) CE_SWAP(f32x4, 8); else CE_SWAP(f32x4, 16);
@@ -1426,7 +1786,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
         const int64_t cnt = std::min(chunk, m - off);
         if (off > 0) CE_HIP_CHECK(hipStreamSynchronize(s));      // the staging buffer is reused
         const int32_t* rows = h->list_host + off;
-        parallel_rows(cnt, h->host_threads, [=](int64_t lo, int64_t hi) {
+        host_pool(h)->parallel(cnt, [=](int64_t lo, int64_t hi) {
           for (int64_t i = lo; i < hi; ++i) memcpy(st + (size_t)i * D, table + (size_t)rows[i] * D, rowbytes);
         });
         CE_HIP_CHECK(hipMemcpyAsync(h->stage_dev, h->stage_host, (size_t)cnt * rowbytes, hipMemcpyHostToDevice, s));
@@ -1443,7 +1803,9 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
                      (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl);
+                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl, slot,
+                     (long long)h->seq);
+  CE_PHASE();
   if (n > 0 && lfu) {
     // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
     hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, ids, n, c.idx_map,
@@ -1452,6 +1814,9 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map, c.inverted_cached_idx,
                        N, slots_out, (const Ctl*)h->ctl);
   }
+  CE_PHASE();
+#undef CE_PHASE
+  if (prof) prof->pending[pslot] = true;
   CE_LAUNCH_CHECK();
   CE_HIP_CHECK(hipEventRecord(h->ev, s));
   return CE_OK;
@@ -1488,15 +1853,25 @@ extern "C" int ce_cache_totals(ce_cache_t* h, int64_t* cpu_to_cuda_numel, int64_
   return CE_OK;
 }
 
+extern "C" int ce_cache_failures(ce_cache_t* h, int64_t* n_failed, int32_t* last_status, int64_t* last_seq) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  drain(h);
+  if (n_failed) *n_failed = h->n_failed;
+  if (last_status) *last_status = h->last_fail_status;
+  if (last_seq) *last_seq = h->last_fail_seq;
+  return CE_OK;
+}
+
 extern "C" int64_t ce_cache_history(ce_cache_t* h, int64_t first_seq, ce_call_stats_t* out, int64_t cap) {
   if (!h || !out || cap <= 0) return 0;
   drain(h);
+  if (h->history.empty()) return 0;
+  // records are stored in call order with consecutive seq: index directly (records older than the kept window
+  // are gone)
+  int64_t i = first_seq - h->hist_base;
+  if (i < 0) i = 0;
   int64_t w = 0;
-  for (const auto& r : h->history) {
-    if (r.seq < first_seq) continue;
-    if (w >= cap) break;
-    out[w++] = r;
-  }
+  for (; i < (int64_t)h->history.size() && w < cap; ++i) out[w++] = h->history[(size_t)i];
   return w;
 }
 
@@ -1519,6 +1894,13 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const ce_cache_config_t& c = h->cfg;
   const int64_t C = c.cuda_row_num;
+  if (h->wb) {
+    // queued write-backs land first (a row they carry may be resident again and is about to be written by
+    // k_flush_rows with its newer value), and no staged copy may shadow the host table afterwards
+    rc = h->wb->wait(h->wb->issued);
+    if (rc) return rc;
+    for (int b = 0; b < 2; ++b) CE_HIP_CHECK(hipMemsetAsync(h->pend_hash[b], 0xff, (size_t)h->L.hash_entries * 8, s));
+  }
   h->seq += 1;
   const int gpb = 256 >> h->g_log2;
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
@@ -1550,9 +1932,71 @@ extern "C" int ce_cache_set_buffer_rows(ce_cache_t* h, int64_t rows) {
 }
 
 extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
-  CE_REQUIRE(h && (transport == CE_TRANSPORT_ZEROCOPY || transport == CE_TRANSPORT_STAGED), CE_ERR_INVALID,
-             "bad transport");
+  CE_REQUIRE(h && (transport == CE_TRANSPORT_ZEROCOPY || transport == CE_TRANSPORT_STAGED ||
+                   transport == CE_TRANSPORT_WORKER), CE_ERR_INVALID, "bad transport");
+  if (h->cfg.transport == transport) return CE_OK;
+  if (h->wb) {
+    // leaving (or re-entering) the worker transport: everything queued reaches the table, nothing stays findable
+    // in the staging buffers.  Blocks.
+    int rc = h->wb->wait(h->wb->issued);
+    if (rc) return rc;
+    CE_HIP_CHECK(hipEventSynchronize(h->ev));
+    for (int b = 0; b < 2; ++b) CE_HIP_CHECK(hipMemset(h->pend_hash[b], 0xff, (size_t)h->L.hash_entries * 8));
+  }
   h->cfg.transport = transport;
+  if (transport == CE_TRANSPORT_WORKER) return ensure_writeback(h);
+  return CE_OK;
+}
+
+extern "C" int ce_cache_set_profiling(ce_cache_t* h, int32_t on) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  if (on && !h->prof) h->prof = new PhaseProf();
+  if (!on && h->prof) {
+    for (int i = 0; i < kProfDepth; ++i) h->prof->collect(i);
+    delete h->prof;
+    h->prof = nullptr;
+  }
+  return CE_OK;
+}
+
+extern "C" int32_t ce_cache_phase_count(void) { return kPhases; }
+extern "C" const char* ce_cache_phase_name(int32_t i) { return (i >= 0 && i < kPhases) ? kPhaseNames[i] : ""; }
+
+extern "C" int ce_cache_phase_times(ce_cache_t* h, double* ms_out, int32_t cap, int64_t* calls, int32_t reset) {
+  CE_REQUIRE(h && ms_out && cap >= kPhases, CE_ERR_INVALID, "bad arguments");
+  for (int j = 0; j < kPhases; ++j) ms_out[j] = 0;
+  if (calls) *calls = 0;
+  if (!h->prof) return CE_OK;
+  for (int i = 0; i < kProfDepth; ++i) h->prof->collect(i);
+  for (int j = 0; j < kPhases; ++j) ms_out[j] = h->prof->ms[j];
+  if (calls) *calls = h->prof->calls;
+  if (reset) {
+    for (int j = 0; j < kPhases; ++j) h->prof->ms[j] = 0;
+    h->prof->calls = 0;
+  }
+  return CE_OK;
+}
+
+extern "C" int ce_cache_writeback_wait(ce_cache_t* h) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  if (!h->wb) return CE_OK;
+  return h->wb->wait(h->wb->issued);
+}
+
+extern "C" int ce_cache_writeback_stats(ce_cache_t* h, double* wait_s, double* copy_s, double* scatter_s,
+                                        int64_t* rows, int64_t* jobs) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  double a = 0, b = 0, c = 0;
+  long long r = 0, j = 0;
+  if (h->wb) {
+    std::lock_guard<std::mutex> g(h->wb->m);
+    a = h->wb->wait_s; b = h->wb->copy_s; c = h->wb->scatter_s; r = h->wb->rows; j = h->wb->jobs;
+  }
+  if (wait_s) *wait_s = a;
+  if (copy_s) *copy_s = b;
+  if (scatter_s) *scatter_s = c;
+  if (rows) *rows = r;
+  if (jobs) *jobs = j;
   return CE_OK;
 }
 

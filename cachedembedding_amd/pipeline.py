@@ -40,7 +40,9 @@ def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.
 
 class PrefetchWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
-                 presort: bool = False):
+                 presort: bool = False, transport: Optional[str] = "worker"):
+        # transport (overlap=True only): how rows move while the cache op runs beside training; "worker" keeps the
+        # write-back off the CUs (CachedParamMgr.set_transport), None leaves the manager's setting alone
         assert prefetch_num >= 1
         # presort=True: the cache op also sorts the window's slots in 16384-lookup segments (ce_bag_presort), so the
         # fused backward neither sorts nor issues as many row updates; the keys of the last prepared/collected window
@@ -57,6 +59,8 @@ class PrefetchWindow:
             self._side = make_side_stream(self.mgr.device, cache_cus)
             self.mgr.set_protect_depth(1)
             self.mgr.strict = False   # no host sync inside the pipelined cache op
+            if transport:
+                self.mgr.set_transport(transport)
 
     @torch.no_grad()
     def _cache_op(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -100,6 +104,9 @@ class PrefetchWindow:
         assert self._pending is not None
         ev, slots, keys = self._pending
         self._pending = None
+        # strict=False: a cache op that overflowed (unique(window k U k+1) > cuda_row_num) or met a bad id handed
+        # back slots of -1; raise like the reference as soon as its record has arrived (no host wait)
+        self.mgr.raise_on_failed_calls()
         cur = torch.cuda.current_stream(self.mgr.device)
         cur.wait_event(ev)
         for s in slots:
@@ -122,7 +129,8 @@ class GraphedWindow:
     All tensors it reads besides `slots_i` must be static (offsets, upstream gradient / dense inputs)."""
 
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
-                 warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False):
+                 warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
+                 transport: Optional[str] = "worker"):
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
         self.P = prefetch_num
@@ -142,6 +150,8 @@ class GraphedWindow:
         if overlap:
             self.mgr.set_protect_depth(1)
             self.mgr.strict = False
+            if transport:
+                self.mgr.set_transport(transport)
         # eager warm-up on real slots (lazy initialisation must not happen during capture), then capture
         if warmup_values is not None:
             self.mgr.prepare_ids(torch.cat(list(warmup_values)), out=self._bufs[0])
@@ -202,12 +212,23 @@ class GraphedWindow:
                 self._presort(buf)
             self._events[buf] = None
 
+    def run_steps(self, buf: int, first: int, last: int) -> None:
+        """Batches [first, last) of the window in buffer `buf`, launched one by one (a window that a caller only
+        trains in part, or across two timed regions)."""
+        if self._events[buf] is not None:
+            torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
+            self._events[buf] = None
+        for i in range(first, last):
+            self._call(self._step_fn, buf, i)
+
     def run(self, buf: int, steps: Optional[int] = None) -> None:
         """Replay the P training steps on the slots in buffer `buf` (waits for its cache op).  steps < P runs
         only the first `steps` batches, eagerly (a trailing partial window)."""
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
+        if not self.mgr.strict:
+            self.mgr.raise_on_failed_calls()     # non-blocking; see PrefetchWindow.collect
         if steps is None or steps >= self.P:
             self._graphs[buf].replay()
         else:

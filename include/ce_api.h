@@ -49,6 +49,12 @@ extern "C" {
 /* how missed / evicted rows move between the host table and the HBM cache */
 #define CE_TRANSPORT_ZEROCOPY 0  /* swap kernels read/write the mapped pinned host table over PCIe */
 #define CE_TRANSPORT_STAGED 1    /* host threads gather/scatter through pinned staging + hipMemcpyAsync */
+#define CE_TRANSPORT_WORKER 2    /* admissions: zero-copy reads of the host table by a small kernel.  Evictions:
+                                    packed in HBM by the cache op, then copied out with ONE pinned hipMemcpyAsync
+                                    (SDMA) on a private stream and scattered into the host table by a worker
+                                    thread inside the library -- no CU and no launch-thread time is spent on the
+                                    write-back, and prepare_ids returns before the host table has the rows
+                                    (ce_cache_writeback_wait / ce_cache_flush make it current).  Not capture-safe. */
 
 typedef void* ce_stream_t; /* hipStream_t */
 typedef struct ce_cache ce_cache_t;
@@ -232,7 +238,12 @@ int ce_cache_last_stats(ce_cache_t* h, ce_call_stats_t* out);
  * exact values): _cpu_to_cuda_numel, _cuda_to_cpu_numel, _cache_miss, _total_cache. */
 int ce_cache_totals(ce_cache_t* h, int64_t* cpu_to_cuda_numel, int64_t* cuda_to_cpu_numel,
                     int64_t* cache_miss, int64_t* total_cache, int64_t* n_calls);
-/* Copies up to `cap` per-call records of finished calls starting at call `first_seq`. */
+/* Non-blocking: how many FINISHED calls ended with a status other than CE_OK (capacity overflow, bad id), and the
+ * status / call number of the latest one.  A pipeline that never blocks on a call's record (strict = False) polls
+ * this once per window and raises the reference's AssertionError one window late instead of never. */
+int ce_cache_failures(ce_cache_t* h, int64_t* n_failed, int32_t* last_status, int64_t* last_seq);
+/* Copies up to `cap` per-call records of finished calls starting at call `first_seq` (the library keeps the most
+ * recent 65536 records). */
 int64_t ce_cache_history(ce_cache_t* h, int64_t first_seq, ce_call_stats_t* out, int64_t cap);
 
 /* _id_to_cached_cuda_id [A.6] alone (no cache maintenance): slots_out = inverted[idx_map[ids]] */
@@ -244,7 +255,25 @@ int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t*
 int ce_cache_flush(ce_cache_t* h, ce_stream_t stream);
 
 int ce_cache_set_protect_depth(ce_cache_t* h, int32_t depth);
+/* Switching away from / to CE_TRANSPORT_WORKER blocks until the queued write-backs have landed. */
 int ce_cache_set_transport(ce_cache_t* h, int32_t transport);
+/* Phase timers of prepare_ids (upstream's per-phase Timer / record_function ranges, recsys/dlrm_main.py:258,294):
+ * when on, every call brackets its phases with hipEvents on its own stream (no host sync); ce_cache_phase_times
+ * blocks until the calls issued so far have finished and returns the accumulated milliseconds per phase
+ * (ce_cache_phase_count() values, named by ce_cache_phase_name) and the number of calls they cover. */
+int ce_cache_set_profiling(ce_cache_t* h, int32_t on);
+int32_t ce_cache_phase_count(void);
+const char* ce_cache_phase_name(int32_t i);
+int ce_cache_phase_times(ce_cache_t* h, double* ms_out, int32_t cap, int64_t* calls, int32_t reset);
+/* CE_TRANSPORT_WORKER: blocks until every eviction of the calls issued so far has reached the host table (the
+ * reference's `weight` is current the moment prepare_ids returns; with the worker transport it is current after
+ * this call or after ce_cache_flush).  No-op for the other transports. */
+int ce_cache_writeback_wait(ce_cache_t* h);
+/* Worker-side accounting of the write-back (upstream's swap_out_bandwidth, recsys/dlrm_main.py:294 prints it via
+ * print_comm_stats): seconds the worker waited for staging events, spent in the D2H copies and in the scatter into
+ * the table; rows and jobs moved. */
+int ce_cache_writeback_stats(ce_cache_t* h, double* wait_s, double* copy_s, double* scatter_s, int64_t* rows,
+                             int64_t* jobs);
 /* upstream buffer_size / LimitBuffIndexCopyer: rows > 0 bounds the pinned + device staging of the STAGED
  * transport to `rows` rows; larger swaps walk it in chunks.  0 (default) = stage a whole swap at once. */
 int ce_cache_set_buffer_rows(ce_cache_t* h, int64_t rows);

@@ -241,3 +241,29 @@ def test_non_strict_overflow_yields_minus_one_slots_and_zero_rows():
     out.backward(torch.ones_like(out))
     assert torch.equal(before, emb.cache_weight_mgr.cuda_cached_weight.detach())
     assert emb.cache_weight_mgr.sync_stats().status == 3     # CE_ERR_CAPACITY
+
+
+@pytest.mark.parametrize("N", [256, 65536, 1 << 24])
+def test_dataset_keys_sharing_the_top_byte_with_ineligible_slots(N):
+    """N - 1 has 0xff in its top byte, so the DATASET keys N-1-row of the hottest rows (row < 256^t) share the top
+    radix digit with the all-ones key of empty / protected slots; the capacity check must not count them out
+    (it rejected legal calls with CE_ERR_CAPACITY).  Evicts rows 0..255 and checks ids against the oracle."""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    D = 4
+    C = max(8, min(N // 100, 1000)) if N > 256 else 16
+    rng = np.random.default_rng(N)
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 1.0)            # rows 0..C-1 resident: the cache is full of the lowest (= hottest) rows
+    mgr = _mk(ce, w, C, "dataset", None, 1.0)
+    for c in range(6):
+        n_new = int(C * 0.7)
+        ids = rng.choice(np.arange(C, N), size=n_new, replace=False) if c % 2 == 0 else \
+            rng.choice(np.arange(0, min(N, 2 * C)), size=n_new, replace=False)
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())       # strict: raises on a spurious capacity error
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        _state_equal(mgr, ora, False)
+    assert sum(ora.num_write_back_history) > 0
+    assert mgr.num_write_back_history == ora.num_write_back_history

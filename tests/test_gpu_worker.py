@@ -1,0 +1,197 @@
+"""Worker write-back transport (CE_TRANSPORT_WORKER: admissions by zero-copy reads, evictions packed in HBM,
+copied out by ONE pinned hipMemcpyAsync on a private stream and scattered into the host table by a thread inside
+libce_hip) against the CPU oracle.  Same bar as the other transports: slots, maps, counters, histories and the
+cache payloads bit-exact after every call, the host table bit-exact once the write-backs have landed -- including
+rows that are re-admitted in the very call after the one that evicted them (their payload must come from the
+staging buffer, the host row is stale at that moment)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _ce():
+    import cachedembedding_amd as ce
+    return ce
+
+
+def _strat(ce, s):
+    return ce.EvictionStrategy.LFU if s == "lfu" else ce.EvictionStrategy.DATASET
+
+
+def _state_equal(mgr, ora, lfu):
+    assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+    assert np.array_equal(mgr.inverted_cached_idx.cpu().numpy().astype(np.int64), ora.inverted_cached_idx)
+    if lfu:
+        assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+    np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
+
+
+@pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"),
+                                           ("cache_lfu_freq", "lfu"), ("cache_lfu_nofreq", "lfu")])
+def test_golden_streams_worker(name, strategy):
+    ce = _ce()
+    z = np.load(GOLD / f"{name}.npz")
+    N, C, D, n_ids, calls, warm = (int(v) for v in z["meta"])
+    freq = z["freq"] if z["freq"].size else None
+    mgr = ce.CachedParamMgr(torch.from_numpy(z["weight"].copy()), C, evict_strategy=_strat(ce, strategy))
+    mgr.reorder(freq, warm / 1000.0)
+    mgr.set_transport("worker")
+    for c in range(calls):
+        slots = mgr.prepare_ids(torch.from_numpy(z["ids"][c]).cuda())
+        assert np.array_equal(slots.cpu().numpy(), z["slots"][c])
+        assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), z["cached_idx_map"][c])
+        if strategy == "lfu":
+            assert np.array_equal(mgr.freq_cnter.cpu().numpy(), z["freq_cnter"][c])
+        with torch.no_grad():
+            mgr.cuda_cached_weight[torch.unique(slots)] += 0.5
+    assert mgr.num_hits_history == z["hits"].tolist()
+    assert mgr.num_miss_history == z["misses"].tolist()
+    mgr.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), z["weight_after_flush"])
+    assert mgr.writeback_stats()["jobs"] == calls
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+@pytest.mark.parametrize("depth", [0, 1])
+@pytest.mark.parametrize("N,C,D,per_call", [(6000, 700, 128, 300), (20000, 1500, 32, 500), (3001, 257, 20, 100)])
+def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call):
+    """Every call asks for half of the rows the previous call evicted (plus fresh ones): their only up-to-date copy is
+    the previous call's staging buffer while the worker is still copying it out.  Cache payloads are compared after
+    every call, the host table at the end and at two intermediate writeback_wait() points."""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+    rng = np.random.default_rng(N * 7 + C + depth)
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+    ora.protect_depth = depth
+    ora.reorder(None, 1.0)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C, evict_strategy=_strat(ce, strategy))
+    mgr.reorder(None, 1.0)
+    mgr.set_transport("worker")
+    mgr.set_protect_depth(depth)
+    lfu = strategy == "lfu"
+    prev_evicted = np.zeros(0, dtype=np.int64)
+    readmitted = 0
+    if depth:
+        per_call //= 2                # unique(call c U call c-1) must fit the cache when the previous call is protected
+    for c in range(24):
+        fresh = rng.integers(0, N, size=per_call)
+        again = prev_evicted[rng.permutation(len(prev_evicted))[: len(prev_evicted) // 2]]
+        ids = np.concatenate([fresh, again, again[: len(again) // 3]])       # some of them more than once
+        rng.shuffle(ids)
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        readmitted += int(np.isin(ora.traces[-1].miss_rows, prev_evicted).sum())
+        prev_evicted = ora.traces[-1].evicted_rows.copy()                    # no frequency map: row == id
+        # a training step on the touched rows: every write-back carries a payload the host table has never seen
+        ora.cuda_cached_weight[np.unique(eslots)] += np.float32(0.25 * (c + 1))
+        with torch.no_grad():
+            mgr.cuda_cached_weight[torch.unique(slots)] += 0.25 * (c + 1)
+        _state_equal(mgr, ora, lfu)
+        if c in (7, 15):
+            np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)   # .weight waits for the worker
+    assert readmitted > 50, "the stream did not exercise the pending-row path"
+    assert mgr.num_write_back_history == ora.num_write_back_history
+    mgr.flush()
+    ora.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+    st = mgr.writeback_stats()
+    assert st["rows"] == sum(ora.num_write_back_history)
+
+
+def test_transport_switches_keep_the_table_consistent():
+    """zerocopy -> worker -> staged -> worker -> zerocopy in the middle of a stream"""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    rng = np.random.default_rng(5)
+    N, C, D = 5000, 400, 64
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 0.7)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C)
+    mgr.reorder(None, 0.7)
+    order = ["zerocopy", "worker", "staged", "worker", "zerocopy"]
+    for c in range(20):
+        mgr.set_transport(order[(c // 4) % len(order)])
+        ids = rng.integers(0, N, size=250)
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        ora.cuda_cached_weight[np.unique(eslots)] *= np.float32(1.5)
+        with torch.no_grad():
+            mgr.cuda_cached_weight[torch.unique(slots)] *= 1.5
+        _state_equal(mgr, ora, False)
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+    mgr.flush()
+    ora.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+
+
+def test_more_victims_than_the_staging_buffer_holds():
+    """stage_rows is min(C, 262144): with a bigger cache the overflow takes the direct zero-copy path even under the
+    worker transport; here the whole cache turns over in one call at D = 4 (C = 300k slots)."""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    rng = np.random.default_rng(11)
+    N, C, D = 900_000, 300_000, 4
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 1.0)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C)
+    mgr.reorder(None, 1.0)
+    mgr.set_transport("worker")
+    for c in range(3):
+        ids = np.arange(C) + C * ((c + 1) % 3)            # a disjoint block of C rows: evicts everything
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        ora.cuda_cached_weight += np.float32(1.0)
+        with torch.no_grad():
+            mgr.cuda_cached_weight += 1.0
+    assert ora.num_write_back_history[-1] == C
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+
+
+def test_overlapped_window_raises_on_overflow():
+    """strict=False pipelines must not train on -1 slots silently: the failed call is reported one window late"""
+    ce = _ce()
+    from cachedembedding_amd.pipeline import PrefetchWindow
+    N, D, C = 4000, 16, 300
+    emb = ce.CachedEmbeddingBag(N, D, sparse=True, mode="sum", include_last_offset=True, cuda_row_num=C,
+                                warmup_ratio=0.7)
+    win = PrefetchWindow(emb, 2, overlap=True)
+    g = torch.Generator().manual_seed(0)
+    ok = [torch.randint(0, N, (64,), generator=g).cuda() for _ in range(2)]
+    too_many = [torch.arange(0, 400).cuda(), torch.arange(400, 800).cuda()]      # 800 unique rows > 300 slots
+    win.submit(ok)
+    win.collect()
+    win.submit(too_many)
+    slots = win.collect()
+    torch.cuda.synchronize()
+    assert int(slots[0].min()) == -1
+    win.submit(ok)
+    with pytest.raises(AssertionError, match="increase cuda_row_num"):
+        win.collect()
+
+
+def test_phase_timers_and_history_window():
+    ce = _ce()
+    N, D, C = 3000, 32, 200
+    mgr = ce.CachedParamMgr(torch.randn(N, D), C)
+    mgr.reorder(None, 0.5)
+    mgr.set_profiling(True)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(20):
+        mgr.prepare_ids(torch.randint(0, N, (150,), generator=g).cuda())
+    t = mgr.phase_times()
+    assert t["calls"] == 20
+    names = [k for k in t if k != "calls"]
+    assert len(names) == 6 and all(t[k] >= 0.0 for k in names) and sum(t[k] for k in names) > 0.0
+    assert len(mgr.num_hits_history) == 20
+    mgr.set_profiling(False)
