@@ -326,6 +326,9 @@ def main():
         win = PrefetchWindow(embed, P, overlap=True, presort=presort, transport=None)
         fwd_pipe, bwd_pipe = event_pass(ev_first + 4 * P)
         torch.cuda.synchronize()
+    excl_frac = None
+    if presort and win.keys:
+        excl_frac = sum(int(k[1].item()) for k in win.keys) / len(win.keys)
     row_b = 4 * D
     fwd_bytes = B * F * (L * (row_b + 8) + 8 + row_b)            # 1040 B/lookup at D=128, L=1
     # backward: per bag read the gradient row (4D) + offset (8), per lookup the slot (8); per UNIQUE
@@ -340,6 +343,7 @@ def main():
     bwd_roof = dict(kernel="k_bag_bwd(sgd)", bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=bwd_avg, bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
+    bwd_roof["exclusive_batches_frac"] = excl_frac     # batches whose rows never span two segments (no-atomics path)
     fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
     for r in (fwd_roof, bwd_roof):
         r["frac"] = r["achieved"] / r["peak"]
@@ -364,28 +368,36 @@ def main():
     rows_in_t = (tot["cpu_to_cuda_numel"] - tot0["cpu_to_cuda_numel"]) // D
     rows_out_t = (tot["cuda_to_cpu_numel"] - tot0["cuda_to_cpu_numel"]) // D
     swap_ms = phases.get("admit_swap", 0.0) / calls_t
-    both = transport == "zerocopy"
-    swap_bytes = (rows_in_t + (rows_out_t if both else 0)) * row_b / calls_t
-    swap_peak = 63.0 * (2 if both else 1)
-    swap_roof = dict(kernel="k_swap (admit%s)" % (" + write-back" if both else ""), bound="pcie",
-                     achieved=swap_bytes / max(swap_ms, 1e-9) / 1e6, peak=swap_peak, unit="GB/s",
-                     avg_ms=swap_ms, bytes_per_launch=swap_bytes, launches_per_step=1.0 / P,
-                     rows_in_per_launch=rows_in_t / calls_t, rows_out_per_launch=rows_out_t / calls_t, traffic=None,
-                     note="timed in the pipeline (side stream) by hipEvents around the phase")
-    swap_roof["frac"] = swap_roof["achieved"] / swap_roof["peak"]
     wbs = mgr.writeback_stats()
-    if wbs["jobs"]:
-        moved = wbs["rows"] * row_b
-        swap_roof["writeback_worker"] = dict(jobs=wbs["jobs"], rows=wbs["rows"],
-                                             copy_GBps=moved / max(wbs["copy_s"], 1e-9) / 1e9,
-                                             scatter_GBps=moved / max(wbs["scatter_s"], 1e-9) / 1e9,
-                                             copy_ms_per_job=1e3 * wbs["copy_s"] / wbs["jobs"],
-                                             scatter_ms_per_job=1e3 * wbs["scatter_s"] / wbs["jobs"])
+    if transport == "worker" and wbs["in_jobs"]:
+        # both directions are pinned hipMemcpyAsync copies driven by the library's worker threads: no kernel; the
+        # figure is the admission direction (the one the cache-op stream waits for): rows x 4D over the worker's busy
+        # time (gather out of the host table + H2D copies).  avg_ms = how long the cache-op stream sat in the phase
+        # (parked in hipStreamWaitValue64, then k_unpack_admitted).
+        in_busy_ms = 1e3 * wbs["in_busy_s"] / wbs["in_jobs"]
+        swap_bytes = wbs["in_rows"] * row_b / wbs["in_jobs"]
+        swap_roof = dict(kernel="row swap: SDMA copies + host workers (no kernel)", bound="pcie",
+                         achieved=swap_bytes / max(in_busy_ms, 1e-9) / 1e6, peak=63.0, unit="GB/s", avg_ms=swap_ms,
+                         bytes_per_launch=swap_bytes, worker_in_busy_ms=in_busy_ms,
+                         worker_out_busy_ms=1e3 * wbs["out_busy_s"] / max(1, wbs["jobs"]),
+                         worker_out_GBps=wbs["rows"] * row_b / max(wbs["out_busy_s"], 1e-9) / 1e9,
+                         worker_in_wait_ms=1e3 * wbs["in_wait_s"] / wbs["in_jobs"])
+    else:
+        both = transport == "zerocopy"
+        swap_bytes = (rows_in_t + (rows_out_t if both else 0)) * row_b / calls_t
+        swap_roof = dict(kernel="k_swap (admit + write-back)" if both else "staged swap", bound="pcie",
+                         achieved=swap_bytes / max(swap_ms, 1e-9) / 1e6, peak=63.0 * (2 if both else 1), unit="GB/s",
+                         avg_ms=swap_ms, bytes_per_launch=swap_bytes)
+    swap_roof.update(launches_per_step=1.0 / P, rows_in_per_launch=rows_in_t / calls_t,
+                     rows_out_per_launch=rows_out_t / calls_t, traffic=None,
+                     note="timed in the pipeline (cache-op stream) by hipEvents around the phase")
+    swap_roof["frac"] = swap_roof["achieved"] / swap_roof["peak"]
     # `roofline` = the kernel with the largest share of a step's GPU time (a step = 1 fwd + 1 bwd + 1/P swap)
     for r, per_step in ((fwd_roof, 1.0), (bwd_roof, 1.0), (swap_roof, 1.0 / P)):
         r["ms_per_step_share"] = r["avg_ms"] * per_step
-    ranked = sorted((fwd_roof, bwd_roof, swap_roof), key=lambda r: -r["ms_per_step_share"])
-    dominant, other = ranked[0], ranked[1:]
+    cands = (fwd_roof, bwd_roof) if transport == "worker" else (fwd_roof, bwd_roof, swap_roof)
+    ranked = sorted(cands, key=lambda r: -r["ms_per_step_share"])
+    dominant, other = ranked[0], ranked[1:] + ([swap_roof] if transport == "worker" else [])
     cache_phases = {k: v / calls_t for k, v in phases.items() if k != "calls"}
 
     result = {
@@ -404,9 +416,11 @@ def main():
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
                    "transport": transport, "overlap": bool(args.overlap),
                    "launch": "hipGraph per window" if use_graph else "python per step",
-                   "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window (ce_bag_presort)"
-                   if presort else "1024-lookup tiles sorted inside every backward",
-                   "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
+                   "bwd_duplicate_fold": "slots sorted by row per 16384-lookup segment, once per window "
+                                         "(ce_bag_presort_window)" if presort else "1024-lookup tiles sorted inside every backward",
+                   "update": "sorted" if args.deterministic else
+                             ("plain read-modify-write for rows private to a lane group, fp32 atomics for runs cut by a "
+                              "chunk edge" if presort else "atomic"), "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,
                   "prefill_cache_ops": prefill, "setup_s": setup_s,

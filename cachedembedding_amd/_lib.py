@@ -88,7 +88,7 @@ SIGNATURES = {
     "ce_bag_backward_dense": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
                                       c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_dense_presorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
-                                      c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+                                      c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ce_bag_backward_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                      c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
@@ -97,7 +97,10 @@ SIGNATURES = {
     "ce_bag_presort": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd_presorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                               c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,
-                                              c_void_p, c_void_p]),
+                                              c_void_p, c_void_p, c_void_p]),
+    "ce_bag_presort_window_scratch": (c_int64, [c_int64, c_int64]),
+    "ce_bag_presort_window": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "ce_bag_backward_sgd_sorted_workspace": (c_size_t, [c_int64, c_int64]),
     "ce_bag_backward_sgd_sorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                            c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,
@@ -121,8 +124,7 @@ SIGNATURES = {
     "ce_cache_phase_name": (c_char_p, [c_int32]),
     "ce_cache_phase_times": (c_int, [c_void_p, POINTER(c_double), c_int32, POINTER(c_int64), c_int32]),
     "ce_cache_writeback_wait": (c_int, [c_void_p]),
-    "ce_cache_writeback_stats": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double),
-                                         POINTER(c_int64), POINTER(c_int64)]),
+    "ce_cache_swap_stats": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "ce_cache_failures": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64)]),
     "ce_cache_free_rows": (c_int, [c_void_p, POINTER(c_int64)]),
     "ce_dedupe_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -324,10 +324,11 @@ class CachedParamMgr(torch.nn.Module):
                f"lookups ({100.0 * t['cache_miss'] / max(1, t['total_cache']):.2f} %)")
         wb = self.writeback_stats()
         if wb["jobs"]:
-            moved = wb["rows"] * self.embedding_dim * esz
-            msg += (f"; write-back worker: {wb['jobs']} jobs, {moved / 1e6:.2f} MB, copy "
-                    f"{moved / max(wb['copy_s'], 1e-9) / 1e9:.1f} GB/s, scatter "
-                    f"{moved / max(wb['scatter_s'], 1e-9) / 1e9:.1f} GB/s")
+            row_b = self.embedding_dim * esz
+            msg += (f"; swap workers: out {wb['jobs']} jobs {wb['rows'] * row_b / 1e6:.2f} MB at "
+                    f"{wb['rows'] * row_b / max(wb['out_busy_s'], 1e-9) / 1e9:.1f} GB/s, in {wb['in_jobs']} jobs "
+                    f"{wb['in_rows'] * row_b / 1e6:.2f} MB at "
+                    f"{wb['in_rows'] * row_b / max(wb['in_busy_s'], 1e-9) / 1e9:.1f} GB/s")
         print(msg)
         return msg
 
@@ -369,11 +370,12 @@ class CachedParamMgr(torch.nn.Module):
         check(lib.ce_cache_writeback_wait(self._handle))
 
     def writeback_stats(self) -> dict:
-        a, b, c = (ctypes.c_double() for _ in range(3))
-        r, j = ctypes.c_int64(), ctypes.c_int64()
-        check(lib.ce_cache_writeback_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
-                                           ctypes.byref(r), ctypes.byref(j)))
-        return dict(wait_s=a.value, copy_s=b.value, scatter_s=c.value, rows=r.value, jobs=j.value)
+        """Worker-transport accounting: rows / jobs / seconds of the write-back (out) and admission (in) workers."""
+        sec = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_int64 * 4)()
+        check(lib.ce_cache_swap_stats(self._handle, sec, cnt))
+        return dict(out_wait_s=sec[0], out_busy_s=sec[1], in_wait_s=sec[2], in_busy_s=sec[3],
+                    rows=cnt[0], jobs=cnt[1], in_rows=cnt[2], in_jobs=cnt[3])
 
     def raise_on_failed_calls(self):
         """Non-blocking check used by the pipelines that run prepare_ids with strict=False: raises the reference's

@@ -59,10 +59,15 @@ struct Ctl {                 // device control block (one per manager)
   int status;
 };
 
+struct WbMail {              // pinned host mailbox: how many rows a worker job moves (written by the device)
+  long long job;
+  long long count;
+};
+
 struct Layout {              // byte offsets inside the caller-provided workspace
   size_t ctl, bitmap, blk_unique, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      stage_idx, stage, stage_idx2, stage2, pend_hash[2], total;
-  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows, hash_entries;
+      stage_idx, stage, stage_idx2, stage2, in_stage, total;
+  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
 
 constexpr int64_t kStageRowsMax = 262144;   // write-back staging: 128 MB at D = 128
@@ -89,15 +94,12 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
   L.stage_idx = o;  o = al(o + (size_t)L.stage_rows * 4);
   L.stage = o;      o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
-  // worker write-back (CE_TRANSPORT_WORKER): the staging is double-buffered -- the victims of call w stay in HBM
-  // until the host worker has copied them out, while call w+1 stages into the other buffer -- and every staged
-  // row is findable by row id (open-addressing table, row << 32 | position) so that a row re-admitted before its
-  // write-back reached the host table is taken from the staging buffer instead of the (stale) host row
+  // worker transport (CE_TRANSPORT_WORKER): the eviction staging is double-buffered -- the victims of call w stay
+  // in HBM until the host worker has copied them out, while call w+1 stages into the other buffer -- and the
+  // admitted rows arrive in `in_stage` (one pinned hipMemcpyAsync per chunk) before a kernel moves them to their slots
   L.stage_idx2 = o; o = al(o + (size_t)L.stage_rows * 4);
   L.stage2 = o;     o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
-  L.hash_entries = 64;
-  while (L.hash_entries < 2 * L.stage_rows) L.hash_entries <<= 1;
-  for (int b = 0; b < 2; ++b) { L.pend_hash[b] = o; o = al(o + (size_t)L.hash_entries * 8); }
+  L.in_stage = o;   o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
   L.total = o;
   return L;
 }
@@ -306,7 +308,8 @@ __device__ void scan_inplace_1024(int32_t* a, int64_t n, long long* total_out) {
 
 __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk_miss, int64_t n_chunks,
                                                int64_t C, int64_t n_ids, Ctl* ctl,
-                                               ce_call_stats_t* ring_slot) {
+                                               ce_call_stats_t* ring_slot, WbMail* mail_in, long long job,
+                                               long long in_cap) {
   long long tu, tm;
   scan_inplace_1024(blk_unique, n_chunks, &tu);
   scan_inplace_1024(blk_miss, n_chunks, &tm);
@@ -332,6 +335,11 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
     ring_slot->n_free_after = ctl->n_free;
     ring_slot->status = status;
     ring_slot->kind = CE_CALL_PREPARE;
+    if (mail_in) {      // rows the admission worker gathers for this call (read after the event behind k_emit)
+      const long long m = (status == CE_OK) ? tm : 0;
+      mail_in->count = m < in_cap ? m : in_cap;
+      mail_in->job = job;
+    }
     // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
     // record (k_pick can turn it into a capacity failure): k_admit_maps
   }
@@ -339,7 +347,8 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
 
 __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
                                               const int32_t* __restrict__ blk_miss_off, int32_t* miss_list,
-                                              int32_t* slot_epoch, int32_t epoch, const Ctl* ctl) {
+                                              int32_t* slot_epoch, int32_t epoch, const Ctl* ctl,
+                                              int32_t* miss_host, int in_cap) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const uint4 q = bitmap4[v];
   const bool ok = (ctl->status == CE_OK);
@@ -367,8 +376,13 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             if (!((bits >> (4 * j + c)) & 1)) continue;
-            if (sl[c] < 0) miss_list[pos++] = (int32_t)(row0 + 4 * j + c);
-            else slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
+            if (sl[c] < 0) {
+              const int32_t mr = (int32_t)(row0 + 4 * j + c);
+              if (miss_host && pos < in_cap) miss_host[pos] = mr;      // the admission worker's copy (pinned host)
+              miss_list[pos++] = mr;
+            } else {
+              slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
+            }
           }
         }
         continue;
@@ -378,8 +392,12 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
         bits &= bits - 1;
         const int64_t row = row0 + b;
         const int32_t slot = inverted[row];
-        if (slot < 0) miss_list[pos++] = (int32_t)row;
-        else slot_epoch[slot] = epoch;        // evict_backlist membership [A.3-3]
+        if (slot < 0) {
+          if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)row;
+          miss_list[pos++] = (int32_t)row;
+        } else {
+          slot_epoch[slot] = epoch;        // evict_backlist membership [A.3-3]
+        }
       }
     }
   }
@@ -553,21 +571,12 @@ __global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ vict
 // host table from the staging buffer while its other workgroups read the missed rows -- PCIe carries both
 // directions at once.  Victims beyond the staging capacity (rare) are
 // written back directly by k_evict (`first` = staging capacity).
-// pending-row table of the worker write-back: open addressing, entry = row << 32 | staging position, empty = ~0
-__device__ __forceinline__ uint32_t pend_slot(uint32_t row, uint32_t mask) { return (row * 2654435761u) & mask; }
-
-struct WbMail {              // pinned host mailbox, one per staging buffer: what the worker copies out
-  long long job;
-  long long count;
-};
-
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
                                                      const int32_t* __restrict__ cached_idx_map,
                                                      const VT* __restrict__ cache, VT* stage, int32_t* stage_rows_idx,
                                                      long long cap, int rowlen, int g_log2, const Ctl* ctl,
-                                                     unsigned long long* pend_hash, uint32_t pend_mask, WbMail* mail,
-                                                     long long job) {
+                                                     WbMail* mail, long long job) {
   long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
   if (k > cap) k = cap;
   if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // read by the worker after this kernel's event
@@ -579,15 +588,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < k; i += gstride) {
     const int32_t slot = victims[i];
-    if (gl == 0) {
-      const int32_t row = cached_idx_map[slot];
-      stage_rows_idx[i] = row;
-      if (pend_hash) {
-        const unsigned long long e = ((unsigned long long)(uint32_t)row << 32) | (unsigned long long)i;
-        uint32_t hs = pend_slot((uint32_t)row, pend_mask);
-        while (atomicCAS(&pend_hash[hs], ~0ull, e) != ~0ull) hs = (hs + 1) & pend_mask;   // table is < half full
-      }
-    }
+    if (gl == 0) stage_rows_idx[i] = cached_idx_map[slot];
     copy_row(cache + (int64_t)slot * rowlen, stage + i * rowlen, rowlen, gl, G);
   }
 }
@@ -684,54 +685,30 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
   }
 }
 
-// rows[i] -> slots[i] (slots == nullptr: slot i; rows == nullptr: row i).  pend_hash != nullptr (worker
-// write-back): a missed row that the PREVIOUS call evicted may not have reached the host table yet -- it is
-// then read from that call's HBM staging buffer, where the table above finds it.
-template <typename VT>
-__device__ __forceinline__ const VT* admit_src(int64_t row, const VT* __restrict__ host, int rowlen,
-                                               const unsigned long long* __restrict__ pend_hash, uint32_t pend_mask,
-                                               const VT* __restrict__ pend_stage) {
-  if (pend_hash) {
-    uint32_t hs = pend_slot((uint32_t)row, pend_mask);
-    for (;;) {
-      const unsigned long long e = pend_hash[hs];
-      if (e == ~0ull) break;
-      if ((uint32_t)(e >> 32) == (uint32_t)row) return pend_stage + (int64_t)(uint32_t)e * rowlen;
-      hs = (hs + 1) & pend_mask;
-    }
-  }
-  return host + row * rowlen;
-}
-
+// rows[i] -> slots[i] for first <= i < n (slots == nullptr: slot i; rows == nullptr: row i)
 template <typename VT, int R>
 __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                            const long long* n_ptr, long long n_imm, const VT* __restrict__ host,
                                            VT* cache, int rowlen, int g_log2, const Ctl* ctl, int block, int nblocks,
-                                           const unsigned long long* __restrict__ pend_hash = nullptr,
-                                           uint32_t pend_mask = 0, const VT* __restrict__ pend_stage = nullptr) {
+                                           long long first = 0) {
   if (ctl && ctl->status != CE_OK) return;
   const long long n = n_ptr ? *n_ptr : n_imm;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
+  for (int64_t i = first + (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
     if (rowlen <= G) {          // R host rows in flight per lane group (see k_evict)
       VT v[R];
       int64_t dst[R];
-      const VT* src[R];
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         dst[t] = -1;
-        src[t] = host;
         if (i + t < n) {
           const int64_t row = rows ? rows[i + t] : i + t;
           dst[t] = slots ? slots[i + t] : i + t;
-          src[t] = admit_src<VT>(row, host, rowlen, pend_hash, pend_mask, pend_stage);
+          if (gl < rowlen) v[t] = host[row * rowlen + gl];
         }
       }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        if (dst[t] >= 0 && gl < rowlen) v[t] = src[t][gl];
 #pragma unroll
       for (int t = 0; t < R; ++t)
         if (dst[t] >= 0 && gl < rowlen) cache[dst[t] * rowlen + gl] = v[t];
@@ -739,8 +716,7 @@ __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, con
       for (int t = 0; t < R && i + t < n; ++t) {
         const int64_t row = rows ? rows[i + t] : i + t;
         const int64_t slot = slots ? slots[i + t] : i + t;
-        copy_row(admit_src<VT>(row, host, rowlen, pend_hash, pend_mask, pend_stage), cache + slot * rowlen, rowlen,
-                 gl, G);
+        copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
       }
     }
   }
@@ -750,9 +726,24 @@ template <typename VT>
 __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                                const long long* n_ptr, long long n_imm,
                                                const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
-                                               const Ctl* ctl) {
+                                               const Ctl* ctl, long long first) {
   admit_rows<VT, kSwapRows>(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x,
-                            (int)gridDim.x);
+                            (int)gridDim.x, first);
+}
+
+// worker transport: rows [0, min(n_miss, cap)) arrived contiguously in `in_stage`; move them to their slots
+template <typename VT>
+__global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restrict__ slots, const long long* n_ptr,
+                                                         long long cap, const VT* __restrict__ in_stage, VT* cache,
+                                                         int rowlen, int g_log2, const Ctl* ctl) {
+  if (ctl->status != CE_OK) return;
+  long long n = *n_ptr;
+  if (n > cap) n = cap;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride)
+    copy_row(in_stage + i * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
 }
 
 // Full-duplex swap in ONE launch: the first wb_blocks workgroups stream the staged victims to the host table,
@@ -764,13 +755,12 @@ __global__ __launch_bounds__(1024) void k_swap(const int32_t* __restrict__ stage
                                               const VT* __restrict__ stage, long long cap, int wb_blocks,
                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                               const long long* n_ptr, VT* host, VT* cache, int rowlen, int g_log2,
-                                              const Ctl* ctl, const unsigned long long* pend_hash,
-                                              uint32_t pend_mask, const VT* pend_stage) {
+                                              const Ctl* ctl) {
   if ((int)blockIdx.x < wb_blocks)
     writeback_rows<VT, R>(stage_rows_idx, stage, host, cap, rowlen, g_log2, ctl, (int)blockIdx.x, wb_blocks);
   else
     admit_rows<VT, R>(rows, slots, n_ptr, 0ll, (const VT*)host, cache, rowlen, g_log2, ctl,
-                      (int)blockIdx.x - wb_blocks, (int)gridDim.x - wb_blocks, pend_hash, pend_mask, pend_stage);
+                      (int)blockIdx.x - wb_blocks, (int)gridDim.x - wb_blocks);
 }
 
 __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ rows,
@@ -1077,130 +1067,268 @@ struct PhaseProf {
   }
 };
 
-// Worker write-back (CE_TRANSPORT_WORKER).  The cache op leaves the victims of call w packed in an HBM staging
-// buffer (k_evict_stage) and returns; this object's thread waits for that kernel's event ON ITS OWN THREAD, copies
-// the block out with ONE pinned hipMemcpyAsync on a private stream (SDMA: no CU, no posted PCIe writes issued by
-// waves that share the memory pipeline with training) and scatters the rows into the host table with a few helper
-// threads.  Two staging buffers alternate; the launch thread only waits when the worker is two calls behind.
-struct Writeback {
+// Worker transport (CE_TRANSPORT_WORKER): both directions of the row swap leave the CUs.
+//
+// Measured on the box (profiles/r02_probe_sdma.txt): a pinned hipMemcpyAsync runs on an SDMA engine at ~51 GB/s per
+// direction and does NOT slow an HBM-bound kernel running beside it (x1.02), whereas rows moved by waves over the
+// mapped host table (round 1's k_swap) held the training kernels back by 40-47 % for as long as they ran.  So:
+//
+//   out  k_evict_stage packs the victims of call w into an HBM staging buffer; the `out` worker waits for that
+//        kernel's event ON ITS OWN THREAD, copies the block out in chunks (hipMemcpyAsync, private stream) and
+//        scatters each chunk into the host table with helper threads while the next one is in flight.
+//   in   k_emit leaves the ascending list of missed rows in pinned host memory; the `in` worker waits for that
+//        kernel's event, lets helper threads gather the rows out of the table into pinned staging, each helper
+//        pushing its finished 1-2 MB piece to the device at once (hipMemcpyAsync), and finally releases the cache-op
+//        stream, which has been parked in a hipStreamWaitValue64 (no CU, no host thread involved), with a
+//        hipStreamWriteValue64 behind the last copy.  k_unpack_admitted then moves the rows to their slots.
+//
+// Ordering: the gather of call w starts only after the write-back of call w-1 has reached the table (a row evicted
+// by w-1 and missed by w is read back correctly); rows evicted by call w itself are never in its miss list.
+// The launch thread blocks only when a worker is two calls behind.  A failing HIP call inside a worker still
+// releases the stream (the error surfaces at the next call / wait) so the GPU is never left parked.
+struct SwapEngine {
   int device = 0;
   int64_t D = 0, stage_rows = 0;
   float* table = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  // ---- out (evictions)
+  hipStream_t out_stream = nullptr;
+  hipEvent_t out_ev[2] = {nullptr, nullptr};       // staging of the job complete (recorded on the cache-op stream)
+  static constexpr int kOutChunks = 16;
+  hipEvent_t chunk_ev[kOutChunks] = {};
   const float* stage_dev[2] = {nullptr, nullptr};
   const int32_t* idx_dev[2] = {nullptr, nullptr};
-  float* rows_host[2] = {nullptr, nullptr};      // pinned
-  int32_t* idx_host[2] = {nullptr, nullptr};     // pinned
-  WbMail* mail = nullptr;                        // pinned + mapped, [2]
+  float* rows_host[2] = {nullptr, nullptr};        // pinned landing buffers
+  int32_t* idx_host[2] = {nullptr, nullptr};
+  // ---- in (admissions)
+  hipStream_t in_stream = nullptr;
+  hipEvent_t in_ev[2] = {nullptr, nullptr};        // miss list of the job complete (by job parity)
+  float* in_stage_dev = nullptr;
+  float* in_host = nullptr;                        // pinned gather buffer
+  int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
+  int32_t* miss_host_dev = nullptr;
+  unsigned long long* sig = nullptr;               // pinned + mapped: the value the cache-op stream waits for
+  // ---- mailboxes (pinned + mapped): [0], [1] = out staging buffers, [2] = in
+  WbMail* mail = nullptr;
   WbMail* mail_dev = nullptr;
-  std::thread worker;
+  std::thread out_thread, in_thread;
   std::mutex m;
   std::condition_variable cv_job, cv_done;
-  long long issued = 0, done = 0;                // jobs pushed / finished
+  long long out_issued = 0, out_done = 0, in_issued = 0, in_done = 0;
   bool stop = false;
   int err = 0;
   char errmsg[256] = {0};
-  RowPool* pool = nullptr;
-  // statistics (what upstream's swap_out_bandwidth reports)
-  double copy_s = 0, scatter_s = 0, wait_s = 0;
-  long long rows = 0, jobs = 0;
+  RowPool* out_pool = nullptr;
+  RowPool* in_pool = nullptr;
+  // statistics (what upstream's swap_in_bandwidth / swap_out_bandwidth report)
+  double out_wait_s = 0, out_busy_s = 0, in_wait_s = 0, in_busy_s = 0;
+  long long out_rows = 0, out_jobs = 0, in_rows = 0, in_jobs = 0;
 
   void fail(const char* what, hipError_t e) {
     std::lock_guard<std::mutex> g(m);
     if (!err) {
       err = CE_ERR_HIP;
-      snprintf(errmsg, sizeof errmsg, "write-back worker: %s failed: %s", what, hipGetErrorString(e));
+      snprintf(errmsg, sizeof errmsg, "swap worker: %s failed: %s", what, hipGetErrorString(e));
     }
   }
+  bool failed() {
+    std::lock_guard<std::mutex> g(m);
+    return err != 0;
+  }
 
-  void run() {
+  void run_out() {
     (void)hipSetDevice(device);
     for (;;) {
       long long job;
       {
         std::unique_lock<std::mutex> g(m);
-        cv_job.wait(g, [&] { return stop || done < issued; });
-        if (done >= issued) return;      // stop requested and nothing left
-        job = done + 1;
+        cv_job.wait(g, [&] { return stop || out_done < out_issued; });
+        if (out_done >= out_issued) return;
+        job = out_done + 1;
       }
       const int b = (int)(job & 1);
       const auto t0 = std::chrono::steady_clock::now();
-      hipError_t e = hipEventSynchronize(ev[b]);
-      if (e != hipSuccess) fail("hipEventSynchronize", e);
+      hipError_t e = hipEventSynchronize(out_ev[b]);
+      if (e != hipSuccess) fail("hipEventSynchronize(out)", e);
       const auto t1 = std::chrono::steady_clock::now();
       long long k = mail[b].count;
-      if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record copies nothing
-      double cs = 0, ss = 0;
-      if (k > 0 && !err) {
-        e = hipMemcpyAsync(idx_host[b], idx_dev[b], (size_t)k * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess)
-          e = hipMemcpyAsync(rows_host[b], stage_dev[b], (size_t)k * D * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        const auto t2 = std::chrono::steady_clock::now();
-        cs = std::chrono::duration<double>(t2 - t1).count();
-        if (e != hipSuccess) {
-          fail("hipMemcpyAsync(D2H)", e);
-        } else {
+      if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record moves nothing
+      if (k > 0 && !failed()) {
+        e = hipMemcpyAsync(idx_host[b], idx_dev[b], (size_t)k * 4, hipMemcpyDeviceToHost, out_stream);
+        const int64_t per = std::max<int64_t>(4096, cdiv(k, kOutChunks));
+        int nch = 0;
+        for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++nch) {
+          const int64_t cnt = std::min<int64_t>(per, k - off);
+          e = hipMemcpyAsync(rows_host[b] + off * D, stage_dev[b] + off * D, (size_t)cnt * D * 4,
+                             hipMemcpyDeviceToHost, out_stream);
+          if (e == hipSuccess) e = hipEventRecord(chunk_ev[nch], out_stream);
+        }
+        if (e != hipSuccess) fail("hipMemcpyAsync(D2H)", e);
+        int c = 0;
+        for (int64_t off = 0; off < k && c < nch; off += per, ++c) {
+          const int64_t cnt = std::min<int64_t>(per, k - off);
+          e = hipEventSynchronize(chunk_ev[c]);
+          if (e != hipSuccess) { fail("hipEventSynchronize(chunk)", e); break; }
           float* tb = table;
-          const float* st = rows_host[b];
-          const int32_t* ri = idx_host[b];
+          const float* st = rows_host[b] + off * D;
+          const int32_t* ri = idx_host[b] + off;
           const int64_t d = D;
-          pool->parallel(k, [=](int64_t lo, int64_t hi) {
+          out_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
             for (int64_t i = lo; i < hi; ++i) memcpy(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d * 4);
           });
-          ss = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
         }
+        (void)hipStreamSynchronize(out_stream);
       }
+      const auto t2 = std::chrono::steady_clock::now();
       {
         std::lock_guard<std::mutex> g(m);
-        done = job;
-        wait_s += std::chrono::duration<double>(t1 - t0).count();
-        copy_s += cs;
-        scatter_s += ss;
-        rows += k;
-        jobs += 1;
+        out_done = job;
+        out_wait_s += std::chrono::duration<double>(t1 - t0).count();
+        out_busy_s += std::chrono::duration<double>(t2 - t1).count();
+        out_rows += k;
+        out_jobs += 1;
       }
       cv_done.notify_all();
     }
   }
 
-  // blocks until job `upto` has reached the host table
-  int wait(long long upto) {
-    std::unique_lock<std::mutex> g(m);
-    cv_done.wait(g, [&] { return done >= upto || done >= issued; });
+  void run_in() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      long long job, need_out;
+      {
+        std::unique_lock<std::mutex> g(m);
+        cv_job.wait(g, [&] { return stop || in_done < in_issued; });
+        if (in_done >= in_issued) return;
+        job = in_done + 1;
+        need_out = out_issued_at[job & 7];
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      hipError_t e = hipEventSynchronize(in_ev[job & 1]);
+      if (e != hipSuccess) fail("hipEventSynchronize(in)", e);
+      {
+        // rows the earlier calls evicted must be in the table before it is read
+        std::unique_lock<std::mutex> g(m);
+        cv_done.wait(g, [&] { return out_done >= need_out || err != 0; });
+      }
+      const auto t1 = std::chrono::steady_clock::now();
+      long long n = mail[2].count;
+      if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
+      if (n > 0 && !failed()) {
+        const float* tb = table;
+        float* st = in_host;
+        float* dv = in_stage_dev;
+        const int32_t* rows = miss_host;
+        const int64_t d = D;
+        hipStream_t cs = in_stream;
+        std::atomic<int> bad{0};
+        in_pool->parallel(n, [&, tb, st, dv, rows, d, cs](int64_t lo, int64_t hi) {
+          constexpr int64_t kPiece = 2048;          // rows per H2D copy (1 MB at D = 128)
+          constexpr int kAhead = 8;
+          for (int64_t p0 = lo; p0 < hi; p0 += kPiece) {
+            const int64_t p1 = std::min(hi, p0 + kPiece);
+            for (int64_t i = p0; i < p1; ++i) {
+              if (i + kAhead < p1) {
+                const char* q = (const char*)(tb + (size_t)rows[i + kAhead] * d);
+                for (int64_t l = 0; l < d * 4; l += 64) __builtin_prefetch(q + l);
+              }
+              memcpy(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d * 4);
+            }
+            if (hipMemcpyAsync(dv + (size_t)p0 * d, st + (size_t)p0 * d, (size_t)(p1 - p0) * d * 4,
+                               hipMemcpyHostToDevice, cs) != hipSuccess)
+              bad.store(1);
+          }
+        });
+        if (bad.load()) fail("hipMemcpyAsync(H2D)", hipGetLastError());
+      }
+      // release the cache-op stream behind the last copy; if that cannot be enqueued, release it from here
+      e = hipStreamWriteValue64(in_stream, sig, (uint64_t)job, 0);
+      if (e != hipSuccess) {
+        fail("hipStreamWriteValue64", e);
+        (void)hipStreamSynchronize(in_stream);
+        *(volatile unsigned long long*)sig = (unsigned long long)job;
+      }
+      e = hipStreamSynchronize(in_stream);           // in_host / miss_host are reused by the next job
+      if (e != hipSuccess) {
+        fail("hipStreamSynchronize(in)", e);
+        *(volatile unsigned long long*)sig = (unsigned long long)job;
+      }
+      const auto t2 = std::chrono::steady_clock::now();
+      {
+        std::lock_guard<std::mutex> g(m);
+        in_done = job;
+        in_wait_s += std::chrono::duration<double>(t1 - t0).count();
+        in_busy_s += std::chrono::duration<double>(t2 - t1).count();
+        in_rows += n;
+        in_jobs += 1;
+      }
+      cv_done.notify_all();
+    }
+  }
+  long long out_issued_at[8] = {0};      // write-back jobs that must have landed before in-job j gathers
+
+  int check() {
+    std::lock_guard<std::mutex> g(m);
     if (err) {
       set_error("%s", errmsg);
       return err;
     }
     return CE_OK;
   }
-
-  void push() {
+  int wait_out(long long upto) {       // blocks until write-back job `upto` has reached the host table
+    {
+      std::unique_lock<std::mutex> g(m);
+      cv_done.wait(g, [&] { return out_done >= upto || out_done >= out_issued; });
+    }
+    return check();
+  }
+  int wait_in(long long upto) {
+    {
+      std::unique_lock<std::mutex> g(m);
+      cv_done.wait(g, [&] { return in_done >= upto || in_done >= in_issued; });
+    }
+    return check();
+  }
+  void push_out() {
     {
       std::lock_guard<std::mutex> g(m);
-      ++issued;
+      ++out_issued;
     }
-    cv_job.notify_one();
+    cv_job.notify_all();
+  }
+  void push_in(long long need_out) {
+    {
+      std::lock_guard<std::mutex> g(m);
+      ++in_issued;
+      out_issued_at[in_issued & 7] = need_out;
+    }
+    cv_job.notify_all();
   }
 
-  ~Writeback() {
-    if (worker.joinable()) {
-      {
-        std::lock_guard<std::mutex> g(m);
-        stop = true;
-      }
-      cv_job.notify_all();
-      worker.join();
+  ~SwapEngine() {
+    {
+      std::lock_guard<std::mutex> g(m);
+      stop = true;
     }
-    delete pool;
+    cv_job.notify_all();
+    if (in_thread.joinable()) in_thread.join();
+    if (out_thread.joinable()) out_thread.join();
+    delete out_pool;
+    delete in_pool;
     for (int b = 0; b < 2; ++b) {
-      if (ev[b]) (void)hipEventDestroy(ev[b]);
+      if (out_ev[b]) (void)hipEventDestroy(out_ev[b]);
       if (rows_host[b]) (void)hipHostFree(rows_host[b]);
       if (idx_host[b]) (void)hipHostFree(idx_host[b]);
     }
+    for (int c = 0; c < kOutChunks; ++c)
+      if (chunk_ev[c]) (void)hipEventDestroy(chunk_ev[c]);
+    for (int b = 0; b < 2; ++b)
+      if (in_ev[b]) (void)hipEventDestroy(in_ev[b]);
+    if (in_host) (void)hipHostFree(in_host);
+    if (miss_host) (void)hipHostFree(miss_host);
+    if (sig) (void)hipHostFree(sig);
     if (mail) (void)hipHostFree(mail);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (out_stream) (void)hipStreamDestroy(out_stream);
+    if (in_stream) (void)hipStreamDestroy(in_stream);
   }
 };
 
@@ -1236,10 +1364,10 @@ struct ce_cache {
   int64_t list_rows;           // capacity of list_host
   int64_t buffer_rows;         // > 0: staged transfers go through at most this many staging rows at a time
   ce::RowPool* pool;           // host threads of the staged transport (created on first use)
-  ce::Writeback* wb;           // CE_TRANSPORT_WORKER state (created on first use)
-  float* stage2;               // second device staging buffer + row list + the two pending-row tables (workspace)
+  ce::SwapEngine* wb;          // CE_TRANSPORT_WORKER state (created on first use)
+  float* stage2;               // second eviction staging buffer + row list, admission staging (workspace)
   int32_t* stage_idx2;
-  unsigned long long* pend_hash[2];
+  float* in_stage;
   long long hist_base;         // seq of history[0]
   ce::PhaseProf* prof;         // optional per-phase hipEvent timers (ce_cache_set_profiling)
   long long n_failed;          // finished prepare_ids calls whose status was not CE_OK
@@ -1359,7 +1487,7 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->last_fail_seq = 0;
   h->stage2 = (float*)(h->ws + L.stage2);
   h->stage_idx2 = (int32_t*)(h->ws + L.stage_idx2);
-  for (int b = 0; b < 2; ++b) h->pend_hash[b] = (unsigned long long*)(h->ws + L.pend_hash[b]);
+  h->in_stage = (float*)(h->ws + L.in_stage);
 
   hipStream_t s = (hipStream_t)stream;
   void* ring_host = nullptr;
@@ -1384,7 +1512,6 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   // empty-cache state of A.1
   const int64_t N = cfg->num_embeddings, C = cfg->cuda_row_num;
   (void)hipMemsetAsync(h->ws, 0, L.stage_idx, s);
-  for (int b = 0; b < 2; ++b) (void)hipMemsetAsync(h->pend_hash[b], 0xff, (size_t)L.hash_entries * 8, s);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(N, 256)), dim3(256), 0, s, cfg->inverted_cached_idx, N, -1);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, cfg->cached_idx_map, C, -1);
   hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(C, 256)), dim3(256), 0, s, h->slot_epoch, C, kEpochNever);
@@ -1419,7 +1546,7 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
 extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
   (void)hipEventSynchronize(h->ev);
-  delete h->wb;          // finishes the queued write-backs, joins the worker
+  delete h->wb;          // finishes the queued jobs, joins the workers
   delete h->pool;
   delete h->prof;
   (void)hipEventDestroy(h->ev);
@@ -1465,14 +1592,21 @@ static RowPool* host_pool(ce_cache* h) {
   return h->pool;
 }
 
-// CE_TRANSPORT_WORKER state: pinned landing buffers for both staging buffers, the copy stream, the worker thread
+// CE_TRANSPORT_WORKER state: pinned landing / gather buffers, mailboxes, the two copy streams, the two workers
 static int ensure_writeback(ce_cache* h) {
   if (h->wb) return CE_OK;
   const Layout& L = h->L;
-  Writeback* w = new Writeback();
+  SwapEngine* w = new SwapEngine();
   int rc = CE_OK;
   do {
+    int can = 0;
     if (hipGetDevice(&w->device) != hipSuccess) { rc = CE_ERR_HIP; break; }
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, w->device);
+    if (!can) {
+      delete w;
+      set_error("the worker transport needs hipStreamWaitValue64, which this device does not support");
+      return CE_ERR_UNSUPPORTED;
+    }
     w->D = h->cfg.embedding_dim;
     w->stage_rows = L.stage_rows;
     w->table = h->cfg.host_weight;
@@ -1480,29 +1614,45 @@ static int ensure_writeback(ce_cache* h) {
     w->stage_dev[1] = h->stage2;
     w->idx_dev[0] = h->stage_idx;
     w->idx_dev[1] = h->stage_idx2;
-    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { rc = CE_ERR_HIP; break; }
-    void* mail = nullptr;
-    if (hipHostMalloc(&mail, sizeof(WbMail) * 2, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_HIP; break; }
-    memset(mail, 0, sizeof(WbMail) * 2);
-    w->mail = (WbMail*)mail;
-    void* md = nullptr;
-    if (hipHostGetDevicePointer(&md, mail, 0) != hipSuccess) md = mail;
-    w->mail_dev = (WbMail*)md;
+    w->in_stage_dev = h->in_stage;
+    const size_t rows_bytes = (size_t)L.stage_rows * w->D * 4, idx_bytes = (size_t)L.stage_rows * 4;
+    if (hipStreamCreateWithFlags(&w->out_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&w->in_stream, hipStreamNonBlocking) != hipSuccess) { rc = CE_ERR_HIP; break; }
+    void* p = nullptr;
+    void* pd = nullptr;
+    if (hipHostMalloc(&p, sizeof(WbMail) * 3, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    memset(p, 0, sizeof(WbMail) * 3);
+    w->mail = (WbMail*)p;
+    if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
+    w->mail_dev = (WbMail*)pd;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    memset(p, 0, 64);
+    w->sig = (unsigned long long*)p;
+    if (hipHostMalloc(&p, idx_bytes, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    w->miss_host = (int32_t*)p;
+    if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
+    w->miss_host_dev = (int32_t*)pd;
+    if (hipHostMalloc((void**)&w->in_host, rows_bytes, hipHostMallocDefault) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    if (hipEventCreateWithFlags(&w->in_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w->in_ev[1], hipEventDisableTiming) != hipSuccess) { rc = CE_ERR_HIP; break; }
     for (int b = 0; b < 2 && rc == CE_OK; ++b) {
-      if (hipEventCreateWithFlags(&w->ev[b], hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
-      else if (hipHostMalloc((void**)&w->rows_host[b], (size_t)L.stage_rows * w->D * 4, hipHostMallocDefault) !=
-               hipSuccess) rc = CE_ERR_NOMEM;
-      else if (hipHostMalloc((void**)&w->idx_host[b], (size_t)L.stage_rows * 4, hipHostMallocDefault) != hipSuccess)
-        rc = CE_ERR_NOMEM;
+      if (hipEventCreateWithFlags(&w->out_ev[b], hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
+      else if (hipHostMalloc((void**)&w->rows_host[b], rows_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
+      else if (hipHostMalloc((void**)&w->idx_host[b], idx_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
     }
+    for (int c = 0; c < SwapEngine::kOutChunks && rc == CE_OK; ++c)
+      if (hipEventCreateWithFlags(&w->chunk_ev[c], hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
     if (rc) break;
-    static const int wb_threads = [] { const char* e = getenv("CE_WB_THREADS"); return e ? atoi(e) : 8; }();
-    w->pool = new RowPool(std::max(1, std::min(wb_threads, 64)));
-    w->worker = std::thread([w] { w->run(); });
+    static const int out_threads = [] { const char* e = getenv("CE_WB_THREADS"); return e ? atoi(e) : 8; }();
+    static const int in_threads = [] { const char* e = getenv("CE_GATHER_THREADS"); return e ? atoi(e) : 8; }();
+    w->out_pool = new RowPool(std::max(1, std::min(out_threads, 64)));
+    w->in_pool = new RowPool(std::max(1, std::min(in_threads, 64)));
+    w->out_thread = std::thread([w] { w->run_out(); });
+    w->in_thread = std::thread([w] { w->run_in(); });
   } while (0);
   if (rc) {
     delete w;
-    set_error("write-back worker setup failed (pinned landing buffers / stream / events)");
+    set_error("swap worker setup failed (pinned buffers / streams / events)");
     return rc;
   }
   h->wb = w;
@@ -1531,12 +1681,12 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
     hipLaunchKernelGGL((k_admit<f32x4>), dim3(grid_for(n, (int)groups_per_block * kSwapRows)), dim3(256), 0, s, rows,
                        (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
                        (const f32x4*)c.host_weight_dev, (f32x4*)c.cache_weight, h->rowlen, h->g_log2,
-                       (const Ctl*)nullptr);
+                       (const Ctl*)nullptr, 0ll);
   else
     hipLaunchKernelGGL((k_admit<float>), dim3(grid_for(n, (int)groups_per_block * kSwapRows)), dim3(256), 0, s, rows,
                        (const int32_t*)nullptr, (const long long*)nullptr, (long long)n,
                        (const float*)c.host_weight_dev, (float*)c.cache_weight, h->rowlen, h->g_log2,
-                       (const Ctl*)nullptr);
+                       (const Ctl*)nullptr, 0ll);
   // preloaded rows must not look "protected" to the first prepare_ids: stamp them as never used
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(n, 256)), dim3(256), 0, s, rows, (const int32_t*)nullptr,
                      (const long long*)nullptr, (long long)n, c.cached_idx_map, c.inverted_cached_idx,
@@ -1629,6 +1779,21 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   const dim3 swap_block(swap_threads);
   const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, (swap_threads >> h->g_log2) * kSwapRows)));
 
+  // worker transport: job numbers / staging buffer of this call; the launch thread only waits here when a worker
+  // is two calls behind (its buffers and events are about to be reused)
+  const bool worker = c.transport == CE_TRANSPORT_WORKER;
+  long long out_job = 0, in_job = 0;
+  int wbuf = 0;
+  if (worker) {
+    rc = ensure_writeback(h);
+    if (rc) return rc;
+    out_job = h->wb->out_issued + 1;
+    in_job = h->wb->in_issued + 1;
+    wbuf = (int)(out_job & 1);
+    rc = h->wb->wait_out(out_job - 2);
+    if (rc == CE_OK) rc = h->wb->wait_in(in_job - 2);
+    if (rc) return rc;
+  }
   PhaseProf* const prof = h->prof;
   const int pslot = (int)(h->seq % kProfDepth);
   int pmark = 0;
@@ -1662,9 +1827,17 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n, h->ctl, slot);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n, h->ctl, slot,
+                     worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows);
   hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap,
-                     c.inverted_cached_idx, N, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl);
+                     c.inverted_cached_idx, N, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl,
+                     worker ? h->wb->miss_host_dev : (int32_t*)nullptr, (int)L.stage_rows);
+  if (worker) {
+    // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) while this
+    // stream selects and stages the victims; it first lets every earlier write-back land
+    CE_HIP_CHECK(hipEventRecord(h->wb->in_ev[in_job & 1], s));
+    h->wb->push_in(out_job - 1);
+  }
   CE_PHASE();
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
@@ -1684,18 +1857,6 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl);
   CE_PHASE();
-  const bool worker = c.transport == CE_TRANSPORT_WORKER;
-  // worker write-back: staging buffer / pending table of this call (alternating), and of the previous one
-  int wbuf = 0;
-  if (worker) {
-    rc = ensure_writeback(h);
-    if (rc) return rc;
-    const long long job = h->wb->issued + 1;
-    wbuf = (int)(job & 1);
-    rc = h->wb->wait(job - 2);        // the buffers of job-2 are about to be reused: only blocks a launch thread
-    if (rc) return rc;                //   that runs two cache ops ahead of the worker
-    CE_HIP_CHECK(hipMemsetAsync(h->pend_hash[wbuf], 0xff, (size_t)L.hash_entries * 8, s));
-  }
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
   int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
   if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
@@ -1703,30 +1864,26 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     // by k_evict; map clear, free-slot list, admit stay on the caller's stream
     const long long scap = (long long)L.stage_rows;
     const int sgrid = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
-    unsigned long long* const ph = worker ? h->pend_hash[wbuf] : nullptr;
-    const uint32_t pmask = (uint32_t)(L.hash_entries - 1);
     WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
-    const long long job = worker ? h->wb->issued + 1 : 0;
     if (h->vec) {
       hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
                          (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
-                         h->ctl, ph, pmask, mail, job);
+                         h->ctl, mail, out_job);
       hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
                          (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
-                         h->ctl, ph, pmask, mail, job);
+                         h->ctl, mail, out_job);
       hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
                          h->rowlen, h->g_log2, h->ctl);
     }
     if (worker) {
-      // the worker thread takes it from here: D2H of the packed block + scatter into the table, while this
-      // stream goes on with the admissions
-      CE_HIP_CHECK(hipEventRecord(h->wb->ev[wbuf], s));
-      h->wb->push();
+      // the write-back worker takes it from here: D2H of the packed block + scatter into the table
+      CE_HIP_CHECK(hipEventRecord(h->wb->out_ev[wbuf], s));
+      h->wb->push_out();
     }
     hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
                        c.cached_idx_map, c.inverted_cached_idx, (int32_t*)nullptr, h->ctl);
@@ -1741,28 +1898,44 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                      h->blk_free, h->free_list, h->ctl);
   CE_PHASE();
-  if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
-    // zero-copy: write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions
-    // busy.  worker: admission only (the write-back left through the SDMA copy above); a missed row that the
-    // previous call evicted is read from that call's staging buffer (pending-row table).
+  if (worker) {
+    // the missed rows arrive in in_stage through the admission worker's hipMemcpyAsync pieces; this stream parks in
+    // the command processor until the worker's hipStreamWriteValue64 behind the last piece has executed
+    const long long scap = (long long)L.stage_rows;
+    CE_HIP_CHECK(hipStreamWaitValue64(s, h->wb->sig, (uint64_t)in_job, hipStreamWaitValueGte, ~0ull));
+    const int ugrid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    if (h->vec) {
+      hipLaunchKernelGGL((k_unpack_admitted<f32x4>), dim3(ugrid), dim3(256), 0, s, h->free_list,
+                         (const long long*)&h->ctl->n_miss, scap, (const f32x4*)h->in_stage, (f32x4*)c.cache_weight,
+                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+      if (L.list_cap > L.stage_rows)      // more misses than the staging holds (rare): the rest is read zero-copy
+        hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
+                           (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
+                           (f32x4*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl, scap);
+    } else {
+      hipLaunchKernelGGL((k_unpack_admitted<float>), dim3(ugrid), dim3(256), 0, s, h->free_list,
+                         (const long long*)&h->ctl->n_miss, scap, (const float*)h->in_stage, (float*)c.cache_weight,
+                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+      if (L.list_cap > L.stage_rows)
+        hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
+                           (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
+                           (float*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl, scap);
+    }
+  } else if (c.transport == CE_TRANSPORT_ZEROCOPY) {
+    // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy
     const long long scap = (long long)L.stage_rows;
     static const int swap_rows = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : kSwapRows; }();
     // workgroups of the write-back part: as many as admit when the call has the GPU to itself; half as many when it
     // overlaps with training (protect_depth > 0) -- PCIe writes are what slows the kernels next to them, and fewer
     // rows leave than enter (32 + 16 workgroups: 2.11 -> 2.22 G lookups/s; 32 + 8 makes the write-back the bottleneck)
     static const int wb_env = [] { const char* e = getenv("CE_SWAP_WB_BLOCKS"); return e ? atoi(e) : 0; }();
-    const int wb_groups = worker ? 0
-                                 : (wb_env > 0 ? std::min(wb_env, cap_groups)
-                                               : (c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups));
-    const unsigned long long* const ph = worker ? h->pend_hash[wbuf ^ 1] : nullptr;
-    const uint32_t pmask = (uint32_t)(L.hash_entries - 1);
-    const float* const pstage = (wbuf ^ 1) ? h->stage2 : h->stage;
+    const int wb_groups = wb_env > 0 ? std::min(wb_env, cap_groups)
+                                     : (c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups);
 #define CE_SWAP(VT, R)                                                                                          \
   hipLaunchKernelGGL((k_swap<VT, R>), dim3(wb_groups + cap_groups), swap_block, 0, s, h->stage_idx,             \
                      (const VT*)h->stage, scap, wb_groups, h->miss_list, h->free_list,                           \
                      (const long long*)&h->ctl->n_miss,                                                          \
-                     (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl, ph,  \
-                     pmask, (const VT*)pstage)
+                     (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl)
     if (h->vec) {
       if (swap_rows == 2) CE_SWAP(f32x4, 2); else if (swap_rows == 4) CE_SWAP(f32x4, 4);
       else if (swap_rows == 8) CE_SWAP(f32x4, 8); else CE_SWAP(f32x4, 16);
@@ -1896,10 +2069,9 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
   const int64_t C = c.cuda_row_num;
   if (h->wb) {
     // queued write-backs land first (a row they carry may be resident again and is about to be written by
-    // k_flush_rows with its newer value), and no staged copy may shadow the host table afterwards
-    rc = h->wb->wait(h->wb->issued);
+    // k_flush_rows with its newer value)
+    rc = h->wb->wait_out(h->wb->out_issued);
     if (rc) return rc;
-    for (int b = 0; b < 2; ++b) CE_HIP_CHECK(hipMemsetAsync(h->pend_hash[b], 0xff, (size_t)h->L.hash_entries * 8, s));
   }
   h->seq += 1;
   const int gpb = 256 >> h->g_log2;
@@ -1936,12 +2108,11 @@ extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
                    transport == CE_TRANSPORT_WORKER), CE_ERR_INVALID, "bad transport");
   if (h->cfg.transport == transport) return CE_OK;
   if (h->wb) {
-    // leaving (or re-entering) the worker transport: everything queued reaches the table, nothing stays findable
-    // in the staging buffers.  Blocks.
-    int rc = h->wb->wait(h->wb->issued);
+    // leaving (or re-entering) the worker transport: everything queued reaches the table first.  Blocks.
+    int rc = h->wb->wait_out(h->wb->out_issued);
+    if (rc == CE_OK) rc = h->wb->wait_in(h->wb->in_issued);
     if (rc) return rc;
     CE_HIP_CHECK(hipEventSynchronize(h->ev));
-    for (int b = 0; b < 2; ++b) CE_HIP_CHECK(hipMemset(h->pend_hash[b], 0xff, (size_t)h->L.hash_entries * 8));
   }
   h->cfg.transport = transport;
   if (transport == CE_TRANSPORT_WORKER) return ensure_writeback(h);
@@ -1980,23 +2151,19 @@ extern "C" int ce_cache_phase_times(ce_cache_t* h, double* ms_out, int32_t cap, 
 extern "C" int ce_cache_writeback_wait(ce_cache_t* h) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
   if (!h->wb) return CE_OK;
-  return h->wb->wait(h->wb->issued);
+  return h->wb->wait_out(h->wb->out_issued);
 }
 
-extern "C" int ce_cache_writeback_stats(ce_cache_t* h, double* wait_s, double* copy_s, double* scatter_s,
-                                        int64_t* rows, int64_t* jobs) {
-  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
-  double a = 0, b = 0, c = 0;
-  long long r = 0, j = 0;
+extern "C" int ce_cache_swap_stats(ce_cache_t* h, double* seconds4, int64_t* counts4) {
+  CE_REQUIRE(h && seconds4 && counts4, CE_ERR_INVALID, "null argument");
+  for (int i = 0; i < 4; ++i) { seconds4[i] = 0; counts4[i] = 0; }
   if (h->wb) {
     std::lock_guard<std::mutex> g(h->wb->m);
-    a = h->wb->wait_s; b = h->wb->copy_s; c = h->wb->scatter_s; r = h->wb->rows; j = h->wb->jobs;
+    seconds4[0] = h->wb->out_wait_s; seconds4[1] = h->wb->out_busy_s;
+    seconds4[2] = h->wb->in_wait_s;  seconds4[3] = h->wb->in_busy_s;
+    counts4[0] = h->wb->out_rows; counts4[1] = h->wb->out_jobs;
+    counts4[2] = h->wb->in_rows;  counts4[3] = h->wb->in_jobs;
   }
-  if (wait_s) *wait_s = a;
-  if (copy_s) *copy_s = b;
-  if (scatter_s) *scatter_s = c;
-  if (rows) *rows = r;
-  if (jobs) *jobs = j;
   return CE_OK;
 }
 
