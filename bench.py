@@ -326,9 +326,6 @@ def main():
         win = PrefetchWindow(embed, P, overlap=True, presort=presort, transport=None)
         fwd_pipe, bwd_pipe = event_pass(ev_first + 4 * P)
         torch.cuda.synchronize()
-    excl_frac = None
-    if presort and win.keys:
-        excl_frac = sum(int(k[1].item()) for k in win.keys) / len(win.keys)
     row_b = 4 * D
     fwd_bytes = B * F * (L * (row_b + 8) + 8 + row_b)            # 1040 B/lookup at D=128, L=1
     # backward: per bag read the gradient row (4D) + offset (8), per lookup the slot (8); per UNIQUE
@@ -343,7 +340,6 @@ def main():
     bwd_roof = dict(kernel="k_bag_bwd(sgd)", bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=bwd_avg, bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
-    bwd_roof["exclusive_batches_frac"] = excl_frac     # batches whose rows never span two segments (no-atomics path)
     fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
     for r in (fwd_roof, bwd_roof):
         r["frac"] = r["achieved"] / r["peak"]
@@ -381,7 +377,8 @@ def main():
                          bytes_per_launch=swap_bytes, worker_in_busy_ms=in_busy_ms,
                          worker_out_busy_ms=1e3 * wbs["out_busy_s"] / max(1, wbs["jobs"]),
                          worker_out_GBps=wbs["rows"] * row_b / max(wbs["out_busy_s"], 1e-9) / 1e9,
-                         worker_in_wait_ms=1e3 * wbs["in_wait_s"] / wbs["in_jobs"])
+                         worker_in_wait_ms=1e3 * wbs["in_wait_s"] / wbs["in_jobs"],
+                         worker_in_gather_ms=1e3 * wbs["in_gather_s"] / wbs["in_jobs"])
     else:
         both = transport == "zerocopy"
         swap_bytes = (rows_in_t + (rows_out_t if both else 0)) * row_b / calls_t
@@ -416,11 +413,9 @@ def main():
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
                    "transport": transport, "overlap": bool(args.overlap),
                    "launch": "hipGraph per window" if use_graph else "python per step",
-                   "bwd_duplicate_fold": "slots sorted by row per 16384-lookup segment, once per window "
+                   "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "
                                          "(ce_bag_presort_window)" if presort else "1024-lookup tiles sorted inside every backward",
-                   "update": "sorted" if args.deterministic else
-                             ("plain read-modify-write for rows private to a lane group, fp32 atomics for runs cut by a "
-                              "chunk edge" if presort else "atomic"), "lr": args.lr},
+                   "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,
                   "prefill_cache_ops": prefill, "setup_s": setup_s,
@@ -632,7 +627,9 @@ def cpu_baseline(embed, gen, args, B, F, L, D):
         phys = psutil.cpu_count(logical=False) or hw
     except Exception:
         phys = hw
-    cand = sorted({min(hw, 64), min(hw, phys), hw})
+    from cachedembedding_amd import _lib
+    budget = int(_lib.lib.ce_cpu_budget())          # hardware threads capped by affinity and the cgroup CPU quota
+    cand = sorted({min(hw, 64), min(hw, phys), hw, max(1, min(hw, budget))})
     table = embed.weight                      # CPU view of the pinned [N, D] host table
     w = torch.nn.Parameter(table)             # shares memory, no 91 GB clone
     opt = torch.optim.SGD([w], lr=args.lr)
@@ -660,7 +657,8 @@ def cpu_baseline(embed, gen, args, B, F, L, D):
     return {"value": B * F * L / med, "unit": "lookups/s", "cores": best, "kind": "port",
             "sample": f"{n_timed} iterations of torch-CPU F.embedding_bag fwd+bwd(sparse)+SGD.step, B={B} F={F} L={L} "
                       f"D={D} over the full {table.shape[0]}-row host table (the bench workload's table), median per "
-                      f"thread count; host has {phys} physical cores / {hw} hw threads",
+                      f"thread count; host has {phys} physical cores / {hw} hw threads, this process may use "
+                      f"{budget} CPUs (cgroup quota)",
             "threads_swept": {str(k): B * F * L / v for k, v in sweep.items()},
             "it_per_s": 1.0 / med}
 

@@ -75,6 +75,7 @@ class CeCallStats(Structure):
 _BAG_COMMON = [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_int64]
 SIGNATURES = {
     "ce_version": (c_int, []),
+    "ce_cpu_budget": (c_int32, []),
     "ce_last_error": (c_char_p, []),
     "ce_stream_create_cu_mask": (c_int, [c_void_p, c_int32, POINTER(c_void_p)]),
     "ce_stream_destroy": (c_int, [c_void_p]),
@@ -88,7 +89,7 @@ SIGNATURES = {
     "ce_bag_backward_dense": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
                                       c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_dense_presorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
-                                      c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "ce_bag_backward_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                      c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
@@ -97,10 +98,8 @@ SIGNATURES = {
     "ce_bag_presort": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd_presorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                               c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,
-                                              c_void_p, c_void_p, c_void_p]),
-    "ce_bag_presort_window_scratch": (c_int64, [c_int64, c_int64]),
-    "ce_bag_presort_window": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
-                                      c_void_p]),
+                                              c_void_p, c_void_p]),
+    "ce_bag_presort_window": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd_sorted_workspace": (c_size_t, [c_int64, c_int64]),
     "ce_bag_backward_sgd_sorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                            c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,

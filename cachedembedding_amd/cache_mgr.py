@@ -371,10 +371,10 @@ class CachedParamMgr(torch.nn.Module):
 
     def writeback_stats(self) -> dict:
         """Worker-transport accounting: rows / jobs / seconds of the write-back (out) and admission (in) workers."""
-        sec = (ctypes.c_double * 4)()
+        sec = (ctypes.c_double * 6)()
         cnt = (ctypes.c_int64 * 4)()
         check(lib.ce_cache_swap_stats(self._handle, sec, cnt))
-        return dict(out_wait_s=sec[0], out_busy_s=sec[1], in_wait_s=sec[2], in_busy_s=sec[3],
+        return dict(out_wait_s=sec[0], out_busy_s=sec[1], in_wait_s=sec[2], in_busy_s=sec[3], in_gather_s=sec[4],
                     rows=cnt[0], jobs=cnt[1], in_rows=cnt[2], in_jobs=cnt[3])
 
     def raise_on_failed_calls(self):

@@ -93,7 +93,7 @@ class CachedEmbeddingBag(nn.Module):
 
     def forward(self, input: torch.Tensor, offsets: Optional[torch.Tensor] = None,
                 per_sample_weights: Optional[torch.Tensor] = None, shape_hook: Optional[Callable] = None,
-                *, hook_features: int = 0, presorted=None) -> torch.Tensor:
+                *, hook_features: int = 0, presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.cache_op:
             with torch.no_grad():
                 input = self.cache_weight_mgr.prepare_ids(input)

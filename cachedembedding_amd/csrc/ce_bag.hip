@@ -40,8 +40,7 @@ struct BagParams {
   int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
   uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
   int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
-  const unsigned long long* presorted;   // optional: segment-sorted keys from ce_bag_presort (no sort in the kernel)
-  const long long* excl_flag;            // optional (with presorted): device flag, != 0 = no row is shared between segments
+  const unsigned long long* presorted;   // optional: segment-grouped keys from ce_bag_presort* (no sort in the kernel)
 };
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -412,323 +411,92 @@ __device__ __forceinline__ void tile_sort_1024(KT (&key)[4], KT* lds, int tid) {
 }
 
 // The order the backward folds duplicates in does not depend on the gradient, only on the slots the cache op
-// returns -- so it is computed once per window on the cache-op stream (ce_bag_presort*), over a much wider scope
-// than a workgroup can sort inside the backward: SEGMENTS of 16384 consecutive lookups (one Criteo feature at
-// B = 16384).  Round 1 only grouped a segment approximately (buckets of row & 8191), which left a row split into
-// several runs, so every row update had to stay an fp32 atomic -- and the memory side retires those at ~1.5 TB/s,
-// 37 us of a 74 us backward.  Here the segment is SORTED by row, exactly and stably (lookup order inside a row), with
-// an LSD counting sort in LDS: 11-bit digits, per-wave counters (16 x 2049 x u16 -- wave-private, so no atomics and
-// the ranks are deterministic), lanes of a wave that hold the same digit matched with ballots.  Two passes cover
-// caches up to 4 M rows, three up to 2^31.  Between passes only the permutation (u16 lookup index) lives in LDS;
-// rows are re-fetched from the L2-resident slot array.  With equal rows adjacent, a row whose run lies inside one
-// lane group's chunk can be updated with a PLAIN read-modify-write -- provided no other segment of the batch holds the
-// row, which k_bag_excl_flags decides from the id ranges of the segments (distinct ids <-> distinct rows).
-// One workgroup of 1024 threads per segment, 16 keys per thread; wave w owns lookups [1024 w, 1024 (w + 1)).
-// Key = row << 32 | lookup-in-segment; ignored lookups (out-of-range row) and padding = all ones, sorted last.
+// returns -- so it can be computed once per window on the cache-op stream (ce_bag_presort), and over a much wider
+// scope than a workgroup can sort inside the backward: SEGMENTS of 16384 consecutive lookups (one Criteo feature
+// at B = 16384).  The scope matters because the memory side retires fp32 atomics at only ~1.5 TB/s (one 64-byte
+// line-op per ~5 ns and channel): 1024-lookup tiles leave 109 k row updates per batch, 16384-lookup segments ~55 k.
+// The backward only needs EQUAL ROWS TO BE ADJACENT, not a total order, so the segment is not sorted (a 16 k
+// bitonic network in registers / shuffles / LDS took 170 us per window, as much as it saved) but GROUPED with one
+// counting pass: bucket = row & 8191; the lanes of a wave that hold the same bucket are matched with ballots and
+// their leader reserves their places with ONE returning LDS atomic; a scan of the 8192 counters turns
+// (bucket, place) into the output position.  ~2 keys share a bucket, so a hot row's lookups end up contiguous
+// apart from the odd cold row of the same bucket.  One workgroup of 1024 threads per segment, 16 keys per thread.
+// Key = row << 32 | lookup-in-segment; ignored lookups (out-of-range row) and padding = all ones, placed last.
 constexpr int kSegLen = 16384;
 constexpr int kSegKeys = 16;          // per thread
-constexpr int kDigitBits = 11;
-constexpr int kDigits = 1 << kDigitBits;
-constexpr int kDigitsPad = kDigits + 4;       // + the "ignored" digit of the last pass (kDigits), padded
-
-__global__ __launch_bounds__(1024) void k_bag_sort_seg(const int64_t* __restrict__ indices,
-                                                      const int64_t* __restrict__ ids, int64_t nnz_per_batch,
-                                                      int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
-                                                      int npass, unsigned long long* __restrict__ keys_out,
-                                                      long long* __restrict__ seg_range) {
-  __shared__ unsigned short cnt[16][kDigitsPad];        // 64.1 KB
-  __shared__ int dbase[kDigitsPad];                     // 8 KB
-  __shared__ unsigned short perm[2][kSegLen];           // 64 KB
+#ifndef CE_SEG_BUCKETS
+#define CE_SEG_BUCKETS 8192
+#endif
+constexpr int kSegBuckets = CE_SEG_BUCKETS;
+// Window form: n_segs = n_batches * segs_per_batch; batch b owns lookups [b * nnz_per_batch, (b + 1) * nnz_per_batch)
+// and the keys [b * segs_per_batch * kSegLen, ...) -- segments never straddle two batches.
+__global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz_per_batch,
+                                                         int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
+                                                         unsigned long long* __restrict__ keys_out) {
+  __shared__ int cnt[kSegBuckets + 1];                  // [kSegBuckets] = ignored lookups
   __shared__ int wsum[16];
-  __shared__ long long rmin[16], rmax[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int64_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
     const int64_t batch = seg / segs_per_batch;
-    const int sib = (int)(seg - batch * segs_per_batch);            // segment inside the batch
+    const int sib = (int)(seg - batch * segs_per_batch);
     const int64_t in_base = batch * nnz_per_batch + (int64_t)sib * kSegLen;
-    const int64_t out_base = seg * kSegLen;
+    const int64_t base = seg * kSegLen;
     const int n_here = (int)min((int64_t)kSegLen, nnz_per_batch - (int64_t)sib * kSegLen);
-    if (ids && seg_range) {            // id range of the segment (exclusivity test)
-      long long lo = INT64_MAX, hi = INT64_MIN;
-#pragma unroll 4
-      for (int r = 0; r < kSegKeys; ++r) {
-        const int e = r * 1024 + tid;
-        if (e < n_here) {
-          const long long v = ids[in_base + e];
-          lo = v < lo ? v : lo;
-          hi = v > hi ? v : hi;
+    for (int i = tid; i <= kSegBuckets; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    unsigned long long key[kSegKeys];
+    int place[kSegKeys], bkt[kSegKeys];                  // place inside the bucket (a bucket can hold the whole segment)
+#pragma unroll
+    for (int r = 0; r < kSegKeys; ++r) {
+      // lane-interleaved ownership: lookup e = r * 1024 + tid (coalesced loads; the order inside a row's group
+      // follows the lookup order up to the atomic race between waves)
+      const int e = r * 1024 + tid;
+      key[r] = ~0ull;
+      bkt[r] = kSegBuckets;
+      if (e < n_here) {
+        const int64_t row = indices[in_base + e];
+        if ((uint64_t)row < (uint64_t)num_rows) {
+          key[r] = ((unsigned long long)row << 32) | (unsigned)e;
+          bkt[r] = (int)(row & (kSegBuckets - 1));
         }
       }
+      // wave match on the 13-bit bucket id, leader reserves popcount places
+      unsigned long long pm = ~0ull;
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        const long long a = __shfl_xor(lo, d), c = __shfl_xor(hi, d);
-        lo = a < lo ? a : lo;
-        hi = c > hi ? c : hi;
+      for (int b = 0; (1 << b) <= kSegBuckets; ++b) {
+        const unsigned long long m = __ballot((bkt[r] >> b) & 1);
+        pm &= ((bkt[r] >> b) & 1) ? m : ~m;
       }
-      if (lane == 0) { rmin[wv] = lo; rmax[wv] = hi; }
-      __syncthreads();
-      if (tid == 0) {
-        for (int k = 1; k < 16; ++k) { lo = rmin[k] < lo ? rmin[k] : lo; hi = rmax[k] > hi ? rmax[k] : hi; }
-        seg_range[2 * seg] = lo;
-        seg_range[2 * seg + 1] = hi;
-      }
-    }
-    for (int pass = 0; pass < npass; ++pass) {
-      const bool last = pass == npass - 1;
-      const int shift = pass * kDigitBits;
-      {                                                    // clear the per-wave counters (as 32-bit words)
-        uint32_t* c32 = (uint32_t*)&cnt[0][0];
-        for (int i = tid; i < 16 * kDigitsPad / 2; i += 1024) c32[i] = 0;
-      }
-      __syncthreads();
-      // per key only (place | digit << 16) stays in registers between the count and the scatter; the lookup index
-      // and the row are cheap to fetch again (LDS / L2), 64 registers of state are not (1024-thread workgroup)
-      uint32_t meta[kSegKeys];
-      auto key_of = [&](int r, int& e) -> uint32_t {
-        const int pos = wv * 1024 + r * 64 + lane;         // wave-contiguous, ascending: the sort is stable
-        e = pass == 0 ? pos : (int)perm[(pass - 1) & 1][pos];
-        uint32_t row = 0xffffffffu;
-        if (e < n_here) {
-          const int64_t r64 = indices[in_base + e];
-          if ((uint64_t)r64 < (uint64_t)num_rows) row = (uint32_t)r64;
-        }
-        return row;
-      };
-#pragma unroll
-      for (int r = 0; r < kSegKeys; ++r) {
-        int e;
-        const uint32_t row = key_of(r, e);
-        const bool ok = row != 0xffffffffu;
-        const int d = ok ? (int)((row >> shift) & (kDigits - 1)) : (last ? kDigits : 0);
-        unsigned long long pm = ~0ull;
-#pragma unroll
-        for (int b = 0; b <= kDigitBits; ++b) {
-          const unsigned long long m = __ballot((d >> b) & 1);
-          pm &= ((d >> b) & 1) ? m : ~m;
-        }
-        const int leader = __ffsll((long long)pm) - 1;
-        int first = 0;
-        if (lane == leader) {
-          first = cnt[wv][d];
-          cnt[wv][d] = (unsigned short)(first + __popcll(pm));
-        }
-        meta[r] = (uint32_t)(__shfl(first, leader) + __popcll(pm & lt)) | ((uint32_t)d << 16);
-      }
-      __syncthreads();
-      // per digit: exclusive prefix over the waves (in place), total per digit; then exclusive scan over the digits
-      int tot2[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int d = tid * 2 + q;
-        int run = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-          const int c = cnt[w][d];
-          cnt[w][d] = (unsigned short)run;
-          run += c;
-        }
-        tot2[q] = run;
-      }
-      const int sum = tot2[0] + tot2[1];
-      int inc = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-      }
-      if (lane == 63) wsum[wv] = inc;
-      __syncthreads();
-      int pre = inc - sum, total = 0;
-      for (int k = 0; k < 16; ++k) {
-        if (k < wv) pre += wsum[k];
-        total += wsum[k];
-      }
-      dbase[tid * 2] = pre;
-      dbase[tid * 2 + 1] = pre + tot2[0];
-      if (tid == 0) {                                       // the ignored digit follows every row digit
-        dbase[kDigits] = total;
-        int run = 0;
-        for (int w = 0; w < 16; ++w) {
-          const int c = cnt[w][kDigits];
-          cnt[w][kDigits] = (unsigned short)run;
-          run += c;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < kSegKeys; ++r) {
-        const int d = (int)(meta[r] >> 16);
-        const int dest = dbase[d] + (int)cnt[wv][d] + (int)(meta[r] & 0xffffu);
-        int e;
-        if (!last) {
-          const int pos = wv * 1024 + r * 64 + lane;
-          e = pass == 0 ? pos : (int)perm[(pass - 1) & 1][pos];
-          perm[pass & 1][dest] = (unsigned short)e;
-        } else {
-          const uint32_t row = key_of(r, e);
-          keys_out[out_base + dest] = row != 0xffffffffu ? (((unsigned long long)row << 32) | (unsigned)e) : ~0ull;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// flags[b] = 1 when no row can appear in two segments of batch b: the id ranges of its segments are pairwise
-// disjoint (ids map 1:1 to rows, so disjoint ids mean disjoint rows).  One wave per batch; a few dozen segments.
-__global__ __launch_bounds__(64) void k_bag_excl_flags(const long long* __restrict__ seg_range, int32_t segs_per_batch,
-                                                       long long* __restrict__ flags) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const long long* r = seg_range + 2ll * b * segs_per_batch;
-  int bad = 0;
-  for (int i = lane; i < segs_per_batch; i += 64) {
-    const long long lo = r[2 * i], hi = r[2 * i + 1];
-    if (lo > hi) continue;                                  // empty segment
-    for (int j = 0; j < segs_per_batch; ++j) {
-      if (j == i) continue;
-      const long long lo2 = r[2 * j], hi2 = r[2 * j + 1];
-      if (lo2 > hi2) continue;
-      if (!(hi < lo2 || hi2 < lo)) bad = 1;
-    }
-  }
-  if (lane == 0) flags[b] = 0;
-  const bool any_bad = __any(bad);
-  if (lane == 0) flags[b] = any_bad ? 0 : 1;
-}
-
-// Backward over exactly sorted segments (ce_bag_presort*).  A workgroup walks 1024 consecutive sorted positions
-// with no sort at all; lane groups fold runs of equal rows inside 64-position chunks, 16 gradient rows in flight.
-// A run that lies inside its chunk is the ONLY contribution to its row in this launch when the batch's exclusive
-// flag is set, so it is applied with a plain read-modify-write whose load is issued at the end of the run and
-// consumed at the end of the NEXT run (the gradient loads of that run cover its latency).  Runs cut by a chunk
-// edge (and everything when the flag is clear) use the lane-block transposed atomics of flush_chunk.
-constexpr uint32_t kNoRow = 0xffffffffu;
-
-template <typename VT, int NCH, int R>
-__global__ __launch_bounds__(256) void k_bag_bwd_grouped(BagParams p, const long long* __restrict__ excl_flag) {
-  __shared__ uint32_t rowl[kBwdTile + 2];         // [0] = row before the tile, [1 + i], [1025] = row after it
-  __shared__ int orowl[kBwdTile];                 // gradient row of the lookup behind position i
-  __shared__ float scl[kBwdTile];
-  const int tid = threadIdx.x;
-  const int G = 1 << p.g_log2;
-  const int ngroups = 256 >> p.g_log2;
-  const int grp = tid >> p.g_log2;
-  const int gl = tid & (G - 1);
-  const int rowlen = p.rowlen;
-  const int dim = rowlen * (int)(sizeof(VT) / 4);
-  const VT* __restrict__ GO = (const VT*)p.grad_out;
-  const int ntiles = (int)(((p.nnz + kSegLen - 1) / kSegLen) * (kSegLen / kBwdTile));
-  const bool excl = excl_flag && *excl_flag != 0;
-  constexpr int kChunk = 64;
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t t0 = (int64_t)tile * kBwdTile;
-    const int seg_base = (int)((t0 / kSegLen) * kSegLen);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = tid * 4 + r;
-      const unsigned long long sk = p.presorted[t0 + i];
-      uint32_t row = kNoRow;
-      int orow = 0;
-      float sc = 0.f;
-      if (sk != ~0ull) {
-        row = (uint32_t)(sk >> 32);
-        const int j = seg_base + (int)(uint32_t)sk;
-        const int bag = find_bag(p, j);
-        sc = p.alpha;
-        if (p.psw) sc *= p.psw[j];
-        if (p.mode == CE_MODE_MEAN) {
-          const int len = bag_end(p, bag) - ld_off(p, bag);
-          if (len > 1) sc = sc / (float)len;
-        }
-        orow = (int)out_row(p, bag);
-      }
-      rowl[1 + i] = row;
-      orowl[i] = orow;
-      scl[i] = sc;
-    }
-    if (tid == 0) {
-      unsigned long long sk = ~0ull;
-      if (t0 % kSegLen != 0) sk = p.presorted[t0 - 1];
-      rowl[0] = sk != ~0ull ? (uint32_t)(sk >> 32) : kNoRow;
-    } else if (tid == 64) {
-      unsigned long long sk = ~0ull;
-      if ((t0 + kBwdTile) % kSegLen != 0) sk = p.presorted[t0 + kBwdTile];
-      rowl[kBwdTile + 1] = sk != ~0ull ? (uint32_t)(sk >> 32) : kNoRow;
+      const int leader = __ffsll((long long)pm) - 1;
+      int first = 0;
+      if (lane == leader) first = atomicAdd(&cnt[bkt[r]], __popcll(pm));
+      place[r] = __shfl(first, leader) + __popcll(pm & lt);
     }
     __syncthreads();
-    for (int ck = grp; ck < kBwdTile / kChunk; ck += ngroups) {
-      const int s0 = ck * kChunk, s1 = s0 + kChunk;
-      VT acc[NCH], pend_acc[NCH], pend_val[NCH];
+    // exclusive scan of the 4097 counters (thread t owns 4t..4t+3; the ignored bucket follows everything)
+    constexpr int kPer = kSegBuckets / 1024;
+    int c4[kPer], sum = 0;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
-      VT* pend_ptr = nullptr;
-      uint32_t cur = rowl[1 + s0];
-      // a run is private to this lane group unless the chunk edge cuts it
-      bool priv = excl && rowl[s0] != cur;
-      auto finish = [&]() {
-        if (pend_ptr) {
+    for (int q = 0; q < kPer; ++q) { c4[q] = cnt[tid * kPer + q]; sum += c4[q]; }
+    int inc = sum;
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int ch = gl + c * G;
-            if (ch < rowlen) pend_ptr[ch] = pend_val[c] + pend_acc[c];
-          }
-          pend_ptr = nullptr;
-        }
-      };
-      auto flush = [&](bool is_priv) {
-        if (cur == kNoRow) return;
-        if (is_priv) {
-          finish();
-          pend_ptr = (VT*)(p.dst + (int64_t)cur * dim);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int ch = gl + c * G;
-            pend_acc[c] = acc[c];
-            pend_val[c] = vzero<VT>();
-            if (ch < rowlen) pend_val[c] = pend_ptr[ch];
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, 0);
-        }
-      };
-      for (int q = s0; q < s1; q += R) {
-        VT v[R][NCH];
-        float sc[R];
-        uint32_t rw[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-          rw[t] = rowl[1 + q + t];
-          const bool on = rw[t] != kNoRow;
-          sc[t] = scl[q + t];
-          const int64_t orow = orowl[q + t];
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int ch = gl + c * G;
-            v[t][c] = vzero<VT>();
-            if (on && ch < rowlen) v[t][c] = __builtin_nontemporal_load(&GO[orow * rowlen + ch]);
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-          if (rw[t] != kNoRow) {            // group-uniform; ignored lookups are sorted last
-            if (rw[t] != cur) {
-              flush(priv);
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
-              cur = rw[t];
-              priv = excl;
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * sc[t];
-          }
-        }
-      }
-      flush(priv && rowl[1 + s1] != cur);
-      finish();
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
     }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int pre = inc - sum;
+    for (int k = 0; k < wv; ++k) pre += wsum[k];
+    int total = 0;
+    for (int k = 0; k < 16; ++k) total += wsum[k];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) { cnt[tid * kPer + q] = pre; pre += c4[q]; }
+    if (tid == 0) cnt[kSegBuckets] = total;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSegKeys; ++r) keys_out[base + cnt[bkt[r]] + place[r]] = key[r];
     __syncthreads();
   }
 }
@@ -751,13 +519,16 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   // tile_len <= kBwdTile is chosen by the launcher so that the tile count is a multiple of the CU count
   // (425,984 lookups -> 512 tiles of 832: two per CU, instead of 416 tiles = 1 or 2 per CU)
   const int tile_len = p.tile_len;
-  const int ntiles = (int)((p.nnz + tile_len - 1) / tile_len);
+  // presorted: the tiles are 1024 consecutive SORTED positions of the segment-padded key array
+  const int ntiles = p.presorted ? (int)(((p.nnz + kSegLen - 1) / kSegLen) * (kSegLen / kBwdTile))
+                                 : (int)((p.nnz + tile_len - 1) / tile_len);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int j0 = tile * tile_len;
-    const int nv = min(tile_len, (int)(p.nnz - j0));
+    const int nv = p.presorted ? kBwdTile : min(tile_len, (int)(p.nnz - j0));
     // ---- a. keys, bag and scale of every lookup of the tile (out-of-range rows become invalid keys);
     //         thread t owns lookups 4t..4t+3 of the tile
+    const bool presorted = p.presorted != nullptr;
     KT kr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -765,7 +536,14 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       kr[r] = K::invalid();
       int j = j0 + i;                                          // the lookup behind position i
       uint32_t row = 0xffffffffu;
-      if (i < nv) {
+      if (presorted) {
+        const unsigned long long sk = p.presorted[(int64_t)tile * kBwdTile + i];
+        j = -1;
+        if (sk != ~0ull) {
+          row = (uint32_t)(sk >> 32);
+          j = (int)(((int64_t)tile * kBwdTile / kSegLen) * kSegLen) + (int)(uint32_t)sk;
+        }
+      } else if (i < nv) {
         const int64_t r64 = p.indices[j];
         if ((uint64_t)r64 < (uint64_t)p.num_rows) row = (uint32_t)r64;
       } else {
@@ -786,7 +564,14 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
     }
     if (p.debug == 3) { __syncthreads(); continue; }
     // ---- b. sort (row major, lookup minor) -> runs are in lookup order, invalid keys last
-    tile_sort_1024<KT>(kr, keys, tid);
+    //         (skipped when the cache op already sorted this tile: ce_bag_presort)
+    if (presorted) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) keys[tid * 4 + r] = kr[r];
+      __syncthreads();
+    } else {
+      tile_sort_1024<KT>(kr, keys, tid);
+    }
     // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, R gradient rows in flight,
     // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated n
     // times in the tile costs n/kChunk+1 atomics instead of n.
@@ -932,29 +717,15 @@ static int bag_grid(int64_t num_bags) {
   return grid_for(tiles, 4);
 }
 
-// grad accumulation / fused SGD by target row: sorted segments (ce_bag_presort*) -> k_bag_bwd_grouped, else the
-// kernel that sorts 1024-lookup tiles itself
+// grad accumulation / fused SGD by target row: grouped segments (ce_bag_presort*) are walked as they are, otherwise
+// the kernel sorts 1024-lookup tiles itself
 static int launch_bwd_scatter(const BagParams& p, bool vec, int nch, hipStream_t s) {
   BagParams q = p;
   const char* dbg = getenv("CE_BWD_DEBUG");
   q.debug = dbg ? atoi(dbg) : 0;
   q.tile_len = kBwdTile;      // (a CU-multiple tile count, 512 x 832, measured no better: 0.105 -> 0.108 ms)
   static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
-  if (p.presorted) {
-    const int ntiles = (int)(cdiv(p.nnz, kSegLen) * (kSegLen / kBwdTile));
-    dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
-#define CE_BWG(VT, N, R) hipLaunchKernelGGL((k_bag_bwd_grouped<VT, N, R>), grid, block, 0, s, q, p.excl_flag)
-    if (vec) {
-      if (nch == 1) { if (r_env == 8) CE_BWG(f32x4, 1, 8); else CE_BWG(f32x4, 1, 16); }
-      else if (nch == 2) CE_BWG(f32x4, 2, 4); else CE_BWG(f32x4, 4, 2);
-    } else {
-      if (nch == 1) CE_BWG(float, 1, 8); else if (nch == 2) CE_BWG(float, 2, 4); else CE_BWG(float, 4, 2);
-    }
-#undef CE_BWG
-    CE_LAUNCH_CHECK();
-    return CE_OK;
-  }
-  const int ntiles = (int)cdiv(p.nnz, kBwdTile);
+  const int ntiles = p.presorted ? (int)(cdiv(p.nnz, kSegLen) * (kSegLen / kBwdTile)) : (int)cdiv(p.nnz, kBwdTile);
   dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
   const bool k32 = q.num_rows <= (1u << 22) - 2;
 #define CE_BWT(VT, N, R)                                                                              \
@@ -1033,7 +804,7 @@ static int backward_dense_impl(float* grad_weight, int64_t num_rows, int32_t dim
                                const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                                int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                int64_t hook_features, const float* grad_out, const unsigned long long* presorted,
-                               const int64_t* excl_flag, ce_stream_t stream) {
+                               ce_stream_t stream) {
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(grad_weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -1048,7 +819,6 @@ static int backward_dense_impl(float* grad_weight, int64_t num_rows, int32_t dim
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
   p.num_rows = (uint32_t)num_rows;
   p.presorted = presorted;
-  p.excl_flag = (const long long*)excl_flag;
   return launch_bwd_scatter(p, vec, nch, (hipStream_t)stream);
 }
 
@@ -1058,8 +828,7 @@ extern "C" int ce_bag_backward_dense(float* grad_weight, int64_t num_rows, int32
                                      const float* per_sample_weights, int32_t mode, int64_t hook_features,
                                      const float* grad_out, ce_stream_t stream) {
   return backward_dense_impl(grad_weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
-                             include_last_offset, per_sample_weights, mode, hook_features, grad_out, nullptr, nullptr,
-                             stream);
+                             include_last_offset, per_sample_weights, mode, hook_features, grad_out, nullptr, stream);
 }
 
 extern "C" int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_t dim,
@@ -1067,20 +836,18 @@ extern "C" int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_r
                                                int32_t offsets_are_i64, int64_t num_bags,
                                                int32_t include_last_offset, const float* per_sample_weights,
                                                int32_t mode, int64_t hook_features, const float* grad_out,
-                                               const uint64_t* presorted_keys, const int64_t* exclusive_flag,
-                                               ce_stream_t stream) {
+                                               const uint64_t* presorted_keys, ce_stream_t stream) {
   CE_REQUIRE(presorted_keys, CE_ERR_INVALID, "null presorted_keys");
   return backward_dense_impl(grad_weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
                              include_last_offset, per_sample_weights, mode, hook_features, grad_out,
-                             (const unsigned long long*)presorted_keys, exclusive_flag, stream);
+                             (const unsigned long long*)presorted_keys, stream);
 }
 
 static int backward_sgd_impl(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
                              const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                              int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                              int64_t hook_features, const float* grad_out, float lr,
-                             const unsigned long long* presorted, const int64_t* excl_flag,
-                             ce_stream_t stream) {
+                             const unsigned long long* presorted, ce_stream_t stream) {
   if (num_bags == 0 || nnz == 0) return CE_OK;
   CE_REQUIRE(weight && grad_out && offsets && indices, CE_ERR_INVALID, "null pointer");
   BagParams p{};
@@ -1095,7 +862,6 @@ static int backward_sgd_impl(float* weight, int64_t num_rows, int32_t dim, const
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
   p.num_rows = (uint32_t)num_rows;
   p.presorted = presorted;
-  p.excl_flag = (const long long*)excl_flag;
   return launch_bwd_scatter(p, vec, nch, (hipStream_t)stream);
 }
 
@@ -1104,8 +870,7 @@ extern "C" int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
                                    int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                    int64_t hook_features, const float* grad_out, float lr, ce_stream_t stream) {
   return backward_sgd_impl(weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
-                           include_last_offset, per_sample_weights, mode, hook_features, grad_out, lr, nullptr, nullptr,
-                           stream);
+                           include_last_offset, per_sample_weights, mode, hook_features, grad_out, lr, nullptr, stream);
 }
 
 extern "C" int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices,
@@ -1113,60 +878,34 @@ extern "C" int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, in
                                              int64_t num_bags, int32_t include_last_offset,
                                              const float* per_sample_weights, int32_t mode, int64_t hook_features,
                                              const float* grad_out, float lr, const uint64_t* presorted_keys,
-                                             const int64_t* exclusive_flag, ce_stream_t stream) {
+                                             ce_stream_t stream) {
   CE_REQUIRE(presorted_keys, CE_ERR_INVALID, "null presorted_keys");
   return backward_sgd_impl(weight, num_rows, dim, indices, nnz, offsets, offsets_are_i64, num_bags,
                            include_last_offset, per_sample_weights, mode, hook_features, grad_out, lr,
-                           (const unsigned long long*)presorted_keys, exclusive_flag, stream);
+                           (const unsigned long long*)presorted_keys, stream);
 }
 
 extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }
 
-static int sort_passes(int64_t num_rows) {
-  int bits = 1;
-  while ((1ll << bits) < num_rows) ++bits;
-  return std::max(1, (bits + kDigitBits - 1) / kDigitBits);
-}
-
-extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out,
-                              ce_stream_t stream) {
-  if (nnz == 0) return CE_OK;
-  CE_REQUIRE(indices && keys_out && nnz > 0 && nnz < (int64_t)INT32_MAX - kSegLen, CE_ERR_INVALID, "bad arguments");
-  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
-  const int nseg = (int)cdiv(nnz, kSegLen);
-  hipLaunchKernelGGL(k_bag_sort_seg, dim3(std::min(nseg, kMaxBlocks)), dim3(1024), 0, (hipStream_t)stream, indices,
-                     (const int64_t*)nullptr, nnz, nseg, (int64_t)nseg, (uint32_t)num_rows, sort_passes(num_rows),
-                     (unsigned long long*)keys_out, (long long*)nullptr);
-  CE_LAUNCH_CHECK();
-  return CE_OK;
-}
-
-extern "C" int64_t ce_bag_presort_window_scratch(int64_t nnz_per_batch, int64_t n_batches) {
-  if (nnz_per_batch <= 0 || n_batches <= 0) return 0;
-  return 2 * n_batches * cdiv(nnz_per_batch, kSegLen);
-}
-
-extern "C" int ce_bag_presort_window(const int64_t* indices, const int64_t* ids, int64_t nnz_per_batch,
-                                     int64_t n_batches, int64_t num_rows, uint64_t* keys_out,
-                                     int64_t* exclusive_flags, int64_t* scratch, ce_stream_t stream) {
+extern "C" int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
+                                     int64_t num_rows, uint64_t* keys_out, ce_stream_t stream) {
   if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
   CE_REQUIRE(indices && keys_out && nnz_per_batch > 0 && n_batches > 0, CE_ERR_INVALID, "bad arguments");
   CE_REQUIRE(nnz_per_batch < (int64_t)INT32_MAX - kSegLen, CE_ERR_INVALID, "batch too large");
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
-  CE_REQUIRE(!exclusive_flags || (ids && scratch), CE_ERR_INVALID, "exclusive_flags needs ids and scratch");
   const int64_t spb = cdiv(nnz_per_batch, kSegLen);
   const int64_t nseg = spb * n_batches;
   CE_REQUIRE(spb < (int64_t)INT32_MAX && nseg < (int64_t)INT32_MAX, CE_ERR_INVALID, "too many segments");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bag_sort_seg, dim3((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), dim3(1024), 0, s, indices,
-                     exclusive_flags ? ids : (const int64_t*)nullptr, nnz_per_batch, (int32_t)spb, nseg,
-                     (uint32_t)num_rows, sort_passes(num_rows), (unsigned long long*)keys_out,
-                     exclusive_flags ? (long long*)scratch : (long long*)nullptr);
-  if (exclusive_flags)
-    hipLaunchKernelGGL(k_bag_excl_flags, dim3((unsigned)n_batches), dim3(64), 0, s, (const long long*)scratch,
-                       (int32_t)spb, (long long*)exclusive_flags);
+  hipLaunchKernelGGL(k_bag_presort_seg, dim3((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), dim3(1024), 0,
+                     (hipStream_t)stream, indices, nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows,
+                     (unsigned long long*)keys_out);
   CE_LAUNCH_CHECK();
   return CE_OK;
+}
+
+extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out,
+                              ce_stream_t stream) {
+  return ce_bag_presort_window(indices, nnz, 1, num_rows, keys_out, stream);
 }
 
 extern "C" int ce_rows_axpy(float* weight, int64_t num_rows, int32_t dim, const int64_t* index, int64_t n,

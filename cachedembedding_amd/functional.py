@@ -87,11 +87,10 @@ class _BagFn(torch.autograd.Function):
                                                          mode, hook_features, ptr(grad_out), float(fused.lr),
                                                          ptr(ws), ws.numel(), stream_ptr()))
                 elif ctx.presorted is not None:
-                    keys, flag = ctx.presorted
                     check(lib.ce_bag_backward_sgd_presorted(ptr(weight), weight.shape[0], dim, ptr(indices), nnz,
                                                             ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
                                                             mode, hook_features, ptr(grad_out), float(fused.lr),
-                                                            ptr(keys), ptr(flag), stream_ptr()))
+                                                            ptr(ctx.presorted), stream_ptr()))
                 else:
                     check(lib.ce_bag_backward_sgd(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets),
                                                   off64, num_bags, int(include_last), ptr(psw), mode, hook_features,
@@ -104,10 +103,9 @@ class _BagFn(torch.autograd.Function):
         else:
             gw = torch.zeros_like(weight)
             if ctx.presorted is not None:
-                keys, flag = ctx.presorted
                 check(lib.ce_bag_backward_dense_presorted(ptr(gw), weight.shape[0], dim, ptr(indices), nnz,
                                                           ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
-                                                          mode, hook_features, ptr(grad_out), ptr(keys), ptr(flag),
+                                                          mode, hook_features, ptr(grad_out), ptr(ctx.presorted),
                                                           stream_ptr()))
             else:
                 check(lib.ce_bag_backward_dense(ptr(gw), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
@@ -139,7 +137,7 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   mode: str = "mean", sparse: bool = False, per_sample_weights: Optional[torch.Tensor] = None,
                   include_last_offset: bool = False, padding_idx: Optional[int] = None, *,
                   hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None,
-                  presorted=None) -> torch.Tensor:
+                  presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
     if max_norm is not None:
         raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
     if scale_grad_by_freq:
@@ -159,13 +157,8 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
     if presorted is not None:
-        # keys from presort_slots / presort_window, optionally with the batch's exclusive flag (a 1-element int64
-        # view: rows private to one segment are then updated without atomics)
-        keys, flag = presorted if isinstance(presorted, (tuple, list)) else (presorted, None)
-        assert keys.is_cuda and keys.dtype == torch.int64 and keys.is_contiguous() and \
-            keys.numel() == lib.ce_bag_presort_len(indices.numel()), "presorted must come from presort_slots"
-        assert flag is None or (flag.is_cuda and flag.dtype == torch.int64 and flag.numel() == 1)
-        presorted = (keys, flag)
+        assert presorted.is_cuda and presorted.dtype == torch.int64 and presorted.is_contiguous() and \
+            presorted.numel() == lib.ce_bag_presort_len(indices.numel()), "presorted must come from presort_slots"
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
                         int(hook_features), bool(sparse), fused_sgd, presorted)
 
@@ -187,30 +180,15 @@ def presort_slots(slots: torch.Tensor, num_rows: int, out: Optional[torch.Tensor
     return out
 
 
-def presort_window(slots: torch.Tensor, num_rows: int, ids: Optional[torch.Tensor] = None,
-                   keys_out: Optional[torch.Tensor] = None, flags_out: Optional[torch.Tensor] = None):
-    """Sorted keys for the P equal-sized batches of a prefetch window in one launch (ce_bag_presort_window).
-
-    slots: [P, n] int64 (the cache op's output); ids: the window's ids in the same layout -- when given, the per-batch
-    exclusive flags are computed too (int64[P]; 1 = no row of the batch appears in two 16384-lookup segments, so the
-    fused backward may update rows private to a lane group without atomics).  Returns (keys [P, presort_len(n)],
-    flags or None)."""
+def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Grouped keys for the P equal-sized batches of a prefetch window in one launch (ce_bag_presort_window).
+    slots: [P, n] int64 (the cache op's output) -> keys [P, presort_len(n)]; row b is what
+    embedding_bag(presorted=...) takes for batch b."""
     assert slots.dim() == 2 and slots.is_contiguous() and slots.dtype == torch.int64
     P, n = slots.shape
     klen = presort_len(n)
     if keys_out is None:
         keys_out = torch.empty(P, klen, dtype=torch.int64, device=slots.device)
     assert keys_out.is_contiguous() and keys_out.numel() == P * klen and keys_out.dtype == torch.int64
-    scratch = None
-    if ids is not None:
-        ids = ids.reshape(P, n)
-        assert ids.is_contiguous() and ids.dtype == torch.int64 and ids.device == slots.device
-        if flags_out is None:
-            flags_out = torch.zeros(P, dtype=torch.int64, device=slots.device)
-        assert flags_out.is_contiguous() and flags_out.numel() == P and flags_out.dtype == torch.int64
-        scratch = torch.empty(int(lib.ce_bag_presort_window_scratch(n, P)), dtype=torch.int64, device=slots.device)
-    else:
-        flags_out = None
-    check(lib.ce_bag_presort_window(ptr(slots), ptr(ids), n, P, int(num_rows), ptr(keys_out), ptr(flags_out),
-                                    ptr(scratch), stream_ptr()))
-    return keys_out.view(P, klen), flags_out
+    check(lib.ce_bag_presort_window(ptr(slots), n, P, int(num_rows), ptr(keys_out), stream_ptr()))
+    return keys_out.view(P, klen)

@@ -262,14 +262,9 @@ class HipShardOps(ShardOps):
                                             counts[b].data_ptr(), sp))
             # the fold of the batch's gradients (grad_rows) groups lookups by `pos`: do the grouping here, once,
             # on the planning stream (any pos < n is a valid row of the [n_u, D] gradient buffer)
-            # (sorted per 16384-lookup segment; the exclusive flag -- no unique row in two segments -- lets the fold
-            # write rows private to a lane group without atomics)
             keys = torch.empty(lib.ce_bag_presort_len(n), dtype=torch.int64, device=dev)
-            flag = torch.zeros(1, dtype=torch.int64, device=dev)
-            scratch = torch.empty(int(lib.ce_bag_presort_window_scratch(n, 1)), dtype=torch.int64, device=dev)
-            check(lib.ce_bag_presort_window(ptr(pos), ptr(ids), n, 1, max(n, 1), ptr(keys), ptr(flag), ptr(scratch),
-                                            sp))
-            staged.append((rows, pos, (keys, flag)))
+            check(lib.ce_bag_presort(ptr(pos), n, max(n, 1), ptr(keys), sp))
+            staged.append((rows, pos, keys))
         return ("hip", staged, counts)
 
     def bucketize_counts(self, token):
@@ -319,8 +314,7 @@ class HipShardOps(ShardOps):
             check(lib.ce_bag_backward_dense_presorted(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
                                                       int(offsets.dtype == torch.int64), num_bags, int(include_last),
                                                       ptr(psw), _MODES[mode], hook_features,
-                                                      ptr(grad_out.contiguous()), ptr(keys[0]), ptr(keys[1]),
-                                                      stream_ptr()))
+                                                      ptr(grad_out.contiguous()), ptr(keys), stream_ptr()))
         else:
             check(lib.ce_bag_backward_dense(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
                                             int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
@@ -633,8 +627,7 @@ class ShardedWindowPipeline:
         cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
         cur.wait_event(ev)
         for p in plans:
-            ks = p.keys if isinstance(p.keys, (tuple, list)) else (p.keys,)
-            for t in (p.perm, p.recv_rows, p.slots, *ks):
+            for t in (p.perm, p.recv_rows, p.slots, p.keys):
                 if t is not None and t.is_cuda:
                     t.record_stream(cur)
         return plans

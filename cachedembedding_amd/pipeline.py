@@ -71,16 +71,12 @@ class PrefetchWindow:
         parts = list(torch.split(slots, counts))
         self._keys_tmp = None
         if self.presort:
-            # per batch: (sorted keys, exclusive flag) -- what embedding_bag(presorted=...) takes
             C = self.mgr.cuda_row_num
             if len(set(counts)) == 1:                           # equal batches: one launch for the window
-                keys, flags = presort_window(slots.view(len(counts), counts[0]), C, ids=cat.view(len(counts), -1))
-                self._keys_tmp = [(keys[i], flags[i:i + 1]) for i in range(len(counts))]
+                keys = presort_window(slots.view(len(counts), counts[0]), C)
+                self._keys_tmp = [keys[i] for i in range(len(counts))]
             else:
-                self._keys_tmp = []
-                for p_, v in zip(parts, values):
-                    keys, flags = presort_window(p_.view(1, -1), C, ids=v.reshape(1, -1).contiguous())
-                    self._keys_tmp.append((keys[0], flags[0:1]))
+                self._keys_tmp = [presort_window(p_.view(1, -1), C)[0] for p_ in parts]
         return parts
 
     def prepare(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -117,8 +113,7 @@ class PrefetchWindow:
         for s in slots:
             s.record_stream(cur)
         for k in keys or []:
-            k[0].record_stream(cur)
-            k[1].record_stream(cur)
+            k.record_stream(cur)
         self.keys = keys
         return slots
 
@@ -144,13 +139,12 @@ class GraphedWindow:
         self.overlap = overlap
         dev = self.mgr.device
         self._bufs = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
-        # presort=True: step_fn(slots_i, i, (keys_i, exclusive_flag_i)); the segment-sorted keys of the window
-        # (ce_bag_presort_window) are produced behind the cache op into static buffers next to the slots
+        # presort=True: step_fn(slots_i, i, keys_i); the segment-grouped keys of the window (ce_bag_presort_window)
+        # are produced behind the cache op into a static buffer next to the slots
         self.presort = presort
         self._klen = presort_len(self.n)
         self._keys = [torch.full((self.P, self._klen), -1, dtype=torch.int64, device=dev) for _ in range(2)] \
             if self.presort else None
-        self._flags = [torch.zeros(self.P, dtype=torch.int64, device=dev) for _ in range(2)] if self.presort else None
         self._side = make_side_stream(dev, cache_cus) if overlap else None
         self._events = [None, None]
         self._step_fn = step_fn
@@ -165,9 +159,8 @@ class GraphedWindow:
             self.mgr.prepare_ids(wcat, out=self._bufs[0])
             self._bufs[1].copy_(self._bufs[0])
             if self.presort:
-                self._presort(0, wcat)
+                self._presort(0)
                 self._keys[1].copy_(self._keys[0])
-                self._flags[1].copy_(self._flags[0])
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -185,14 +178,13 @@ class GraphedWindow:
 
     def _call(self, step_fn, buf: int, i: int) -> None:
         if self.presort:
-            step_fn(self._bufs[buf][i], i, (self._keys[buf][i], self._flags[buf][i:i + 1]))
+            step_fn(self._bufs[buf][i], i, self._keys[buf][i])
         else:
             step_fn(self._bufs[buf][i], i)
 
-    def _presort(self, buf: int, ids: torch.Tensor) -> None:
-        # one launch for the window: every batch's segments sorted by row + its exclusive flag (from the ids)
-        presort_window(self._bufs[buf], self.mgr.cuda_row_num, ids=ids.view(self.P, self.n),
-                       keys_out=self._keys[buf], flags_out=self._flags[buf])
+    def _presort(self, buf: int) -> None:
+        # one launch for the window: every batch's 16384-lookup segments grouped by row
+        presort_window(self._bufs[buf], self.mgr.cuda_row_num, keys_out=self._keys[buf])
 
     @torch.no_grad()
     def submit(self, values: Sequence[torch.Tensor], buf: int) -> None:
@@ -207,7 +199,7 @@ class GraphedWindow:
             with torch.cuda.stream(self._side):
                 self.mgr.prepare_ids(cat, out=self._bufs[buf])
                 if self.presort:
-                    self._presort(buf, cat)
+                    self._presort(buf)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             cat.record_stream(self._side)
@@ -215,7 +207,7 @@ class GraphedWindow:
         else:
             self.mgr.prepare_ids(cat, out=self._bufs[buf])
             if self.presort:
-                self._presort(buf, cat)
+                self._presort(buf)
             self._events[buf] = None
 
     def run_steps(self, buf: int, first: int, last: int) -> None:

@@ -63,6 +63,9 @@ typedef void* ce_stream_t; /* hipStream_t */
 typedef struct ce_cache ce_cache_t;
 
 int ce_version(void);
+/* CPUs this process may use: hardware threads capped by the affinity mask and the cgroup CPU quota (what the
+ * library sizes its helper-thread pools against). */
+int32_t ce_cpu_budget(void);
 const char* ce_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -137,39 +140,31 @@ int ce_bag_backward_sgd(float* weight, int64_t num_rows, int32_t dim,
 
 /* The (row, lookup) order the backward folds duplicates in depends only on the slots, so it is computed ahead of
  * the backward, once per prefetch window on the cache-op stream right after ce_cache_prepare_ids, and over a wider
- * scope than a workgroup can sort on the fly: every SEGMENT of 16384 consecutive lookups is sorted by row, exactly
- * and stably (LSD counting sort in LDS), into keys (row << 32 | lookup-in-segment, all-ones = ignored / padding,
- * sorted last).  ce_bag_presort handles one batch: keys_out is device uint64[ce_bag_presort_len(nnz)] (nnz rounded
- * up to whole segments).  ce_bag_presort_window handles the n_batches equal-sized batches of a window in ONE
- * launch (indices = the window's slots, batch b at [b * nnz_per_batch, (b + 1) * nnz_per_batch); keys of batch b
- * at keys_out + b * ce_bag_presort_len(nnz_per_batch)) and, when exclusive_flags != NULL, also decides per batch
- * whether a row can appear in two different segments of the batch: flags[b] = 1 when the id ranges of the
- * batch's segments (`ids` = the window's ids, same layout as indices) are pairwise disjoint -- true for the
- * feature-major KJT batches of the reference (recsys/datasets/criteo.py:127-134) whenever a segment does not
- * straddle the ids of one table.  scratch: device int64[ce_bag_presort_window_scratch(...)].
+ * scope than a workgroup can sort on the fly: every SEGMENT of 16384 consecutive lookups is grouped by row (one
+ * counting pass in LDS) into keys (row << 32 | lookup-in-segment, all-ones = ignored / padding, placed last).
+ * ce_bag_presort handles one batch: keys_out is device uint64[ce_bag_presort_len(nnz)] (nnz rounded up to whole
+ * segments).  ce_bag_presort_window handles the n_batches equal-sized batches of a window in ONE launch (indices =
+ * the window's slots, batch b at [b * nnz_per_batch, (b + 1) * nnz_per_batch); keys of batch b at keys_out +
+ * b * ce_bag_presort_len(nnz_per_batch); a segment never straddles two batches).
  * The *_presorted backward entry points consume the keys: same result as the unsorted forms up to fp32 summation
- * order.  With exclusive_flag (device int64, NULL = treat as 0) set, rows whose run lies inside one lane group's
- * 64-position chunk are updated with a plain read-modify-write instead of fp32 atomics. */
+ * order, about half the atomic row updates. */
 int64_t ce_bag_presort_len(int64_t nnz);
 int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out, ce_stream_t stream);
-int64_t ce_bag_presort_window_scratch(int64_t nnz_per_batch, int64_t n_batches);
-int ce_bag_presort_window(const int64_t* indices, const int64_t* ids, int64_t nnz_per_batch, int64_t n_batches,
-                          int64_t num_rows, uint64_t* keys_out, int64_t* exclusive_flags, int64_t* scratch,
-                          ce_stream_t stream);
+int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                          uint64_t* keys_out, ce_stream_t stream);
 int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, int32_t dim,
                                   const int64_t* indices, int64_t nnz,
                                   const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                                   int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                   int64_t hook_features, const float* grad_out, float lr,
-                                  const uint64_t* presorted_keys, const int64_t* exclusive_flag, ce_stream_t stream);
+                                  const uint64_t* presorted_keys, ce_stream_t stream);
 /* the same for the plain accumulation (ce_bag_backward_dense): grad_weight += folded gradients */
 int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_t dim,
                                     const int64_t* indices, int64_t nnz,
                                     const void* offsets, int32_t offsets_are_i64, int64_t num_bags,
                                     int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                     int64_t hook_features, const float* grad_out,
-                                    const uint64_t* presorted_keys, const int64_t* exclusive_flag,
-                                    ce_stream_t stream);
+                                    const uint64_t* presorted_keys, ce_stream_t stream);
 
 /* Deterministic variant of the fused update: lookups are stably radix-sorted by target row
  * (workspace from ce_bag_backward_sgd_sorted_workspace), each row's gradients are summed in
@@ -287,10 +282,10 @@ int ce_cache_phase_times(ce_cache_t* h, double* ms_out, int32_t cap, int64_t* ca
  * this call or after ce_cache_flush).  No-op for the other transports. */
 int ce_cache_writeback_wait(ce_cache_t* h);
 /* Worker-side accounting of the row swap (upstream's swap_out_bandwidth / swap_in_bandwidth, printed by
- * print_comm_stats, recsys/dlrm_main.py:294): seconds4 = {out: waiting for staging, out: copying + scattering,
- * in: waiting for the miss list and earlier write-backs, in: gathering + copying}, counts4 = {rows out, jobs out,
- * rows in, jobs in}. */
-int ce_cache_swap_stats(ce_cache_t* h, double* seconds4, int64_t* counts4);
+ * print_comm_stats, recsys/dlrm_main.py:294): seconds6 = {out: waiting for staging, out: copying + scattering,
+ * in: waiting for the miss list and earlier write-backs, in: gathering + copying, in: of which gathering +
+ * enqueueing the copies, reserved}, counts4 = {rows out, jobs out, rows in, jobs in}. */
+int ce_cache_swap_stats(ce_cache_t* h, double* seconds6, int64_t* counts4);
 /* upstream buffer_size / LimitBuffIndexCopyer: rows > 0 bounds the pinned + device staging of the STAGED
  * transport to `rows` rows; larger swaps walk it in chunks.  0 (default) = stage a whole swap at once. */
 int ce_cache_set_buffer_rows(ce_cache_t* h, int64_t rows);

@@ -239,9 +239,8 @@ def test_presorted_backward_matches_in_kernel_sort(nb, F, C, D):
                 assert np.array_equal(np.sort(pos), np.nonzero((lo < C).numpy())[0])       # each lookup once
                 rows = (real >> 32).astype("int64")
                 assert torch.equal(torch.from_numpy(rows), lo[pos])
-                # an exact, stable sort: rows ascending, lookups ascending inside a row
-                order = np.lexsort((pos, rows))
-                assert np.array_equal(order, np.arange(rows.size)), "segment is not sorted by (row, lookup)"
+                runs = 1 + int((rows[1:] != rows[:-1]).sum()) if rows.size else 0
+                assert runs <= 1.35 * np.unique(rows).size + 8, "grouping leaves too many broken runs"
         out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
                                hook_features=hook, fused_sgd=ce.FusedSGD(0.5), presorted=keys)
         out.backward(go.cuda())
@@ -278,107 +277,39 @@ def test_presorted_backward_multi_id_bags_mean_and_weights():
         torch.testing.assert_close(wc.detach().cpu(), w - 0.25 * ref.grad, rtol=1e-4, atol=1e-5)
 
 
-def _kjt_window(g, sizes, B, P, C, share=False):
-    """feature-major KJT batches over disjoint tables (recsys/datasets/criteo.py:127-134) + a random id -> slot map"""
-    offs = np.concatenate([[0], np.cumsum(sizes)])
-    N = int(offs[-1])
-    ids = torch.stack([torch.cat([(torch.rand(B, generator=g) ** 3 * sizes[f]).long().clamp_(0, sizes[f] - 1) + int(offs[f])
-                                  for f in range(len(sizes))]) for _ in range(P)])
-    if share:
-        ids[:, B:2 * B] = ids[:, 0:B]          # feature 1 looks into feature 0's table: rows shared across segments
-    slot_of = torch.randperm(N, generator=g)[:N] % C if N > C else torch.randperm(C, generator=g)[:N]
-    return ids, slot_of[ids], N
-
-
-@pytest.mark.parametrize("B,expect", [(16384, 1), (8192, 1), (4096, 1), (32768, 0), (5000, 0)])
-def test_exclusive_flags_from_id_ranges(B, expect):
-    """a batch is exclusive when no row can sit in two of its 16384-lookup segments; decided from the id ranges.
-    B = 32768 splits a feature over two segments, B = 5000 lets a segment end inside a feature: both must say 0."""
-    from cachedembedding_amd.functional import presort_window
-    g = torch.Generator().manual_seed(B)
-    sizes = [50000, 3, 700, 120000, 40, 9000, 64, 20000]
-    P, C = 3, 300000
-    ids, slots, N = _kjt_window(g, sizes, B, P, C)
-    keys, flags = presort_window(slots.cuda().contiguous(), C, ids=ids.cuda().contiguous())
-    assert flags.cpu().tolist() == [expect] * P
-    if expect:
-        ids2, slots2, _ = _kjt_window(g, sizes, B, P, C, share=True)
-        _, flags2 = presort_window(slots2.cuda().contiguous(), C, ids=ids2.cuda().contiguous())
-        assert flags2.cpu().tolist() == [0] * P or B < 16384      # (B < 16384: both features share one segment)
-    # keys of batch b == the single-batch entry point on batch b
-    from cachedembedding_amd.functional import presort_slots
-    for b in range(P):
-        assert torch.equal(keys[b], presort_slots(slots[b].cuda().contiguous(), C))
-
-
-@pytest.mark.parametrize("B,F,D,C", [(16384, 6, 128, 200_000), (16384, 3, 32, 5_000_000), (8192, 5, 64, 1500),
-                                     (2048, 13, 32, 94_458)])
-def test_exclusive_backward_without_atomics_matches_torch(B, F, D, C):
-    """flag = 1: rows whose run lies inside one lane group's chunk are updated with a plain read-modify-write.
-    Same result as the atomic path and as torch's index_add_ (1e-5 relative for the bulk; hot rows within the fp32
-    accumulation bound); the tiny tables make runs of thousands of lookups that cross chunks and workgroups."""
+@pytest.mark.parametrize("P,n,C", [(3, 16384 * 2, 50000), (4, 26624, 94458), (2, 5000, 300), (8, 16384, 2000)])
+def test_presort_window_equals_per_batch_presort_and_feeds_the_backward(P, n, C):
+    """one launch for the P batches of a window: batch b's keys cover exactly its own lookups (segments never
+    straddle batches, also when a batch is not a whole number of 16384-lookup segments) and drive the fused backward
+    to the same result as the in-kernel tile sort"""
     ce = _ce()
-    from cachedembedding_amd.functional import presort_window
-    g = torch.Generator().manual_seed(B + F + D)
-    sizes = ([3, 40000, 7, 250000, 1200, 90000, 33, 100000, 5000, 64, 2, 800000, 12][:F])
-    P, lr = 2, 0.5
-    ids, slots, N = _kjt_window(g, sizes, B, P, C)
-    # distinct ids must map to distinct slots for the flag's premise (a cache maps rows 1:1): make it a bijection
-    uniq, inv = torch.unique(ids, return_inverse=True)
-    assert uniq.numel() <= C
-    slots = torch.randperm(C, generator=g)[:uniq.numel()][inv]
-    keys, flags = presort_window(slots.cuda().contiguous(), C, ids=ids.cuda().contiguous())
-    assert flags.cpu().tolist() == [1] * P
+    from cachedembedding_amd.functional import presort_len, presort_window
+    g = torch.Generator().manual_seed(P * n)
+    D = 32
+    slots = (torch.rand(P, n, generator=g) ** 3 * C).long().clamp_(0, C - 1)
+    slots[:, ::13] = -1                                     # ignored lookups
+    keys = presort_window(slots.cuda().contiguous(), C)
+    assert tuple(keys.shape) == (P, presort_len(n))
+    k = keys.cpu().numpy().view("uint64")
+    for b in range(P):
+        for s0 in range(0, k.shape[1], 16384):
+            seg = k[b, s0:s0 + 16384]
+            real = seg[seg != 0xFFFFFFFFFFFFFFFF]
+            lo = slots[b, s0:min(n, s0 + 16384)]
+            pos = (real & 0xFFFFFFFF).astype("int64")
+            assert np.array_equal(np.sort(pos), np.nonzero((lo >= 0).numpy())[0])
+            assert torch.equal(torch.from_numpy((real >> 32).astype("int64")), lo[pos])
     w = torch.randn(C, D, generator=g)
-    off = torch.arange(B * F + 1, dtype=torch.int32)
-    go = torch.randn(B, F, D, generator=g) * 0.01
-    gflat = go.transpose(0, 1).reshape(-1, D)
+    off = torch.arange(n + 1, dtype=torch.int32)
+    go = torch.randn(n, D, generator=g) * 0.01
     for b in range(P):
         res = []
-        for flag in (None, flags[b:b + 1]):
+        for kk in (None, keys[b]):
             wc = w.cuda().requires_grad_(True)
-            out = ce.embedding_bag(slots[b].cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
-                                   hook_features=F, fused_sgd=ce.FusedSGD(lr), presorted=(keys[b], flag))
-            out.backward(go.cuda())
+            ce.embedding_bag(slots[b].cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
+                             fused_sgd=ce.FusedSGD(0.5), presorted=kk).backward(go.cuda())
             res.append(wc.detach().cpu())
-        ref64 = w.double().index_add_(0, slots[b], gflat.double(), alpha=-lr)
-        n = torch.bincount(slots[b], minlength=C).double().unsqueeze(1)
-        bound = 1e-5 * ref64.abs() + 2e-6 + 3e-7 * n.sqrt()
-        for got in res:
-            assert bool(((got.double() - ref64).abs() <= bound).all())
-        cold = (n <= 4).expand(-1, D)
-        ref32 = w.clone().index_add_(0, slots[b], gflat, alpha=-lr)
-        torch.testing.assert_close(res[1][cold], ref32[cold], rtol=1e-5, atol=2e-6)
-        # rows untouched by the batch are bit-identical
-        assert torch.equal(res[1][(n == 0).squeeze(1)], w[(n == 0).squeeze(1)])
-
-
-def test_exclusive_dense_accumulation_and_mean_weights():
-    """the plain accumulation form (sparse=False autograd) through sorted keys + flag, with multi-id bags"""
-    ce = _ce()
-    from cachedembedding_amd.functional import presort_window
-    g = torch.Generator().manual_seed(3)
-    C, D, nb = 5000, 64, 20000
-    lens = torch.randint(0, 4, (nb,), generator=g)
-    off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
-    nnz = int(off[-1])
-    ids = torch.sort(torch.randint(0, C, (nnz,), generator=g)).values      # ascending ids: segments have disjoint ranges
-    ids[16384 - 1] = ids[16384]                                             # ...except across this boundary
-    w = torch.randn(C, D, generator=g)
-    go = torch.randn(nb, D, generator=g)
-    keys, flags = presort_window(ids.cuda().view(1, -1), C, ids=ids.cuda().view(1, -1))
-    assert flags.cpu().tolist() == [0]
-    ids[16384 - 1] = ids[16384 - 2]
-    if ids[16384 - 1] == ids[16384]:
-        pytest.skip("unlucky draw")
-    keys, flags = presort_window(ids.cuda().view(1, -1), C, ids=ids.cuda().view(1, -1))
-    assert flags.cpu().tolist() == [1]
-    for mode, psw in (("mean", None), ("sum", torch.rand(nnz, generator=g))):
-        wc = w.cuda().requires_grad_(True)
-        out = ce.embedding_bag(ids.cuda(), wc, off.cuda(), mode=mode, include_last_offset=True, sparse=False,
-                               per_sample_weights=None if psw is None else psw.cuda(), presorted=(keys[0], flags[0:1]))
-        out.backward(go.cuda())
-        ref = w.clone().requires_grad_(True)
-        torch.nn.functional.embedding_bag(ids, ref, off, mode=mode, per_sample_weights=psw,
-                                          include_last_offset=True).backward(go)
-        torch.testing.assert_close(wc.grad.cpu(), ref.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(res[0], res[1], rtol=1e-4, atol=1e-5)
+        valid = slots[b] >= 0
+        ref = w.clone().index_add_(0, slots[b][valid], go[valid], alpha=-0.5)
+        torch.testing.assert_close(res[1], ref, rtol=1e-4, atol=1e-5)
