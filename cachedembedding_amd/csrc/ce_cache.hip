@@ -984,18 +984,27 @@ class RowPool {
       fn(0, n);
       return;
     }
+    start(n, t, fn);
+    wait();
+  }
+  // non-blocking form: worker i < parts runs fn(lo_i, hi_i) over its share of [0, n); `fn` must outlive wait()
+  void start(int64_t n, int parts, const std::function<void(int64_t, int64_t)>& fn) {
+    parts = std::max(1, std::min(parts, (int)workers_.size()));
     {
       std::lock_guard<std::mutex> g(m_);
       fn_ = &fn;
       n_ = n;
-      parts_ = t;
-      pending_ = t;
+      parts_ = parts;
+      pending_ = parts;
       ++gen_;
     }
     cv_.notify_all();
+  }
+  void wait() {
     std::unique_lock<std::mutex> g(m_);
     done_.wait(g, [this] { return pending_ == 0; });
   }
+  int size() const { return (int)workers_.size(); }
 
  private:
   void run(int id) {
@@ -1079,9 +1088,10 @@ struct PhaseProf {
 //        scatters each chunk into the host table with helper threads while the next one is in flight.
 //   in   k_emit leaves the ascending list of missed rows in pinned host memory; the `in` worker waits for that
 //        kernel's event, lets helper threads gather the rows out of the table into pinned staging, each helper
-//        pushing its finished 1-2 MB piece to the device at once (hipMemcpyAsync), and finally releases the cache-op
-//        stream, which has been parked in a hipStreamWaitValue64 (no CU, no host thread involved), with a
-//        hipStreamWriteValue64 behind the last copy.  k_unpack_admitted then moves the rows to their slots.
+//        the worker copying each gathered chunk to the device at once (hipMemcpyAsync), and finally releases the
+//        cache-op stream, which has been parked in a hipStreamWaitValue64 (no CU involved), with a plain store to the
+//        pinned word the stream polls, once the copies have completed.  k_unpack_admitted then moves the rows to
+//        their slots.
 //
 // Ordering: the gather of call w starts only after the write-back of call w-1 has reached the table (a row evicted
 // by w-1 and missed by w is read back correctly); rows evicted by call w itself are never in its miss list.
@@ -1092,11 +1102,9 @@ struct SwapEngine {
   int64_t D = 0, stage_rows = 0;
   float* table = nullptr;
   // ---- out (evictions)
-  hipStream_t out_stream = nullptr;
+  hipStream_t out_stream = nullptr, out_stream2 = nullptr;      // alternating D2H copy streams
   hipEvent_t out_ev[2] = {nullptr, nullptr};       // staging of the job complete (recorded on the cache-op stream)
   static constexpr int kOutChunks = 4;
-  static constexpr int kInChunks = 6;
-  hipEvent_t chunk_ev[kOutChunks] = {};
   const float* stage_dev[2] = {nullptr, nullptr};
   const int32_t* idx_dev[2] = {nullptr, nullptr};
   float* rows_host[2] = {nullptr, nullptr};        // pinned landing buffers
@@ -1104,7 +1112,6 @@ struct SwapEngine {
   // ---- in (admissions)
   hipStream_t in_stream = nullptr;
   hipEvent_t in_ev[2] = {nullptr, nullptr};        // miss list of the job complete (by job parity)
-  hipEvent_t in_done_ev = nullptr;                 // copies of the job complete (in_stream)
   float* in_stage_dev = nullptr;
   float* in_host = nullptr;                        // pinned gather buffer
   int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
@@ -1156,23 +1163,23 @@ struct SwapEngine {
       long long k = mail[b].count;
       if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record moves nothing
       if (k > 0 && !failed()) {
-        // a handful of big copies, all enqueued up front (every hipMemcpyAsync costs the calling thread tens of
-        // microseconds); chunk c is scattered into the table while chunk c+1 is still on the wire
+        // a handful of big copies on two alternating copy streams: chunk c is scattered into the table while chunk
+        // c+1 is on the wire.  The host waits with hipStreamSynchronize only (see run_in: no queue packets).
         e = hipMemcpyAsync(idx_host[b], idx_dev[b], (size_t)k * 4, hipMemcpyDeviceToHost, out_stream);
         const int64_t per = std::max<int64_t>(8192, cdiv(k, kOutChunks));
-        int nch = 0;
-        for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++nch) {
+        auto copy_chunk = [&](int64_t off, int c) {
           const int64_t cnt = std::min<int64_t>(per, k - off);
-          e = hipMemcpyAsync(rows_host[b] + off * D, stage_dev[b] + off * D, (size_t)cnt * D * 4,
-                             hipMemcpyDeviceToHost, out_stream);
-          if (e == hipSuccess) e = hipEventRecord(chunk_ev[nch], out_stream);
-        }
-        if (e != hipSuccess) fail("hipMemcpyAsync(D2H)", e);
+          return hipMemcpyAsync(rows_host[b] + off * D, stage_dev[b] + off * D, (size_t)cnt * D * 4,
+                                hipMemcpyDeviceToHost, (c & 1) ? out_stream2 : out_stream);
+        };
+        if (e == hipSuccess) e = copy_chunk(0, 0);
         int c = 0;
-        for (int64_t off = 0; off < k && c < nch; off += per, ++c) {
+        for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++c) {
           const int64_t cnt = std::min<int64_t>(per, k - off);
-          e = hipEventSynchronize(chunk_ev[c]);
-          if (e != hipSuccess) { fail("hipEventSynchronize(chunk)", e); break; }
+          if (off + per < k) e = copy_chunk(off + per, c + 1);                 // next chunk in flight
+          hipError_t e2 = hipStreamSynchronize((c & 1) ? out_stream2 : out_stream);
+          if (e == hipSuccess) e = e2;
+          if (e != hipSuccess) break;
           float* tb = table;
           const float* st = rows_host[b] + off * D;
           const int32_t* ri = idx_host[b] + off;
@@ -1181,6 +1188,7 @@ struct SwapEngine {
             for (int64_t i = lo; i < hi; ++i) memcpy(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d * 4);
           });
         }
+        if (e != hipSuccess) fail("D2H copy", e);
       }
       const auto t2 = std::chrono::steady_clock::now();
       {
@@ -1224,42 +1232,58 @@ struct SwapEngine {
         const int32_t* rows = miss_host;
         const int64_t d = D;
         hipStream_t cs = in_stream;
-        // chunks: helpers gather chunk c out of the table while the copy of chunk c-1 is on the wire; only this
-        // thread talks to the runtime (one hipMemcpyAsync per chunk)
+        // ONE wake-up of the helpers per job (a condition-variable round trip per chunk cost more than the chunk):
+        // they pull 2048-row pieces off a shared counter and flag each finished piece; this thread -- the only one
+        // that talks to the runtime -- copies every run of finished pieces to the device as soon as it is 8192 rows
+        // long, so the copies trail the gather by one chunk.
         constexpr int kAhead = 8;
-        const int64_t per = std::max<int64_t>(8192, cdiv(n, kInChunks));
-        for (int64_t off = 0; off < n; off += per) {
-          const int64_t cnt = std::min<int64_t>(per, n - off);
-          const int32_t* rr = rows + off;
-          float* ss = st + (size_t)off * d;
-          in_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
+        constexpr int64_t kPiece = 2048, kCopyPieces = 4;
+        const int64_t npieces = cdiv(n, kPiece);
+        std::atomic<int64_t> next{0};
+        std::vector<std::atomic<unsigned char>> ready((size_t)npieces);
+        for (auto& r : ready) r.store(0, std::memory_order_relaxed);
+        const std::function<void(int64_t, int64_t)> work = [&](int64_t, int64_t) {
+          for (;;) {
+            const int64_t pc = next.fetch_add(1, std::memory_order_relaxed);
+            if (pc >= npieces) break;
+            const int64_t lo = pc * kPiece, hi = std::min<int64_t>(n, lo + kPiece);
             for (int64_t i = lo; i < hi; ++i) {
               if (i + kAhead < hi) {
-                const char* q = (const char*)(tb + (size_t)rr[i + kAhead] * d);
+                const char* q = (const char*)(tb + (size_t)rows[i + kAhead] * d);
                 for (int64_t l = 0; l < d * 4; l += 64) __builtin_prefetch(q + l);
               }
-              memcpy(ss + (size_t)i * d, tb + (size_t)rr[i] * d, (size_t)d * 4);
+              memcpy(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d * 4);
             }
-          });
-          e = hipMemcpyAsync(dv + (size_t)off * d, ss, (size_t)cnt * d * 4, hipMemcpyHostToDevice, cs);
-          if (e != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); break; }
+            ready[(size_t)pc].store(1, std::memory_order_release);
+          }
+        };
+        const int helpers = (int)std::min<int64_t>(in_pool->size(), npieces);
+        in_pool->start(helpers, helpers, work);
+        int64_t cursor = 0;
+        while (cursor < npieces) {
+          int64_t k = 0;
+          while (cursor + k < npieces && ready[(size_t)(cursor + k)].load(std::memory_order_acquire)) ++k;
+          if (k >= kCopyPieces || (k > 0 && cursor + k == npieces)) {
+            const int64_t lo = cursor * kPiece, hi = std::min<int64_t>(n, (cursor + k) * kPiece);
+            e = hipMemcpyAsync(dv + (size_t)lo * d, st + (size_t)lo * d, (size_t)(hi - lo) * d * 4,
+                               hipMemcpyHostToDevice, cs);
+            if (e != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); break; }
+            cursor += k;
+          } else {
+            std::this_thread::yield();
+          }
         }
+        in_pool->wait();
       }
       const auto tg = std::chrono::steady_clock::now();
-      // release the cache-op stream behind the last copy; if that cannot be enqueued, release it from here
-      e = hipStreamWriteValue64(in_stream, sig, (uint64_t)job, 0);
-      if (e != hipSuccess) {
-        fail("hipStreamWriteValue64", e);
-        (void)hipStreamSynchronize(in_stream);
-        *(volatile unsigned long long*)sig = (unsigned long long)job;
-      }
-      e = hipEventRecord(in_done_ev, in_stream);     // in_host / miss_host are reused by the next job
-      if (e == hipSuccess) e = hipEventSynchronize(in_done_ev);
-      if (e != hipSuccess) {
-        fail("hipEventSynchronize(in copies)", e);
-        (void)hipStreamSynchronize(in_stream);
-        *(volatile unsigned long long*)sig = (unsigned long long)job;
-      }
+      // Wait for the copies on the host (their completion signals: no packet goes through a hardware queue), then
+      // release the cache-op stream with a plain store to the pinned word it polls.  Nothing here may depend on a
+      // GPU queue making progress: HIP multiplexes streams onto a few hardware queues (4 by default), so the copy
+      // stream can share one with the parked stream -- a hipStreamWriteValue64 / event marker queued behind the
+      // parked wait would never execute (seen as a hang of the full test suite).
+      e = hipStreamSynchronize(in_stream);
+      if (e != hipSuccess) fail("hipStreamSynchronize(in)", e);
+      __atomic_store_n(sig, (unsigned long long)job, __ATOMIC_RELEASE);
       const auto t2 = std::chrono::steady_clock::now();
       {
         std::lock_guard<std::mutex> g(m);
@@ -1328,16 +1352,14 @@ struct SwapEngine {
       if (rows_host[b]) (void)hipHostFree(rows_host[b]);
       if (idx_host[b]) (void)hipHostFree(idx_host[b]);
     }
-    for (int c = 0; c < kOutChunks; ++c)
-      if (chunk_ev[c]) (void)hipEventDestroy(chunk_ev[c]);
     for (int b = 0; b < 2; ++b)
       if (in_ev[b]) (void)hipEventDestroy(in_ev[b]);
-    if (in_done_ev) (void)hipEventDestroy(in_done_ev);
     if (in_host) (void)hipHostFree(in_host);
     if (miss_host) (void)hipHostFree(miss_host);
     if (sig) (void)hipHostFree(sig);
     if (mail) (void)hipHostFree(mail);
     if (out_stream) (void)hipStreamDestroy(out_stream);
+    if (out_stream2) (void)hipStreamDestroy(out_stream2);
     if (in_stream) (void)hipStreamDestroy(in_stream);
   }
 };
@@ -1650,6 +1672,7 @@ static int ensure_writeback(ce_cache* h) {
     w->in_stage_dev = h->in_stage;
     const size_t rows_bytes = (size_t)L.stage_rows * w->D * 4, idx_bytes = (size_t)L.stage_rows * 4;
     if (hipStreamCreateWithFlags(&w->out_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&w->out_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&w->in_stream, hipStreamNonBlocking) != hipSuccess) { rc = CE_ERR_HIP; break; }
     void* p = nullptr;
     void* pd = nullptr;
@@ -1670,15 +1693,12 @@ static int ensure_writeback(ce_cache* h) {
     // the helpers need
     const unsigned evf = hipEventDisableTiming | hipEventBlockingSync;
     if (hipEventCreateWithFlags(&w->in_ev[0], evf) != hipSuccess ||
-        hipEventCreateWithFlags(&w->in_ev[1], evf) != hipSuccess ||
-        hipEventCreateWithFlags(&w->in_done_ev, evf) != hipSuccess) { rc = CE_ERR_HIP; break; }
+        hipEventCreateWithFlags(&w->in_ev[1], evf) != hipSuccess) { rc = CE_ERR_HIP; break; }
     for (int b = 0; b < 2 && rc == CE_OK; ++b) {
       if (hipEventCreateWithFlags(&w->out_ev[b], evf) != hipSuccess) rc = CE_ERR_HIP;
       else if (hipHostMalloc((void**)&w->rows_host[b], rows_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
       else if (hipHostMalloc((void**)&w->idx_host[b], idx_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
     }
-    for (int c = 0; c < SwapEngine::kOutChunks && rc == CE_OK; ++c)
-      if (hipEventCreateWithFlags(&w->chunk_ev[c], evf) != hipSuccess) rc = CE_ERR_HIP;
     if (rc) break;
     // helper threads per direction: a quarter of the CPU budget each (measured on a 16-CPU quota: 4 + 4 helpers
     // 0.78 / 1.03 ms per job, 8 + 8 1.24 / 1.43 ms, 16 + 16 1.28 / 1.29 ms -- the launch thread and the two workers

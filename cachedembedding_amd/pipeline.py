@@ -169,12 +169,20 @@ class GraphedWindow:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self._graphs = []
+        self._step_graphs = []          # [buf][i]: batch i alone (windows a caller trains in part)
         for b in range(2):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for i in range(self.P):
                     self._call(step_fn, b, i)
             self._graphs.append(g)
+            per_step = []
+            for i in range(self.P if self.P > 1 else 0):
+                gi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gi):
+                    self._call(step_fn, b, i)
+                per_step.append(gi)
+            self._step_graphs.append(per_step)
 
     def _call(self, step_fn, buf: int, i: int) -> None:
         if self.presort:
@@ -211,13 +219,16 @@ class GraphedWindow:
             self._events[buf] = None
 
     def run_steps(self, buf: int, first: int, last: int) -> None:
-        """Batches [first, last) of the window in buffer `buf`, launched one by one (a window that a caller only
-        trains in part, or across two timed regions)."""
+        """Batches [first, last) of the window in buffer `buf`, one single-step graph each (a window that a caller
+        only trains in part, or across two timed regions)."""
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
         for i in range(first, last):
-            self._call(self._step_fn, buf, i)
+            if self._step_graphs[buf]:
+                self._step_graphs[buf][i].replay()
+            else:
+                self._call(self._step_fn, buf, i)
 
     def run(self, buf: int, steps: Optional[int] = None) -> None:
         """Replay the P training steps on the slots in buffer `buf` (waits for its cache op).  steps < P runs
@@ -230,5 +241,4 @@ class GraphedWindow:
         if steps is None or steps >= self.P:
             self._graphs[buf].replay()
         else:
-            for i in range(steps):
-                self._call(self._step_fn, buf, i)
+            self.run_steps(buf, 0, steps)

@@ -197,3 +197,46 @@ def test_phase_timers_and_history_window():
     assert len(names) == 6 and all(t[k] >= 0.0 for k in names) and sum(t[k] for k in names) > 0.0
     assert len(mgr.num_hits_history) == 20
     mgr.set_profiling(False)
+
+
+@pytest.mark.timeout(300)
+def test_worker_transport_with_more_streams_than_hardware_queues():
+    """HIP multiplexes streams onto a few hardware queues (4 unless GPU_MAX_HW_QUEUES says otherwise).  The cache-op
+    stream parks in hipStreamWaitValue64 while the admission worker copies rows in: nothing that releases it may sit
+    in a hardware queue behind the parked wait.  Many live streams force queue sharing; the calls go round them."""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    extra = [torch.cuda.Stream() for _ in range(24)]
+    x = torch.ones(1 << 20, device="cuda")
+    for st in extra:
+        with torch.cuda.stream(st):
+            x.add_(1.0)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(77)
+    N, C, D = 30000, 2000, 64
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 0.7)
+    mgrs = []
+    for k in range(3):                       # several managers alive at once: 3 x (1 admission + 2 write-back streams)
+        m = ce.CachedParamMgr(torch.from_numpy(w.copy()), C)
+        m.reorder(None, 0.7)
+        m.set_transport("worker")
+        mgrs.append(m)
+    oras = [ora] + [None, None]
+    oras[1] = OracleCachedParamMgr(w.copy(), C, DATASET); oras[1].reorder(None, 0.7)
+    oras[2] = OracleCachedParamMgr(w.copy(), C, DATASET); oras[2].reorder(None, 0.7)
+    for c in range(30):
+        st = extra[(5 * c) % len(extra)]
+        ids = rng.integers(0, N, size=900)
+        with torch.cuda.stream(st):
+            for m, o in zip(mgrs, oras):
+                slots = m.prepare_ids(torch.from_numpy(ids).cuda())
+                assert np.array_equal(slots.cpu().numpy(), o.prepare_ids(ids))
+        # busy neighbours on other streams while the next call runs
+        for s2 in extra[c % 7::7]:
+            with torch.cuda.stream(s2):
+                x.mul_(1.0)
+        torch.cuda.synchronize()
+    for m, o in zip(mgrs, oras):
+        np.testing.assert_array_equal(m.weight.numpy(), o.weight)
