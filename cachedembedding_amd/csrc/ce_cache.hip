@@ -1077,6 +1077,32 @@ struct PhaseProf {
   }
 };
 
+// Host-side row copy with non-temporal stores: the destination (a table row that is overwritten whole, or pinned
+// staging that only the DMA engine reads) is written without first being read into the cache -- a plain memcpy of a
+// 512-byte row to a random table address pays a read-for-ownership miss on each of its 8 lines.
+static inline void row_copy_nt(float* __restrict__ dst, const float* __restrict__ src, size_t floats) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && (floats & 3) == 0) {
+    const v4f* s4 = (const v4f*)src;
+    v4f* d4 = (v4f*)dst;
+    const size_t n4 = floats >> 2;
+    for (size_t i = 0; i < n4; ++i) __builtin_nontemporal_store(s4[i], d4 + i);
+  } else {
+    memcpy(dst, src, floats * sizeof(float));
+  }
+}
+
+// waiting for a copy stream without burning a CPU of a quota-limited host and without any packet in a hardware
+// queue: poll hipStreamQuery with short sleeps
+static inline hipError_t stream_wait_polite(hipStream_t st) {
+  for (int spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (spins < 50) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(15));
+  }
+}
+
 // Worker transport (CE_TRANSPORT_WORKER): both directions of the row swap leave the CUs.
 //
 // Measured on the box (profiles/r02_probe_sdma.txt): a pinned hipMemcpyAsync runs on an SDMA engine at ~51 GB/s per
@@ -1177,7 +1203,7 @@ struct SwapEngine {
         for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++c) {
           const int64_t cnt = std::min<int64_t>(per, k - off);
           if (off + per < k) e = copy_chunk(off + per, c + 1);                 // next chunk in flight
-          hipError_t e2 = hipStreamSynchronize((c & 1) ? out_stream2 : out_stream);
+          hipError_t e2 = stream_wait_polite((c & 1) ? out_stream2 : out_stream);
           if (e == hipSuccess) e = e2;
           if (e != hipSuccess) break;
           float* tb = table;
@@ -1185,7 +1211,8 @@ struct SwapEngine {
           const int32_t* ri = idx_host[b] + off;
           const int64_t d = D;
           out_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) memcpy(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d * 4);
+            for (int64_t i = lo; i < hi; ++i) row_copy_nt(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);          // non-temporal stores are weakly ordered
           });
         }
         if (e != hipSuccess) fail("D2H copy", e);
@@ -1252,14 +1279,16 @@ struct SwapEngine {
                 const char* q = (const char*)(tb + (size_t)rows[i + kAhead] * d);
                 for (int64_t l = 0; l < d * 4; l += 64) __builtin_prefetch(q + l);
               }
-              memcpy(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d * 4);
+              row_copy_nt(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d);
             }
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);            // non-temporal stores are weakly ordered
             ready[(size_t)pc].store(1, std::memory_order_release);
           }
         };
         const int helpers = (int)std::min<int64_t>(in_pool->size(), npieces);
         in_pool->start(helpers, helpers, work);
         int64_t cursor = 0;
+        int idle = 0;
         while (cursor < npieces) {
           int64_t k = 0;
           while (cursor + k < npieces && ready[(size_t)(cursor + k)].load(std::memory_order_acquire)) ++k;
@@ -1269,8 +1298,11 @@ struct SwapEngine {
                                hipMemcpyHostToDevice, cs);
             if (e != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); break; }
             cursor += k;
-          } else {
+            idle = 0;
+          } else if (++idle < 64) {
             std::this_thread::yield();
+          } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
           }
         }
         in_pool->wait();
@@ -1281,8 +1313,8 @@ struct SwapEngine {
       // GPU queue making progress: HIP multiplexes streams onto a few hardware queues (4 by default), so the copy
       // stream can share one with the parked stream -- a hipStreamWriteValue64 / event marker queued behind the
       // parked wait would never execute (seen as a hang of the full test suite).
-      e = hipStreamSynchronize(in_stream);
-      if (e != hipSuccess) fail("hipStreamSynchronize(in)", e);
+      e = stream_wait_polite(in_stream);
+      if (e != hipSuccess) fail("waiting for the H2D copies", e);
       __atomic_store_n(sig, (unsigned long long)job, __ATOMIC_RELEASE);
       const auto t2 = std::chrono::steady_clock::now();
       {
@@ -1700,10 +1732,11 @@ static int ensure_writeback(ce_cache* h) {
       else if (hipHostMalloc((void**)&w->idx_host[b], idx_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
     }
     if (rc) break;
-    // helper threads per direction: a quarter of the CPU budget each (measured on a 16-CPU quota: 4 + 4 helpers
-    // 0.78 / 1.03 ms per job, 8 + 8 1.24 / 1.43 ms, 16 + 16 1.28 / 1.29 ms -- the launch thread and the two workers
-    // need cores too)
-    static const int dflt = std::max(2, std::min(8, cpu_budget() / 4));
+    // helper threads per direction: half of what the CPU budget leaves after the launch thread and the two
+    // (mostly sleeping) workers.  A helper is bound by the cache misses it can keep in flight (~45-75 ns per
+    // 512-byte row), so the job time falls with the helper count until the quota is reached; beyond it the threads
+    // only fight (16-CPU quota, spinning waits: 4 + 4 helpers 0.78 / 1.03 ms per job, 8 + 8 1.24 / 1.43 ms)
+    static const int dflt = std::max(2, std::min(8, (cpu_budget() - 2) / 2));
     static const int out_threads = [] { const char* e = getenv("CE_WB_THREADS"); return e ? atoi(e) : dflt; }();
     static const int in_threads = [] { const char* e = getenv("CE_GATHER_THREADS"); return e ? atoi(e) : dflt; }();
     w->out_pool = new RowPool(std::max(1, std::min(out_threads, 64)));
