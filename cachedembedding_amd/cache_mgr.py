@@ -225,6 +225,8 @@ class CachedParamMgr(torch.nn.Module):
                 fvals = freq[order[:n]].contiguous()
             with torch.cuda.device(self.device):
                 check(lib.ce_cache_preload(self._handle, ptr(rows), ptr(fvals), n, stream_ptr()))
+                if fvals is not None:
+                    check(lib.ce_cache_set_freq_bound(self._handle, int(fvals.max().item())))
                 torch.cuda.current_stream().synchronize()
 
     def _recreate_with_idx_map(self):

@@ -686,6 +686,50 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
   }
 }
 
+// small caches: count, scan and emit of the free-slot list in ONE workgroup (three launches otherwise; a
+// prefetch_num = 1 step is a chain of such launches).  Walks the slots in order, 4096 per round, and stops as soon
+// as the first n_miss free slots are out.
+__global__ __launch_bounds__(1024) void k_free_single(const int32_t* __restrict__ cached_idx_map, int64_t C,
+                                                      int32_t* free_list, const Ctl* ctl) {
+  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
+  const long long need = ctl->n_miss;
+  __shared__ int wtot[16];
+  __shared__ long long base_s;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t s0 = 0; s0 < C; s0 += 4096) {
+    const long long base = base_s;
+    if (base >= need) break;                       // block-uniform
+    const int64_t i0 = s0 + (int64_t)threadIdx.x * 4;
+    int fl[4], f = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fl[t] = (i0 + t < C) && (cached_idx_map[i0 + t] < 0);
+      f += fl[t];
+    }
+    const int inc = wave_incl_scan(f, lane);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < w) pre += wtot[k];
+      tot += wtot[k];
+    }
+    long long pos = base + pre + inc - f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (fl[t]) {
+        if (pos < need) free_list[pos] = (int32_t)(i0 + t);
+        ++pos;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base_s = base + tot;
+    __syncthreads();
+  }
+}
+
 // rows[i] -> slots[i] for first <= i < n (slots == nullptr: slot i; rows == nullptr: row i)
 template <typename VT, int R>
 __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
@@ -1103,6 +1147,17 @@ static inline hipError_t stream_wait_polite(hipStream_t st) {
   }
 }
 
+static const bool g_trace = [] { const char* e = getenv("CE_WORKER_TRACE"); return e && atoi(e) != 0; }();
+#define CE_TRACE(...)                                                                            \
+  do {                                                                                           \
+    if (ce::g_trace) {                                                                           \
+      const double t_ = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); \
+      fprintf(stderr, "[ce %.6f %p] ", t_, (void*)this);                                         \
+      fprintf(stderr, __VA_ARGS__);                                                              \
+      fputc('\n', stderr);                                                                       \
+    }                                                                                            \
+  } while (0)
+
 // Worker transport (CE_TRANSPORT_WORKER): both directions of the row swap leave the CUs.
 //
 // Measured on the box (profiles/r02_probe_sdma.txt): a pinned hipMemcpyAsync runs on an SDMA engine at ~51 GB/s per
@@ -1183,10 +1238,12 @@ struct SwapEngine {
       }
       const int b = (int)(job & 1);
       const auto t0 = std::chrono::steady_clock::now();
+      CE_TRACE("out job %lld: waiting for its staging event", job);
       hipError_t e = hipEventSynchronize(out_ev[b]);
       if (e != hipSuccess) fail("hipEventSynchronize(out)", e);
       const auto t1 = std::chrono::steady_clock::now();
       long long k = mail[b].count;
+      CE_TRACE("out job %lld: event done (%s), mail job %lld count %lld", job, hipGetErrorString(e), mail[b].job, k);
       if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record moves nothing
       if (k > 0 && !failed()) {
         // a handful of big copies on two alternating copy streams: chunk c is scattered into the table while chunk
@@ -1218,6 +1275,7 @@ struct SwapEngine {
         if (e != hipSuccess) fail("D2H copy", e);
       }
       const auto t2 = std::chrono::steady_clock::now();
+      CE_TRACE("out job %lld: done", job);
       {
         std::lock_guard<std::mutex> g(m);
         out_done = job;
@@ -1242,8 +1300,10 @@ struct SwapEngine {
         need_out = out_issued_at[job & 7];
       }
       const auto t0 = std::chrono::steady_clock::now();
+      CE_TRACE("in job %lld: waiting for its miss-list event (needs out job %lld)", job, need_out);
       hipError_t e = hipEventSynchronize(in_ev[job & 1]);
       if (e != hipSuccess) fail("hipEventSynchronize(in)", e);
+      CE_TRACE("in job %lld: event done (%s)", job, hipGetErrorString(e));
       {
         // rows the earlier calls evicted must be in the table before it is read
         std::unique_lock<std::mutex> g(m);
@@ -1251,6 +1311,7 @@ struct SwapEngine {
       }
       const auto t1 = std::chrono::steady_clock::now();
       long long n = mail[2].count;
+      CE_TRACE("in job %lld: earlier write-backs landed; mail job %lld count %lld", job, mail[2].job, n);
       if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
       if (n > 0 && !failed()) {
         const float* tb = table;
@@ -1313,9 +1374,11 @@ struct SwapEngine {
       // GPU queue making progress: HIP multiplexes streams onto a few hardware queues (4 by default), so the copy
       // stream can share one with the parked stream -- a hipStreamWriteValue64 / event marker queued behind the
       // parked wait would never execute (seen as a hang of the full test suite).
+      CE_TRACE("in job %lld: rows gathered, copies enqueued", job);
       e = stream_wait_polite(in_stream);
       if (e != hipSuccess) fail("waiting for the H2D copies", e);
       __atomic_store_n(sig, (unsigned long long)job, __ATOMIC_RELEASE);
+      CE_TRACE("in job %lld: released the stream (%s)", job, hipGetErrorString(e));
       const auto t2 = std::chrono::steady_clock::now();
       {
         std::lock_guard<std::mutex> g(m);
@@ -1357,6 +1420,7 @@ struct SwapEngine {
     {
       std::lock_guard<std::mutex> g(m);
       ++out_issued;
+      CE_TRACE("push out job %lld", out_issued);
     }
     cv_job.notify_all();
   }
@@ -1365,6 +1429,7 @@ struct SwapEngine {
       std::lock_guard<std::mutex> g(m);
       ++in_issued;
       out_issued_at[in_issued & 7] = need_out;
+      CE_TRACE("push in job %lld (needs out %lld)", in_issued, need_out);
     }
     cv_job.notify_all();
   }
@@ -1434,6 +1499,8 @@ struct ce_cache {
   float* in_stage;
   long long hist_base;         // seq of history[0]
   ce::PhaseProf* prof;         // optional per-phase hipEvent timers (ce_cache_set_profiling)
+  uint64_t freq_bound;         // LFU: upper bound of any freq_cnter value (shortens the radix select)
+  bool freq_bound_known;       // false after a preload with caller-supplied counters until the caller states their max
   long long n_failed;          // finished prepare_ids calls whose status was not CE_OK
   int last_fail_status;
   long long last_fail_seq;
@@ -1546,6 +1613,8 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->wb = nullptr;
   h->hist_base = 1;
   h->prof = nullptr;
+  h->freq_bound = 0;
+  h->freq_bound_known = true;
   h->n_failed = 0;
   h->last_fail_status = CE_OK;
   h->last_fail_seq = 0;
@@ -1703,9 +1772,20 @@ static int ensure_writeback(ce_cache* h) {
     w->idx_dev[1] = h->stage_idx2;
     w->in_stage_dev = h->in_stage;
     const size_t rows_bytes = (size_t)L.stage_rows * w->D * 4, idx_bytes = (size_t)L.stage_rows * 4;
-    if (hipStreamCreateWithFlags(&w->out_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&w->out_stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&w->in_stream, hipStreamNonBlocking) != hipSuccess) { rc = CE_ERR_HIP; break; }
+    // The copy streams must never share a hardware queue with the parked cache-op stream: a hipMemcpyAsync is not
+    // queue-free (the runtime brackets the SDMA copy with barrier packets in the stream's queue), so a copy queued
+    // behind the parked hipStreamWaitValue64 never starts and the wait is never released -- seen as a hang once
+    // enough streams were alive for HIP to double them up on its (by default 4) hardware queues.  HIP keeps a
+    // separate pool of hardware queues per stream priority, so the copy streams are created at the HIGHEST
+    // priority: they only ever share queues with each other (and nothing of theirs ever waits).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&w->out_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&w->out_stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&w->in_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+      rc = CE_ERR_HIP;
+      break;
+    }
     void* p = nullptr;
     void* pd = nullptr;
     if (hipHostMalloc(&p, sizeof(WbMail) * 3, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
@@ -1759,11 +1839,19 @@ static int64_t staged_chunk(const ce_cache* h, int64_t rows) {
   return (h->buffer_rows > 0 && h->buffer_rows < rows) ? h->buffer_rows : rows;
 }
 
+extern "C" int ce_cache_set_freq_bound(ce_cache_t* h, int64_t bound) {
+  CE_REQUIRE(h && bound >= 0, CE_ERR_INVALID, "bad bound");
+  h->freq_bound = std::max<uint64_t>(h->freq_bound, (uint64_t)bound);
+  h->freq_bound_known = true;
+  return CE_OK;
+}
+
 extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_vals, int64_t n,
                                 ce_stream_t stream) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
   CE_REQUIRE(n >= 0 && n <= h->cfg.cuda_row_num, CE_ERR_INVALID, "preload count out of range");
   if (n == 0) return CE_OK;
+  if (freq_vals) h->freq_bound_known = false;      // until ce_cache_set_freq_bound states their maximum
   int rc = before_call(h);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1881,6 +1969,15 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   if (worker) {
     rc = ensure_writeback(h);
     if (rc) return rc;
+    {
+      // the stream about to be parked must not live in the copy streams' hardware-queue pool (see ensure_writeback)
+      int prio = 0, prio_lo = 0, prio_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      if (s != nullptr && prio_hi != prio_lo && hipStreamGetPriority(s, &prio) == hipSuccess)
+        CE_REQUIRE(prio != prio_hi, CE_ERR_UNSUPPORTED,
+                   "the worker transport cannot run its cache op on a highest-priority stream (its copy streams "
+                   "use that priority to stay out of the parked stream's hardware queue)");
+    }
     out_job = h->wb->out_issued + 1;
     in_job = h->wb->in_issued + 1;
     wbuf = (int)(out_job & 1);
@@ -1943,8 +2040,17 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   if (!lfu) {
     top_pass = 0;
     while (top_pass < 3 && ((uint64_t)(N - 1) >> (8 * (top_pass + 1))) != 0) ++top_pass;
+  } else {
+    // LFU keys are freq << slot_bits | slot.  No counter can exceed the largest value ever preloaded plus the ids
+    // seen so far (a call adds at most its own length to a counter), so the bytes above that bound are zero in
+    // every eligible key: 5 passes instead of 8 for the first few thousand calls of benchmark_cache.py's shape.
+    h->freq_bound += (uint64_t)n;
+    const int bits = 64 - __builtin_clzll(h->freq_bound | 1ull) + h->slot_bits;
+    top_pass = h->freq_bound_known ? std::min(7, std::max(0, (bits + 7) / 8 - 1)) : 7;
   }
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
+  // (one launch per pass with the last workgroup picking the digit was tried: the agent-scope fences it needs
+  // write back the L2 of every XCD, and the select went from 0.22 to 0.72 ms beside the training kernels)
   for (int pass = top_pass; pass >= 0; --pass) {
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, h->hist, pass, top_pass, h->ctl, slot);
@@ -1963,16 +2069,18 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
       hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
                          (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job);
-      hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
-                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
-                         h->rowlen, h->g_log2, h->ctl);
+      if (L.list_cap > L.stage_rows)
+        hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
+                           c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
+                           h->rowlen, h->g_log2, h->ctl);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
                          (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job);
-      hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
-                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
-                         h->rowlen, h->g_log2, h->ctl);
+      if (L.list_cap > L.stage_rows)
+        hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
+                           c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
+                           h->rowlen, h->g_log2, h->ctl);
     }
     if (worker) {
       // the write-back worker takes it from here: D2H of the packed block + scatter into the table
@@ -1986,11 +2094,15 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     if (rc) return rc;
   }
   CE_PHASE();
-  hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
-                     h->blk_free, h->ctl);
-  hipLaunchKernelGGL(k_free_scan, dim3(1), dim3(1024), 0, s, h->blk_free, L.n_slot_blocks, h->ctl);
-  hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
-                     h->blk_free, h->free_list, h->ctl);
+  if (C <= 262144) {
+    hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, h->free_list, h->ctl);
+  } else {
+    hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
+                       h->blk_free, h->ctl);
+    hipLaunchKernelGGL(k_free_scan, dim3(1), dim3(1024), 0, s, h->blk_free, L.n_slot_blocks, h->ctl);
+    hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
+                       h->blk_free, h->free_list, h->ctl);
+  }
   CE_PHASE();
   if (worker) {
     // the missed rows arrive in in_stage through the admission worker's hipMemcpyAsync pieces; this stream parks in

@@ -235,6 +235,11 @@ int ce_cache_destroy(ce_cache_t* h);
 int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_vals, int64_t n,
                      ce_stream_t stream);
 
+/* LFU only: tells the manager that no freq_cnter value exceeds `bound` (the largest value handed to
+ * ce_cache_preload); together with the ids seen since, this bounds every counter and lets the victim select skip the
+ * radix passes above it.  Optional: without it the select runs all 8 byte passes until the bound is known. */
+int ce_cache_set_freq_bound(ce_cache_t* h, int64_t bound);
+
 /* prepare_ids [A.3] -- recsys/dlrm_main.py:259: unique rows of `ids` (device int64[n]) are
  * made resident (victim selection A.5 with the canonical tie rule, write-back, admit A.4),
  * slots_out (device int64[n]) receives inverted_cached_idx[idx_map[ids]] [A.6], LFU

@@ -247,3 +247,77 @@ def test_baseline_configs_at_real_index_sizes_exact_vs_oracle(workload, ratio, P
     assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
     assert mgr.num_write_back_history == ora.num_write_back_history
     assert sum(ora.num_write_back_history) > 0, "the stream must reach eviction"
+
+
+@pytest.mark.parametrize("transport", ["zerocopy", "worker"])
+def test_config0_regime_whole_kaggle_table_resident_exact_vs_oracle(transport):
+    """BASELINE.json configs[0]: Criteo-Kaggle, cache_ratio = 1.0 -- C = N = 33,762,577, every row fits, so after the
+    warm-up (70 % preloaded) misses only ever fill free slots: the select never runs, nothing is ever written
+    back ("K5: no select when free slots suffice").  Slots, maps and histories exact vs the oracle at
+    the real index size (D = 4 keeps the tables at 0.5 GB; the cache op does not depend on D)."""
+    ce = _ce()
+    from cachedembedding_amd import synthetic
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    sizes = synthetic.TABLES["criteo_kaggle"]
+    N, D, B = sum(sizes), 4, 16384
+    assert N == 33_762_577
+    gen = synthetic.SyntheticKJT(sizes, B, 1, "power_law", 0.25, seed=5, device="cuda")
+    freq = gen.id_freq_map(8).cpu().numpy()
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), N, DATASET)
+    ora.reorder(freq, 0.7)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), N, evict_strategy=ce.EvictionStrategy.DATASET)
+    mgr.reorder(freq, 0.7)
+    mgr.set_transport(transport)
+    assert np.array_equal(mgr.idx_map.cpu().numpy().astype(np.int64), ora.idx_map)
+    for c in range(6):
+        ids = gen.next_values(1).view(-1)                       # one batch: 425,984 ids (prefetch_num = 1)
+        exp = ora.prepare_ids(ids.cpu().numpy())
+        got = mgr.prepare_ids(ids)
+        assert np.array_equal(got.cpu().numpy(), exp)
+    assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+    assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
+    assert mgr.num_write_back_history == [0] * 6 == ora.num_write_back_history
+    assert sum(mgr.num_miss_history) > 0
+    assert mgr.cuda_available_row_num == ora.cuda_available_row_num > 0
+    # admitted payloads are the host rows
+    occ = np.nonzero(ora.cached_idx_map >= 0)[0]
+    samp = torch.from_numpy(rng.choice(occ, size=200_000, replace=False)).cuda()
+    np.testing.assert_array_equal(mgr.cuda_cached_weight.detach()[samp].cpu().numpy(),
+                                  ora.cuda_cached_weight[samp.cpu().numpy()])
+
+
+@pytest.mark.parametrize("strategy", ["lfu", "dataset"])
+def test_micro_benchmark_shape_200_calls_exact_vs_oracle(strategy):
+    """benchmark/benchmark_cache.py:58-72,83-95 in its own shape -- Avazu table (N = 9,445,823), B = 2048, F = 13,
+    cache op in every iteration, 200 iterations -- ids exact vs the oracle on every call, counters at the end
+    (BASELINE.json configs[4]: LFU evict-rate stress with power-law ids)."""
+    ce = _ce()
+    from cachedembedding_amd import synthetic
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+    sizes = synthetic.TABLES["avazu"]
+    N, D, B = sum(sizes), 4, 2048
+    C = int(N * 0.01)
+    assert N == 9_445_823 and C == 94_458
+    gen = synthetic.SyntheticKJT(sizes, B, 1, "power_law", 0.25, seed=7, device="cuda")
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    lfu = strategy == "lfu"
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if lfu else DATASET)
+    ora.reorder(None, 0.7)                                       # benchmark_cache.py passes no frequency map (B#7)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C,
+                            evict_strategy=ce.EvictionStrategy.LFU if lfu else ce.EvictionStrategy.DATASET)
+    mgr.reorder(None, 0.7)
+    for it in range(200):
+        ids = gen.next_values(1).view(-1)                        # 26,624 ids
+        exp = ora.prepare_ids(ids.cpu().numpy())
+        got = mgr.prepare_ids(ids)
+        assert np.array_equal(got.cpu().numpy(), exp), f"call {it}"
+    assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), ora.cached_idx_map)
+    if lfu:
+        assert np.array_equal(mgr.freq_cnter.cpu().numpy(), ora.freq_cnter)
+    assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
+    assert mgr.num_write_back_history == ora.num_write_back_history and sum(ora.num_write_back_history) > 0
+    t = mgr.totals()
+    assert (t["cache_miss"], t["total_cache"]) == (ora.cache_miss, ora.total_cache)

@@ -247,3 +247,77 @@ def test_benchmark_cache_counterpart_runs(use_lfu, capsys):
     rate = bc.benchmark_cache_embedding(512, 32, 0.02, g.id_freq_map(8), 0.7, use_lfu, "avazu", iters=6)
     out = capsys.readouterr().out
     assert rate > 0 and "it/s" in out and "unique-row hit rate" in out and "CUDA->CPU" in out
+
+
+@pytest.mark.parametrize("strategy,use_freq", [("dataset", True), ("dataset", False), ("lfu", True)])
+@pytest.mark.parametrize("transport", ["zerocopy", "worker"])
+def test_flush_save_reload_continue_training_round_trip(strategy, use_freq, transport, tmp_path):
+    """flush() makes the host table the checkpoint.  Train, flush, save the table, rebuild
+    the module from the file with from_pretrained (pin_weight as at benchmark/benchmark_fbgemm_uvm.py:98-105), keep
+    training: outputs and the final table equal those of a module that never stopped, and of a plain nn.EmbeddingBag
+    over the same logical rows."""
+    import cachedembedding_amd as ce
+    g = torch.Generator().manual_seed(3)
+    N, D, C, B, lr = 4000, 32, 500, 256, 0.1
+    w0 = torch.randn(N, D, generator=g)
+    freq = torch.randint(0, 30, (N,), generator=g) if use_freq else None
+    strat = ce.EvictionStrategy.LFU if strategy == "lfu" else ce.EvictionStrategy.DATASET
+    kw = dict(sparse=True, mode="sum", include_last_offset=True, cuda_row_num=C, ids_freq_mapping=freq,
+              warmup_ratio=0.7, evict_strategy=strat, pin_weight=True)
+
+    def batches(n, seed):
+        gg = torch.Generator().manual_seed(seed)
+        out = []
+        for _ in range(n):
+            lens = torch.randint(0, 3, (B,), generator=gg)
+            off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
+            out.append((torch.randint(0, N, (int(off[-1]),), generator=gg), off, torch.randn(B, D, generator=gg)))
+        return out
+
+    first, second = batches(8, 1), batches(8, 2)
+
+    def train(m, data):
+        outs = []
+        for ids, off, go in data:
+            o = m(ids.cuda(), off.cuda())
+            o.backward(go.cuda())
+            outs.append(o.detach().cpu())
+        return outs
+
+    a = ce.CachedEmbeddingBag.from_pretrained(w0.clone(), freeze=False, **kw)
+    assert a.cache_weight_mgr.cuda_cached_weight.requires_grad
+    a.cache_weight_mgr.set_transport(transport)
+    a.set_fused_sgd(lr)
+    train(a, first)
+    a.flush()
+    path = tmp_path / "table.pt"
+    torch.save(a.weight.clone(), path)
+    # the uninterrupted module keeps going; the reloaded one starts from the file
+    b = ce.CachedEmbeddingBag.from_pretrained(torch.load(path), freeze=False, **kw)
+    b.cache_weight_mgr.set_transport(transport)
+    b.set_fused_sgd(lr)
+    oa, ob = train(a, second), train(b, second)
+    for x, y in zip(oa, ob):
+        torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-6)
+    a.flush()
+    b.flush()
+    torch.testing.assert_close(a.weight, b.weight, rtol=1e-6, atol=1e-6)
+    # reference: plain EmbeddingBag + SGD over the logical rows (DATASET + frequency map re-ranks rows, B#3)
+    id2row = a.cache_weight_mgr.idx_map.cpu().long()
+    ref = torch.nn.EmbeddingBag.from_pretrained(w0.clone(), freeze=False, mode="sum", include_last_offset=True, sparse=False)
+    opt = torch.optim.SGD(ref.parameters(), lr=lr)
+    for (ids, off, go), got in zip(first + second, [None] * 8 + oa):
+        o = ref(id2row[ids], off)
+        if got is not None:
+            torch.testing.assert_close(got, o.detach(), rtol=1e-5, atol=1e-6)
+        opt.zero_grad()
+        o.backward(go)
+        opt.step()
+    torch.testing.assert_close(a.weight, ref.weight.detach(), rtol=1e-5, atol=1e-6)
+    # freeze=True keeps the cache parameter out of autograd
+    c = ce.CachedEmbeddingBag.from_pretrained(w0.clone(), **kw)
+    assert not c.cache_weight_mgr.cuda_cached_weight.requires_grad
+    ids, off, _ = first[0]
+    torch.testing.assert_close(c(ids.cuda(), off.cuda()).cpu(),
+                               torch.nn.functional.embedding_bag(c.cache_weight_mgr.idx_map.cpu().long()[ids], w0, off,
+                                                                 mode="sum", include_last_offset=True))

@@ -141,3 +141,94 @@ def test_power_law_generator_shape():
     assert ids.min() >= 0 and ids.max() < 10_000
     f = id_freq_map(ids, 10_000)
     assert f.sum() == 200_000 and f[0] > f[100] > f[5000]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# second oracle: the op-sequence-literal torch restatement (oracle/cache_oracle_torch.py) against the set-based one
+
+
+def _same_state(a, t, lfu):
+    assert np.array_equal(a.cached_idx_map, t.cached_idx_map.numpy())
+    assert np.array_equal(a.inverted_cached_idx, t.inverted_cached_idx.numpy())
+    assert a.cuda_available_row_num == t._cuda_available_row_num
+    if lfu:
+        assert np.array_equal(a.freq_cnter, t.freq_cnter.numpy())
+    np.testing.assert_array_equal(a.cuda_cached_weight, t.cuda_cached_weight.numpy())
+    np.testing.assert_array_equal(a.weight, t.weight.numpy())
+
+
+@pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", DATASET), ("cache_dataset_nofreq", DATASET),
+                                           ("cache_lfu_freq", LFU), ("cache_lfu_nofreq", LFU)])
+def test_torch_literal_oracle_replays_golden_streams(name, strategy):
+    from oracle.cache_oracle_torch import TorchCachedParamMgr
+    z = np.load(GOLD / f"{name}.npz")
+    N, C, D, n_ids, calls, warm = z["meta"]
+    t = TorchCachedParamMgr(torch.from_numpy(z["weight"].copy()), int(C), strategy)
+    t.reorder(z["freq"] if z["freq"].size else None, warm / 1000.0)
+    assert np.array_equal(t.idx_map.numpy(), z["idx_map"])
+    assert np.array_equal(t.cached_idx_map.numpy(), z["cached_idx_map_0"])
+    for c in range(int(calls)):
+        slots = t.prepare_ids(torch.from_numpy(z["ids"][c]))
+        t.cuda_cached_weight[torch.unique(slots)] += 0.5
+        assert np.array_equal(slots.numpy(), z["slots"][c])
+        assert np.array_equal(t.cached_idx_map.numpy(), z["cached_idx_map"][c])
+        ev = z["evicted_rows"][c]
+        assert set(t.last_evicted_rows.tolist()) == set(ev[ev >= 0].tolist())
+        if strategy == LFU:
+            assert np.array_equal(t.freq_cnter.numpy(), z["freq_cnter"][c])
+    assert t.num_hits_history == z["hits"].tolist() and t.num_miss_history == z["misses"].tolist()
+    t.flush()
+    np.testing.assert_array_equal(t.weight.numpy(), z["weight_after_flush"])
+
+
+@pytest.mark.parametrize("strategy", [DATASET, LFU])
+@pytest.mark.parametrize("depth", [0, 1])
+@pytest.mark.parametrize("use_freq", [False, True])
+@pytest.mark.parametrize("N,C,n_ids,s", [(3000, 400, 350, 1.05), (20000, 900, 700, 0.25), (257, 256, 200, 0.5),
+                                         (5000, 5000, 3000, 0.25)])
+def test_two_oracles_agree_on_random_streams(strategy, depth, use_freq, N, C, n_ids, s):
+    """set-based numpy restatement == op-sequence-literal torch restatement: slots, maps, counters, payloads, host
+    table, histories and totals after every call (ties, masking order and counter updates included)"""
+    from oracle.cache_oracle_torch import TorchCachedParamMgr
+    rng = np.random.default_rng(N * 31 + C + depth * 7 + int(use_freq))
+    D = 8
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    perm = rng.permutation(N)
+    freq = id_freq_map(perm[power_law_ids(rng, N, 50000, s)], N) if use_freq else None
+    a = OracleCachedParamMgr(w.copy(), C, strategy)
+    t = TorchCachedParamMgr(torch.from_numpy(w.copy()), C, strategy)
+    a.protect_depth = t.protect_depth = depth
+    a.reorder(freq, 0.7)
+    t.reorder(freq, 0.7)
+    assert np.array_equal(a.idx_map, t.idx_map.numpy())
+    _same_state(a, t, strategy == LFU)
+    if depth:
+        n_ids = n_ids // 3
+    for c in range(25):
+        ids = perm[power_law_ids(rng, N, n_ids, s)]
+        sa = a.prepare_ids(ids)
+        st = t.prepare_ids(torch.from_numpy(ids))
+        assert np.array_equal(sa, st.numpy())
+        assert set(a.traces[-1].evicted_rows.tolist()) == set(t.last_evicted_rows.tolist())
+        u = np.unique(sa)
+        a.cuda_cached_weight[u] *= np.float32(1.25)
+        t.cuda_cached_weight[torch.from_numpy(u)] *= 1.25
+        _same_state(a, t, strategy == LFU)
+    assert a.num_hits_history == t.num_hits_history and a.num_miss_history == t.num_miss_history
+    assert a.num_write_back_history == t.num_write_back_history
+    assert (a.cache_miss, a.total_cache, a.cpu_to_cuda_numel, a.cuda_to_cpu_numel) == \
+        (t._cache_miss, t._total_cache, t._cpu_to_cuda_numel, t._cuda_to_cpu_numel)
+    a.flush()
+    t.flush()
+    _same_state(a, t, strategy == LFU)
+
+
+@pytest.mark.parametrize("init_freq", [False, True])
+def test_torch_literal_oracle_lfu_known_answer(init_freq):
+    """upstream's only known-answer test, through the op-sequence-literal restatement"""
+    from oracle.cache_oracle_torch import TorchCachedParamMgr
+    t = TorchCachedParamMgr(torch.randn(5, 5), 3, LFU)
+    t.reorder([4, 2, 1, 3, 1] if init_freq else None, warmup_ratio=1.0)
+    for ids in LFU_SCRIPT:
+        t.prepare_ids(torch.tensor(ids))
+    assert t.num_hits_history[-6:] == [3, 0, 1, 0, 1, 1]
