@@ -96,7 +96,14 @@ class CachedEmbeddingBag(nn.Module):
                 *, hook_features: int = 0, presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.cache_op:
             with torch.no_grad():
-                input = self.cache_weight_mgr.prepare_ids(input)
+                ids = input
+                input = self.cache_weight_mgr.prepare_ids(ids)
+                if self.padding_idx is not None:
+                    # nn.EmbeddingBag semantics in ID space (upstream hands padding_idx to F.embedding_bag in slot
+                    # space, which is not meaningful): lookups of the padding id take no part in the
+                    # reduction and get no gradient -- the kernels skip slot -1.  With cache_op=False the caller
+                    # passes slots and masks them itself.
+                    input = torch.where(ids == self.padding_idx, torch.full_like(input, -1), input)
         out = embedding_bag(input, self.cache_weight_mgr.cuda_cached_weight, offsets, self.max_norm,
                             self.norm_type, self.scale_grad_by_freq, self.mode, self.sparse, per_sample_weights,
                             self.include_last_offset, None, hook_features=hook_features,

@@ -48,7 +48,8 @@ def _prep(indices: torch.Tensor, offsets: Optional[torch.Tensor], include_last_o
 
 class _BagFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, indices, offsets, psw, mode, include_last, hook_features, sparse, fused, presorted):
+    def forward(ctx, weight, indices, offsets, psw, mode, include_last, hook_features, sparse, fused, presorted,
+                bwd_scale=None, masked=False):
         _lib.require_gpu()
         assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
@@ -61,10 +62,12 @@ class _BagFn(torch.autograd.Function):
         check(lib.ce_bag_forward(ptr(weight), weight.shape[0], dim, ptr(indices), indices.numel(), ptr(offsets),
                                  int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw), mode,
                                  hook_features, ptr(out), stream_ptr()))
-        ctx.save_for_backward(indices, offsets, psw)
+        # bwd_scale (scale_grad_by_freq): per-lookup factor of the backward only; it takes the place of psw there
+        ctx.save_for_backward(indices, offsets, psw if bwd_scale is None else bwd_scale.contiguous())
         ctx.weight = weight
         ctx.args = (mode, include_last, hook_features, sparse, fused, num_bags)
         ctx.presorted = presorted
+        ctx.masked = masked
         return out
 
     @staticmethod
@@ -99,6 +102,9 @@ class _BagFn(torch.autograd.Function):
             rows = torch.empty(nnz, dim, device=weight.device, dtype=torch.float32)
             check(lib.ce_bag_backward_rows(ptr(rows), None, dim, nnz, ptr(offsets), off64, num_bags, int(include_last),
                                            ptr(psw), mode, hook_features, ptr(grad_out), stream_ptr()))
+            if ctx.masked:          # lookups masked to -1 (padding_idx): zero contribution at a valid index
+                rows = rows * (indices >= 0).unsqueeze(1)
+                indices = indices.clamp(min=0)
             gw = torch.sparse_coo_tensor(indices.view(1, -1), rows, weight.shape, check_invariants=False)
         else:
             gw = torch.zeros_like(weight)
@@ -111,7 +117,7 @@ class _BagFn(torch.autograd.Function):
                 check(lib.ce_bag_backward_dense(ptr(gw), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
                                                 num_bags, int(include_last), ptr(psw), mode, hook_features,
                                                 ptr(grad_out), stream_ptr()))
-        return gw, None, None, None, None, None, None, None, None, None
+        return gw, None, None, None, None, None, None, None, None, None, None, None
 
 
 class FusedSGD:
@@ -140,8 +146,6 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
     if max_norm is not None:
         raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
-    if scale_grad_by_freq:
-        raise NotImplementedError("scale_grad_by_freq is not implemented by the HIP path")
     if mode not in _MODES:
         raise NotImplementedError(f"mode={mode!r}: only 'sum' and 'mean' are implemented")
     if per_sample_weights is not None:
@@ -154,13 +158,33 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
     indices, offsets, include_last_offset, num_bags = _prep(indices, offsets, include_last_offset)
     if per_sample_weights is not None and per_sample_weights.numel() != indices.numel():
         raise ValueError("per_sample_weights must have the same number of elements as input")
+    bwd_scale = None
+    if scale_grad_by_freq:
+        # torch: the gradient of a row is divided by the number of times the row occurs in the mini-batch
+        if mode != "sum":
+            raise NotImplementedError("scale_grad_by_freq is implemented for mode='sum' only")
+        if presorted is not None:
+            raise NotImplementedError("scale_grad_by_freq cannot be combined with presorted keys")
+        _, inv, cnt = torch.unique(indices, return_inverse=True, return_counts=True)
+        bwd_scale = (1.0 / cnt.to(torch.float32))[inv]
+        if per_sample_weights is not None:
+            bwd_scale = bwd_scale * per_sample_weights
+    if padding_idx is not None:
+        # entries equal to padding_idx take no part in the reduction and receive no gradient: the kernels skip
+        # out-of-range rows, so they are redirected to -1
+        if mode != "sum":
+            raise NotImplementedError("padding_idx is implemented for mode='sum' only (mean would need the "
+                                      "per-bag count of non-padding entries)")
+        if padding_idx < 0:
+            padding_idx += weight.shape[0]
+        indices = torch.where(indices == padding_idx, torch.full_like(indices, -1), indices)
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
     if presorted is not None:
         assert presorted.is_cuda and presorted.dtype == torch.int64 and presorted.is_contiguous() and \
             presorted.numel() == lib.ce_bag_presort_len(indices.numel()), "presorted must come from presort_slots"
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
-                        int(hook_features), bool(sparse), fused_sgd, presorted)
+                        int(hook_features), bool(sparse), fused_sgd, presorted, bwd_scale, padding_idx is not None)
 
 
 def presort_len(n: int) -> int:

@@ -395,10 +395,6 @@ class RowwiseExchange:
         return {"phase": 2, "P": len(ids_list), "token": token, "counts_host": host, "counts_event": ev,
                 "keep": both}
 
-    def plan_mid(self, st):
-        """kept for callers of the three-phase form; the size exchange now happens in plan_begin"""
-        return st
-
     @torch.no_grad()
     def plan_end(self, st) -> List[BatchPlan]:
         W, P = self.world, st["P"]
@@ -568,7 +564,10 @@ class ShardedWindowPipeline:
     Call order per window (identical on every rank, which keeps the collectives matched):
         submit(ids of window k+1)  ->  collect()  ->  train on the returned plans of window k ..."""
 
-    def __init__(self, embed: "RowwiseShardedEmbeddingBag", overlap: bool = True):
+    def __init__(self, embed: "RowwiseShardedEmbeddingBag", overlap: bool = True,
+                 transport: Optional[str] = "worker"):
+        # transport (overlap only): how the owner-side cache op moves rows while training runs beside it;
+        # "worker" = both directions through pinned hipMemcpyAsync + the library's worker threads (no CU time)
         self.embed = embed
         self.overlap = overlap
         self._pending = []
@@ -580,6 +579,8 @@ class ShardedWindowPipeline:
         if overlap:
             embed.cache_weight_mgr.set_protect_depth(1)
             embed.cache_weight_mgr.strict = False
+            if transport:
+                embed.cache_weight_mgr.set_transport(transport)
 
     def submit(self, ids_list: Sequence[torch.Tensor], wait_for_current: bool = True) -> None:
         """Phase 1 of the next window's plan (dedupe kernels + async count readback) on the side stream."""

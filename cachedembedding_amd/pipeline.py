@@ -20,6 +20,7 @@ import torch
 from . import _lib
 from .cached_embedding import CachedEmbeddingBag
 from .functional import presort_len, presort_window
+from .tracing import phase
 
 
 def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.cuda.Stream:
@@ -66,7 +67,8 @@ class PrefetchWindow:
     def _cache_op(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         counts = [int(v.numel()) for v in values]
         cat = values[0] if len(values) == 1 else torch.cat(list(values))
-        slots = self.mgr.prepare_ids(cat)
+        with phase("prefetch cache"):                      # the reference's range name (recsys/dlrm_main.py:258)
+            slots = self.mgr.prepare_ids(cat)
         # split by per-batch id counts (torch.chunk in the reference is only right for equal sizes, B#13)
         parts = list(torch.split(slots, counts))
         self._keys_tmp = None
@@ -204,7 +206,7 @@ class GraphedWindow:
         if self.overlap:
             cur = torch.cuda.current_stream(self.mgr.device)
             self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(self._side), phase("prefetch cache"):
                 self.mgr.prepare_ids(cat, out=self._bufs[buf])
                 if self.presort:
                     self._presort(buf)

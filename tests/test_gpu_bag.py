@@ -313,3 +313,35 @@ def test_presort_window_equals_per_batch_presort_and_feeds_the_backward(P, n, C)
         valid = slots[b] >= 0
         ref = w.clone().index_add_(0, slots[b][valid], go[valid], alpha=-0.5)
         torch.testing.assert_close(res[1], ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_padding_idx_and_scale_grad_by_freq_match_torch(sparse):
+    """the two F.embedding_bag arguments the reference forwards that round 1 rejected (sum mode)"""
+    ce = _ce()
+    g = torch.Generator().manual_seed(21)
+    N, D, nb = 300, 48, 500
+    lens = torch.randint(0, 5, (nb,), generator=g)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
+    nnz = int(off[-1])
+    idx = (torch.rand(nnz, generator=g) ** 2 * N).long().clamp_(0, N - 1)
+    idx[::7] = 17                                          # the padding id, often
+    w0 = torch.randn(N, D, generator=g)
+    go = torch.randn(nb, D, generator=g)
+    for kw in (dict(padding_idx=17), dict(scale_grad_by_freq=True), dict(padding_idx=17, scale_grad_by_freq=True)):
+        wc = w0.clone().cuda().requires_grad_(True)
+        out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=sparse, **kw)
+        out.backward(go.cuda())
+        ref = w0.clone().requires_grad_(True)
+        ro = torch.nn.functional.embedding_bag(idx, ref, off, mode="sum", include_last_offset=True, **kw)
+        ro.backward(go)
+        torch.testing.assert_close(out.detach().cpu(), ro.detach(), rtol=1e-5, atol=1e-5)
+        got = wc.grad.to_dense().cpu() if sparse else wc.grad.cpu()
+        torch.testing.assert_close(got, ref.grad, rtol=1e-4, atol=1e-5)
+    # the module: padding in ID space, cache op on
+    emb = ce.CachedEmbeddingBag(N, D, padding_idx=17, sparse=False, _weight=w0.clone(), mode="sum",
+                                include_last_offset=True, cuda_row_num=N, warmup_ratio=0.5)
+    emb.cache_weight_mgr.cuda_cached_weight.grad = None
+    out = emb(idx.cuda(), off.cuda())
+    ro = torch.nn.functional.embedding_bag(idx, w0, off, mode="sum", include_last_offset=True, padding_idx=17)
+    torch.testing.assert_close(out.detach().cpu(), ro, rtol=1e-5, atol=1e-5)

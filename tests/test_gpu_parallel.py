@@ -22,13 +22,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _entry(fn, rank, world, port, q, args):
+def _entry(fn, rank, world, port, q, args, backend="gloo"):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            # one rank per GPU over RCCL / xGMI: the way bench.py --gpus N runs
+            torch.cuda.set_device(rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        else:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         fn(rank, world, *args)
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -37,11 +43,11 @@ def _entry(fn, rank, world, port, q, args):
         q.put((rank, "fail", traceback.format_exc()))
 
 
-def _spawn(fn, world, *args):
+def _spawn(fn, world, *args, backend="gloo"):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args)) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args, backend)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -229,3 +235,14 @@ def test_rows_axpy_matches_index_add():
         exp = w.clone().index_add_(0, idx[ok], src[ok], alpha=-0.5)
         check(lib.ce_rows_axpy(ptr(w), R, D, ptr(idx), n, ptr(src), -0.5, stream_ptr()))
         torch.testing.assert_close(w, exp, rtol=1e-5, atol=1e-5)   # fp32 sums, atomic order differs
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rowwise_sharded_over_rccl(overlap):
+    """the row-wise exchange with the `nccl` (= RCCL) backend, one rank per GPU: all_to_all_single with zero-length
+    splits, the side streams of the window pipeline against RCCL's own stream, the worker transport beside the
+    collectives.  Same oracle as the single-GPU runs: plain torch on the full table.  Skipped on one-GPU boxes."""
+    world = min(torch.cuda.device_count(), 4)
+    _spawn(_rowwise, world, "dataset", True, overlap, backend="nccl")
+    _spawn(_rowwise, 2, "lfu", False, overlap, backend="nccl")
