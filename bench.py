@@ -263,33 +263,38 @@ def main():
     barrier()
     warm_s = time.perf_counter() - tw
     note(f"warmup done ({W} steps, {1e3 * warm_s / max(W, 1):.3f} ms/step incl. pipeline fill)")
-    # ---- timed region: blocks of EXACTLY K steps, each bracketed by barrier + synchronize; the block is repeated
-    # until the region is >= --min_time long and the MEDIAN block is reported.  A 20-step block is 4 ms: one block
-    # alone measures the pipeline fill, not the pipeline.
+    # ---- timed region.  K steps at the default sizes are 4-50 ms: a region that short measures pipeline fill and
+    # drain (one cache op of ~1 ms cannot overlap with anything when both ends are synchronised), not the pipeline.
+    # So: (1) one K-step block bracketed by barrier + synchronize on its own -- reported as block_ms.single, and used
+    # to size (2) the MEASUREMENT: `reps` x K consecutive steps (reps >= 3, region >= --min_time seconds) bracketed
+    # by barrier + synchronize ONCE; value = reps * K * lookups-per-step / that time.  Every cache op, presort and
+    # training step enqueued for those steps is inside the region.
     mgr.set_profiling(True)
+    g = W
+    need_windows(g + K, g)
+    barrier()
+    t1 = time.perf_counter()
+    run_range(g, g + K)
+    barrier()
+    single = time.perf_counter() - t1
+    g += K
+    reps = int(min(args.max_reps, max(3, -(-args.min_time // max(single, 1e-6)))))
+    need_windows(g + reps * K, g)
     mgr.phase_times(reset=True)
     tot0 = mgr.totals()
-    blocks = []
-    enqueue_s = 0.0
-    g = W
-    while True:
-        need_windows(g + K, g)
-        barrier()
-        t1 = time.perf_counter()
-        run_range(g, g + K)
-        enqueue_s += time.perf_counter() - t1
-        barrier()
-        blocks.append(time.perf_counter() - t1)
-        g += K
-        if (sum(blocks) >= args.min_time and len(blocks) >= 3) or len(blocks) >= args.max_reps:
-            break
-    reps = len(blocks)
-    elapsed = sorted(blocks)[reps // 2]
+    barrier()
+    t1 = time.perf_counter()
+    run_range(g, g + reps * K)
+    enqueue_s = time.perf_counter() - t1
+    barrier()
+    region = time.perf_counter() - t1
+    g += reps * K
+    elapsed = region / reps                      # seconds per K steps
+    blocks = [single]
     phases = mgr.phase_times()
     mgr.set_profiling(False)
-    note(f"timed region done: {reps} blocks of {K} steps, {sum(blocks):.3f}s in total, median block "
-         f"{1e3 * elapsed:.3f} ms (min {1e3 * min(blocks):.3f}, max {1e3 * max(blocks):.3f}); host enqueue "
-         f"{enqueue_s:.3f}s")
+    note(f"timed region done: {reps} x {K} steps in {region:.3f}s = {1e3 * elapsed / K:.4f} ms/step (one K-step block "
+         f"bracketed on its own: {1e3 * single:.3f} ms = {1e3 * single / K:.4f} ms/step); host enqueue {enqueue_s:.3f}s")
     st = mgr.sync_stats()
     if st.status != 0:
         raise AssertionError(f"cache op failed with status {st.status}: unique rows of a window exceed cuda_row_num={C}")
@@ -401,10 +406,10 @@ def main():
         "metric": "embedding lookups/sec (cache op + EmbeddingBag fwd + bwd/SGD), Criteo-1TB table @1% cache",
         "value": value, "unit": "lookups/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "warmup_steps_run": W, "reps": reps,
-        "timing": "median of `reps` consecutive blocks of `steps` steps, each bracketed by barrier + synchronize; "
-                  "every cache op is enqueued inside one block",
-        "block_ms": {"median": 1e3 * elapsed, "min": 1e3 * min(blocks), "max": 1e3 * max(blocks),
-                     "first": 1e3 * blocks[0]},
+        "timing": "`reps` x `steps` consecutive steps timed as ONE region bracketed by barrier + synchronize (a "
+                  "region of `steps` steps alone is a few ms and measures pipeline fill/drain); ms_per_step = region / "
+                  "(reps * steps); block_ms.single = one `steps`-step block bracketed on its own",
+        "block_ms": {"single": 1e3 * single, "region": 1e3 * region},
         "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
@@ -540,7 +545,8 @@ def run_sharded(args, sizes, rank, world, dev):
     grad = torch.randn(B, F, D, device=dev) * 1e-3
 
     from cachedembedding_amd.parallel import ShardedWindowPipeline
-    pipe = ShardedWindowPipeline(embed, overlap=args.overlap)
+    st = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or "none")
+    pipe = ShardedWindowPipeline(embed, overlap=args.overlap, transport=None if st == "none" else st)
     # finish the next window's plan after a few steps: its dedupe kernels (~0.1 ms per batch on the side stream)
     # have run by then, so the host does not wait, and the cache op still gets most of the window as lead
     pump_at = {int(os.environ.get("CE_BENCH_PUMP_AT", min(2, P - 1)))} if P >= 2 else set()

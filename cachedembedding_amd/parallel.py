@@ -565,9 +565,11 @@ class ShardedWindowPipeline:
         submit(ids of window k+1)  ->  collect()  ->  train on the returned plans of window k ..."""
 
     def __init__(self, embed: "RowwiseShardedEmbeddingBag", overlap: bool = True,
-                 transport: Optional[str] = "worker"):
-        # transport (overlap only): how the owner-side cache op moves rows while training runs beside it;
-        # "worker" = both directions through pinned hipMemcpyAsync + the library's worker threads (no CU time)
+                 transport: Optional[str] = None):
+        # transport (overlap only): how the owner-side cache op moves rows while training runs beside it; None keeps
+        # the manager's setting (zero-copy).  "worker" measured SLOWER here at W = 1 (1.29 vs 1.59 G lookups/s): the
+        # plan stream parks in the worker transport's wait, and this pipeline queues the next window's id exchange
+        # behind it
         self.embed = embed
         self.overlap = overlap
         self._pending = []

@@ -316,8 +316,12 @@ def test_presort_window_equals_per_batch_presort_and_feeds_the_backward(P, n, C)
 
 
 @pytest.mark.parametrize("sparse", [False, True])
-def test_padding_idx_and_scale_grad_by_freq_match_torch(sparse):
-    """the two F.embedding_bag arguments the reference forwards that round 1 rejected (sum mode)"""
+def test_padding_idx_and_scale_grad_by_freq(sparse):
+    """the two F.embedding_bag arguments the reference forwards that round 1 rejected (sum mode).
+    padding_idx is checked against torch-CPU.  scale_grad_by_freq is checked against its documented meaning (every
+    row's gradient divided by the number of times the row occurs in the mini-batch): torch's own CPU kernel leaves
+    duplicates INSIDE one bag unscaled (probed here: a row looked up twice by the same bag gets the full gradient
+    twice), a quirk this path does not copy."""
     ce = _ce()
     g = torch.Generator().manual_seed(21)
     N, D, nb = 300, 48, 500
@@ -328,20 +332,27 @@ def test_padding_idx_and_scale_grad_by_freq_match_torch(sparse):
     idx[::7] = 17                                          # the padding id, often
     w0 = torch.randn(N, D, generator=g)
     go = torch.randn(nb, D, generator=g)
+    bag = torch.repeat_interleave(torch.arange(nb), lens)
+    cnt = torch.bincount(idx, minlength=N).float()
     for kw in (dict(padding_idx=17), dict(scale_grad_by_freq=True), dict(padding_idx=17, scale_grad_by_freq=True)):
         wc = w0.clone().cuda().requires_grad_(True)
         out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=sparse, **kw)
         out.backward(go.cuda())
-        ref = w0.clone().requires_grad_(True)
-        ro = torch.nn.functional.embedding_bag(idx, ref, off, mode="sum", include_last_offset=True, **kw)
-        ro.backward(go)
-        torch.testing.assert_close(out.detach().cpu(), ro.detach(), rtol=1e-5, atol=1e-5)
+        ro = torch.nn.functional.embedding_bag(idx, w0, off, mode="sum", include_last_offset=True,
+                                               padding_idx=kw.get("padding_idx"))
+        torch.testing.assert_close(out.detach().cpu(), ro, rtol=1e-5, atol=1e-5)
+        keep = idx != 17 if "padding_idx" in kw else torch.ones_like(idx, dtype=torch.bool)
+        scale = (1.0 / cnt[idx]) if kw.get("scale_grad_by_freq") else torch.ones(nnz)
+        want = torch.zeros(N, D).index_add_(0, idx[keep], go[bag[keep]] * scale[keep].unsqueeze(1))
         got = wc.grad.to_dense().cpu() if sparse else wc.grad.cpu()
-        torch.testing.assert_close(got, ref.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+        if "scale_grad_by_freq" not in kw:                 # plain padding: torch agrees
+            ref = w0.clone().requires_grad_(True)
+            torch.nn.functional.embedding_bag(idx, ref, off, mode="sum", include_last_offset=True, **kw).backward(go)
+            torch.testing.assert_close(got, ref.grad, rtol=1e-4, atol=1e-5)
     # the module: padding in ID space, cache op on
     emb = ce.CachedEmbeddingBag(N, D, padding_idx=17, sparse=False, _weight=w0.clone(), mode="sum",
                                 include_last_offset=True, cuda_row_num=N, warmup_ratio=0.5)
-    emb.cache_weight_mgr.cuda_cached_weight.grad = None
     out = emb(idx.cuda(), off.cuda())
     ro = torch.nn.functional.embedding_bag(idx, w0, off, mode="sum", include_last_offset=True, padding_idx=17)
     torch.testing.assert_close(out.detach().cpu(), ro, rtol=1e-5, atol=1e-5)
