@@ -127,8 +127,6 @@ SIGNATURES = {
     "ce_cache_swap_stats": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "ce_cache_failures": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int32), POINTER(c_int64)]),
     "ce_cache_free_rows": (c_int, [c_void_p, POINTER(c_int64)]),
-    "ce_dedupe_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p]),
     "ce_bucketize_workspace": (c_size_t, [c_int64, c_int32]),
     "ce_bucketize_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

@@ -222,71 +222,6 @@ __global__ __launch_bounds__(256) void k_seg_sgd(SegArgs a) {
   }
 }
 
-// ---- batch dedupe for the row-wise exchange: first lookup of a row (per call tag) claims a compact index
-__global__ __launch_bounds__(256) void k_dedupe_claim(const int64_t* __restrict__ ids, int64_t n,
-                                                      const int32_t* __restrict__ idx_map, int64_t num_rows,
-                                                      int32_t tag, int row_bits, int32_t* stamp, int32_t* slot_of_row,
-                                                      int64_t* uniq_rows, unsigned long long* n_unique) {
-  __shared__ int wave_cnt[4];
-  __shared__ unsigned long long blk_base;
-  const int lane = threadIdx.x & 63;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // block-uniform trip count (the loop body synchronises the workgroup)
-  for (int64_t b0 = (int64_t)blockIdx.x * blockDim.x; b0 < n; b0 += stride) {
-    const int64_t i = b0 + threadIdx.x;
-    bool on = i < n;
-    int32_t row = 0;
-    if (on) {
-      const int64_t id = ids[i];
-      on = (unsigned long long)id < (unsigned long long)num_rows;
-      if (on) row = idx_map ? idx_map[id] : (int32_t)id;
-    }
-    // equal rows of the wave are merged (hot rows would otherwise serialise on one stamp word)
-    unsigned long long pm = __ballot(on);
-    if (!on) pm = 0;
-    for (int b = 0; b < row_bits; ++b) {
-      const unsigned long long m = __ballot((row >> b) & 1);
-      pm &= ((row >> b) & 1) ? m : ~m;
-    }
-    bool claim = false;
-    // (a load-before-exchange filter was measured 2.4x slower: the random uncached load costs as much as the
-    // atomic it saves)
-    if (on && (__ffsll((long long)pm) - 1) == lane) claim = atomicExch(&stamp[row], tag) != tag;
-    // compact numbering: one bump of the global counter per WORKGROUP per iteration (a single word hit once
-    // per unique row -- or even once per wave -- serialises at ~12 ns per atomic: 100 us for 426 k lookups)
-    const unsigned long long cm = __ballot(claim);
-    const int wv = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wv] = __popcll(cm);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-      blk_base = tot ? atomicAdd(n_unique, (unsigned long long)tot) : 0ull;
-    }
-    __syncthreads();
-    if (claim) {
-      unsigned long long p = blk_base;
-      for (int k = 0; k < wv; ++k) p += wave_cnt[k];
-      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      p += (unsigned long long)__popcll(cm & lt);
-      uniq_rows[p] = row;
-      slot_of_row[row] = (int32_t)p;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256) void k_dedupe_index(const int64_t* __restrict__ ids, int64_t n,
-                                                      const int32_t* __restrict__ idx_map, int64_t num_rows,
-                                                      const int32_t* __restrict__ slot_of_row, int64_t* inv) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t id = ids[i];
-    int64_t v = -1;
-    if ((unsigned long long)id < (unsigned long long)num_rows) v = slot_of_row[idx_map ? idx_map[id] : (int32_t)id];
-    inv[i] = v;
-  }
-}
-
 // ---- fused dedupe + owner bucketing (row-wise exchange, requester side).  Three passes, no sort, no histogram /
 // scan chain, no host sync and NO returning atomics (a random device-scope atomic with return costs a
 // ~2 us round trip to the memory side and a CU keeps only a few dozen in flight: 426 k of them took 90 us):
@@ -469,25 +404,6 @@ extern "C" int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* i
   hipLaunchKernelGGL(k_bucket_counts, dim3(1), dim3(256), 0, s, (const int32_t*)a.hist, n > 0 ? (int32_t)n : 0,
                      ntiles, world, counts_out);
   hipLaunchKernelGGL((k_split_scatter<1, 1, true>), dim3(ntiles), dim3(256), 0, s, a);
-  CE_LAUNCH_CHECK();
-  return CE_OK;
-}
-
-extern "C" int ce_dedupe_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows, int32_t tag,
-                              int32_t* stamp, int32_t* slot_of_row, int64_t* uniq_rows_out, int64_t* inv_out,
-                              int64_t* n_unique_out, ce_stream_t stream) {
-  CE_REQUIRE(n >= 0 && num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "bad sizes");
-  CE_REQUIRE(stamp && slot_of_row && n_unique_out, CE_ERR_INVALID, "null pointer");
-  hipStream_t s = (hipStream_t)stream;
-  CE_HIP_CHECK(hipMemsetAsync(n_unique_out, 0, sizeof(int64_t), s));
-  if (n == 0) return CE_OK;
-  CE_REQUIRE(ids && uniq_rows_out && inv_out, CE_ERR_INVALID, "null pointer");
-  int bits = 1;
-  while ((1ll << bits) < num_rows && bits < 31) ++bits;
-  hipLaunchKernelGGL(k_dedupe_claim, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows, tag, bits,
-                     stamp, slot_of_row, uniq_rows_out, (unsigned long long*)n_unique_out);
-  hipLaunchKernelGGL(k_dedupe_index, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows,
-                     (const int32_t*)slot_of_row, inv_out);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }

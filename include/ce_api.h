@@ -305,14 +305,6 @@ int ce_cache_free_rows(ce_cache_t* h, int64_t* out);
  * counting sort by owner: local_rows_out[perm position] = row / world (int64),
  * perm_out[j] = position of lookup j in the bucketed order, counts_out[w] (device int64[world]).
  */
-/* ce_dedupe_rows: the unique rows of a batch and, per lookup, the index of its row in that list (any order;
- * no sort, no host sync).  stamp: device int32[num_rows], zeroed once by the caller and reused across calls;
- * slot_of_row: device int32[num_rows] scratch; tag: a value no earlier call on the same stamp array used
- * (a call counter >= 1).  uniq_rows_out: int64[n] (first *n_unique_out entries valid), inv_out: int64[n],
- * n_unique_out: device int64.  Only unique rows travel in the row-wise exchange. */
-int ce_dedupe_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows, int32_t tag,
-                   int32_t* stamp, int32_t* slot_of_row, int64_t* uniq_rows_out, int64_t* inv_out,
-                   int64_t* n_unique_out, ce_stream_t stream);
 size_t ce_bucketize_workspace(int64_t n, int32_t world);
 int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int32_t world,
                       int64_t* local_rows_out, int64_t* perm_out, int64_t* counts_out,

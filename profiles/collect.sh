@@ -15,7 +15,7 @@ python bench.py --no_cpu_baseline --use_lfu > gpurun_out/bench_lfu.json 2>/dev/n
 python bench.py --no_cpu_baseline --async_copy 2>/dev/null | tail -1 > gpurun_out/bench_staged.json
 python bench.py --force_sharded --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_sharded_w1.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 64 --warmup 16 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_torchrun1.json
-python scratch/probe_sdma.py > gpurun_out/probe_sdma.txt 2>&1
+python profiles/probe_sdma.py > gpurun_out/probe_sdma.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_seq -o r02 -- python $R/bench.py --no_cpu_baseline --no_overlap --no_graph --transport zerocopy > $R/gpurun_out/prof_seq.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ov -o r02 -- python $R/bench.py --no_cpu_baseline > $R/gpurun_out/prof_ov.log 2>&1
