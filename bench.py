@@ -71,9 +71,9 @@ def parse():
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport (= --transport staged)")
     ap.add_argument("--transport", default=None, choices=["worker", "zerocopy", "staged"],
                     help="how rows move between the host table and the cache.  worker (default when the cache op "
-                         "overlaps training): admissions by zero-copy reads, evictions by ONE pinned hipMemcpyAsync "
-                         "+ a worker thread in libce_hip; zerocopy (default with --no_overlap): one kernel moves "
-                         "both directions over the mapped host table; staged: upstream's async_copy")
+                         "overlaps training and a call covers >= 1.5 M ids): both directions by pinned "
+                         "hipMemcpyAsync driven by worker threads in libce_hip; zerocopy (default otherwise): one "
+                         "kernel moves both directions over the mapped host table; staged: upstream's async_copy")
     ap.add_argument("--min_time", type=float, default=0.5, help="the K-step block is repeated until the timed "
                     "region is at least this long (seconds); the median block is reported")
     ap.add_argument("--max_reps", type=int, default=400)
@@ -138,7 +138,9 @@ def main():
                                   cache_ratio=args.cache_ratio, ids_freq_mapping=freq, warmup_ratio=args.warmup_ratio,
                                   pin_weight=True, evict_strategy=strategy, init_seed=args.seed, strict=False)
     del freq
-    transport = args.transport or ("staged" if args.async_copy else ("worker" if args.overlap else "zerocopy"))
+    from cachedembedding_amd.pipeline import pick_transport
+    transport = args.transport or ("staged" if args.async_copy else
+                                   (pick_transport("auto", P * B * F * L) if args.overlap else "zerocopy"))
     embed.cache_weight_mgr.set_transport(transport)
     embed.set_fused_sgd(args.lr, deterministic=args.deterministic)
     embed.set_cache_op(False)

@@ -434,9 +434,17 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
     keys[s] = key;
   }
   // evictable slots are counted here, not read off the top-digit histogram: a DATASET key N-1-row can share its
-  // top byte (0xff when N-1 has it, e.g. N = 256, 65536, 2^24) with the all-ones key of an ineligible slot
+  // top byte (0xff when N-1 has it, e.g. N = 256, 65536, 2^24) with the all-ones key of an ineligible slot.
+  // One atomic per WORKGROUP on a grid of at most 512: same-address device atomics serialise at ~7 ns each, and
+  // one per wave of a 1738-workgroup grid cost this kernel 50 us.
+  __shared__ int wsum[4];
   elig = wave_sum(elig);
-  if ((threadIdx.x & 63) == 0 && elig) atomicAdd((unsigned long long*)&ctl->n_eligible, (unsigned long long)elig);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = elig;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tot) atomicAdd((unsigned long long*)&ctl->n_eligible, (unsigned long long)tot);
+  }
 }
 
 // Few, fat workgroups: every workgroup ends with one device atomic per non-empty bin and same-address atomics
@@ -513,10 +521,20 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
   if (ctl->k_evict == 0) return;
   const unsigned long long T = ctl->sel_prefix;   // k-th smallest key; keys are unique
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
-    const unsigned long long key = keys[s];
-    if (key <= T && key != ~0ull) {
-      const int pos = atomicAdd(&ctl->victims_count, 1);
+  const int lane = threadIdx.x & 63;
+  // wave-uniform trip count; the victims of a wave reserve their places with ONE returning atomic (a returning
+  // device atomic is a ~2 us round trip and a CU keeps only a few dozen in flight)
+  for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); s0 < C; s0 += stride) {
+    const int64_t s = s0 + lane;
+    const unsigned long long key = s < C ? keys[s] : ~0ull;
+    const bool hit = key <= T && key != ~0ull;
+    const unsigned long long m = __ballot(hit);
+    if (m == 0) continue;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ctl->victims_count, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (hit) {
+      const int pos = base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
       if (pos < cap) victims[pos] = (int32_t)s;
     }
   }
@@ -2032,7 +2050,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   CE_PHASE();
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
-  hipLaunchKernelGGL(k_keys, dim3(cgrid), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
+  hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
                      epoch, c.protect_depth, h->slot_bits, lfu, h->keys, h->hist, h->ctl);
   // DATASET keys are < N: the bytes above the highest byte of N-1 are zero for every eligible slot, so the
   // radix select starts there (4 passes at N = 178 M instead of 8)

@@ -627,6 +627,9 @@ class ShardedWindowPipeline:
             self.pump()
             st = self._pending.pop(0)
         plans, ev = st["plans"], st["event"]
+        # strict=False: an owner-side cache op that overflowed handed back slots of -1; raise like the reference as
+        # soon as its record has arrived (non-blocking)
+        self.embed.cache_weight_mgr.raise_on_failed_calls()
         cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
         cur.wait_event(ev)
         for p in plans:

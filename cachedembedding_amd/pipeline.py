@@ -39,11 +39,25 @@ def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
+# ids per cache op from which the worker transport pays: it costs a host round trip (event wake-up, gather, copy,
+# release: >= 0.15-0.2 ms whatever the size) and buys the swap traffic off the CUs; the zero-copy swap kernel costs
+# ~0.03 ms per 1000 rows moved.  Measured: Kaggle 5 % P = 1 (426 k ids, ~25 k rows per call) 0.97 G lookups/s
+# zero-copy / 0.81 G worker; P = 8 (3.4 M ids, ~50 k rows) 2.0 G / 2.5 G.
+AUTO_WORKER_MIN_IDS = 1_500_000
+
+
+def pick_transport(transport: Optional[str], ids_per_call: int) -> Optional[str]:
+    if transport == "auto":
+        return "worker" if ids_per_call >= AUTO_WORKER_MIN_IDS else "zerocopy"
+    return transport
+
+
 class PrefetchWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
-                 presort: bool = False, transport: Optional[str] = "worker"):
+                 presort: bool = False, transport: Optional[str] = "auto"):
         # transport (overlap=True only): how rows move while the cache op runs beside training; "worker" keeps the
-        # write-back off the CUs (CachedParamMgr.set_transport), None leaves the manager's setting alone
+        # swap traffic off the CUs (CachedParamMgr.set_transport), "auto" decides by the size of the first window
+        # (pick_transport), None leaves the manager's setting alone
         assert prefetch_num >= 1
         # presort=True: the cache op also sorts the window's slots in 16384-lookup segments (ce_bag_presort), so the
         # fused backward neither sorts nor issues as many row updates; the keys of the last prepared/collected window
@@ -60,13 +74,17 @@ class PrefetchWindow:
             self._side = make_side_stream(self.mgr.device, cache_cus)
             self.mgr.set_protect_depth(1)
             self.mgr.strict = False   # no host sync inside the pipelined cache op
-            if transport:
+            if transport and transport != "auto":
                 self.mgr.set_transport(transport)
+        self._auto = overlap and transport == "auto"
 
     @torch.no_grad()
     def _cache_op(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         counts = [int(v.numel()) for v in values]
         cat = values[0] if len(values) == 1 else torch.cat(list(values))
+        if self._auto:
+            self._auto = False
+            self.mgr.set_transport(pick_transport("auto", int(cat.numel())))
         with phase("prefetch cache"):                      # the reference's range name (recsys/dlrm_main.py:258)
             slots = self.mgr.prepare_ids(cat)
         # split by per-batch id counts (torch.chunk in the reference is only right for equal sizes, B#13)
@@ -133,7 +151,7 @@ class GraphedWindow:
 
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
                  warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
-                 transport: Optional[str] = "worker"):
+                 transport: Optional[str] = "auto"):
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
         self.P = prefetch_num
@@ -153,6 +171,7 @@ class GraphedWindow:
         if overlap:
             self.mgr.set_protect_depth(1)
             self.mgr.strict = False
+            transport = pick_transport(transport, prefetch_num * ids_per_batch)
             if transport:
                 self.mgr.set_transport(transport)
         # eager warm-up on real slots (lazy initialisation must not happen during capture), then capture

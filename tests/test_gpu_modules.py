@@ -165,7 +165,7 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
 
     if mode == "graph":
         gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=[v.cuda() for v in windows[0]],
-                           presort=presort)
+                           presort=presort, transport="worker")
         # the capture warm-up trained on window 0 twice over (eager pass + nothing else): replay that on the ref
         for v in windows[0]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
@@ -175,7 +175,7 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
                 gw.submit([v.cuda() for v in windows[w + 1]], (w + 1) % 2)
             gw.run(w % 2)
     else:
-        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"), presort=presort)
+        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"), presort=presort, transport="worker")
         if mode == "overlap":
             win.submit([v.cuda() for v in windows[0]])
         for w in range(nwin):
@@ -196,7 +196,8 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
     torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("extra", [[], ["--fused_sgd", "--fold_hook", "--use_lfu"], ["--use_cache_mgr_async_copy"]])
+@pytest.mark.parametrize("extra", [[], ["--fused_sgd", "--fold_hook", "--use_lfu"], ["--use_cache_mgr_async_copy"],
+                                   ["--overlap_cache_op"], ["--overlap_cache_op", "--fused_sgd", "--fold_hook"]])
 def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):
     """examples/dlrm_main.py (counterpart of recsys/dlrm_main.py): prefetch window + side-stream loader +
     dense DLRM around the operator; the loss must go down on a learnable synthetic target."""

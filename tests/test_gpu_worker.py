@@ -165,7 +165,7 @@ def test_overlapped_window_raises_on_overflow():
     N, D, C = 4000, 16, 300
     emb = ce.CachedEmbeddingBag(N, D, sparse=True, mode="sum", include_last_offset=True, cuda_row_num=C,
                                 warmup_ratio=0.7)
-    win = PrefetchWindow(emb, 2, overlap=True)
+    win = PrefetchWindow(emb, 2, overlap=True, transport="worker")
     g = torch.Generator().manual_seed(0)
     ok = [torch.randint(0, N, (64,), generator=g).cuda() for _ in range(2)]
     too_many = [torch.arange(0, 400).cuda(), torch.arange(400, 800).cuda()]      # 800 unique rows > 300 slots
