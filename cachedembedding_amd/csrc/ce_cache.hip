@@ -1830,11 +1830,12 @@ static int ensure_writeback(ce_cache* h) {
       else if (hipHostMalloc((void**)&w->idx_host[b], idx_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
     }
     if (rc) break;
-    // helper threads per direction: half of what the CPU budget leaves after the launch thread and the two
-    // (mostly sleeping) workers.  A helper is bound by the cache misses it can keep in flight (~45-75 ns per
+    // helper threads per direction: half of what the CPU budget leaves after the launch thread, the two (mostly
+    // sleeping) workers and the runtime's own threads -- a cgroup that exceeds its CPU quota is frozen until the next
+    // scheduler period, which shows up as millisecond stalls of the admission.  A helper is bound by the cache misses it can keep in flight (~45-75 ns per
     // 512-byte row), so the job time falls with the helper count until the quota is reached; beyond it the threads
     // only fight (16-CPU quota, spinning waits: 4 + 4 helpers 0.78 / 1.03 ms per job, 8 + 8 1.24 / 1.43 ms)
-    static const int dflt = std::max(2, std::min(8, (cpu_budget() - 2) / 2));
+    static const int dflt = std::max(2, std::min(8, (cpu_budget() - 4) / 2));
     static const int out_threads = [] { const char* e = getenv("CE_WB_THREADS"); return e ? atoi(e) : dflt; }();
     static const int in_threads = [] { const char* e = getenv("CE_GATHER_THREADS"); return e ? atoi(e) : dflt; }();
     w->out_pool = new RowPool(std::max(1, std::min(out_threads, 64)));

@@ -1,6 +1,7 @@
 """CPU tests of the drop-in boundary: libce_hip.so loads without a GPU, exports every
 symbol include/ce_api.h declares, and the ctypes mirror matches the header's structs."""
 import ctypes
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -86,3 +87,20 @@ def test_product_never_imports_oracle():
     for p in (ROOT / "cachedembedding_amd").rglob("*.py"):
         txt = p.read_text()
         assert "oracle" not in re.sub(r'""".*?"""', "", txt, flags=re.S).replace("# oracle", ""), p
+
+
+def test_transport_choice_and_tracing_helpers():
+    """host logic that needs no GPU: the size rule of the automatic transport choice, the phase ranges"""
+    from cachedembedding_amd.pipeline import AUTO_WORKER_MIN_IDS, pick_transport
+    assert pick_transport("auto", AUTO_WORKER_MIN_IDS) == "worker"
+    assert pick_transport("auto", 16384 * 26) == "zerocopy"            # one Criteo batch (prefetch_num = 1)
+    assert pick_transport("auto", 8 * 16384 * 26) == "worker"          # the bench window
+    assert pick_transport("staged", 10) == "staged" and pick_transport(None, 10 ** 9) is None
+    from cachedembedding_amd.tracing import phase
+    with phase("prefetch cache"):
+        with phase("forward pass"):
+            pass
+    import cachedembedding_amd as ce
+    assert 1 <= ce._lib.lib.ce_cpu_budget() <= (os.cpu_count() or 1)
+    assert ce._lib.lib.ce_cache_phase_count() == 6
+    assert ce._lib.lib.ce_cache_phase_name(4) == b"admit_swap"
