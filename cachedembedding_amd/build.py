@@ -12,7 +12,8 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libce_hip.so"
-SOURCES = ["ce_host.hip", "ce_bag.hip", "ce_cache.hip", "ce_sort.hip"]
+SOURCES = ["ce_host.hip", "ce_bag.hip", "ce_cache.hip", "ce_sort.hip", "ce_rowcopy.cpp"]
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++"]       # plain C++ sources (host only)
 HEADERS = [ROOT / "include" / "ce_api.h", CSRC / "ce_common.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
@@ -45,7 +46,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     procs = []
     for src in SOURCES:
         obj = objdir / (src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        flags = HOST_FLAGS if src.endswith(".cpp") else FLAGS
+        cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -1139,20 +1139,9 @@ struct PhaseProf {
   }
 };
 
-// Host-side row copy with non-temporal stores: the destination (a table row that is overwritten whole, or pinned
-// staging that only the DMA engine reads) is written without first being read into the cache -- a plain memcpy of a
-// 512-byte row to a random table address pays a read-for-ownership miss on each of its 8 lines.
-static inline void row_copy_nt(float* __restrict__ dst, const float* __restrict__ src, size_t floats) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && (floats & 3) == 0) {
-    const v4f* s4 = (const v4f*)src;
-    v4f* d4 = (v4f*)dst;
-    const size_t n4 = floats >> 2;
-    for (size_t i = 0; i < n4; ++i) __builtin_nontemporal_store(s4[i], d4 + i);
-  } else {
-    memcpy(dst, src, floats * sizeof(float));
-  }
-}
+// host-side row copies of the swap workers: csrc/ce_rowcopy.cpp (widest streaming store the CPU has)
+void row_copy_stream(float* dst, const float* src, size_t floats);
+void row_copy_fence();
 
 // waiting for a copy stream without burning a CPU of a quota-limited host and without any packet in a hardware
 // queue: poll hipStreamQuery with short sleeps
@@ -1286,8 +1275,8 @@ struct SwapEngine {
           const int32_t* ri = idx_host[b] + off;
           const int64_t d = D;
           out_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) row_copy_nt(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
-            __atomic_thread_fence(__ATOMIC_SEQ_CST);          // non-temporal stores are weakly ordered
+            for (int64_t i = lo; i < hi; ++i) row_copy_stream(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
+            row_copy_fence();
           });
         }
         if (e != hipSuccess) fail("D2H copy", e);
@@ -1358,9 +1347,9 @@ struct SwapEngine {
                 const char* q = (const char*)(tb + (size_t)rows[i + kAhead] * d);
                 for (int64_t l = 0; l < d * 4; l += 64) __builtin_prefetch(q + l);
               }
-              row_copy_nt(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d);
+              row_copy_stream(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d);
             }
-            __atomic_thread_fence(__ATOMIC_SEQ_CST);            // non-temporal stores are weakly ordered
+            row_copy_fence();
             ready[(size_t)pc].store(1, std::memory_order_release);
           }
         };
