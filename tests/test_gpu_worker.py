@@ -240,3 +240,36 @@ def test_worker_transport_with_more_streams_than_hardware_queues():
         torch.cuda.synchronize()
     for m, o in zip(mgrs, oras):
         np.testing.assert_array_equal(m.weight.numpy(), o.weight)
+
+
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+def test_worker_transport_empty_and_ragged_calls(strategy):
+    """calls of very different sizes, including empty ones and calls without any miss, back to back"""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+    rng = np.random.default_rng(9)
+    N, C, D = 8000, 900, 32
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+    ora.reorder(None, 0.5)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C, evict_strategy=_strat(ce, strategy))
+    mgr.reorder(None, 0.5)
+    mgr.set_transport("worker")
+    sizes = [0, 1, 700, 0, 0, 5, 850, 3, 0, 600, 600, 1, 0]
+    for c, n in enumerate(sizes):
+        ids = rng.integers(0, N, size=n)
+        if c == 7:
+            ids = np.asarray(ora.cached_idx_map[ora.cached_idx_map >= 0][:3])      # hits only: nothing moves
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        if len(eslots):
+            ora.cuda_cached_weight[np.unique(eslots)] += np.float32(1.0)
+            with torch.no_grad():
+                mgr.cuda_cached_weight[torch.unique(slots)] += 1.0
+        _state_equal(mgr, ora, strategy == "lfu")
+    assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+    mgr.flush()
+    ora.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
