@@ -349,9 +349,17 @@ class CachedParamMgr(torch.nn.Module):
         hipMemcpyAsync + host gather/scatter on the calling thread) or 'worker' (admissions zero-copy, evictions
         through one SDMA copy + a worker thread inside the library; the host table lags until writeback_wait /
         flush / a read of `.weight`)."""
-        self._transport = self._TRANSPORTS[name]
         with torch.cuda.device(self.device):
-            check(lib.ce_cache_set_transport(self._handle, self._transport))
+            rc = lib.ce_cache_set_transport(self._handle, self._TRANSPORTS[name])
+            if rc == _lib.CE_ERR_UNSUPPORTED and name == "worker":
+                # no hipStreamWaitValue64 / no stream priorities on this device: stay on the zero-copy kernels
+                import warnings
+                warnings.warn(f"worker transport unavailable ({_lib.last_error()}); using zerocopy")
+                name = "zerocopy"
+                rc = lib.ce_cache_set_transport(self._handle, self._TRANSPORTS[name])
+            check(rc)
+        self._transport = self._TRANSPORTS[name]
+        self.transport_name = name
 
     def set_profiling(self, on: bool = True):
         """hipEvent timers around the phases of prepare_ids (read them with phase_times())."""

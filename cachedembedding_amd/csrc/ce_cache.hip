@@ -1787,6 +1787,11 @@ static int ensure_writeback(ce_cache* h) {
     // priority: they only ever share queues with each other (and nothing of theirs ever waits).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (prio_lo == prio_hi) {
+      delete w;
+      set_error("the worker transport needs stream priorities (a hardware-queue pool of its own for the copy streams)");
+      return CE_ERR_UNSUPPORTED;
+    }
     if (hipStreamCreateWithPriority(&w->out_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&w->out_stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&w->in_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
