@@ -517,15 +517,15 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
   const int dim = rowlen * (int)(sizeof(VT) / 4);
   const VT* __restrict__ GO = (const VT*)p.grad_out;
   // tile_len <= kBwdTile is chosen by the launcher so that the tile count is a multiple of the CU count
-  // (425,984 lookups -> 512 tiles of 832: two per CU, instead of 416 tiles = 1 or 2 per CU)
+  // (425,984 lookups -> 512 tiles of 832: two per CU, instead of 416 tiles = 1 or 2 per CU).
+  // presorted: the tiles are tile_len consecutive positions of the segment-padded key array (any alignment)
   const int tile_len = p.tile_len;
-  // presorted: the tiles are 1024 consecutive SORTED positions of the segment-padded key array
-  const int ntiles = p.presorted ? (int)(((p.nnz + kSegLen - 1) / kSegLen) * (kSegLen / kBwdTile))
-                                 : (int)((p.nnz + tile_len - 1) / tile_len);
+  const int64_t total = p.presorted ? ((p.nnz + kSegLen - 1) / kSegLen) * kSegLen : p.nnz;
+  const int ntiles = (int)((total + tile_len - 1) / tile_len);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int j0 = tile * tile_len;
-    const int nv = p.presorted ? kBwdTile : min(tile_len, (int)(p.nnz - j0));
+    const int nv = min(tile_len, (int)(total - j0));
     // ---- a. keys, bag and scale of every lookup of the tile (out-of-range rows become invalid keys);
     //         thread t owns lookups 4t..4t+3 of the tile
     const bool presorted = p.presorted != nullptr;
@@ -537,11 +537,11 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       int j = j0 + i;                                          // the lookup behind position i
       uint32_t row = 0xffffffffu;
       if (presorted) {
-        const unsigned long long sk = p.presorted[(int64_t)tile * kBwdTile + i];
+        const unsigned long long sk = i < nv ? p.presorted[(int64_t)j0 + i] : ~0ull;
         j = -1;
         if (sk != ~0ull) {
           row = (uint32_t)(sk >> 32);
-          j = (int)(((int64_t)tile * kBwdTile / kSegLen) * kSegLen) + (int)(uint32_t)sk;
+          j = (int)((((int64_t)j0 + i) / kSegLen) * kSegLen) + (int)(uint32_t)sk;
         }
       } else if (i < nv) {
         const int64_t r64 = p.indices[j];
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
           const int len = bag_end(p, bag) - ld_off(p, bag);
           if (len > 1) sc = sc / (float)len;
         }
-        bagl[i] = bag;
+        bagl[i] = (int)out_row(p, bag);      // row of grad_out this lookup reads (one division per lookup, not per lane)
         scl[i] = sc;
         if (row != 0xffffffffu) kr[r] = K::make(row, i);
       }
@@ -572,11 +572,11 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
     } else {
       tile_sort_1024<KT>(kr, keys, tid);
     }
-    // ---- c. reduce: lane groups walk chunks of kChunk sorted positions, R gradient rows in flight,
-    // folding equal rows in lookup order; one atomic row update per (row, chunk) -- a row repeated n
-    // times in the tile costs n/kChunk+1 atomics instead of n.
-    constexpr int kChunk = 64;
+    // ---- c. reduce: every lane group walks ONE contiguous, equal share of the tile's sorted positions (13 chunks
+    // of 64 over 8 groups cost two rounds -- the same as 16; 104 positions each cost 6.5/8 of that), R gradient
+    // rows in flight, folding equal rows in lookup order; one atomic row update per (row, share).
     if (p.debug == 4) continue;
+    const int kChunk = (nv + ngroups - 1) / ngroups;
     const int nchunks = (nv + kChunk - 1) / kChunk;
     for (int ck = grp; ck < nchunks; ck += ngroups) {
       const int s0 = ck * kChunk, s1 = min(nv, s0 + kChunk);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
           const int li = on ? K::idx(key) : 0;
           rw[t] = on ? K::row(key) : K::row_invalid();
           sc[t] = on ? scl[li] : 0.f;
-          const int64_t orow = out_row(p, bagl[li]);
+          const int64_t orow = bagl[li];
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const int ch = gl + c * G;
@@ -723,9 +723,18 @@ static int launch_bwd_scatter(const BagParams& p, bool vec, int nch, hipStream_t
   BagParams q = p;
   const char* dbg = getenv("CE_BWD_DEBUG");
   q.debug = dbg ? atoi(dbg) : 0;
-  q.tile_len = kBwdTile;      // (a CU-multiple tile count, 512 x 832, measured no better: 0.105 -> 0.108 ms)
+  // sorted keys: a tile count that is a multiple of the CU count (425,984 keys -> 512 tiles of 832, two per CU,
+  // instead of 416 tiles = one or two per CU): 80 -> 72.5 us.  More, smaller tiles lose to the per-tile prologue
+  // (3/CU 77 us, 4/CU 85 us, 8/CU 94 us), and the self-sorting path does not gain (92 us either way).
+  q.tile_len = kBwdTile;
+  if (p.presorted) {
+    static const int per_cu = [] { const char* e = getenv("CE_BWD_TILES_PER_CU"); return e ? atoi(e) : 2; }();
+    const int64_t total = cdiv(p.nnz, kSegLen) * kSegLen;
+    if (per_cu > 0 && total > (int64_t)kNumCU * 256)
+      q.tile_len = (int)std::min<int64_t>(kBwdTile, (cdiv(total, (int64_t)kNumCU * per_cu) + 15) & ~15ll);
+  }
   static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
-  const int ntiles = p.presorted ? (int)(cdiv(p.nnz, kSegLen) * (kSegLen / kBwdTile)) : (int)cdiv(p.nnz, kBwdTile);
+  const int ntiles = (int)cdiv(p.presorted ? cdiv(p.nnz, kSegLen) * kSegLen : p.nnz, q.tile_len);
   dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
   const bool k32 = q.num_rows <= (1u << 22) - 2;
 #define CE_BWT(VT, N, R)                                                                              \
