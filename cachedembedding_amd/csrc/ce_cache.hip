@@ -1202,6 +1202,15 @@ struct SwapEngine {
   hipEvent_t in_ev[2] = {nullptr, nullptr};        // miss list of the job complete (by job parity)
   float* in_stage_dev = nullptr;
   float* in_host = nullptr;                        // pinned gather buffer
+  // admission by kernel (admit_by_kernel): a small grid on in_stream reads the missed rows out of the pinned table
+  // over PCIe into in_stage -- no host gather, no staging copy.  The worker thread still orders it (miss list ready,
+  // earlier write-backs landed) and releases the parked cache-op stream from the host when the kernel has finished.
+  // 16 workgroups x 1024 threads: 28 MB in ~0.6 ms; wider grids finish sooner but slow the training kernels
+  // (8: 0.92 ms admission wait, 2.08 G lookups/s; 16: 0.50 ms, 2.63 G; 32: 0.33 ms, 2.46 G; 64: 0.15 ms, 2.18 G)
+  bool admit_by_kernel = false;
+  const int32_t* miss_list_dev = nullptr;
+  const void* table_dev = nullptr;
+  int rowlen = 0, g_log2 = 0, vec = 0, admit_blocks = 16, admit_threads = 1024;
   int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
   int32_t* miss_host_dev = nullptr;
   unsigned long long* sig = nullptr;               // pinned + mapped: the value the cache-op stream waits for
@@ -1320,7 +1329,18 @@ struct SwapEngine {
       long long n = mail[2].count;
       CE_TRACE("in job %lld: earlier write-backs landed; mail job %lld count %lld", job, mail[2].job, n);
       if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
-      if (n > 0 && !failed()) {
+      if (n > 0 && !failed() && admit_by_kernel) {
+        if (vec)
+          hipLaunchKernelGGL((k_admit<f32x4>), dim3(admit_blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
+                             (const int32_t*)nullptr, (const long long*)nullptr, n, (const f32x4*)table_dev,
+                             (f32x4*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);
+        else
+          hipLaunchKernelGGL((k_admit<float>), dim3(admit_blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
+                             (const int32_t*)nullptr, (const long long*)nullptr, n, (const float*)table_dev,
+                             (float*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);
+        e = hipGetLastError();
+        if (e != hipSuccess) fail("admission kernel launch", e);
+      } else if (n > 0 && !failed()) {
         const float* tb = table;
         float* st = in_host;
         float* dv = in_stage_dev;
@@ -1805,14 +1825,21 @@ static int ensure_writeback(ce_cache* h) {
     w->mail = (WbMail*)p;
     if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
     w->mail_dev = (WbMail*)pd;
-    if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
-    memset(p, 0, 64);
+    if (hipHostMalloc(&p, 128, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    memset(p, 0, 128);
     w->sig = (unsigned long long*)p;
     if (hipHostMalloc(&p, idx_bytes, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
     w->miss_host = (int32_t*)p;
     if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
     w->miss_host_dev = (int32_t*)pd;
-    if (hipHostMalloc((void**)&w->in_host, rows_bytes, hipHostMallocDefault) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    {
+      // admission: by default a small kernel on in_stream reads the missed rows out of the pinned table; CE_WORKER_ADMIT=
+      // sdma selects the host gather + staged copy (also used when the table has no device-visible mapping)
+      const char* e = getenv("CE_WORKER_ADMIT");
+      w->admit_by_kernel = !(e && !strcmp(e, "sdma")) && h->cfg.host_weight_dev != nullptr;
+    }
+    if (!w->admit_by_kernel &&
+        hipHostMalloc((void**)&w->in_host, rows_bytes, hipHostMallocDefault) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
     // the workers sleep in hipEventSynchronize (blocking-sync events): spinning threads would eat the CPU quota
     // the helpers need
     const unsigned evf = hipEventDisableTiming | hipEventBlockingSync;
@@ -1834,6 +1861,17 @@ static int ensure_writeback(ce_cache* h) {
     static const int in_threads = [] { const char* e = getenv("CE_GATHER_THREADS"); return e ? atoi(e) : dflt; }();
     w->out_pool = new RowPool(std::max(1, std::min(out_threads, 64)));
     w->in_pool = new RowPool(std::max(1, std::min(in_threads, 64)));
+    {
+      const char* b = getenv("CE_ADMIT_BLOCKS");
+      if (b && atoi(b) > 0) w->admit_blocks = atoi(b);
+      const char* t = getenv("CE_ADMIT_THREADS");
+      if (t && (atoi(t) == 256 || atoi(t) == 512 || atoi(t) == 1024)) w->admit_threads = atoi(t);
+      w->miss_list_dev = h->miss_list;
+      w->table_dev = h->cfg.host_weight_dev;
+      w->rowlen = h->rowlen;
+      w->g_log2 = h->g_log2;
+      w->vec = h->vec;
+    }
     w->out_thread = std::thread([w] { w->run_out(); });
     w->in_thread = std::thread([w] { w->run_in(); });
   } while (0);
@@ -2035,7 +2073,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                      worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows);
   hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl,
-                     worker ? h->wb->miss_host_dev : (int32_t*)nullptr, (int)L.stage_rows);
+                     worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr, (int)L.stage_rows);
   if (worker) {
     // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) while this
     // stream selects and stages the victims; it first lets every earlier write-back land

@@ -39,11 +39,12 @@ def make_side_stream(device, cache_cus: int = 0, total_cus: int = 256) -> torch.
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
-# ids per cache op from which the worker transport pays: it costs a host round trip (event wake-up, gather, copy,
-# release: >= 0.15-0.2 ms whatever the size) and buys the swap traffic off the CUs; the zero-copy swap kernel costs
-# ~0.03 ms per 1000 rows moved.  Measured: Kaggle 5 % P = 1 (426 k ids, ~25 k rows per call) 0.97 G lookups/s
-# zero-copy / 0.81 G worker; P = 8 (3.4 M ids, ~50 k rows) 2.0 G / 2.5 G.
-AUTO_WORKER_MIN_IDS = 1_500_000
+# ids per cache op from which the worker transport pays: it costs a host round trip (event wake-up, kernel launch
+# from the worker thread, release: >= 0.1 ms whatever the size) and buys the write-back traffic off the CUs and the
+# admission out of the cache-op stream's critical path; the zero-copy swap kernel costs ~0.03 ms per 1000 rows moved.
+# Measured: Kaggle 5 % P = 1 (426 k ids, ~25 k rows per call) 0.82 G lookups/s zero-copy / 0.93 G worker; P = 8
+# (3.4 M ids, ~50 k rows) 2.0 G / 2.6 G; Avazu B = 2048 (45 k ids, ~2.6 k rows) stays zero-copy.
+AUTO_WORKER_MIN_IDS = 300_000
 
 
 def pick_transport(transport: Optional[str], ids_per_call: int) -> Optional[str]:

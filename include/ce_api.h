@@ -51,9 +51,14 @@ extern "C" {
 #define CE_TRANSPORT_STAGED 1    /* host threads gather/scatter through pinned staging + hipMemcpyAsync */
 #define CE_TRANSPORT_WORKER 2    /* both directions leave the CUs: evictions are packed in HBM by the cache op, copied
                                     out with pinned hipMemcpyAsync (SDMA) on a private stream and scattered into the
-                                    host table by a worker thread inside the library; missed rows are gathered out
-                                    of the table into pinned staging by a second worker, copied in the same way, and
-                                    the cache-op stream waits for them in a hipStreamWaitValue64.  prepare_ids stays
+                                    host table by a worker thread inside the library; missed rows are brought into
+                                    an HBM staging block under the control of a second worker thread -- it waits for
+                                    the miss list and for earlier write-backs to land, then either launches a
+                                    16-workgroup kernel on a private stream that reads them out of the mapped table
+                                    (default), or gathers them into pinned staging and copies that with
+                                    hipMemcpyAsync (CE_WORKER_ADMIT=sdma, and tables without a device mapping) --
+                                    and the cache-op stream waits for them in a hipStreamWaitValue64 while it selects
+                                    and stages the victims.  prepare_ids stays
                                     one asynchronous call, but returns before the host table has the evicted rows
                                     (ce_cache_writeback_wait / ce_cache_flush make it current).  Not capture-safe;
                                     the stream must not share a hardware queue with work it must not delay
