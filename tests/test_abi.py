@@ -93,7 +93,8 @@ def test_transport_choice_and_tracing_helpers():
     """host logic that needs no GPU: the size rule of the automatic transport choice, the phase ranges"""
     from cachedembedding_amd.pipeline import AUTO_WORKER_MIN_IDS, pick_transport
     assert pick_transport("auto", AUTO_WORKER_MIN_IDS) == "worker"
-    assert pick_transport("auto", 16384 * 26) == "zerocopy"            # one Criteo batch (prefetch_num = 1)
+    assert pick_transport("auto", 16384 * 26) == "worker"              # one Criteo batch (prefetch_num = 1)
+    assert pick_transport("auto", 2048 * 22) == "zerocopy"             # the micro-benchmark shape
     assert pick_transport("auto", 8 * 16384 * 26) == "worker"          # the bench window
     assert pick_transport("staged", 10) == "staged" and pick_transport(None, 10 ** 9) is None
     from cachedembedding_amd.tracing import phase
