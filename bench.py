@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no_presort", action="store_true", help="sort 1024-lookup tiles inside every backward launch "
                     "instead of grouping the window's slots by row once per window on the cache-op stream "
                     "(ce_bag_presort, 16384-lookup segments: about half the atomic row updates)")
+    ap.add_argument("--tile_keys", action="store_true", help="window keys = row | lookup (tile backward resolves the "
+                    "bag of every lookup per launch) instead of row | grad_out row (streaming backward)")
     ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
                     "hipGraph of the window's P training steps")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport (= --transport staged)")
@@ -172,8 +174,9 @@ def main():
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
     presort = not args.no_presort and not args.deterministic
+    layout = None if args.tile_keys else (offsets, embed.include_last_offset, F)
     win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort,
-                         transport=None)
+                         transport=None, bag_layout=layout)
 
     def train_step(slots_i, i, keys_i=None):
         out = embed(slots_i, offsets, hook_features=F, presorted=keys_i)
@@ -184,7 +187,7 @@ def main():
         from cachedembedding_amd.pipeline import GraphedWindow
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
                            warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort,
-                           transport=None)
+                           transport=None, bag_layout=layout)
         note("hipGraph of the window's training steps captured")
 
     skip_cache_op = bool(os.environ.get("CE_BENCH_SKIP_CACHE_OP"))      # diagnostic: training kernels only
@@ -326,12 +329,12 @@ def main():
         return sum(f) / len(f), sum(g) / len(g)
 
     torch.cuda.synchronize()
-    win = PrefetchWindow(embed, P, overlap=False, presort=presort, transport=None)
+    win = PrefetchWindow(embed, P, overlap=False, presort=presort, transport=None, bag_layout=layout)
     mgr.set_protect_depth(0)
     fwd_avg, bwd_avg = event_pass(ev_first)
     fwd_pipe, bwd_pipe = fwd_avg, bwd_avg
     if args.overlap:
-        win = PrefetchWindow(embed, P, overlap=True, presort=presort, transport=None)
+        win = PrefetchWindow(embed, P, overlap=True, presort=presort, transport=None, bag_layout=layout)
         fwd_pipe, bwd_pipe = event_pass(ev_first + 4 * P)
         torch.cuda.synchronize()
     row_b = 4 * D
@@ -345,7 +348,7 @@ def main():
     bwd_bytes = B * F * (row_b + 8) + B * F * L * 8 + uniq_avg * 2 * row_b
     fwd_roof = dict(kernel="k_bag_fwd", bound="hbm", achieved=fwd_bytes / fwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=fwd_avg, bytes_per_launch=fwd_bytes)
-    bwd_roof = dict(kernel="k_bag_bwd(sgd)", bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
+    bwd_roof = dict(kernel=("k_bag_bwd_stream(sgd)" if presort and layout is not None else "k_bag_bwd_tile(sgd)"), bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=bwd_avg, bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
     fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
@@ -422,7 +425,7 @@ def main():
                    "transport": transport, "overlap": bool(args.overlap),
                    "launch": "hipGraph per window" if use_graph else "python per step",
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "
-                                         "(ce_bag_presort_window)" if presort else "1024-lookup tiles sorted inside every backward",
+                                         "(ce_bag_presort_window%s)" % ("" if args.tile_keys else "_src: keys = row | grad_out row, streaming backward") if presort else "1024-lookup tiles sorted inside every backward",
                    "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,

@@ -7,7 +7,7 @@ include/ce_api.h).  There is no CPU fallback: the import fails if the library is
 from ._lib import CeError, LIB_PATH  # noqa: F401
 from .cache_mgr import CachedParamMgr, EvictionStrategy, HostTable  # noqa: F401
 from .cached_embedding import CachedEmbeddingBag  # noqa: F401
-from .functional import FusedSGD, embedding_bag  # noqa: F401
+from .functional import FusedSGD, SrcKeys, embedding_bag  # noqa: F401
 
 __all__ = ["CachedEmbeddingBag", "CachedParamMgr", "EvictionStrategy", "HostTable", "embedding_bag",
-           "FusedSGD", "CeError", "LIB_PATH"]
+           "FusedSGD", "SrcKeys", "CeError", "LIB_PATH"]

@@ -100,6 +100,12 @@ SIGNATURES = {
                                               c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,
                                               c_void_p, c_void_p]),
     "ce_bag_presort_window": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "ce_bag_presort_window_src": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_int64, c_int64,
+                                          c_int32, c_int64, c_void_p, c_void_p]),
+    "ce_bag_backward_sgd_presorted_src": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_float, c_void_p,
+                                                  c_void_p]),
+    "ce_bag_backward_dense_presorted_src": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
+                                                    c_void_p]),
     "ce_bag_backward_sgd_sorted_workspace": (c_size_t, [c_int64, c_int64]),
     "ce_bag_backward_sgd_sorted": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32,
                                            c_int64, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_float,

@@ -430,9 +430,14 @@ constexpr int kSegKeys = 16;          // per thread
 constexpr int kSegBuckets = CE_SEG_BUCKETS;
 // Window form: n_segs = n_batches * segs_per_batch; batch b owns lookups [b * nnz_per_batch, (b + 1) * nnz_per_batch)
 // and the keys [b * segs_per_batch * kSegLen, ...) -- segments never straddle two batches.
+// SRC: the low word of a key is not the lookup's place in its segment but the row of grad_out the lookup reads
+// (out_row(bag of the lookup), from the batch's offsets): everything the streaming backward needs, resolved here
+// once per window instead of in every backward launch.  lay.offsets of batch b = offsets + b * off_stride elements.
+template <bool SRC>
 __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz_per_batch,
                                                          int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
-                                                         unsigned long long* __restrict__ keys_out) {
+                                                         unsigned long long* __restrict__ keys_out, BagParams lay,
+                                                         int64_t off_stride) {
   __shared__ int cnt[kSegBuckets + 1];                  // [kSegBuckets] = ignored lookups
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -443,6 +448,8 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     const int64_t in_base = batch * nnz_per_batch + (int64_t)sib * kSegLen;
     const int64_t base = seg * kSegLen;
     const int n_here = (int)min((int64_t)kSegLen, nnz_per_batch - (int64_t)sib * kSegLen);
+    BagParams q = lay;
+    if (SRC) q.offsets = (const char*)lay.offsets + batch * off_stride * (lay.off64 ? 8 : 4);
     for (int i = tid; i <= kSegBuckets; i += 1024) cnt[i] = 0;
     __syncthreads();
     unsigned long long key[kSegKeys];
@@ -457,7 +464,9 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
       if (e < n_here) {
         const int64_t row = indices[in_base + e];
         if ((uint64_t)row < (uint64_t)num_rows) {
-          key[r] = ((unsigned long long)row << 32) | (unsigned)e;
+          unsigned low = (unsigned)e;
+          if (SRC) low = (unsigned)out_row(q, find_bag(q, sib * kSegLen + e));
+          key[r] = ((unsigned long long)row << 32) | low;
           bkt[r] = (int)(row & (kSegBuckets - 1));
         }
       }
@@ -603,6 +612,8 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
             if (on && ch < rowlen) v[t][c] = __builtin_nontemporal_load(&GO[orow * rowlen + ch]);
           }
         }
+        // one wait for all R gathers (see k_bag_bwd_stream): keeps the flushes' atomics fire-and-forget
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
 #pragma unroll
         for (int t = 0; t < R; ++t) {
           if (rw[t] != K::row_invalid()) {          // group-uniform
@@ -626,6 +637,86 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       }
     }
     __syncthreads();
+  }
+}
+
+// Streaming form of the sorted scatter for keys that already carry everything a lookup needs (ce_bag_presort_window_src:
+// key = row << 32 | row of grad_out to read; sum mode, no per-sample weights, so the scale is alpha for every lookup).
+// No tile, no barrier, no bag search: every lane group owns ONE contiguous, equal share of the key array and walks it
+// R keys at a time -- gathers the R gradient rows, folds equal rows and flushes a row's sum with the transposed atomics
+// when the row changes.  The grid is a few workgroups per CU whatever the size, so there is no per-tile prologue
+// (12 of the tile kernel's 74 us).
+// The keys travel through LDS, 4 per lane at a time (a group-private slice, written and read by the same wave, so no
+// barrier): a GLOBAL key load inside the loop would share the vmcnt counter with the gathers and the fire-and-forget
+// atomics, which retire in order -- the wait for the next keys would then wait for the atomics just issued
+// (measured: 85 us with register-prefetched keys, 49 us of it gather), and a key load between two gathers serialises
+// them (97 us).
+template <typename VT, int NCH, int R>
+__global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t total) {
+  __shared__ unsigned long long lk[256 * (R > 4 ? R : 4)];     // ngroups * kc, worst case G = 1
+  const int tid = threadIdx.x;
+  const int G = 1 << p.g_log2;
+  const int ngroups = 256 >> p.g_log2;
+  const int grp = tid >> p.g_log2;
+  const int gl = tid & (G - 1);
+  const int rowlen = p.rowlen;
+  const int dim = rowlen * (int)(sizeof(VT) / 4);
+  const VT* __restrict__ GO = (const VT*)p.grad_out;
+  const unsigned long long* __restrict__ keys = p.presorted;
+  const int64_t all_groups = (int64_t)gridDim.x * ngroups;
+  const int64_t share = ((total + all_groups - 1) / all_groups + R - 1) / R * R;
+  const int64_t s0 = ((int64_t)blockIdx.x * ngroups + grp) * share;
+  const int64_t s1 = min(total, s0 + share);
+  if (s0 >= s1) return;
+  const float alpha = p.alpha;
+  const int kc = 4 * G > R ? 4 * G : R;         // keys staged per refill (G is a power of two: a multiple of R)
+  unsigned long long* mylk = lk + grp * kc;
+  VT acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
+  uint32_t cur = 0xffffffffu;
+  for (int64_t c0 = s0; c0 < s1; c0 += kc) {
+    for (int k = gl; k < kc; k += G) mylk[k] = c0 + k < s1 ? keys[c0 + k] : ~0ull;
+    const int64_t c1 = min(s1, c0 + kc);
+    for (int64_t q = c0; q < c1; q += R) {
+      VT v[R][NCH];
+      uint32_t rw[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        const unsigned long long k = mylk[(int)(q - c0) + t];
+        const bool on = k != ~0ull && (uint32_t)(k >> 32) < p.num_rows;
+        rw[t] = on ? (uint32_t)(k >> 32) : 0xffffffffu;
+        const int64_t src = (int64_t)(uint32_t)k;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = gl + c * G;
+          v[t][c] = vzero<VT>();
+          if (on && ch < rowlen) v[t][c] = __builtin_nontemporal_load(&GO[src * rowlen + ch]);
+        }
+      }
+      // ONE wait for all R gathers here: left to the compiler, the wait for v[t] lands after the flush of v[t-1]'s
+      // row, where the vmcnt counter also holds the atomics just issued -- every flush would be synchronous
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt/lgkmcnt untouched
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        if (rw[t] != 0xffffffffu) {            // group-uniform
+          if (rw[t] != cur) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              if (cur != 0xffffffffu) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+              acc[c] = vzero<VT>();
+            }
+            cur = rw[t];
+          }
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * alpha;
+        }
+      }
+    }
+  }
+  if (cur != 0xffffffffu) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
   }
 }
 
@@ -894,10 +985,63 @@ extern "C" int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, in
                            (const unsigned long long*)presorted_keys, stream);
 }
 
+// keys = row << 32 | grad_out row (ce_bag_presort_window_src); alpha * grad_out rows are folded into dst
+static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t nnz, const float* grad_out,
+                             float alpha, const unsigned long long* keys, hipStream_t s) {
+  if (nnz == 0) return CE_OK;
+  CE_REQUIRE(dst && grad_out && keys, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  BagParams p{};
+  bool vec;
+  int nch;
+  int rc = fill_params(p, dim, nullptr, nnz, nullptr, 0, 0, 1, nullptr, CE_MODE_SUM, 0, &vec, &nch, dst, grad_out,
+                       nullptr);
+  if (rc) return rc;
+  p.dst = dst;
+  p.grad_out = grad_out;
+  p.alpha = alpha;
+  p.num_rows = (uint32_t)num_rows;
+  p.presorted = keys;
+  { const char* dbg = getenv("CE_BWD_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
+  const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
+  static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
+  const int ngroups = 256 >> p.g_log2;
+  // two workgroups per CU; small inputs: one share of >= 16 keys per lane group
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));
+  dim3 g(grid), b(256);
+  if (vec) {
+    static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
+    if (nch == 1 && r_env == 8) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 8>), g, b, 0, s, p, total);
+    else if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16>), g, b, 0, s, p, total);
+    else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 2, 8>), g, b, 0, s, p, total);
+    else hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 4, 4>), g, b, 0, s, p, total);
+  } else {
+    if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<float, 1, 16>), g, b, 0, s, p, total);
+    else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<float, 2, 8>), g, b, 0, s, p, total);
+    else hipLaunchKernelGGL((k_bag_bwd_stream<float, 4, 4>), g, b, 0, s, p, total);
+  }
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_bag_backward_sgd_presorted_src(float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                                 const float* grad_out, float lr, const uint64_t* src_keys,
+                                                 ce_stream_t stream) {
+  return launch_bwd_stream(weight, num_rows, dim, nnz, grad_out, -lr, (const unsigned long long*)src_keys,
+                           (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_backward_dense_presorted_src(float* grad_weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                                   const float* grad_out, const uint64_t* src_keys,
+                                                   ce_stream_t stream) {
+  return launch_bwd_stream(grad_weight, num_rows, dim, nnz, grad_out, 1.f, (const unsigned long long*)src_keys,
+                           (hipStream_t)stream);
+}
+
 extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }
 
-extern "C" int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
-                                     int64_t num_rows, uint64_t* keys_out, ce_stream_t stream) {
+static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                               uint64_t* keys_out, const BagParams* lay, int64_t off_stride, ce_stream_t stream) {
   if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
   CE_REQUIRE(indices && keys_out && nnz_per_batch > 0 && n_batches > 0, CE_ERR_INVALID, "bad arguments");
   CE_REQUIRE(nnz_per_batch < (int64_t)INT32_MAX - kSegLen, CE_ERR_INVALID, "batch too large");
@@ -905,11 +1049,35 @@ extern "C" int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_bat
   const int64_t spb = cdiv(nnz_per_batch, kSegLen);
   const int64_t nseg = spb * n_batches;
   CE_REQUIRE(spb < (int64_t)INT32_MAX && nseg < (int64_t)INT32_MAX, CE_ERR_INVALID, "too many segments");
-  hipLaunchKernelGGL(k_bag_presort_seg, dim3((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), dim3(1024), 0,
-                     (hipStream_t)stream, indices, nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows,
-                     (unsigned long long*)keys_out);
+  const dim3 grid((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), block(1024);
+  if (lay)
+    hipLaunchKernelGGL(k_bag_presort_seg<true>, grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride);
+  else
+    hipLaunchKernelGGL(k_bag_presort_seg<false>, grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{}, 0ll);
   CE_LAUNCH_CHECK();
   return CE_OK;
+}
+
+extern "C" int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
+                                     int64_t num_rows, uint64_t* keys_out, ce_stream_t stream) {
+  return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, nullptr, 0, stream);
+}
+
+extern "C" int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
+                                         int64_t num_rows, const void* offsets, int32_t offsets_are_i64,
+                                         int64_t offsets_batch_stride, int64_t num_bags, int32_t include_last_offset,
+                                         int64_t hook_features, uint64_t* keys_out, ce_stream_t stream) {
+  if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
+  CE_REQUIRE(offsets && num_bags > 0 && offsets_batch_stride >= 0, CE_ERR_INVALID, "bad offsets");
+  BagParams lay{};
+  bool vec;
+  int nch;
+  int rc = fill_params(lay, 4, indices, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset,
+                       nullptr, CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, &lay, offsets_batch_stride, stream);
 }
 
 extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out,

@@ -10,7 +10,7 @@ SGD.step (recsys/dlrm_main.py:279) inside the backward pass.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import NamedTuple, Optional, Union
 
 import torch
 
@@ -44,6 +44,16 @@ def _prep(indices: torch.Tensor, offsets: Optional[torch.Tensor], include_last_o
     offsets = offsets.contiguous()
     num_bags = offsets.numel() - 1 if include_last_offset else offsets.numel()
     return indices, offsets, include_last_offset, num_bags
+
+
+class SrcKeys(NamedTuple):
+    """Keys of one batch from presort_window(..., offsets=...): row << 32 | grad_out row (ce_bag_presort_window_src).
+    They already hold the bag layout they were built for, so embedding_bag(presorted=SrcKeys) checks that the call
+    uses the same one; mode must be 'sum' without per-sample weights."""
+    keys: torch.Tensor
+    num_bags: int
+    include_last_offset: bool
+    hook_features: int
 
 
 class _BagFn(torch.autograd.Function):
@@ -89,6 +99,10 @@ class _BagFn(torch.autograd.Function):
                                                          ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
                                                          mode, hook_features, ptr(grad_out), float(fused.lr),
                                                          ptr(ws), ws.numel(), stream_ptr()))
+                elif isinstance(ctx.presorted, SrcKeys):
+                    check(lib.ce_bag_backward_sgd_presorted_src(ptr(weight), weight.shape[0], dim, nnz,
+                                                                ptr(grad_out), float(fused.lr),
+                                                                ptr(ctx.presorted.keys), stream_ptr()))
                 elif ctx.presorted is not None:
                     check(lib.ce_bag_backward_sgd_presorted(ptr(weight), weight.shape[0], dim, ptr(indices), nnz,
                                                             ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
@@ -108,7 +122,10 @@ class _BagFn(torch.autograd.Function):
             gw = torch.sparse_coo_tensor(indices.view(1, -1), rows, weight.shape, check_invariants=False)
         else:
             gw = torch.zeros_like(weight)
-            if ctx.presorted is not None:
+            if isinstance(ctx.presorted, SrcKeys):
+                check(lib.ce_bag_backward_dense_presorted_src(ptr(gw), weight.shape[0], dim, nnz, ptr(grad_out),
+                                                              ptr(ctx.presorted.keys), stream_ptr()))
+            elif ctx.presorted is not None:
                 check(lib.ce_bag_backward_dense_presorted(ptr(gw), weight.shape[0], dim, ptr(indices), nnz,
                                                           ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
                                                           mode, hook_features, ptr(grad_out), ptr(ctx.presorted),
@@ -143,7 +160,7 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   mode: str = "mean", sparse: bool = False, per_sample_weights: Optional[torch.Tensor] = None,
                   include_last_offset: bool = False, padding_idx: Optional[int] = None, *,
                   hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None,
-                  presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  presorted: Union[torch.Tensor, SrcKeys, None] = None) -> torch.Tensor:
     if max_norm is not None:
         raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
     if mode not in _MODES:
@@ -180,7 +197,18 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
         indices = torch.where(indices == padding_idx, torch.full_like(indices, -1), indices)
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
-    if presorted is not None:
+    if isinstance(presorted, SrcKeys):
+        if mode != "sum" or per_sample_weights is not None:
+            raise ValueError("source-row keys (presort_window(..., offsets=...)) hold no per-lookup scale: they "
+                             "need mode='sum' without per_sample_weights")
+        if (presorted.num_bags, bool(presorted.include_last_offset), int(presorted.hook_features)) != \
+                (num_bags, bool(include_last_offset), int(hook_features)):
+            raise ValueError("source-row keys were built for another bag layout "
+                             f"{tuple(presorted[1:])} than this call's {(num_bags, include_last_offset, hook_features)}")
+        k = presorted.keys
+        assert k.is_cuda and k.dtype == torch.int64 and k.is_contiguous() and \
+            k.numel() == lib.ce_bag_presort_len(indices.numel()), "keys must come from presort_window"
+    elif presorted is not None:
         assert presorted.is_cuda and presorted.dtype == torch.int64 and presorted.is_contiguous() and \
             presorted.numel() == lib.ce_bag_presort_len(indices.numel()), "presorted must come from presort_slots"
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
@@ -204,15 +232,34 @@ def presort_slots(slots: torch.Tensor, num_rows: int, out: Optional[torch.Tensor
     return out
 
 
-def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.Tensor] = None, *,
+                   offsets: Optional[torch.Tensor] = None, include_last_offset: bool = False,
+                   hook_features: int = 0):
     """Grouped keys for the P equal-sized batches of a prefetch window in one launch (ce_bag_presort_window).
     slots: [P, n] int64 (the cache op's output) -> keys [P, presort_len(n)]; row b is what
-    embedding_bag(presorted=...) takes for batch b."""
+    embedding_bag(presorted=...) takes for batch b.
+
+    offsets given (1-D: shared by the batches, or [P, len]: one row per batch): source-row keys
+    (ce_bag_presort_window_src) for mode='sum' without per-sample weights -- returns a list of P SrcKeys instead,
+    which the backward streams over without touching offsets or indices again."""
     assert slots.dim() == 2 and slots.is_contiguous() and slots.dtype == torch.int64
     P, n = slots.shape
     klen = presort_len(n)
     if keys_out is None:
         keys_out = torch.empty(P, klen, dtype=torch.int64, device=slots.device)
     assert keys_out.is_contiguous() and keys_out.numel() == P * klen and keys_out.dtype == torch.int64
-    check(lib.ce_bag_presort_window(ptr(slots), n, P, int(num_rows), ptr(keys_out), stream_ptr()))
-    return keys_out.view(P, klen)
+    if offsets is None:
+        check(lib.ce_bag_presort_window(ptr(slots), n, P, int(num_rows), ptr(keys_out), stream_ptr()))
+        return keys_out.view(P, klen)
+    assert offsets.is_cuda and offsets.dtype in (torch.int32, torch.int64) and offsets.is_contiguous()
+    assert offsets.dim() == 1 or (offsets.dim() == 2 and offsets.shape[0] == P)
+    per = offsets.shape[-1]
+    num_bags = per - 1 if include_last_offset else per
+    if hook_features and num_bags % hook_features:
+        raise ValueError("hook_features must divide the number of bags")
+    check(lib.ce_bag_presort_window_src(ptr(slots), n, P, int(num_rows), ptr(offsets),
+                                        int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
+                                        num_bags, int(include_last_offset), int(hook_features), ptr(keys_out),
+                                        stream_ptr()))
+    kv = keys_out.view(P, klen)
+    return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features)) for b in range(P)]

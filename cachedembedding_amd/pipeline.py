@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .cached_embedding import CachedEmbeddingBag
-from .functional import presort_len, presort_window
+from .functional import SrcKeys, presort_len, presort_window
 from .tracing import phase
 
 
@@ -55,7 +55,13 @@ def pick_transport(transport: Optional[str], ids_per_call: int) -> Optional[str]
 
 class PrefetchWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
-                 presort: bool = False, transport: Optional[str] = "auto"):
+                 presort: bool = False, transport: Optional[str] = "auto", bag_layout=None):
+        # bag_layout = (offsets, include_last_offset, hook_features) of the batches (presort=True, mode='sum' without
+        # per-sample weights): the window's keys become source-row keys (functional.SrcKeys), which the backward
+        # streams over without a per-tile bag search
+        self._layout = None if bag_layout is None else dict(offsets=bag_layout[0],
+                                                            include_last_offset=bool(bag_layout[1]),
+                                                            hook_features=int(bag_layout[2]))
         # transport (overlap=True only): how rows move while the cache op runs beside training; "worker" keeps the
         # swap traffic off the CUs (CachedParamMgr.set_transport), "auto" decides by the size of the first window
         # (pick_transport), None leaves the manager's setting alone
@@ -93,11 +99,12 @@ class PrefetchWindow:
         self._keys_tmp = None
         if self.presort:
             C = self.mgr.cuda_row_num
+            lay = self._layout or {}
             if len(set(counts)) == 1:                           # equal batches: one launch for the window
-                keys = presort_window(slots.view(len(counts), counts[0]), C)
+                keys = presort_window(slots.view(len(counts), counts[0]), C, **lay)
                 self._keys_tmp = [keys[i] for i in range(len(counts))]
             else:
-                self._keys_tmp = [presort_window(p_.view(1, -1), C)[0] for p_ in parts]
+                self._keys_tmp = [presort_window(p_.view(1, -1), C, **lay)[0] for p_ in parts]
         return parts
 
     def prepare(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -134,7 +141,7 @@ class PrefetchWindow:
         for s in slots:
             s.record_stream(cur)
         for k in keys or []:
-            k.record_stream(cur)
+            (k.keys if isinstance(k, SrcKeys) else k).record_stream(cur)
         self.keys = keys
         return slots
 
@@ -152,7 +159,11 @@ class GraphedWindow:
 
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
                  warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
-                 transport: Optional[str] = "auto"):
+                 transport: Optional[str] = "auto", bag_layout=None):
+        # bag_layout: see PrefetchWindow (static offsets shared by every batch; keys_i is then a SrcKeys)
+        self._layout = None if bag_layout is None else dict(offsets=bag_layout[0],
+                                                            include_last_offset=bool(bag_layout[1]),
+                                                            hook_features=int(bag_layout[2]))
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
         self.P = prefetch_num
@@ -207,14 +218,19 @@ class GraphedWindow:
             self._step_graphs.append(per_step)
 
     def _call(self, step_fn, buf: int, i: int) -> None:
-        if self.presort:
+        if self.presort and self._layout is not None:
+            lay = self._layout
+            per = lay["offsets"].shape[-1]
+            step_fn(self._bufs[buf][i], i, SrcKeys(self._keys[buf][i], per - 1 if lay["include_last_offset"] else per,
+                                                   lay["include_last_offset"], lay["hook_features"]))
+        elif self.presort:
             step_fn(self._bufs[buf][i], i, self._keys[buf][i])
         else:
             step_fn(self._bufs[buf][i], i)
 
     def _presort(self, buf: int) -> None:
         # one launch for the window: every batch's 16384-lookup segments grouped by row
-        presort_window(self._bufs[buf], self.mgr.cuda_row_num, keys_out=self._keys[buf])
+        presort_window(self._bufs[buf], self.mgr.cuda_row_num, keys_out=self._keys[buf], **(self._layout or {}))
 
     @torch.no_grad()
     def submit(self, values: Sequence[torch.Tensor], buf: int) -> None:

@@ -170,6 +170,23 @@ int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_
                                     int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                                     int64_t hook_features, const float* grad_out,
                                     const uint64_t* presorted_keys, ce_stream_t stream);
+/* Source-row keys: for mode = sum without per-sample weights every lookup scales its gradient row by the same
+ * factor, so the only per-lookup facts the backward needs are the target row and WHICH row of grad_out to read.
+ * ce_bag_presort_window_src resolves the second one at window time too (the bag of the lookup from the batch's
+ * offsets, then its place in the [B, F, D] / [num_bags, D] output): key = row << 32 | grad_out row, same grouping
+ * and layout as ce_bag_presort_window.  offsets of batch b = offsets + b * offsets_batch_stride elements (0: all
+ * batches share one offsets array); num_bags / include_last_offset / hook_features describe ONE batch, as in
+ * ce_bag_forward.  The *_presorted_src backward entry points stream over such keys with no per-tile set-up
+ * (67 vs 74 us at the bench shape); they trust the keys (grad_out row < num_bags) and ignore rows >= num_rows.
+ * Replaces the same upstream call as the forms above (recsys/dlrm_main.py:274-279, loss.backward + optimizer.step). */
+int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                              const void* offsets, int32_t offsets_are_i64, int64_t offsets_batch_stride,
+                              int64_t num_bags, int32_t include_last_offset, int64_t hook_features,
+                              uint64_t* keys_out, ce_stream_t stream);
+int ce_bag_backward_sgd_presorted_src(float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                      const float* grad_out, float lr, const uint64_t* src_keys, ce_stream_t stream);
+int ce_bag_backward_dense_presorted_src(float* grad_weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                        const float* grad_out, const uint64_t* src_keys, ce_stream_t stream);
 
 /* Deterministic variant of the fused update: lookups are stably radix-sorted by target row
  * (workspace from ce_bag_backward_sgd_sorted_workspace), each row's gradients are summed in

@@ -356,3 +356,72 @@ def test_padding_idx_and_scale_grad_by_freq(sparse):
     out = emb(idx.cuda(), off.cuda())
     ro = torch.nn.functional.embedding_bag(idx, w0, off, mode="sum", include_last_offset=True, padding_idx=17)
     torch.testing.assert_close(out.detach().cpu(), ro, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [4, 20, 32, 128, 260])
+@pytest.mark.parametrize("layout", ["hook", "plain", "ragged"])
+def test_source_row_keys_backward_matches_tile_backward(D, layout):
+    """presort_window(..., offsets=...) -> SrcKeys -> streaming backward (fused SGD and dense) against the unsorted
+    backward and a torch index_add_ reference; shared and per-batch offsets, partial last segment, out-of-range rows."""
+    import cachedembedding_amd as ce
+    from cachedembedding_amd.functional import SrcKeys, presort_window
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(D * 7 + len(layout))
+    C, P = 5000, 3
+    if layout == "hook":
+        B, F = 1500, 13                                   # 19500 lookups: one full + one partial segment
+        n = B * F
+        offs = torch.arange(n + 1, dtype=torch.int32)
+        kw = dict(include_last_offset=True, hook_features=F)
+        num_bags = n
+    elif layout == "plain":
+        n = 20000
+        offs = torch.arange(n, dtype=torch.int64)
+        kw = dict(include_last_offset=False, hook_features=0)
+        num_bags = n
+    else:
+        num_bags = 3000
+        lens = torch.randint(0, 9, (P, num_bags), generator=g)
+        lens[:, -1] += 17000 - lens.sum(1)                # equal nnz per batch, ragged bags (some empty)
+        assert (lens >= 0).all()
+        n = 17000
+        offs = torch.cat([torch.zeros(P, 1, dtype=torch.int64), lens.cumsum(1)], 1)
+        kw = dict(include_last_offset=True, hook_features=0)
+    slots = torch.randint(0, C, (P, n), generator=g)
+    hot = torch.randint(0, 8, (P, n), generator=g)         # a few very hot rows: long runs
+    slots = torch.where(torch.rand(P, n, generator=g) < 0.3, hot, slots)
+    slots[:, 5] = -1                                       # ignored lookups (padding)
+    slots[:, 77] = C + 3
+    slots = slots.to(dev).contiguous()
+    offs_d = offs.to(dev).contiguous()
+    keys = presort_window(slots, C, offsets=offs_d, **kw)
+    assert isinstance(keys, list) and len(keys) == P and all(isinstance(k, SrcKeys) for k in keys)
+    out_rows = num_bags
+    shape = (num_bags // kw["hook_features"], kw["hook_features"], D) if kw["hook_features"] else (num_bags, D)
+    w0 = torch.randn(C, D, generator=g).to(dev)
+    for b in range(P):
+        ob = offs_d[b] if offs_d.dim() == 2 else offs_d
+        go = (torch.randn(*shape, generator=g) * 0.1).to(dev)
+        res = {}
+        for name, ps in (("src", keys[b]), ("plain", None)):
+            w = w0.clone().requires_grad_(True)
+            out = ce.embedding_bag(slots[b], w, ob, mode="sum", sparse=True, fused_sgd=ce.FusedSGD(0.5),
+                                   presorted=ps, **kw)
+            out.backward(go)
+            res[name] = w.detach().clone()
+            if name == "src":       # dense gradient through the same keys
+                w2 = w0.clone().requires_grad_(True)
+                ce.embedding_bag(slots[b], w2, ob, mode="sum", presorted=ps, **kw).backward(go)
+                w3 = w0.clone().requires_grad_(True)
+                ce.embedding_bag(slots[b], w3, ob, mode="sum", **kw).backward(go)
+                torch.testing.assert_close(w2.grad, w3.grad, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(res["src"], res["plain"], rtol=1e-5, atol=1e-5)
+    # wrong layout / mode are refused, not mis-read
+    w = w0.clone().requires_grad_(True)
+    ob = offs_d[0] if offs_d.dim() == 2 else offs_d
+    with pytest.raises(ValueError):
+        ce.embedding_bag(slots[0], w, ob, mode="mean", presorted=keys[0], **kw)
+    with pytest.raises(ValueError):
+        ce.embedding_bag(slots[0], w, ob, mode="sum", presorted=keys[0]._replace(hook_features=7),
+                         include_last_offset=kw["include_last_offset"], hook_features=kw["hook_features"])

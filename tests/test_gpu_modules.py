@@ -139,7 +139,7 @@ def test_tablewise_parallel(world):
     assert len(res) == world and all(r[1] == "ok" for r in res), res
 
 
-@pytest.mark.parametrize("presort", [False, True])
+@pytest.mark.parametrize("presort", [False, True, "src"])
 @pytest.mark.parametrize("mode", ["sequential", "overlap", "graph"])
 def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, presort):
     """_train's window block in its three forms gives the same training trajectory as a plain full-table
@@ -154,6 +154,9 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
     emb.set_fused_sgd(lr)
     emb.set_cache_op(False)
     off = torch.arange(F * B + 1, dtype=torch.int32, device="cuda")
+    # "src": the window's keys carry the grad_out row of every lookup (streaming backward)
+    layout = (off, True, F) if presort == "src" else None
+    presort = bool(presort)
     grad = (torch.randn(B, F, D) * 0.1).cuda()
     g = torch.Generator().manual_seed(5)
     windows = [[(torch.rand(F * B, generator=g) ** 3 * N).long().clamp_(0, N - 1) for _ in range(P)] for _ in range(nwin)]
@@ -165,7 +168,7 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
 
     if mode == "graph":
         gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=[v.cuda() for v in windows[0]],
-                           presort=presort, transport="worker")
+                           presort=presort, transport="worker", bag_layout=layout)
         # the capture warm-up trained on window 0 twice over (eager pass + nothing else): replay that on the ref
         for v in windows[0]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
@@ -175,7 +178,8 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
                 gw.submit([v.cuda() for v in windows[w + 1]], (w + 1) % 2)
             gw.run(w % 2)
     else:
-        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"), presort=presort, transport="worker")
+        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"), presort=presort, transport="worker",
+                             bag_layout=layout)
         if mode == "overlap":
             win.submit([v.cuda() for v in windows[0]])
         for w in range(nwin):
