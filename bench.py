@@ -173,7 +173,10 @@ def main():
     need_windows(W + K)
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
-    presort = not args.no_presort and not args.deterministic
+    # grouping the window's slots costs one workgroup per 16384-lookup segment on the cache-op stream: with only a
+    # few segments per batch (B = 2048 shapes) that is ~30 us of latency for a backward of ~18 us -- leave those to
+    # the backward's own 1024-lookup tile sort
+    presort = not args.no_presort and not args.deterministic and B * F * L >= 8 * 16384
     layout = None if args.tile_keys else (offsets, embed.include_last_offset, F)
     win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort,
                          transport=None, bag_layout=layout)
@@ -345,11 +348,16 @@ def main():
         wi0 = ev_first // P + 3          # a window of the event pass: its rows are still resident
         uniq = [int(torch.unique(mgr._id_to_cached_cuda_id(windows[wi0][i])).numel()) for i in range(P)]
     uniq_avg = sum(uniq) / len(uniq)
-    bwd_bytes = B * F * (row_b + 8) + B * F * L * 8 + uniq_avg * 2 * row_b
+    streaming = presort and layout is not None
+    if streaming:      # the key (8 B) replaces slot + offset: gradient row + key per lookup, RMW per unique row
+        bwd_bytes = B * F * L * (row_b + 8) + uniq_avg * 2 * row_b
+    else:
+        bwd_bytes = B * F * (row_b + 8) + B * F * L * 8 + uniq_avg * 2 * row_b
     fwd_roof = dict(kernel="k_bag_fwd", bound="hbm", achieved=fwd_bytes / fwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=fwd_avg, bytes_per_launch=fwd_bytes)
-    bwd_roof = dict(kernel=("k_bag_bwd_stream(sgd)" if presort and layout is not None else "k_bag_bwd_tile(sgd)"), bound="hbm", achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS,
-                    unit="GB/s", avg_ms=bwd_avg, bytes_per_launch=bwd_bytes)
+    bwd_roof = dict(kernel="k_bag_bwd_stream(sgd)" if streaming else "k_bag_bwd_tile(sgd)", bound="hbm",
+                    achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS, unit="GB/s", avg_ms=bwd_avg,
+                    bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
     fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
     for r in (fwd_roof, bwd_roof):
@@ -377,13 +385,16 @@ def main():
     swap_ms = phases.get("admit_swap", 0.0) / calls_t
     wbs = mgr.writeback_stats()
     if transport == "worker" and wbs["in_jobs"]:
-        # both directions are pinned hipMemcpyAsync copies driven by the library's worker threads: no kernel; the
-        # figure is the admission direction (the one the cache-op stream waits for): rows x 4D over the worker's busy
-        # time (gather out of the host table + H2D copies).  avg_ms = how long the cache-op stream sat in the phase
-        # (parked in hipStreamWaitValue64, then k_unpack_admitted).
+        # write-back = SDMA copies + host scatter, admission = a 16-workgroup kernel on the worker's private stream
+        # reading the mapped table (CE_WORKER_ADMIT=sdma: host gather + SDMA copies), both ordered by the library's
+        # worker threads; the figure is the admission direction (the one the cache-op stream waits for): rows x 4D
+        # over the worker's busy time.  avg_ms = how long the cache-op stream sat in the phase (parked in
+        # hipStreamWaitValue64, then k_unpack_admitted).  worker_in_gather_ms: host gather (sdma) / kernel launch.
         in_busy_ms = 1e3 * wbs["in_busy_s"] / wbs["in_jobs"]
         swap_bytes = wbs["in_rows"] * row_b / wbs["in_jobs"]
-        swap_roof = dict(kernel="row swap: SDMA copies + host workers (no kernel)", bound="pcie",
+        swap_roof = dict(kernel="row swap (worker transport): admission %s, write-back SDMA + host scatter"
+                                % ("by host gather + SDMA" if os.environ.get("CE_WORKER_ADMIT") == "sdma"
+                                   else "k_admit on a private stream, 16 workgroups"), bound="pcie",
                          achieved=swap_bytes / max(in_busy_ms, 1e-9) / 1e6, peak=63.0, unit="GB/s", avg_ms=swap_ms,
                          bytes_per_launch=swap_bytes, worker_in_busy_ms=in_busy_ms,
                          worker_out_busy_ms=1e3 * wbs["out_busy_s"] / max(1, wbs["jobs"]),

@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import cachedembedding_amd as ce  # noqa: E402
 from cachedembedding_amd import synthetic  # noqa: E402
-from cachedembedding_amd.functional import presort_slots  # noqa: E402
+from cachedembedding_amd.functional import presort_window  # noqa: E402
 
 mode = sys.argv[1]
 B, F, D = 16384, 26, 128
@@ -46,7 +46,9 @@ else:
     for win in range(14):
         vals = gen.next_values(P)
         slots = emb.cache_weight_mgr.prepare_ids(vals.view(-1)).view(P, -1)
-        keys = [presort_slots(slots[i], emb.cache_weight_mgr.cuda_row_num) for i in range(P)]   # as bench.py does
+        # as bench.py does: source-row keys for the streaming backward
+        keys = presort_window(slots.contiguous(), emb.cache_weight_mgr.cuda_row_num, offsets=off,
+                              include_last_offset=True, hook_features=F)
         for i in range(P):
             out = emb(slots[i], off, hook_features=F, presorted=keys[i])
             out.backward(grad)

@@ -17,7 +17,7 @@ for mode in ("calib", "bench"):
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != counter:
                     continue
-                for k in ("k_bag_bwd_tile", "k_bag_fwd", "k_rows_axpy"):
+                for k in ("k_bag_bwd_tile", "k_bag_bwd_stream", "k_bag_fwd", "k_rows_axpy"):
                     if k in r["Kernel_Name"]:
                         vals[k].append(float(r["Counter_Value"]))
         parts = []
