@@ -570,6 +570,8 @@ def run_sharded(args, sizes, rank, world, dev):
     grad = torch.randn(B, F, D, device=dev) * 1e-3
 
     from cachedembedding_amd.parallel import ShardedWindowPipeline
+    if not args.tile_keys:        # every batch has these offsets: the plan stage emits source-row keys
+        embed.ops.set_bag_layout(offsets, True, F)
     st = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or "none")
     pipe = ShardedWindowPipeline(embed, overlap=args.overlap, transport=None if st == "none" else st)
     # finish the next window's plan after a few steps: its dedupe kernels (~0.1 ms per batch on the side stream)

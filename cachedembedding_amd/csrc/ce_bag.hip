@@ -212,6 +212,11 @@ __device__ __forceinline__ void atomic_add_vec(f32x4* dst, f32x4 v) {
 // (2 x 2 xor-shuffles) regroups the data so that atomic instruction c covers one contiguous block of G
 // floats: 4x fewer line requests per row (255 -> ~150 us/step measured).
 __device__ __forceinline__ void flush_chunk(float* row_base, f32x4 v, int gl, int G, int c, int rowlen, int debug) {
+  if (debug == 6) {                                          // ablation: plain store instead of the atomics (wrong result)
+    const int ch6 = gl + c * G;
+    if (ch6 < rowlen) ((f32x4*)row_base)[ch6] = v;
+    return;
+  }
   if (G >= 4 && debug == 0 && (c + 1) * G <= rowlen) {      // group-uniform: whole chunk present
     const int q = G >> 2;                     // lanes per lane block
     const int kb = gl / q;                    // my lane block 0..3

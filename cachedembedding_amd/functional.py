@@ -192,6 +192,10 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
         if mode != "sum":
             raise NotImplementedError("padding_idx is implemented for mode='sum' only (mean would need the "
                                       "per-bag count of non-padding entries)")
+        if presorted is not None:
+            # the keys hold the rows they were built from: mask the slots BEFORE presort_window instead
+            raise NotImplementedError("padding_idx cannot be combined with presorted keys (mask the indices to -1 "
+                                      "before building the keys)")
         if padding_idx < 0:
             padding_idx += weight.shape[0]
         indices = torch.where(indices == padding_idx, torch.full_like(indices, -1), indices)
@@ -241,7 +245,9 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
 
     offsets given (1-D: shared by the batches, or [P, len]: one row per batch): source-row keys
     (ce_bag_presort_window_src) for mode='sum' without per-sample weights -- returns a list of P SrcKeys instead,
-    which the backward streams over without touching offsets or indices again."""
+    which the backward streams over without touching offsets or indices again.  The keys ARE the batch as far as the
+    backward is concerned: pass them only to the embedding_bag call that uses the same slots and the same offsets
+    (the bag layout is checked, the contents cannot be)."""
     assert slots.dim() == 2 and slots.is_contiguous() and slots.dtype == torch.int64
     P, n = slots.shape
     klen = presort_len(n)

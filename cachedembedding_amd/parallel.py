@@ -31,7 +31,7 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 from .cache_mgr import CachedParamMgr, EvictionStrategy, HostTable
 from .cached_embedding import CachedEmbeddingBag
-from .functional import _MODES
+from .functional import _MODES, SrcKeys
 
 
 def get_partition(embedding_dim: int, rank: int, world_size: int) -> Tuple[int, int, bool]:
@@ -235,6 +235,16 @@ class HipShardOps(ShardOps):
         self.num_global_rows = num_global_rows
         self._stamp = None                # ce_dedupe_bucket_rows scratch: int32[N] x 2
         self._slot_of_row = None
+        self._layout = None               # (offsets, include_last, hook_features) -> source-row keys at plan time
+
+    def set_bag_layout(self, offsets: Optional[torch.Tensor], include_last_offset: bool = True,
+                       hook_features: int = 0) -> None:
+        """Static bag layout of the batches this rank trains on (every batch uses these offsets).  With it the plan
+        stage groups the lookups into source-row keys (ce_bag_presort_window_src) and the fold of a batch's gradients
+        (grad_rows, mode='sum' without per-sample weights) runs the streaming backward; None restores the
+        (row, lookup) keys that any layout can use."""
+        self._layout = None if offsets is None else (offsets.contiguous(), bool(include_last_offset),
+                                                     int(hook_features))
 
     def bucketize_launch(self, ids_list):
         """ce_dedupe_bucket_rows per batch (2 launches each, no sync); the bucket sizes stay on the device."""
@@ -263,7 +273,16 @@ class HipShardOps(ShardOps):
             # the fold of the batch's gradients (grad_rows) groups lookups by `pos`: do the grouping here, once,
             # on the planning stream (any pos < n is a valid row of the [n_u, D] gradient buffer)
             keys = torch.empty(lib.ce_bag_presort_len(n), dtype=torch.int64, device=dev)
-            check(lib.ce_bag_presort(ptr(pos), n, max(n, 1), ptr(keys), sp))
+            lay = self._layout
+            if lay is not None:
+                off, incl, hookf = lay
+                nb = off.numel() - 1 if incl else off.numel()
+                check(lib.ce_bag_presort_window_src(ptr(pos), n, 1, max(n, 1), ptr(off),
+                                                    int(off.dtype == torch.int64), 0, nb, int(incl), hookf,
+                                                    ptr(keys), sp))
+                keys = SrcKeys(keys, nb, incl, hookf)
+            else:
+                check(lib.ce_bag_presort(ptr(pos), n, max(n, 1), ptr(keys), sp))
             staged.append((rows, pos, keys))
         return ("hip", staged, counts)
 
@@ -275,7 +294,7 @@ class HipShardOps(ShardOps):
         return [(rows[:sum(c)], pos, list(c), keys) for (rows, pos, keys), c in zip(staged, counts_host)]
 
     def token_tensors(self, token):
-        return [t for tup in token[1] for t in tup] + [token[2]]
+        return [t.keys if isinstance(t, SrcKeys) else t for tup in token[1] for t in tup] + [token[2]]
 
     def bucketize(self, ids):
         return self.bucketize_many([ids])[0]
@@ -310,7 +329,14 @@ class HipShardOps(ShardOps):
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
         g = torch.zeros(n_u, self.dim, dtype=torch.float32, device=grad_out.device)
         # duplicates of a row inside the batch are summed here, before they travel
-        if keys is not None:
+        if isinstance(keys, SrcKeys):
+            if psw is not None or mode != "sum" or (keys.num_bags, keys.include_last_offset, keys.hook_features) != \
+                    (num_bags, bool(include_last), int(hook_features)):
+                raise ValueError("this batch was planned with source-row keys for another bag layout / mode "
+                                 "(HipShardOps.set_bag_layout)")
+            check(lib.ce_bag_backward_dense_presorted_src(ptr(g), n_u, self.dim, pos.numel(),
+                                                          ptr(grad_out.contiguous()), ptr(keys.keys), stream_ptr()))
+        elif keys is not None:
             check(lib.ce_bag_backward_dense_presorted(ptr(g), n_u, self.dim, ptr(pos), pos.numel(), ptr(offsets),
                                                       int(offsets.dtype == torch.int64), num_bags, int(include_last),
                                                       ptr(psw), _MODES[mode], hook_features,
@@ -633,7 +659,7 @@ class ShardedWindowPipeline:
         cur = torch.cuda.current_stream(self.embed.cache_weight_mgr.device)
         cur.wait_event(ev)
         for p in plans:
-            for t in (p.perm, p.recv_rows, p.slots, p.keys):
+            for t in (p.perm, p.recv_rows, p.slots, p.keys.keys if isinstance(p.keys, SrcKeys) else p.keys):
                 if t is not None and t.is_cuda:
                     t.record_stream(cur)
         return plans

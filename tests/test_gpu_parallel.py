@@ -85,6 +85,8 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
     ref_w = w_full.clone()
     nwin = 4 if overlap else 2
     all_ids = [[torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)] for _ in range(nwin)]
+    if overlap:     # static bag layout known at plan time: the gradient fold streams over source-row keys
+        emb.ops.set_bag_layout(offsets, True, F)
     pipe = ShardedWindowPipeline(emb, overlap=overlap)
     pipe.submit([i.cuda() for i in all_ids[0]])
     for window in range(nwin):

@@ -1,6 +1,7 @@
-"""Worker write-back transport (CE_TRANSPORT_WORKER: admissions by zero-copy reads, evictions packed in HBM,
-copied out by ONE pinned hipMemcpyAsync on a private stream and scattered into the host table by a thread inside
-libce_hip) against the CPU oracle.  Same bar as the other transports: slots, maps, counters, histories and the
+"""Worker transport (CE_TRANSPORT_WORKER: evictions packed in HBM, copied out with pinned hipMemcpyAsync on private
+streams and scattered into the host table by a thread inside libce_hip; admissions by a small kernel on a private
+stream launched by a second library thread -- or, CE_WORKER_ADMIT=sdma, gathered by host threads and copied in --
+while the cache-op stream parks until they have arrived) against the CPU oracle.  Same bar as the other transports: slots, maps, counters, histories and the
 cache payloads bit-exact after every call, the host table bit-exact once the write-backs have landed -- including
 rows that are re-admitted in the very call after the one that evicted them (their payload must come from the
 staging buffer, the host row is stale at that moment)."""
@@ -31,10 +32,12 @@ def _state_equal(mgr, ora, lfu):
     np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
 
 
+@pytest.mark.parametrize("admit", ["kernel", "sdma"])
 @pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"),
                                            ("cache_lfu_freq", "lfu"), ("cache_lfu_nofreq", "lfu")])
-def test_golden_streams_worker(name, strategy):
+def test_golden_streams_worker(name, strategy, admit, monkeypatch):
     ce = _ce()
+    monkeypatch.setenv("CE_WORKER_ADMIT", admit)      # read when the manager's swap engine is created
     z = np.load(GOLD / f"{name}.npz")
     N, C, D, n_ids, calls, warm = (int(v) for v in z["meta"])
     freq = z["freq"] if z["freq"].size else None
@@ -56,13 +59,15 @@ def test_golden_streams_worker(name, strategy):
     assert mgr.writeback_stats()["jobs"] == calls
 
 
+@pytest.mark.parametrize("admit", ["kernel", "sdma"])
 @pytest.mark.parametrize("strategy", ["dataset", "lfu"])
 @pytest.mark.parametrize("depth", [0, 1])
 @pytest.mark.parametrize("N,C,D,per_call", [(6000, 700, 128, 300), (20000, 1500, 32, 500), (3001, 257, 20, 100)])
-def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call):
+def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call, admit, monkeypatch):
     """Every call asks for half of the rows the previous call evicted (plus fresh ones): their only up-to-date copy is
     the previous call's staging buffer while the worker is still copying it out.  Cache payloads are compared after
     every call, the host table at the end and at two intermediate writeback_wait() points."""
+    monkeypatch.setenv("CE_WORKER_ADMIT", admit)
     ce = _ce()
     from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
     rng = np.random.default_rng(N * 7 + C + depth)
