@@ -27,8 +27,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _extra_flags():
+    # CE_BUILD_ABLATIONS=1: compile the backward kernels' ablation switches in (CE_BWD_DEBUG; wrong results by design)
+    return ["-DCE_ABLATIONS"] if os.environ.get("CE_BUILD_ABLATIONS") else []
+
+
 def _digest() -> str:
     h = hashlib.sha256()
+    h.update(" ".join(_extra_flags()).encode())
     for p in [CSRC / s for s in SOURCES] + HEADERS + [Path(__file__)]:
         h.update(p.read_bytes())
     return h.hexdigest()
@@ -47,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     for src in SOURCES:
         obj = objdir / (src.rsplit(".", 1)[0] + ".o")
         flags = HOST_FLAGS if src.endswith(".cpp") else FLAGS
-        cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *flags, *_extra_flags(), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -20,6 +20,15 @@
 
 namespace ce {
 
+// Ablation switches of the backward kernels (CE_BWD_DEBUG: 1 = racy read-modify-write instead of atomics, 2 = no
+// update traffic, 3 / 4 = tile prologue only, 5 = untransposed atomics, 6 = plain stores; DESIGN.md section 4 quotes
+// them).  They produce WRONG results by design, so a product build compiles them out: -DCE_ABLATIONS brings them back.
+#ifdef CE_ABLATIONS
+#define CE_DBG(x) (x)
+#else
+#define CE_DBG(x) 0
+#endif
+
 struct BagParams {
   const float* weight;      // fwd: rows to gather from
   float* dst;               // fwd: out; bwd: grad_weight / weight / grad_rows
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
         if (row != 0xffffffffu) kr[r] = K::make(row, i);
       }
     }
-    if (p.debug == 3) { __syncthreads(); continue; }
+    if (CE_DBG(p.debug) == 3) { __syncthreads(); continue; }
     // ---- b. sort (row major, lookup minor) -> runs are in lookup order, invalid keys last
     //         (skipped when the cache op already sorted this tile: ce_bag_presort)
     if (presorted) {
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
     // ---- c. reduce: every lane group walks ONE contiguous, equal share of the tile's sorted positions (13 chunks
     // of 64 over 8 groups cost two rounds -- the same as 16; 104 positions each cost 6.5/8 of that), R gradient
     // rows in flight, folding equal rows in lookup order; one atomic row update per (row, share).
-    if (p.debug == 4) continue;
+    if (CE_DBG(p.debug) == 4) continue;
     const int kChunk = (nv + ngroups - 1) / ngroups;
     const int nchunks = (nv + kChunk - 1) / kChunk;
     for (int ck = grp; ck < nchunks; ck += ngroups) {
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c) {
                 if (cur != K::row_invalid())
-                  flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+                  flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
                 acc[c] = vzero<VT>();
               }
               cur = rw[t];
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (cur != K::row_invalid()) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+        if (cur != K::row_invalid()) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
       }
     }
     __syncthreads();
@@ -708,7 +717,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
           if (rw[t] != cur) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-              if (cur != 0xffffffffu) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+              if (cur != 0xffffffffu) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
               acc[c] = vzero<VT>();
             }
             cur = rw[t];
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
   }
   if (cur != 0xffffffffu) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, p.debug);
+    for (int c = 0; c < NCH; ++c) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
   }
 }
 
