@@ -10,7 +10,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import sys
 import weakref
 from enum import Enum
 from typing import List, Optional

@@ -12,13 +12,12 @@ any object with `.values() .offsets() .stride()` (torchrec's KeyedJaggedTensor q
 """
 from __future__ import annotations
 
-from typing import Any, Iterable, Iterator, List, Optional, Sequence, Union
+from typing import Any, Iterable, List, Optional, Sequence, Union
 
 import torch
 import torch.nn as nn
 
 from .cache_mgr import EvictionStrategy
-from .cached_embedding import CachedEmbeddingBag
 from .parallel import KJTAllToAll, ParallelCachedEmbeddingBag
 
 

@@ -13,7 +13,7 @@ Everything is generated with torch on the target device (plumbing, not the produ
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import torch
 
