@@ -425,3 +425,35 @@ def test_source_row_keys_backward_matches_tile_backward(D, layout):
     with pytest.raises(ValueError):
         ce.embedding_bag(slots[0], w, ob, mode="sum", presorted=keys[0]._replace(hook_features=7),
                          include_last_offset=kw["include_last_offset"], hook_features=kw["hook_features"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [8, 128])
+def test_hooked_forward_in_output_order_with_ragged_bags_of_total_length_num_bags(D):
+    """nnz == num_bags selects the output-order tiles of the hooked forward (lane i owns output row b0 + i); the bags
+    need not hold one id each -- empty and multi-id bags with the same total take the general path of that mapping."""
+    import cachedembedding_amd as ce
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(D)
+    B, F, N = 150, 7, 500                                  # 1050 bags: 16 full tiles + a partial one
+    nb = B * F
+    for ragged in (False, True):
+        if ragged:
+            lens = torch.ones(nb, dtype=torch.long)
+            src = torch.randperm(nb, generator=g)[:300]
+            lens[src[:150]] -= 1                           # 150 empty bags ...
+            lens[src[150:]] += 1                           # ... 150 bags of two ids: the total stays nb
+        else:
+            lens = torch.ones(nb, dtype=torch.long)
+        off = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+        idx = torch.randint(0, N, (nb,), generator=g)
+        w = torch.randn(N, D, generator=g)
+        ref = torch.nn.functional.embedding_bag(idx, w, off[:-1], mode="sum").view(F, B, D).transpose(0, 1)
+        wd = w.to(dev).requires_grad_(True)
+        out = ce.embedding_bag(idx.to(dev), wd, off.to(dev), mode="sum", include_last_offset=True, hook_features=F)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+        go = torch.randn(B, F, D, generator=g)
+        out.backward(go.to(dev))
+        wr = w.clone().requires_grad_(True)
+        torch.nn.functional.embedding_bag(idx, wr, off[:-1], mode="sum").view(F, B, D).transpose(0, 1).backward(go)
+        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
