@@ -49,7 +49,6 @@ struct BagParams {
   int32_t debug;            // ablation switch (CE_BWD_DEBUG): 0 = normal
   uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
   int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
-  int32_t out_order;        // fwd, hookF > 0, single-id batches: lane i of a tile owns OUTPUT row b0 + i (see k_bag_fwd)
   const unsigned long long* presorted;   // optional: segment-grouped keys from ce_bag_presort* (no sort in the kernel)
 };
 
@@ -89,23 +88,13 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
   // resident-sized grid measured 15 % slower: 0.060 -> 0.069 ms)
   const int ntiles = (p.num_bags + 63) >> 6;
 
-  // out_order (shape hook folded in, one id per bag): a tile is 64 consecutive rows of the [B, F, D] OUTPUT, i.e. 2.5
-  // samples x F features, so a wave's stores are 32 KB of contiguous memory instead of 64 pieces of 512 B at a
-  // stride of F rows (the fill kernel's write pattern instead of a scatter: 56 -> 5x us); the price is that the 64
-  // ids come from F different places (a 64-byte sector per feature instead of one 512-byte line per tile)
-  const bool out_order = !STAGE && p.out_order;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int b0 = (int)(tile << 6);
     const int nb = min(64, p.num_bags - b0);
     int lo = 0, hi = 0;
-    int mybag = b0 + lane;
-    if (out_order) {
-      const int smp = (b0 + lane) / p.hookF;
-      mybag = (b0 + lane - smp * p.hookF) * p.hookB + smp;
-    }
     if (lane < nb) {
-      lo = ld_off(p, mybag);
-      hi = bag_end(p, mybag);
+      lo = ld_off(p, b0 + lane);
+      hi = bag_end(p, b0 + lane);
     }
     const bool single = (hi - lo == 1) || (lane >= nb);
     if (__all(single)) {
@@ -134,7 +123,7 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
           const int bi = base + u * gpw + grp;
           const float wi = __shfl(w, bi & 63);
           if (bi < nb) {
-            const int64_t orow = out_order ? (int64_t)(b0 + bi) : out_row(p, b0 + bi);
+            const int64_t orow = out_row(p, b0 + bi);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
               const int ch = gl + c * G;
@@ -203,7 +192,7 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
           for (int c = 0; c < NCH; ++c) acc[c] = acc[c] * inv;
         }
         if (bi < nb) {
-          const int64_t orow = out_order ? (int64_t)(b0 + bi) : out_row(p, b0 + bi);
+          const int64_t orow = out_row(p, b0 + bi);
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const int ch = gl + c * G;
@@ -906,8 +895,6 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
   dim3 grid(bag_grid(num_bags)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool stage = nnz != num_bags;      // multi-id bags possible
-  static const int oo_env = [] { const char* e = getenv("CE_FWD_OUT_ORDER"); return e ? atoi(e) : 1; }();
-  p.out_order = (!stage && p.hookF > 1 && oo_env) ? 1 : 0;
   static const int u_env = [] { const char* e = getenv("CE_FWD_U"); return e ? atoi(e) : 16; }();
 #define CE_FWD(VT, N, U)                                                                   \
   do {                                                                                     \

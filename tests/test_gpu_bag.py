@@ -429,9 +429,9 @@ def test_source_row_keys_backward_matches_tile_backward(D, layout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("D", [8, 128])
-def test_hooked_forward_in_output_order_with_ragged_bags_of_total_length_num_bags(D):
-    """nnz == num_bags selects the output-order tiles of the hooked forward (lane i owns output row b0 + i); the bags
-    need not hold one id each -- empty and multi-id bags with the same total take the general path of that mapping."""
+def test_hooked_forward_with_ragged_bags_of_total_length_num_bags(D):
+    """nnz == num_bags selects the LDS-free forward variant (meant for one id per bag); the bags need not hold one id
+    each -- empty and multi-id bags with the same total must take its general path and still land in [B, F, D]."""
     import cachedembedding_amd as ce
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(D)
