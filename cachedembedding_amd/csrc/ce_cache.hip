@@ -11,7 +11,7 @@
 //   count     popcount the bitmap per 32768-row chunk; miss = inverted[row] < 0     [K4]
 //   plan      one block: exclusive scan of chunk counts, capacity check, k = miss - free
 //   emit      miss rows in ascending order; hit slots stamped with the call epoch; bitmap cleared
-//   keys/hist/pick x8/victims   exact k-smallest selection over all slots          [K5]
+//   keys/hist x<=8/victims      exact k-smallest selection over all slots          [K5]
 //   evict     victims' rows written back to the host table, maps cleared           [K6]
 //   free      first n_miss free slots ascending (ordered compaction)              [K7]
 //   admit     miss rows host -> cache rows, maps + counters updated               [K8/K9]
@@ -53,7 +53,7 @@ struct Ctl {                 // device control block (one per manager)
   long long n_miss;
   long long k_evict;
   long long miss_lookups;
-  unsigned long long sel_prefix;   // radix-select state
+  unsigned long long sel_prefix;   // (unused since the digits are recomputed from the histograms: select_chain)
   long long sel_krem;
   long long n_eligible;      // slots that may be evicted in this call (resident and not protected)
   int victims_count;
@@ -88,7 +88,7 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.miss_list = o;  o = al(o + (size_t)L.list_cap * 4);
   L.slot_epoch = o; o = al(o + (size_t)C * 4);
   L.keys = o;       o = al(o + (size_t)C * 8);
-  L.hist = o;       o = al(o + 256 * 4);
+  L.hist = o;       o = al(o + 8 * 256 * 4);      // one 256-bin histogram per radix pass
   L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
   L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
   L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
       mail_in->job = job;
     }
     // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
-    // record (k_pick can turn it into a capacity failure): k_admit_maps
+    // record (k_victims can turn it into a capacity failure): k_admit_maps
   }
 }
 
@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
                                               int32_t epoch, int32_t depth, int slot_bits, int lfu,
                                               unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
   if (ctl->k_evict == 0) return;
-  if (blockIdx.x == 0) hist[threadIdx.x] = 0;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) hist[i] = 0;      // all passes' histograms
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const unsigned long long fmax = (1ull << (63 - slot_bits)) - 1;
   int elig = 0;
@@ -450,14 +451,67 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
 // Few, fat workgroups: every workgroup ends with one device atomic per non-empty bin and same-address atomics
 // serialise (~7 ns each), so 1738 workgroups of 256 cost 12 us per pass in the histogram flush alone; 256
 // workgroups of 1024 threads with 4 independent key loads per thread read the 14 MB of keys just as fast.
+// Digits of the k-th smallest key decided so far, from the per-pass histograms hist[q][256] of the passes q > lowest
+// (what the single-thread k_pick kernel between two histogram passes used to compute and leave in ctl): one wave,
+// 4 bins per lane, all levels' bins loaded together, then per level a wave scan and the first lane whose running
+// count reaches k.  Every workgroup of the NEXT kernel recomputes it in its prologue (a few hundred bytes out of
+// L2) -- that removes one launch per pass (5-8 us each: 4 per call at the bench shape, 5-8 for LFU).  The inputs
+// (k in ctl->sel_krem, the histograms) are read-only while it runs, so all workgroups agree.
+struct SelState {
+  unsigned long long prefix;
+  int krem;
+  int fail;      // fewer evictable slots than k: capacity overflow of the overlapped pipeline
+};
+__device__ __forceinline__ SelState select_chain(const uint32_t* __restrict__ hist, int top_pass, int lowest,
+                                                 const Ctl* ctl, int lane) {
+  SelState st;
+  st.prefix = 0;
+  st.krem = (int)ctl->sel_krem;
+  // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the capacity overflow of
+  // the overlapped pipeline (unique(window k u k+1) > cuda_row_num); evictable slots are counted by k_keys
+  st.fail = ctl->n_eligible < (long long)st.krem;
+  uint4 h[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q > lowest && q <= top_pass) h[q] = ((const uint4*)(hist + q * 256))[lane];
+#pragma unroll
+  for (int q = 7; q >= 0; --q) {
+    if (q > top_pass || q <= lowest) continue;
+    const int a = (int)h[q].x, b = (int)h[q].y, c = (int)h[q].z, d = (int)h[q].w;
+    const int sum = a + b + c + d;
+    const int inc = wave_incl_scan(sum, lane);
+    const unsigned long long m = __ballot(inc >= st.krem);
+    const int L = m ? __ffsll((long long)m) - 1 : 63;
+    const int r = st.krem - __shfl(inc - sum, L);          // rank inside lane L's four bins
+    const int la = __shfl(a, L), lb = __shfl(b, L), lc = __shfl(c, L);
+    int dd = 3, cum = la + lb + lc;
+    if (r <= la) { dd = 0; cum = 0; }
+    else if (r <= la + lb) { dd = 1; cum = la; }
+    else if (r <= la + lb + lc) { dd = 2; cum = la + lb; }
+    st.prefix |= ((unsigned long long)(4 * L + dd)) << (q * 8);
+    st.krem = r - cum;
+  }
+  return st;
+}
+
 __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restrict__ keys, int64_t C, int pass,
                                                int top_pass, uint32_t* hist, const Ctl* ctl) {
   if (ctl->k_evict == 0) return;
   __shared__ uint32_t sh[256];
+  __shared__ unsigned long long prefix_s;
+  __shared__ int fail_s;
   if (threadIdx.x < 256) sh[threadIdx.x] = 0;
+  if (threadIdx.x < 64) {
+    const SelState st = select_chain(hist, top_pass, pass, ctl, threadIdx.x);
+    if (threadIdx.x == 0) {
+      prefix_s = st.prefix;
+      fail_s = st.fail;
+    }
+  }
   __syncthreads();
+  if (fail_s) return;                  // k_victims records the failure
   const int shift = pass * 8;
-  const unsigned long long prefix = ctl->sel_prefix;
+  const unsigned long long prefix = prefix_s;
   constexpr int U = 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
   for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; s0 < C; s0 += stride) {
@@ -475,51 +529,39 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
     }
   }
   __syncthreads();
-  if (threadIdx.x < 256 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
-}
-
-// one block of 256: pick the digit holding the k-th smallest key, refine prefix/k, clear the histogram
-__global__ __launch_bounds__(256) void k_pick(uint32_t* hist, int pass, int top_pass, Ctl* ctl,
-                                              ce_call_stats_t* ring_slot) {
-  if (ctl->k_evict == 0) return;
-  __shared__ uint32_t sh[256];
-  const uint32_t mine = hist[threadIdx.x];
-  sh[threadIdx.x] = mine;
-  hist[threadIdx.x] = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long krem = ctl->sel_krem;
-    if (pass == top_pass) {
-      // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the
-      // capacity overflow of the overlapped pipeline (unique(window k u k+1) > cuda_row_num).
-      const long long eligible = ctl->n_eligible;      // counted by k_keys
-      if (eligible < krem) {
-        ctl->n_free = ctl->n_free - ctl->k_evict + ctl->n_miss;
-        ctl->k_evict = 0;
-        ctl->status = CE_ERR_CAPACITY;
-        ring_slot->status = CE_ERR_CAPACITY;
-        ring_slot->n_evict = 0;
-        ring_slot->n_free_after = ctl->n_free;
-        __threadfence_system();
-        return;
-      }
-    }
-    long long cum = 0;
-    int d = 0;
-    for (; d < 256; ++d) {
-      if (cum + (long long)sh[d] >= krem) break;
-      cum += sh[d];
-    }
-    if (d > 255) d = 255;
-    ctl->sel_prefix |= ((unsigned long long)d) << (pass * 8);
-    ctl->sel_krem = krem - cum;
-  }
+  uint32_t* const mine = hist + pass * 256;
+  if (threadIdx.x < 256 && sh[threadIdx.x]) atomicAdd(&mine[threadIdx.x], sh[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
-                                                 int32_t* victims, int64_t cap, Ctl* ctl) {
+                                                 int32_t* victims, int64_t cap, Ctl* ctl, const uint32_t* hist,
+                                                 int top_pass, ce_call_stats_t* ring_slot) {
   if (ctl->k_evict == 0) return;
-  const unsigned long long T = ctl->sel_prefix;   // k-th smallest key; keys are unique
+  __shared__ unsigned long long prefix_s;
+  __shared__ int fail_s;
+  if (threadIdx.x < 64) {
+    const SelState st = select_chain(hist, top_pass, -1, ctl, threadIdx.x);
+    if (threadIdx.x == 0) {
+      prefix_s = st.prefix;
+      fail_s = st.fail;
+    }
+  }
+  __syncthreads();
+  if (fail_s) {
+    // every workgroup sees the same failure (read-only inputs); ONE thread turns the call into a capacity failure:
+    // nothing is evicted or admitted, the record says so.  The kernels that follow read k_evict / status.
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ctl->n_free = ctl->n_free - ctl->k_evict + ctl->n_miss;
+      ctl->k_evict = 0;
+      ctl->status = CE_ERR_CAPACITY;
+      ring_slot->status = CE_ERR_CAPACITY;
+      ring_slot->n_evict = 0;
+      ring_slot->n_free_after = ctl->n_free;
+      __threadfence_system();
+    }
+    return;
+  }
+  const unsigned long long T = prefix_s;   // k-th smallest key; keys are unique
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
   // wave-uniform trip count; the victims of a wave reserve their places with ONE returning atomic (a returning
@@ -2104,15 +2146,15 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     top_pass = h->freq_bound_known ? std::min(7, std::max(0, (bits + 7) / 8 - 1)) : 7;
   }
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
-  // (one launch per pass with the last workgroup picking the digit was tried: the agent-scope fences it needs
-  // write back the L2 of every XCD, and the select went from 0.22 to 0.72 ms beside the training kernels)
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
-  // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs)
-  for (int pass = top_pass; pass >= 0; --pass) {
+  // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs; one launch per pass with the LAST
+  // workgroup picking the digit: the agent-scope fences it needs write back the L2 of every XCD, 0.22 -> 0.72 ms
+  // beside the training kernels.  What works: every workgroup of pass p recomputes the digits of the passes above
+  // it from their histograms in its prologue -- select_chain -- so there is no pick kernel at all)
+  for (int pass = top_pass; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
-    hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, h->hist, pass, top_pass, h->ctl, slot);
-  }
-  hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl);
+  hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
+                     (const uint32_t*)h->hist, top_pass, slot);
   CE_PHASE();
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
   int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
@@ -2187,7 +2229,10 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   } else if (c.transport == CE_TRANSPORT_ZEROCOPY) {
     // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy
     const long long scap = (long long)L.stage_rows;
-    static const int swap_rows = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : kSwapRows; }();
+    // rows in flight per lane group: 16 keeps a window-sized swap (50 k rows) on a small grid; a call of a few thousand
+    // rows (B = 2048 shapes) would then fill only a handful of groups -- 4 spreads it (38 -> 21 us per call)
+    static const int swap_rows_env = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : 0; }();
+    const int swap_rows = swap_rows_env > 0 ? swap_rows_env : (n <= 131072 ? 4 : kSwapRows);
     // workgroups of the write-back part: as many as admit when the call has the GPU to itself; half as many when it
     // overlaps with training (protect_depth > 0) -- PCIe writes are what slows the kernels next to them, and fewer
     // rows leave than enter (32 + 16 workgroups: 2.11 -> 2.22 G lookups/s; 32 + 8 makes the write-back the bottleneck)
