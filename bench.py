@@ -293,8 +293,10 @@ def main():
     tot0 = mgr.totals()
     barrier()
     t1 = time.perf_counter()
+    c1 = time.thread_time()
     run_range(g, g + reps * K)
     enqueue_s = time.perf_counter() - t1
+    enqueue_cpu_s = time.thread_time() - c1      # CPU seconds of the launch thread: < enqueue_s means it waited
     barrier()
     region = time.perf_counter() - t1
     g += reps * K
@@ -303,7 +305,7 @@ def main():
     phases = mgr.phase_times()
     mgr.set_profiling(False)
     note(f"timed region done: {reps} x {K} steps in {region:.3f}s = {1e3 * elapsed / K:.4f} ms/step (one K-step block "
-         f"bracketed on its own: {1e3 * single:.3f} ms = {1e3 * single / K:.4f} ms/step); host enqueue {enqueue_s:.3f}s")
+         f"bracketed on its own: {1e3 * single:.3f} ms = {1e3 * single / K:.4f} ms/step); host enqueue {enqueue_s:.3f}s wall / {enqueue_cpu_s:.3f}s CPU")
     st = mgr.sync_stats()
     if st.status != 0:
         raise AssertionError(f"cache op failed with status {st.status}: unique rows of a window exceed cuda_row_num={C}")
