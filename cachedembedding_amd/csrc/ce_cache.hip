@@ -536,17 +536,20 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
 __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
                                                  int32_t* victims, int64_t cap, Ctl* ctl, const uint32_t* hist,
                                                  int top_pass, ce_call_stats_t* ring_slot) {
-  if (ctl->k_evict == 0) return;
   __shared__ unsigned long long prefix_s;
-  __shared__ int fail_s;
+  __shared__ int fail_s, go_s;
   if (threadIdx.x < 64) {
     const SelState st = select_chain(hist, top_pass, -1, ctl, threadIdx.x);
     if (threadIdx.x == 0) {
       prefix_s = st.prefix;
       fail_s = st.fail;
+      // k_evict is cleared by workgroup 0 of THIS kernel when the call fails: it is read once per workgroup, by one
+      // thread, so that all threads of a workgroup take the same way around the barrier below
+      go_s = ctl->k_evict != 0;
     }
   }
   __syncthreads();
+  if (!go_s) return;
   if (fail_s) {
     // every workgroup sees the same failure (read-only inputs); ONE thread turns the call into a capacity failure:
     // nothing is evicted or admitted, the record says so.  The kernels that follow read k_evict / status.
@@ -1871,8 +1874,8 @@ static int ensure_writeback(ce_cache* h) {
     w->mail = (WbMail*)p;
     if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
     w->mail_dev = (WbMail*)pd;
-    if (hipHostMalloc(&p, 128, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
-    memset(p, 0, 128);
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    memset(p, 0, 64);
     w->sig = (unsigned long long*)p;
     if (hipHostMalloc(&p, idx_bytes, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
     w->miss_host = (int32_t*)p;
