@@ -104,6 +104,10 @@ SIGNATURES = {
                                           c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_sgd_presorted_src": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_float, c_void_p,
                                                   c_void_p]),
+    "ce_bag_presort_window_src_excl": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_int64,
+                                               c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ce_bag_backward_sgd_presorted_src_excl": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_float,
+                                                       c_void_p, c_void_p, c_void_p]),
     "ce_bag_backward_dense_presorted_src": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
                                                     c_void_p]),
     "ce_bag_backward_sgd_sorted_workspace": (c_size_t, [c_int64, c_int64]),
@@ -124,6 +128,7 @@ SIGNATURES = {
     "ce_cache_flush": (c_int, [c_void_p, c_void_p]),
     "ce_cache_set_protect_depth": (c_int, [c_void_p, c_int32]),
     "ce_cache_set_transport": (c_int, [c_void_p, c_int32]),
+    "ce_cache_get_transport": (c_int32, [c_void_p]),
     "ce_cache_set_buffer_rows": (c_int, [c_void_p, c_int64]),
     "ce_cache_set_profiling": (c_int, [c_void_p, c_int32]),
     "ce_cache_phase_count": (c_int32, []),

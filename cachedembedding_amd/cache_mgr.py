@@ -154,8 +154,12 @@ class CachedParamMgr(torch.nn.Module):
         cfg.cuda_row_num = C
         cfg.embedding_dim = self.embedding_dim
         cfg.evict_strategy = _lib.CE_EVICT_LFU if self._evict_strategy == EvictionStrategy.LFU else _lib.CE_EVICT_DATASET
-        cfg.transport = getattr(self, "_transport", None) or (
+        tr = getattr(self, "_transport", None)        # None = never set (CE_TRANSPORT_ZEROCOPY is 0: test identity)
+        cfg.transport = tr if tr is not None else (
             _lib.CE_TRANSPORT_STAGED if self._async_copy else _lib.CE_TRANSPORT_ZEROCOPY)
+        reapply_worker = cfg.transport == _lib.CE_TRANSPORT_WORKER
+        if reapply_worker:           # goes through set_transport() below: that path owns the "unsupported" fallback
+            cfg.transport = _lib.CE_TRANSPORT_ZEROCOPY
         cfg.protect_depth = 0
         cfg.max_ids_per_call = self._max_ids
         cfg.host_weight = self._table.host_ptr
@@ -174,6 +178,8 @@ class CachedParamMgr(torch.nn.Module):
         self._fin = weakref.finalize(self, lib.ce_cache_destroy, h)
         if self.buffer_size and self.buffer_size > 0:
             check(lib.ce_cache_set_buffer_rows(h, int(self.buffer_size)))
+        if reapply_worker:
+            self.set_transport("worker")
 
     @property
     def weight(self) -> torch.Tensor:
@@ -358,7 +364,13 @@ class CachedParamMgr(torch.nn.Module):
                 rc = lib.ce_cache_set_transport(self._handle, self._TRANSPORTS[name])
             check(rc)
         self._transport = self._TRANSPORTS[name]
-        self.transport_name = name
+
+    @property
+    def transport_name(self) -> str:
+        """the transport in force -- the library falls back from 'worker' to 'zerocopy' (with a message on stderr)
+        when its first-use self-test finds that the copy streams cannot run beside a parked cache-op stream"""
+        code = lib.ce_cache_get_transport(self._handle)
+        return {v: k for k, v in self._TRANSPORTS.items()}.get(code, "zerocopy")
 
     def set_profiling(self, on: bool = True):
         """hipEvent timers around the phases of prepare_ids (read them with phase_times())."""

@@ -94,11 +94,19 @@ class CachedEmbeddingBag(nn.Module):
     def forward(self, input: torch.Tensor, offsets: Optional[torch.Tensor] = None,
                 per_sample_weights: Optional[torch.Tensor] = None, shape_hook: Optional[Callable] = None,
                 *, hook_features: int = 0, presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
+        masked = False
         if self.cache_op:
             with torch.no_grad():
                 ids = input
                 input = self.cache_weight_mgr.prepare_ids(ids)
                 if self.padding_idx is not None:
+                    if self.mode != "sum":
+                        raise NotImplementedError("padding_idx is implemented for mode='sum' only (mean would need "
+                                                  "the per-bag count of non-padding entries)")
+                    if presorted is not None:
+                        raise NotImplementedError("padding_idx cannot be combined with presorted keys: they were "
+                                                  "built from slots that still hold the padding lookups")
+                    masked = True
                     # nn.EmbeddingBag semantics in ID space (upstream hands padding_idx to F.embedding_bag in slot
                     # space, which is not meaningful): lookups of the padding id take no part in the
                     # reduction and get no gradient -- the kernels skip slot -1.  With cache_op=False the caller
@@ -107,7 +115,7 @@ class CachedEmbeddingBag(nn.Module):
         out = embedding_bag(input, self.cache_weight_mgr.cuda_cached_weight, offsets, self.max_norm,
                             self.norm_type, self.scale_grad_by_freq, self.mode, self.sparse, per_sample_weights,
                             self.include_last_offset, None, hook_features=hook_features,
-                            fused_sgd=self.fused_sgd, presorted=presorted)
+                            fused_sgd=self.fused_sgd, presorted=presorted, masked_indices=masked)
         if shape_hook is not None:
             out = shape_hook(out)
         return out

@@ -50,7 +50,18 @@ struct BagParams {
   uint32_t num_rows;        // rows of the gathered / updated table: out-of-range indices are ignored
   int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
   const unsigned long long* presorted;   // optional: segment-grouped keys from ce_bag_presort* (no sort in the kernel)
+  int32_t policy;           // bit 0: fwd output stores non-temporal; bit 1: bwd gradient-row loads non-temporal
 };
+
+// cache policies of the two big streams (CE_FWD_NT / CE_BWD_NT, default on): see DESIGN.md section 4
+static int bag_policy() {
+  static const int v = [] {
+    const char* f = getenv("CE_FWD_NT");
+    const char* b = getenv("CE_BWD_NT");
+    return ((f ? atoi(f) : 1) ? 1 : 0) | ((b ? atoi(b) : 1) ? 2 : 0);
+  }();
+  return v;
+}
 
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
   return p.off64 ? (int)((const int64_t*)p.offsets)[i] : ((const int32_t*)p.offsets)[i];
@@ -68,9 +79,26 @@ __device__ __forceinline__ int64_t out_row(const BagParams& p, int g) {
 
 constexpr int kIdxStage = 2048;   // indices of one 64-bag tile staged in LDS (8 KB per wave)
 
+// Output store of the forward by cache policy (CE_FWD_STORE): 0 plain, 1 nt (default), 2 sc1 (write-through: the line
+// is not kept in the XCD's L2), 3 sc0 sc1, 4 sc1 nt.  The output is written once and read by another kernel; what
+// matters is how much of the L2 / Infinity Cache it takes from the cache rows the gather wants to find there.
+template <int SP>
+__device__ __forceinline__ void store_out(f32x4* p, f32x4 v) {
+  if (SP == 0) *p = v;
+  else if (SP == 1) __builtin_nontemporal_store(v, p);
+  else if (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (SP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int SP>
+__device__ __forceinline__ void store_out(float* p, float v) {
+  if (SP == 0) *p = v;
+  else __builtin_nontemporal_store(v, p);
+}
+
 // STAGE: tiles with multi-id bags stage their indices in LDS (32 KB per workgroup); the launcher picks the
 // LDS-free variant when nnz == num_bags (single-id batches) so occupancy is set by registers alone.
-template <typename VT, int NCH, bool STAGE, int U>
+template <typename VT, int NCH, bool STAGE, int U, int NTS>
 __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
   __shared__ int lds_idx[STAGE ? 4 : 1][STAGE ? kIdxStage : 1];
   const int lane = threadIdx.x & 63;
@@ -129,7 +157,7 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
               const int ch = gl + c * G;
               if (ch < rowlen) {
                 VT val = p.psw ? v[u][c] * wi : v[u][c];
-                __builtin_nontemporal_store(val, &O[orow * rowlen + ch]);
+                store_out<NTS>(&O[orow * rowlen + ch], val);
               }
             }
           }
@@ -196,7 +224,9 @@ __global__ __launch_bounds__(256) void k_bag_fwd(BagParams p) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const int ch = gl + c * G;
-            if (ch < rowlen) __builtin_nontemporal_store(acc[c], &O[orow * rowlen + ch]);
+            if (ch < rowlen) {
+              store_out<NTS>(&O[orow * rowlen + ch], acc[c]);
+            }
           }
         }
       }
@@ -447,13 +477,26 @@ constexpr int kSegBuckets = CE_SEG_BUCKETS;
 // SRC: the low word of a key is not the lookup's place in its segment but the row of grad_out the lookup reads
 // (out_row(bag of the lookup), from the batch's offsets): everything the streaming backward needs, resolved here
 // once per window instead of in every backward launch.  lay.offsets of batch b = offsets + b * off_stride elements.
-template <bool SRC>
+// EXCL (with SRC): the keys are staged in LDS at their grouped positions, every bucket of at most kExclRun keys is
+// sorted by row there (a handful of keys: insertion sort by the thread that owns the bucket's first position), and
+// the first key of every run that lies inside ONE 16-position block of the segment gets bit 31 of its low word set:
+// "all lookups of this row in this segment follow, and whoever reads this key reads all of them" -- shares of the
+// streaming backward are multiples of 16 positions.  Together with the segment's id range (ids_minmax: no id is
+// shared between two segments of a batch when their ranges are disjoint) that lets the backward update such a row
+// with a plain read-modify-write instead of atomics.  The write-out is then one coalesced sweep.
+constexpr int kExclRun = 32;
+constexpr unsigned kExclFlag = 0x80000000u;
+
+template <bool SRC, bool EXCL>
 __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz_per_batch,
                                                          int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
                                                          unsigned long long* __restrict__ keys_out, BagParams lay,
-                                                         int64_t off_stride) {
-  __shared__ int cnt[kSegBuckets + 1];                  // [kSegBuckets] = ignored lookups
+                                                         int64_t off_stride, const int64_t* __restrict__ ids,
+                                                         int64_t* __restrict__ ids_minmax) {
+  __shared__ unsigned long long lk[EXCL ? kSegLen : (kSegBuckets + 2) / 2];   // EXCL: the segment's keys by position
+  int* const cnt = (int*)lk;                            // [kSegBuckets + 1] bucket counters ([kSegBuckets] = ignored)
   __shared__ int wsum[16];
+  __shared__ long long mm_s[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int64_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
@@ -518,8 +561,84 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     for (int q = 0; q < kPer; ++q) { cnt[tid * kPer + q] = pre; pre += c4[q]; }
     if (tid == 0) cnt[kSegBuckets] = total;
     __syncthreads();
+    if (!EXCL) {
 #pragma unroll
-    for (int r = 0; r < kSegKeys; ++r) keys_out[base + cnt[bkt[r]] + place[r]] = key[r];
+      for (int r = 0; r < kSegKeys; ++r) keys_out[base + cnt[bkt[r]] + place[r]] = key[r];
+      __syncthreads();
+      continue;
+    }
+    // ---- EXCL: keys to their positions in LDS (the counters are dead once every thread has its positions)
+    int pos[kSegKeys];
+#pragma unroll
+    for (int r = 0; r < kSegKeys; ++r) pos[r] = cnt[bkt[r]] + place[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSegKeys; ++r) lk[pos[r]] = key[r];
+    __syncthreads();
+    // thread t owns the buckets that START in positions [16 t, 16 t + 16).  A neighbour sorting a bucket that reaches
+    // into this range only permutes keys of one bucket, so "is p a bucket start" (high words of p - 1 and p) does not
+    // depend on how far it got.
+    {
+      const uint32_t* hi = (const uint32_t*)lk;          // hi[2 p + 1] = row of position p
+      const int p0 = tid * kSegKeys;
+      for (int p = p0; p < p0 + kSegKeys; ++p) {
+        const uint32_t row = hi[2 * p + 1];
+        if (row == 0xffffffffu) break;                   // ignored lookups are last
+        const uint32_t b = row & (kSegBuckets - 1);
+        if (p > 0 && (hi[2 * p - 1] & (kSegBuckets - 1)) == b && hi[2 * p - 1] != 0xffffffffu) continue;   // not a start
+        int e = p + 1;
+        while (e < kSegLen && e - p <= kExclRun && hi[2 * e + 1] != 0xffffffffu && (hi[2 * e + 1] & (kSegBuckets - 1)) == b) ++e;
+        if (e - p > kExclRun) continue;                  // a hot bucket: left as it is, flushed with atomics
+        for (int i = p + 1; i < e; ++i) {                // insertion sort by row (stable)
+          const unsigned long long k = lk[i];
+          int j = i;
+          while (j > p && (uint32_t)(lk[j - 1] >> 32) > (uint32_t)(k >> 32)) { lk[j] = lk[j - 1]; --j; }
+          lk[j] = k;
+        }
+        for (int a = p; a < e;) {                        // runs: flag the head of a run inside one 16-position block
+          int z = a + 1;
+          while (z < e && (uint32_t)(lk[z] >> 32) == (uint32_t)(lk[a] >> 32)) ++z;
+          if ((a >> 4) == ((z - 1) >> 4)) lk[a] |= kExclFlag;
+          a = z;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSegKeys; ++r) keys_out[base + r * 1024 + tid] = lk[r * 1024 + tid];
+    // the segment's id range (ids of ignored lookups included: only ever makes the range wider)
+    if (ids_minmax) {
+      long long lo = INT64_MAX, hi2 = INT64_MIN;
+      if (ids) {
+#pragma unroll
+        for (int r = 0; r < kSegKeys; ++r) {
+          const int e = r * 1024 + tid;
+          if (e < n_here) {
+            const long long v = ids[in_base + e];
+            lo = v < lo ? v : lo;
+            hi2 = v > hi2 ? v : hi2;
+          }
+        }
+      } else {
+        lo = INT64_MIN; hi2 = INT64_MAX;                 // no ids: the range says "everything" (never disjoint)
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi2, d);
+        lo = ol < lo ? ol : lo;
+        hi2 = oh > hi2 ? oh : hi2;
+      }
+      if (lane == 0) { mm_s[0][wv] = lo; mm_s[1][wv] = hi2; }
+      __syncthreads();
+      if (tid == 0) {
+        for (int k = 1; k < 16; ++k) {
+          lo = mm_s[0][k] < lo ? mm_s[0][k] : lo;
+          hi2 = mm_s[1][k] > hi2 ? mm_s[1][k] : hi2;
+        }
+        ids_minmax[2 * seg] = lo;
+        ids_minmax[2 * seg + 1] = hi2;
+      }
+    }
     __syncthreads();
   }
 }
@@ -665,8 +784,17 @@ __global__ __launch_bounds__(256) void k_bag_bwd_tile(BagParams p) {
 // atomics, which retire in order -- the wait for the next keys would then wait for the atomics just issued
 // (measured: 85 us with register-prefetched keys, 49 us of it gather), and a key load between two gathers serialises
 // them (97 us).
-template <typename VT, int NCH, int R>
-__global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t total) {
+// EXCL (keys from ce_bag_presort_window_src_excl + the batch's segment id ranges): a key with kExclFlag set heads a run
+// that holds every lookup of its row in its segment and lies inside one 16-position block, i.e. inside ONE lane
+// group's share (shares are multiples of 16).  If, in addition, no id occurs in two segments of the batch -- checked
+// here, by every workgroup, on the id ranges the presort recorded: pairwise disjoint [min, max] -- that lane group is
+// the only writer of the row in this launch: the row's old value is loaded together with the gradient rows (one more
+// load in flight, no exposed latency), the run is folded on top of it and the result goes back with ONE plain
+// 512-byte store.  Everything else (long runs, rows of hot buckets, runs that straddle a block, batches whose
+// segments share ids) keeps the transposed fire-and-forget atomics.  Why: the L2 atomic units retire ~1 float per
+// clock and channel -- 6.3 M lane-ops per launch = 24 us that do not overlap with the gather (profiles/r03_probe_*).
+template <typename VT, int NCH, int R, bool NTG, bool EXCL>
+__global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t total, const long long* __restrict__ seg_ranges) {
   __shared__ unsigned long long lk[256 * (R > 4 ? R : 4)];     // ngroups * kc, worst case G = 1
   const int tid = threadIdx.x;
   const int G = 1 << p.g_log2;
@@ -676,9 +804,27 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
   const int rowlen = p.rowlen;
   const int dim = rowlen * (int)(sizeof(VT) / 4);
   const VT* __restrict__ GO = (const VT*)p.grad_out;
+  const VT* __restrict__ WV = (const VT*)p.dst;
   const unsigned long long* __restrict__ keys = p.presorted;
+  bool excl = false;
+  if (EXCL) {
+    // no id in two segments <= the segments' id ranges are pairwise disjoint (empty segments: min > max)
+    const int nseg = (int)(total / kSegLen);
+    int clash = nseg > 64 || seg_ranges == nullptr;
+    if (!clash) {
+      for (int pr = tid; pr < nseg * nseg; pr += 256) {
+        const int a = pr / nseg, b2 = pr - a * nseg;
+        if (a >= b2) continue;
+        const long long alo = seg_ranges[2 * a], ahi = seg_ranges[2 * a + 1];
+        const long long blo = seg_ranges[2 * b2], bhi = seg_ranges[2 * b2 + 1];
+        if (alo <= ahi && blo <= bhi && !(ahi < blo || bhi < alo)) clash = 1;
+      }
+    }
+    excl = __syncthreads_or(clash) == 0;
+  }
   const int64_t all_groups = (int64_t)gridDim.x * ngroups;
-  const int64_t share = ((total + all_groups - 1) / all_groups + R - 1) / R * R;
+  const int64_t round = R > 16 ? R : 16;        // shares are whole 16-position blocks (see EXCL)
+  const int64_t share = ((total + all_groups - 1) / all_groups + round - 1) / round * round;
   const int64_t s0 = ((int64_t)blockIdx.x * ngroups + grp) * share;
   const int64_t s1 = min(total, s0 + share);
   if (s0 >= s1) return;
@@ -689,23 +835,33 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
 #pragma unroll
   for (int c = 0; c < NCH; ++c) acc[c] = vzero<VT>();
   uint32_t cur = 0xffffffffu;
+  bool cur_excl = false;
   for (int64_t c0 = s0; c0 < s1; c0 += kc) {
     for (int k = gl; k < kc; k += G) mylk[k] = c0 + k < s1 ? keys[c0 + k] : ~0ull;
     const int64_t c1 = min(s1, c0 + kc);
     for (int64_t q = c0; q < c1; q += R) {
       VT v[R][NCH];
+      VT w2[EXCL ? R : 1][NCH];
       uint32_t rw[R];
+      uint32_t heads = 0;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         const unsigned long long k = mylk[(int)(q - c0) + t];
         const bool on = k != ~0ull && (uint32_t)(k >> 32) < p.num_rows;
         rw[t] = on ? (uint32_t)(k >> 32) : 0xffffffffu;
-        const int64_t src = (int64_t)(uint32_t)k;
+        const uint32_t low = (uint32_t)k;
+        const int64_t src = (int64_t)(low & ~kExclFlag);
+        const bool head = EXCL && excl && on && (low & kExclFlag);
+        if (head) heads |= 1u << t;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int ch = gl + c * G;
           v[t][c] = vzero<VT>();
-          if (on && ch < rowlen) v[t][c] = __builtin_nontemporal_load(&GO[src * rowlen + ch]);
+          if (on && ch < rowlen) v[t][c] = NTG ? __builtin_nontemporal_load(&GO[src * rowlen + ch]) : GO[src * rowlen + ch];
+          if (EXCL) {
+            w2[t][c] = vzero<VT>();
+            if (head && ch < rowlen) w2[t][c] = WV[(int64_t)rw[t] * rowlen + ch];
+          }
         }
       }
       // ONE wait for all R gathers here: left to the compiler, the wait for v[t] lands after the flush of v[t-1]'s
@@ -714,13 +870,22 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         if (rw[t] != 0xffffffffu) {            // group-uniform
-          if (rw[t] != cur) {
+          const bool head = EXCL && ((heads >> t) & 1);
+          if (rw[t] != cur || head) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-              if (cur != 0xffffffffu) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
-              acc[c] = vzero<VT>();
+              if (cur != 0xffffffffu) {
+                if (EXCL && cur_excl) {
+                  const int ch = gl + c * G;
+                  if (ch < rowlen) ((VT*)(p.dst + (int64_t)cur * dim))[ch] = acc[c];
+                } else {
+                  flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
+                }
+              }
+              acc[c] = EXCL ? w2[EXCL ? t : 0][c] : vzero<VT>();
             }
             cur = rw[t];
+            cur_excl = head;
           }
 #pragma unroll
           for (int c = 0; c < NCH; ++c) acc[c] = acc[c] + v[t][c] * alpha;
@@ -730,7 +895,14 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
   }
   if (cur != 0xffffffffu) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
+    for (int c = 0; c < NCH; ++c) {
+      if (EXCL && cur_excl) {
+        const int ch = gl + c * G;
+        if (ch < rowlen) ((VT*)(p.dst + (int64_t)cur * dim))[ch] = acc[c];
+      } else {
+        flush_chunk(p.dst + (int64_t)cur * dim, acc[c], gl, G, c, rowlen, CE_DBG(p.debug));
+      }
+    }
   }
 }
 
@@ -814,6 +986,7 @@ static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_
   p.hookB = hookF ? (int32_t)(num_bags / hookF) : 0;
   p.alpha = 1.f;
   p.num_rows = 0xffffffffu;
+  p.policy = bag_policy();
   return CE_OK;
 }
 
@@ -896,19 +1069,35 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
   hipStream_t s = (hipStream_t)stream;
   const bool stage = nnz != num_bags;      // multi-id bags possible
   static const int u_env = [] { const char* e = getenv("CE_FWD_U"); return e ? atoi(e) : 16; }();
-#define CE_FWD(VT, N, U)                                                                   \
-  do {                                                                                     \
-    if (stage) hipLaunchKernelGGL((k_bag_fwd<VT, N, true, U>), grid, block, 0, s, p);      \
-    else hipLaunchKernelGGL((k_bag_fwd<VT, N, false, U>), grid, block, 0, s, p);           \
+#define CE_FWD(VT, N, U)                                                                          \
+  do {                                                                                            \
+    if (stage) hipLaunchKernelGGL((k_bag_fwd<VT, N, true, U, 1>), grid, block, 0, s, p);          \
+    else if (sp == 0) hipLaunchKernelGGL((k_bag_fwd<VT, N, false, U, 0>), grid, block, 0, s, p);  \
+    else hipLaunchKernelGGL((k_bag_fwd<VT, N, false, U, 1>), grid, block, 0, s, p);               \
   } while (0)
+#define CE_FWD_SP(U)                                                                                        \
+  do {                                                                                                      \
+    if (sp == 2) hipLaunchKernelGGL((k_bag_fwd<f32x4, 1, false, U, 2>), grid, block, 0, s, p);              \
+    else if (sp == 3) hipLaunchKernelGGL((k_bag_fwd<f32x4, 1, false, U, 3>), grid, block, 0, s, p);         \
+    else if (sp == 4) hipLaunchKernelGGL((k_bag_fwd<f32x4, 1, false, U, 4>), grid, block, 0, s, p);         \
+    else CE_FWD(f32x4, 1, U);                                                                               \
+  } while (0)
+  static const int sp_env = [] { const char* e = getenv("CE_FWD_STORE"); return e ? atoi(e) : -1; }();
+  const int sp = sp_env >= 0 ? sp_env : ((p.policy & 1) ? 1 : 0);
+  static const int bpc_env = [] { const char* e = getenv("CE_FWD_WAVES"); return e ? atoi(e) : 0; }();
+  if (bpc_env > 0) grid = dim3((unsigned)std::min<int64_t>(cdiv(cdiv(num_bags, 64), 4), (int64_t)kNumCU * bpc_env));
   if (vec) {
-    if (nch == 1) {
+    if (nch == 1 && !stage) {
+      if (u_env == 4) CE_FWD_SP(4); else if (u_env == 8) CE_FWD_SP(8);
+      else if (u_env == 32) CE_FWD_SP(32); else CE_FWD_SP(16);
+    } else if (nch == 1) {
       if (u_env == 4) CE_FWD(f32x4, 1, 4); else if (u_env == 8) CE_FWD(f32x4, 1, 8);
       else if (u_env == 32) CE_FWD(f32x4, 1, 32); else CE_FWD(f32x4, 1, 16);
     } else if (nch == 2) CE_FWD(f32x4, 2, 4); else CE_FWD(f32x4, 4, 2);
   } else {
     if (nch == 1) CE_FWD(float, 1, 8); else if (nch == 2) CE_FWD(float, 2, 4); else CE_FWD(float, 4, 2);
   }
+#undef CE_FWD_SP
 #undef CE_FWD
   CE_LAUNCH_CHECK();
   return CE_OK;
@@ -999,9 +1188,11 @@ extern "C" int ce_bag_backward_sgd_presorted(float* weight, int64_t num_rows, in
                            (const unsigned long long*)presorted_keys, stream);
 }
 
-// keys = row << 32 | grad_out row (ce_bag_presort_window_src); alpha * grad_out rows are folded into dst
+// keys = row << 32 | grad_out row (ce_bag_presort_window_src); alpha * grad_out rows are folded into dst.
+// seg_ranges (fused SGD only): the batch's segment id ranges from ce_bag_presort_window_src_excl -> owner-exclusive
+// rows are updated with plain read-modify-writes (k_bag_bwd_stream<EXCL>)
 static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t nnz, const float* grad_out,
-                             float alpha, const unsigned long long* keys, hipStream_t s) {
+                             float alpha, const unsigned long long* keys, const int64_t* seg_ranges, hipStream_t s) {
   if (nnz == 0) return CE_OK;
   CE_REQUIRE(dst && grad_out && keys, CE_ERR_INVALID, "null pointer");
   CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
@@ -1019,20 +1210,27 @@ static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t 
   { const char* dbg = getenv("CE_BWD_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
   static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
+  static const int excl_env = [] { const char* e = getenv("CE_BWD_EXCL"); return e ? atoi(e) : 1; }();
   const int ngroups = 256 >> p.g_log2;
   // two workgroups per CU; small inputs: one share of >= 16 keys per lane group
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));
   dim3 g(grid), b(256);
+  const long long* rg = (const long long*)seg_ranges;
+  const bool excl = seg_ranges != nullptr && excl_env != 0 && vec && nch == 1;
   if (vec) {
     static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
-    if (nch == 1 && r_env == 8) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 8>), g, b, 0, s, p, total);
-    else if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16>), g, b, 0, s, p, total);
-    else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 2, 8>), g, b, 0, s, p, total);
-    else hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 4, 4>), g, b, 0, s, p, total);
+    if (nch == 1 && excl && r_env == 8) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 8, true, true>), g, b, 0, s, p, total, rg);
+    else if (nch == 1 && excl && (p.policy & 2)) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, true, true>), g, b, 0, s, p, total, rg);
+    else if (nch == 1 && excl) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, false, true>), g, b, 0, s, p, total, rg);
+    else if (nch == 1 && r_env == 8) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 8, true, false>), g, b, 0, s, p, total, rg);
+    else if (nch == 1 && (p.policy & 2)) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, true, false>), g, b, 0, s, p, total, rg);
+    else if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, false, false>), g, b, 0, s, p, total, rg);
+    else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 2, 8, true, false>), g, b, 0, s, p, total, rg);
+    else hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 4, 4, true, false>), g, b, 0, s, p, total, rg);
   } else {
-    if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<float, 1, 16>), g, b, 0, s, p, total);
-    else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<float, 2, 8>), g, b, 0, s, p, total);
-    else hipLaunchKernelGGL((k_bag_bwd_stream<float, 4, 4>), g, b, 0, s, p, total);
+    if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<float, 1, 16, true, false>), g, b, 0, s, p, total, rg);
+    else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<float, 2, 8, true, false>), g, b, 0, s, p, total, rg);
+    else hipLaunchKernelGGL((k_bag_bwd_stream<float, 4, 4, true, false>), g, b, 0, s, p, total, rg);
   }
   CE_LAUNCH_CHECK();
   return CE_OK;
@@ -1041,21 +1239,29 @@ static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t 
 extern "C" int ce_bag_backward_sgd_presorted_src(float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
                                                  const float* grad_out, float lr, const uint64_t* src_keys,
                                                  ce_stream_t stream) {
-  return launch_bwd_stream(weight, num_rows, dim, nnz, grad_out, -lr, (const unsigned long long*)src_keys,
+  return launch_bwd_stream(weight, num_rows, dim, nnz, grad_out, -lr, (const unsigned long long*)src_keys, nullptr,
                            (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_backward_sgd_presorted_src_excl(float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                                      const float* grad_out, float lr, const uint64_t* src_keys,
+                                                      const int64_t* seg_id_ranges, ce_stream_t stream) {
+  return launch_bwd_stream(weight, num_rows, dim, nnz, grad_out, -lr, (const unsigned long long*)src_keys,
+                           seg_id_ranges, (hipStream_t)stream);
 }
 
 extern "C" int ce_bag_backward_dense_presorted_src(float* grad_weight, int64_t num_rows, int32_t dim, int64_t nnz,
                                                    const float* grad_out, const uint64_t* src_keys,
                                                    ce_stream_t stream) {
-  return launch_bwd_stream(grad_weight, num_rows, dim, nnz, grad_out, 1.f, (const unsigned long long*)src_keys,
+  return launch_bwd_stream(grad_weight, num_rows, dim, nnz, grad_out, 1.f, (const unsigned long long*)src_keys, nullptr,
                            (hipStream_t)stream);
 }
 
 extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }
 
 static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
-                               uint64_t* keys_out, const BagParams* lay, int64_t off_stride, ce_stream_t stream) {
+                               uint64_t* keys_out, const BagParams* lay, int64_t off_stride, const int64_t* ids,
+                               int64_t* ids_minmax, ce_stream_t stream) {
   if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
   CE_REQUIRE(indices && keys_out && nnz_per_batch > 0 && n_batches > 0, CE_ERR_INVALID, "bad arguments");
   CE_REQUIRE(nnz_per_batch < (int64_t)INT32_MAX - kSegLen, CE_ERR_INVALID, "batch too large");
@@ -1064,25 +1270,31 @@ static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, in
   const int64_t nseg = spb * n_batches;
   CE_REQUIRE(spb < (int64_t)INT32_MAX && nseg < (int64_t)INT32_MAX, CE_ERR_INVALID, "too many segments");
   const dim3 grid((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), block(1024);
-  if (lay)
-    hipLaunchKernelGGL(k_bag_presort_seg<true>, grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
-                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride);
+  if (lay && ids_minmax)
+    hipLaunchKernelGGL((k_bag_presort_seg<true, true>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride, ids,
+                       ids_minmax);
+  else if (lay)
+    hipLaunchKernelGGL((k_bag_presort_seg<true, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride,
+                       (const int64_t*)nullptr, (int64_t*)nullptr);
   else
-    hipLaunchKernelGGL(k_bag_presort_seg<false>, grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
-                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{}, 0ll);
+    hipLaunchKernelGGL((k_bag_presort_seg<false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{}, 0ll,
+                       (const int64_t*)nullptr, (int64_t*)nullptr);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }
 
 extern "C" int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
                                      int64_t num_rows, uint64_t* keys_out, ce_stream_t stream) {
-  return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, nullptr, 0, stream);
+  return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, nullptr, 0, nullptr, nullptr, stream);
 }
 
-extern "C" int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
-                                         int64_t num_rows, const void* offsets, int32_t offsets_are_i64,
-                                         int64_t offsets_batch_stride, int64_t num_bags, int32_t include_last_offset,
-                                         int64_t hook_features, uint64_t* keys_out, ce_stream_t stream) {
+static int presort_window_src_impl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                                   const void* offsets, int32_t offsets_are_i64, int64_t offsets_batch_stride,
+                                   int64_t num_bags, int32_t include_last_offset, int64_t hook_features,
+                                   const int64_t* ids, uint64_t* keys_out, int64_t* seg_id_ranges, ce_stream_t stream) {
   if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
   CE_REQUIRE(offsets && num_bags > 0 && offsets_batch_stride >= 0, CE_ERR_INVALID, "bad offsets");
   BagParams lay{};
@@ -1091,7 +1303,28 @@ extern "C" int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per
   int rc = fill_params(lay, 4, indices, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset,
                        nullptr, CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
   if (rc) return rc;
-  return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, &lay, offsets_batch_stride, stream);
+  return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, &lay, offsets_batch_stride, ids,
+                             seg_id_ranges, stream);
+}
+
+extern "C" int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
+                                         int64_t num_rows, const void* offsets, int32_t offsets_are_i64,
+                                         int64_t offsets_batch_stride, int64_t num_bags, int32_t include_last_offset,
+                                         int64_t hook_features, uint64_t* keys_out, ce_stream_t stream) {
+  return presort_window_src_impl(indices, nnz_per_batch, n_batches, num_rows, offsets, offsets_are_i64,
+                                 offsets_batch_stride, num_bags, include_last_offset, hook_features, nullptr, keys_out,
+                                 nullptr, stream);
+}
+
+extern "C" int ce_bag_presort_window_src_excl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
+                                              int64_t num_rows, const void* offsets, int32_t offsets_are_i64,
+                                              int64_t offsets_batch_stride, int64_t num_bags,
+                                              int32_t include_last_offset, int64_t hook_features, const int64_t* ids,
+                                              uint64_t* keys_out, int64_t* seg_id_ranges, ce_stream_t stream) {
+  CE_REQUIRE(seg_id_ranges, CE_ERR_INVALID, "null seg_id_ranges");
+  return presort_window_src_impl(indices, nnz_per_batch, n_batches, num_rows, offsets, offsets_are_i64,
+                                 offsets_batch_stride, num_bags, include_last_offset, hook_features, ids, keys_out,
+                                 seg_id_ranges, stream);
 }
 
 extern "C" int ce_bag_presort(const int64_t* indices, int64_t nnz, int64_t num_rows, uint64_t* keys_out,

@@ -7,10 +7,12 @@
 // every count the host would need (unique rows, misses, victims) stays in a device-side
 // control block, and the per-call statistics are stored straight into a pinned host ring.
 //
-//   mark      ids -> rows (idx_map) -> bits in a row bitmap (N/8 bytes)       [unique, K2/K3]
-//   count     popcount the bitmap per 32768-row chunk; miss = inverted[row] < 0     [K4]
-//   plan      one block: exclusive scan of chunk counts, capacity check, k = miss - free
-//   emit      miss rows in ascending order; hit slots stamped with the call epoch; bitmap cleared
+//   mark      ids -> rows (idx_map) -> bits in a row bitmap (N/8 bytes); the thread whose atomicOr sets a bit first
+//             owns the row: it counts it (unique, missing) and adds it to its 131072-row chunk's miss count;
+//             the row of every id is left in slots_out for the last kernel                  [unique, K2-K4]
+//   emit      every workgroup sums the miss counts of the chunks before its own (that IS the scan), workgroup 0
+//             also does the plan (capacity check, k = miss - free); miss rows in ascending order; hit slots
+//             stamped with the call epoch; bitmap cleared
 //   keys/hist x<=8/victims      exact k-smallest selection over all slots          [K5]
 //   evict     victims' rows written back to the host table, maps cleared           [K6]
 //   free      first n_miss free slots ascending (ordered compaction)              [K7]
@@ -41,9 +43,12 @@
 
 namespace ce {
 
-constexpr int kChunkRows = 32768;     // rows covered by one 256-thread block of the bitmap scan (uint4/thread)
+constexpr int kChunkShift = 15;
+constexpr int kChunkRows = 1 << kChunkShift;   // rows covered by one 256-thread workgroup of the bitmap scan (uint4/thread)
+constexpr int kHotChunksMax = 8;               // k_mark's LDS window covers at most this many chunks (8192 words)
 constexpr int kSlotsPerBlock = 1024;  // slots covered by one block of the slot-space scans (4/thread)
 constexpr int kRing = 1024;           // pinned host ring of per-call stats
+constexpr int kHistWords = 8 * 256;   // one 256-bin histogram per radix pass
 constexpr int32_t kEpochNever = -(1 << 30);
 constexpr int64_t kHistoryKeep = 1 << 16;   // per-call records kept on the host side
 
@@ -58,6 +63,12 @@ struct Ctl {                 // device control block (one per manager)
   long long n_eligible;      // slots that may be evicted in this call (resident and not protected)
   int victims_count;
   int status;
+  int lost;                  // per call: the admission worker reported that the rows did not arrive (see k_admit_maps)
+  int pad_;
+  long long cold_unique;     // per call: unique / missing rows outside k_mark's LDS window (counted by k_mark's owners)
+  long long cold_miss;
+  unsigned long long hot_pub[kHotChunksMax];   // per call: {tag, unique, missing} of the window's chunks, published by
+                                               // the first workgroups of k_emit for all the others
 };
 
 struct WbMail {              // pinned host mailbox: how many rows a worker job moves (written by the device)
@@ -66,7 +77,7 @@ struct WbMail {              // pinned host mailbox: how many rows a worker job 
 };
 
 struct Layout {              // byte offsets inside the caller-provided workspace
-  size_t ctl, bitmap, blk_unique, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
+  size_t ctl, bitmap, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
       stage_idx, stage, stage_idx2, stage2, in_stage, total;
   int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
@@ -83,12 +94,11 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   size_t o = 0;
   L.ctl = o;        o = al(o + sizeof(Ctl));
   L.bitmap = o;     o = al(o + (size_t)L.bitmap_words * 4);
-  L.blk_unique = o; o = al(o + (size_t)(L.n_chunks + 1) * 4);
   L.blk_miss = o;   o = al(o + (size_t)(L.n_chunks + 1) * 4);
   L.miss_list = o;  o = al(o + (size_t)L.list_cap * 4);
   L.slot_epoch = o; o = al(o + (size_t)C * 4);
   L.keys = o;       o = al(o + (size_t)C * 8);
-  L.hist = o;       o = al(o + 8 * 256 * 4);      // one 256-bin histogram per radix pass
+  L.hist = o;       o = al(o + (size_t)kHistWords * 4);
   L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
   L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
   L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
@@ -142,89 +152,31 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // ----------------------------------------------------------------------------- kernels
 
-__global__ void k_begin(Ctl* ctl) {
-  ctl->n_unique = 0;
-  ctl->n_miss = 0;
-  ctl->k_evict = 0;
-  ctl->miss_lookups = 0;
-  ctl->sel_prefix = 0;
-  ctl->sel_krem = 0;
-  ctl->n_eligible = 0;
-  ctl->victims_count = 0;
-  ctl->status = CE_OK;
-}
-
-// Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window
-// sends >100k ids at a 3-row table, so per-id atomicOr on one word would serialise.  Each wave first
-// merges its 64 ids: ballots over the word-index bits give every lane the mask of lanes aiming at the
-// same word, 32 more ballots OR their bits together, and only the lowest lane of each mask issues
-// ONE atomicOr -- and only if a plain load did not already show the bits set.
-template <bool MERGE>
-__global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
-                                               const int32_t* __restrict__ idx_map,
-                                               const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                               int hot_words, uint32_t* bitmap, Ctl* ctl) {
-  // Under DATASET ordering the frequency re-rank packs the hot rows of ALL tables into the lowest
-  // row indices, i.e. into a handful of bitmap words every wave wants.  Those words are staged in an
-  // LDS window per workgroup and flushed once, so a hot word sees one global atomic per workgroup.
-  extern __shared__ uint32_t hot[];
-  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int cold = 0;
-  // wave-uniform trip count: every lane of a wave runs the same number of iterations
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
-    const int64_t i = i0 + lane;
-    bool valid = i < n;
-    int32_t row = 0;
-    if (valid) {
-      const int64_t id = ids[i];
-      if ((unsigned long long)id >= (unsigned long long)N) {
-        ctl->status = CE_ERR_RANGE;
-        valid = false;
-      } else {
-        row = idx_map ? idx_map[id] : (int32_t)id;
-      }
-    }
-    const int word = row >> 5;
-    const int bidx = row & 31;
-    bool need = false;
-    if (valid) {
-      cold += (inverted[row] < 0);
-      if (word < hot_words) atomicOr(&hot[word], 1u << bidx);
-      else need = ((*(volatile uint32_t*)(bitmap + word)) & (1u << bidx)) == 0;
-    }
-    if (!MERGE) {
-      if (need) atomicOr(bitmap + word, 1u << bidx);
-    } else if (__any(need)) {
-      unsigned long long pm = __ballot(need);
-      if (!need) pm = 0;
-      for (int b = 0; b < word_bits; ++b) {
-        const unsigned long long m = __ballot((word >> b) & 1);
-        pm &= ((word >> b) & 1) ? m : ~m;
-      }
-      uint32_t orbits = 0;
-#pragma unroll
-      for (int b = 0; b < 32; ++b) {
-        const unsigned long long m = __ballot(need && bidx == b);
-        if (m & pm) orbits |= (1u << b);
-      }
-      if (need && (__ffsll((long long)pm) - 1) == lane) atomicOr(bitmap + word, orbits);
-    }
+// per-call reset: the control block's call fields, the chunk miss counts k_mark adds to, the radix histograms
+__global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* blk_miss, int n_chunks, uint32_t* hist) {
+  if (threadIdx.x == 0) {
+    ctl->n_unique = 0;
+    ctl->n_miss = 0;
+    ctl->k_evict = 0;
+    ctl->miss_lookups = 0;
+    ctl->sel_prefix = 0;
+    ctl->sel_krem = 0;
+    ctl->n_eligible = 0;
+    ctl->victims_count = 0;
+    ctl->status = CE_OK;
+    ctl->cold_unique = 0;
+    ctl->cold_miss = 0;
+    ctl->lost = 0;
   }
-  cold = wave_sum(cold);
-  if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
-  __syncthreads();
-  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) {
-    const uint32_t v = hot[w];
-    if (v && ((*(volatile uint32_t*)(bitmap + w)) & v) != v) atomicOr(bitmap + w, v);
-  }
+  if (blk_miss)
+    for (int i = threadIdx.x; i < n_chunks; i += blockDim.x) blk_miss[i] = 0;
+  if (hist)
+    for (int i = threadIdx.x; i < kHistWords; i += blockDim.x) hist[i] = 0;
 }
 
 // Bits of one bitmap word (32 consecutive rows from row0) whose row is not resident.  The frequency ranking packs
 // the hot rows into the lowest words, where nearly every bit is set: a lookup per set bit would be up to 128
-// dependent-latency loads in one thread (the tail of k_count / k_emit), so dense words fetch the 32 map entries
+// dependent-latency loads in one thread (the tail of k_emit), so dense words fetch the 32 map entries
 // as eight 16-byte loads instead.
 __device__ __forceinline__ bool dense_word(uint32_t bits, int64_t row0, int64_t N) {
   return __popc(bits) >= 6 && row0 + 32 <= N;
@@ -250,72 +202,221 @@ __device__ __forceinline__ uint32_t miss_mask(const int32_t* __restrict__ invert
   return mm;
 }
 
-// one uint4 (128 rows) per thread
-__global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4,
-                                               const int32_t* __restrict__ inverted, int64_t N,
-                                               int32_t* blk_unique, int32_t* blk_miss) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// ids -> rows -> bitmap, and most of the counting that used to take a second pass over the bitmap (k_count) and a
+// scan kernel (k_plan): outside the LDS window (below) the thread whose atomicOr turns a row's bit on OWNS the row
+// for this call -- it adds 1 to the call's unique count and, if the row is not resident, to the miss count and to
+// the miss count of the row's 32768-row chunk (blk_miss: what k_emit's workgroups sum to find their place in the
+// miss list).
+//
+// Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window sends >100k ids at
+// a 3-row table, so a global atomicOr per id would serialise.  Rows in frequency order (idx_map present): the
+// lowest `hot_words` words live in an LDS window per workgroup and are flushed once at the end with fire-and-forget
+// atomics (who set a bit first cannot be told there: 256 workgroups flush the same words at the same time, and
+// returning atomics for it cost 80 us -- the window's rows are counted by the first workgroups of k_emit instead);
+// a cold id first LOOKS at its word and only issues the atomic when its bit is still clear.  Rows in id order
+// (MERGE): hot rows are scattered, so the lanes of a wave that aim at the same word are merged with ballots first
+// and one lane issues the atomicOr for all of them.
+//
+// U ids per thread are in flight: the kernel is a chain of three dependent random accesses per id (idx_map ->
+// inverted / bitmap word -> atomic), and one id per thread left it latency bound (74 us for 3.4 M ids).
+// rows_out: the row of every id (-1 = bad id), as int64 in the caller's slots buffer -- k_slots turns it into the
+// slot in place, so idx_map is gathered once per id per call.
+template <bool MERGE, int U>
+__global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
+                                              const int32_t* __restrict__ idx_map,
+                                              const int32_t* __restrict__ inverted, int64_t N, int word_bits,
+                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out,
+                                              int32_t* blk_miss) {
+  extern __shared__ uint32_t hot[];
+  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  int cold = 0, uniq = 0, miss = 0;
+  // wave-uniform trip count: a wave owns U * 64 consecutive ids per iteration
+  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * U; i0 < n; i0 += stride) {
+    int32_t row[U], inv[U];
+    uint32_t cur[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 64 + lane;
+      valid[u] = i < n;
+      row[u] = 0;
+      if (valid[u]) {
+        const int64_t id = ids[i];
+        if ((unsigned long long)id >= (unsigned long long)N) {
+          ctl->status = CE_ERR_RANGE;
+          valid[u] = false;
+          rows_out[i] = -1;
+        } else {
+          row[u] = idx_map ? idx_map[id] : (int32_t)id;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 64 + lane;
+      inv[u] = 0;
+      cur[u] = ~0u;
+      if (valid[u]) {
+        rows_out[i] = row[u];
+        inv[u] = inverted[row[u]];
+        const int word = row[u] >> 5;
+        if (word < hot_words) atomicOr(&hot[word], 1u << (row[u] & 31));
+        else cur[u] = *(volatile uint32_t*)(bitmap + word);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int word = row[u] >> 5;
+      const int bidx = row[u] & 31;
+      const bool need = valid[u] && (cur[u] & (1u << bidx)) == 0;
+      if (valid[u]) cold += inv[u] < 0;
+      bool owner = false;
+      if (!MERGE) {
+        if (need) owner = (atomicOr(bitmap + word, 1u << bidx) & (1u << bidx)) == 0;
+      } else if (__any(need)) {
+        // lanes aiming at the same word: one atomicOr by the lowest of them; the lowest lane of every (word, bit)
+        // pair speaks for that row
+        unsigned long long pm = __ballot(need);
+        if (!need) pm = 0;
+        for (int b = 0; b < word_bits; ++b) {
+          const unsigned long long m = __ballot((word >> b) & 1);
+          pm &= ((word >> b) & 1) ? m : ~m;
+        }
+        uint32_t orbits = 0;
+        unsigned long long same = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+          const unsigned long long m = __ballot(need && bidx == b);
+          if (m & pm) orbits |= (1u << b);
+          if (bidx == b) same = m & pm;
+        }
+        const int leader = need ? __ffsll((long long)pm) - 1 : 0;
+        uint32_t old = 0;
+        if (need && leader == lane) old = atomicOr(bitmap + word, orbits);
+        old = __shfl(old, leader);
+        owner = need && (__ffsll((long long)same) - 1) == lane && (old & (1u << bidx)) == 0;
+      }
+      if (owner) {
+        ++uniq;
+        if (inv[u] < 0) {
+          ++miss;
+          atomicAdd(&blk_miss[row[u] >> kChunkShift], 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) {
+    const uint32_t v = hot[w];
+    if (v && ((*(volatile uint32_t*)(bitmap + w)) & v) != v) atomicOr(bitmap + w, v);
+  }
+  // one atomic per counter and workgroup
+  __shared__ int red[3][16];
+  cold = wave_sum(cold);
+  uniq = wave_sum(uniq);
+  miss = wave_sum(miss);
+  if (lane == 0) {
+    red[0][threadIdx.x >> 6] = cold;
+    red[1][threadIdx.x >> 6] = uniq;
+    red[2][threadIdx.x >> 6] = miss;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    long long t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[threadIdx.x][k];
+    unsigned long long* dst = (unsigned long long*)(threadIdx.x == 0 ? &ctl->miss_lookups
+                                                                     : threadIdx.x == 1 ? &ctl->cold_unique : &ctl->cold_miss);
+    if (t) atomicAdd(dst, (unsigned long long)t);
+  }
+}
+
+// Ordered emission of the missing rows + the plan.  One workgroup of 256 threads per 32768-row chunk of the bitmap
+// (one uint4 = 128 rows per thread).  Its place in the miss list is the number of missing rows in the chunks before
+// it; every workgroup adds those up itself (blk_miss: at most ~20 KB out of L2), so there is neither a scan kernel
+// nor a chain between workgroups.  Two sources: rows outside k_mark's LDS window were counted by their owners in
+// k_mark (cold_unique / cold_miss / blk_miss); the window's own rows (the first n_hot chunks, at most 8) are counted
+// here by the workgroups that scan them anyway, which publish {tag, unique, missing} as ONE 8-byte word each
+// (write-through store, polled with device-scope loads: no fence).  Those workgroups have the lowest indices, so
+// they are resident before any workgroup that waits for them.  With the totals every workgroup derives the same
+// verdict; workgroup 0 also records it: capacity check, k = misses - free slots, the stats record, the mailbox.
+__global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
+                                              const int32_t* __restrict__ blk_miss, int n_hot, int64_t hot_rows,
+                                              int32_t* miss_list, int32_t* slot_epoch, int32_t epoch, Ctl* ctl,
+                                              int64_t C, int64_t n_ids, ce_call_stats_t* ring_slot, WbMail* mail_in,
+                                              long long job, long long in_cap, int32_t* miss_host) {
+  __shared__ int wtot[4], wtot2[4];
+  __shared__ int hot_u_s, hot_m_s[kHotChunksMax];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int bid = (int)blockIdx.x;
+  const int st_in = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t v = (int64_t)bid * 256 + threadIdx.x;
   const uint4 q = bitmap4[v];
   const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-  int u = 0, m = 0;
+  // missing rows of this thread's 128 rows (all of them: the list position needs hot and cold alike), and -- in the
+  // window's chunks -- the window's share of unique / missing rows
+  uint32_t mm[4];
+  int m = 0, hu = 0, hm = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    mm[k] = 0;
     if (!wds[k]) continue;
-    u += __popc(wds[k]);
-    m += __popc(miss_mask(inverted, v * 128 + k * 32, wds[k], N));
-  }
-  __shared__ int su[4], sm[4];
-  u = wave_sum(u);
-  m = wave_sum(m);
-  if ((threadIdx.x & 63) == 0) {
-    su[threadIdx.x >> 6] = u;
-    sm[threadIdx.x >> 6] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    blk_unique[blockIdx.x] = su[0] + su[1] + su[2] + su[3];
-    blk_miss[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-  }
-}
-
-// single block of 1024 threads: in-place exclusive scan of `a` (and `b` if non-null) over n entries,
-// totals returned through shared memory to thread 0 which runs the planner lambda-equivalent below.
-__device__ void scan_inplace_1024(int32_t* a, int64_t n, long long* total_out) {
-  __shared__ long long carry;
-  __shared__ int wtot[16];
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t base = 0; base < n; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const int v = (i < n) ? a[i] : 0;
-    int inc = wave_incl_scan(v, lane);
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
-    int pre = 0, tot = 0;
-    for (int k = 0; k < 16; ++k) {
-      if (k < w) pre += wtot[k];
-      tot += wtot[k];
+    const int64_t row0 = v * 128 + k * 32;
+    mm[k] = miss_mask(inverted, row0, wds[k], N);
+    m += __popc(mm[k]);
+    if (row0 < hot_rows) {      // a word is hot or cold as a whole (hot_rows is a multiple of 32)
+      hu += __popc(wds[k]);
+      hm += __popc(mm[k]);
     }
-    const long long c = carry;
-    // block offsets fit int32: they index lists bounded by cuda_row_num < 2^31
-    if (i < n) a[i] = (int32_t)(c + pre + inc - v);
+  }
+  const unsigned long long tag = (unsigned long long)(epoch & 0xffffff);
+  if (bid < n_hot) {
+    const int su = wave_sum(hu), sm = wave_sum(hm);
+    if (lane == 0) { wtot[wv] = su; wtot2[wv] = sm; }
     __syncthreads();
-    if (threadIdx.x == 0) carry = c + tot;
+    if (threadIdx.x == 0) {
+      const unsigned long long u = (unsigned)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
+      const unsigned long long mh = (unsigned)(wtot2[0] + wtot2[1] + wtot2[2] + wtot2[3]);
+      __hip_atomic_store(&ctl->hot_pub[bid], (tag << 40) | (u << 20) | mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
   }
-  *total_out = carry;
-}
-
-__global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk_miss, int64_t n_chunks,
-                                               int64_t C, int64_t n_ids, Ctl* ctl,
-                                               ce_call_stats_t* ring_slot, WbMail* mail_in, long long job,
-                                               long long in_cap) {
-  long long tu, tm;
-  scan_inplace_1024(blk_unique, n_chunks, &tu);
-  scan_inplace_1024(blk_miss, n_chunks, &tm);
-  if (threadIdx.x == 0) {
-    int status = ctl->status;
+  // earlier chunks' missing rows outside the window, while the window's workgroups finish
+  int part = 0;
+  for (int i = threadIdx.x; i < bid; i += 256) part += blk_miss[i];
+  if (threadIdx.x < n_hot) {
+    unsigned long long w;
+    do {
+      w = __hip_atomic_load(&ctl->hot_pub[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((w >> 40) != tag) __builtin_amdgcn_s_sleep(2);
+    } while ((w >> 40) != tag);
+    hot_m_s[threadIdx.x] = (int)(w & 0xfffff);
+    const int u = (int)((w >> 20) & 0xfffff);
+    int us = u;
+#pragma unroll
+    for (int d = 1; d < kHotChunksMax; d <<= 1) {
+      const int o = __shfl_up(us, d);
+      if ((int)threadIdx.x >= d) us += o;
+    }
+    if ((int)threadIdx.x == n_hot - 1) hot_u_s = us;
+  }
+  part = wave_sum(part);
+  if (lane == 0) wtot[wv] = part;
+  __syncthreads();
+  int base = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  long long hot_u = 0, hot_m = 0;
+  if (n_hot > 0) hot_u = hot_u_s;
+  for (int c = 0; c < n_hot; ++c) {
+    hot_m += hot_m_s[c];
+    if (c < bid) base += hot_m_s[c];
+  }
+  const long long tu = ctl->cold_unique + hot_u, tm = ctl->cold_miss + hot_m;
+  // workgroup 0 may already have turned CE_OK into CE_ERR_CAPACITY below: the verdict is the same either way
+  const bool ok = st_in == CE_OK && tu <= C;
+  if (bid == 0 && threadIdx.x == 0) {
+    int status = st_in;
     if (status == CE_OK && tu > C) status = CE_ERR_CAPACITY;
     long long k = 0;
     if (status == CE_OK) {
@@ -323,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
       if (k < 0) k = 0;
       ctl->n_free = ctl->n_free + k - tm;
     }
-    ctl->status = status;
+    __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ctl->n_unique = tu;
     ctl->n_miss = tm;
     ctl->k_evict = k;
@@ -336,32 +437,21 @@ __global__ __launch_bounds__(1024) void k_plan(int32_t* blk_unique, int32_t* blk
     ring_slot->n_free_after = ctl->n_free;
     ring_slot->status = status;
     ring_slot->kind = CE_CALL_PREPARE;
-    if (mail_in) {      // rows the admission worker gathers for this call (read after the event behind k_emit)
-      const long long m = (status == CE_OK) ? tm : 0;
-      mail_in->count = m < in_cap ? m : in_cap;
+    if (mail_in) {      // rows the admission worker gathers for this call (read after the event behind this kernel)
+      const long long mrows = (status == CE_OK) ? tm : 0;
+      mail_in->count = mrows < in_cap ? mrows : in_cap;
       mail_in->job = job;
     }
     // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
     // record (k_victims can turn it into a capacity failure): k_admit_maps
   }
-}
-
-__global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
-                                              const int32_t* __restrict__ blk_miss_off, int32_t* miss_list,
-                                              int32_t* slot_epoch, int32_t epoch, const Ctl* ctl,
-                                              int32_t* miss_host, int in_cap) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint4 q = bitmap4[v];
-  const bool ok = (ctl->status == CE_OK);
-  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-  int m = 0;
-  if (ok) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (wds[k]) m += __popc(miss_mask(inverted, v * 128 + k * 32, wds[k], N));
-  }
-  int tot;
-  int pos = block_excl_scan_256(m, &tot) + blk_miss_off[blockIdx.x];
+  if (!ok) m = 0;
+  const int inc = wave_incl_scan(m, lane);
+  __syncthreads();
+  if (lane == 63) wtot2[wv] = inc;
+  __syncthreads();
+  int pos = base + inc - m;
+  for (int k = 0; k < wv; ++k) pos += wtot2[k];
   if (ok) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -388,16 +478,16 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
         }
         continue;
       }
+      // sparse word: the missing rows are known (mm), the resident ones need their slot for the stamp
       while (bits) {
         const int b = __ffs(bits) - 1;
         bits &= bits - 1;
         const int64_t row = row0 + b;
-        const int32_t slot = inverted[row];
-        if (slot < 0) {
+        if ((mm[k] >> b) & 1) {
           if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)row;
           miss_list[pos++] = (int32_t)row;
         } else {
-          slot_epoch[slot] = epoch;        // evict_backlist membership [A.3-3]
+          slot_epoch[inverted[row]] = epoch;        // evict_backlist membership [A.3-3]
         }
       }
     }
@@ -411,9 +501,7 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
                                               const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
                                               int32_t epoch, int32_t depth, int slot_bits, int lfu,
                                               unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
-  if (ctl->k_evict == 0) return;
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) hist[i] = 0;      // all passes' histograms
+  if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const unsigned long long fmax = (1ull << (63 - slot_bits)) - 1;
   int elig = 0;
@@ -538,6 +626,14 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
                                                  int top_pass, ce_call_stats_t* ring_slot) {
   __shared__ unsigned long long prefix_s;
   __shared__ int fail_s, go_s;
+  // this workgroup's 1024 slots (4 per thread, strided by 256): in flight while wave 0 works out the threshold
+  const int64_t s0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  unsigned long long key[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t sl = s0 + u * 256;
+    key[u] = sl < C ? keys[sl] : ~0ull;
+  }
   if (threadIdx.x < 64) {
     const SelState st = select_chain(hist, top_pass, -1, ctl, threadIdx.x);
     if (threadIdx.x == 0) {
@@ -565,22 +661,23 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
     return;
   }
   const unsigned long long T = prefix_s;   // k-th smallest key; keys are unique
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int lane = threadIdx.x & 63;
-  // wave-uniform trip count; the victims of a wave reserve their places with ONE returning atomic (a returning
-  // device atomic is a ~2 us round trip and a CU keeps only a few dozen in flight)
-  for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); s0 < C; s0 += stride) {
-    const int64_t s = s0 + lane;
-    const unsigned long long key = s < C ? keys[s] : ~0ull;
-    const bool hit = key <= T && key != ~0ull;
-    const unsigned long long m = __ballot(hit);
-    if (m == 0) continue;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ctl->victims_count, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (hit) {
-      const int pos = base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-      if (pos < cap) victims[pos] = (int32_t)s;
+  // the workgroup's victims are counted with a block scan and reserve their places with ONE returning atomic (a returning device atomic is a ~2 us round trip; one
+  // per wave with a victim in it was ~24 k of them on one address per call)
+  __shared__ int base_s;
+  int hits = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hits += (key[u] <= T && key[u] != ~0ull);
+  int tot;
+  int pos = block_excl_scan_256(hits, &tot);
+  if (tot == 0) return;                     // block-uniform
+  if (threadIdx.x == 0) base_s = atomicAdd(&ctl->victims_count, tot);
+  __syncthreads();
+  pos += base_s;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (key[u] <= T && key[u] != ~0ull) {
+      if (pos < cap) victims[pos] = (int32_t)(s0 + u * 256);
+      ++pos;
     }
   }
 }
@@ -635,6 +732,8 @@ __global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ vict
 // host table from the staging buffer while its other workgroups read the missed rows -- PCIe carries both
 // directions at once.  Victims beyond the staging capacity (rare) are
 // written back directly by k_evict (`first` = staging capacity).
+constexpr int kStageRowsInFlight = 4;   // rows in flight per lane group of the HBM-to-HBM row movers
+
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
                                                      const int32_t* __restrict__ cached_idx_map,
@@ -650,10 +749,29 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < k; i += gstride) {
-    const int32_t slot = victims[i];
-    if (gl == 0) stage_rows_idx[i] = cached_idx_map[slot];
-    copy_row(cache + (int64_t)slot * rowlen, stage + i * rowlen, rowlen, gl, G);
+  constexpr int R = kStageRowsInFlight;
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < k; i += gstride * R) {
+    if (rowlen <= G) {          // R rows in flight per lane group (one row at a time left this kernel latency bound)
+      int32_t slot[R];
+      VT v[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) slot[t] = i + t < k ? victims[i + t] : -1;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        if (slot[t] < 0) continue;
+        if (gl == 0) stage_rows_idx[i + t] = cached_idx_map[slot[t]];
+        if (gl < rowlen) v[t] = cache[(int64_t)slot[t] * rowlen + gl];
+      }
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if (slot[t] >= 0 && gl < rowlen) stage[(i + t) * rowlen + gl] = v[t];
+    } else {
+      for (int t = 0; t < R && i + t < k; ++t) {
+        const int32_t slot = victims[i + t];
+        if (gl == 0) stage_rows_idx[i + t] = cached_idx_map[slot];
+        copy_row(cache + (int64_t)slot * rowlen, stage + (i + t) * rowlen, rowlen, gl, G);
+      }
+    }
   }
 }
 
@@ -718,18 +836,20 @@ __global__ __launch_bounds__(256) void k_free_count(const int32_t* __restrict__ 
   if (threadIdx.x == 0) blk_free[blockIdx.x] = sf[0] + sf[1] + sf[2] + sf[3];
 }
 
-__global__ __launch_bounds__(1024) void k_free_scan(int32_t* blk_free, int64_t nb, const Ctl* ctl) {
-  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
-  long long tot;
-  scan_inplace_1024(blk_free, nb, &tot);
-}
-
+// every workgroup adds up the free counts of the blocks before its own (a few KB out of L2): no scan kernel
 __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ cached_idx_map, int64_t C,
-                                                   const int32_t* __restrict__ blk_free_off, int32_t* free_list,
+                                                   const int32_t* __restrict__ blk_free, int32_t* free_list,
                                                    const Ctl* ctl) {
   if (ctl->status != CE_OK || ctl->n_miss == 0) return;
   const long long need = ctl->n_miss;
-  if (blk_free_off[blockIdx.x] >= need) return;   // block-uniform
+  __shared__ int wsum4[4];
+  int part = 0;                       // free slots before this block: < cuda_row_num < 2^31
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += blk_free[i];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) wsum4[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const long long before = (long long)wsum4[0] + wsum4[1] + wsum4[2] + wsum4[3];
+  if (before >= need) return;   // block-uniform
   const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   int fl[4];
   int f = 0;
@@ -739,7 +859,7 @@ __global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ c
     f += fl[t];
   }
   int tot;
-  long long pos = block_excl_scan_256(f, &tot) + blk_free_off[blockIdx.x];
+  long long pos = block_excl_scan_256(f, &tot) + before;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (fl[t]) {
@@ -843,15 +963,38 @@ __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows
 template <typename VT>
 __global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restrict__ slots, const long long* n_ptr,
                                                          long long cap, const VT* __restrict__ in_stage, VT* cache,
-                                                         int rowlen, int g_log2, const Ctl* ctl) {
+                                                         int rowlen, int g_log2, Ctl* ctl,
+                                                         const unsigned long long* fail_word, long long job) {
   if (ctl->status != CE_OK) return;
+  // The admission worker flags a job whose rows did not arrive (a HIP call of its own failed or timed out) in a word
+  // of pinned host memory.  ONE thread fetches it over PCIe and leaves the verdict in the control block for
+  // k_admit_maps, which then marks nothing resident; whatever this kernel copies into the (free) slots meanwhile is
+  // never looked at.
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    ctl->lost = *(volatile const unsigned long long*)fail_word == (unsigned long long)job;
   long long n = *n_ptr;
   if (n > cap) n = cap;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride)
-    copy_row(in_stage + i * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
+  constexpr int R = kStageRowsInFlight;
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
+    if (rowlen <= G) {
+      int32_t slot[R];
+      VT v[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        slot[t] = i + t < n ? slots[i + t] : -1;
+        if (slot[t] >= 0 && gl < rowlen) v[t] = in_stage[(i + t) * rowlen + gl];
+      }
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if (slot[t] >= 0 && gl < rowlen) cache[(int64_t)slot[t] * rowlen + gl] = v[t];
+    } else {
+      for (int t = 0; t < R && i + t < n; ++t)
+        copy_row(in_stage + (i + t) * rowlen, cache + (int64_t)slots[i + t] * rowlen, rowlen, gl, G);
+    }
+  }
 }
 
 // Full-duplex swap in ONE launch: the first wb_blocks workgroups stream the staged victims to the host table,
@@ -875,14 +1018,26 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ slots, const long long* n_ptr,
                                                     long long n_imm, int32_t* cached_idx_map, int32_t* inverted,
                                                     int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
-                                                    int32_t epoch, const Ctl* ctl, ce_call_stats_t* ring_slot,
-                                                    long long seq) {
+                                                    int32_t epoch, Ctl* ctl, ce_call_stats_t* ring_slot,
+                                                    long long seq, const unsigned long long* fail_word,
+                                                    long long job) {
+  // worker transport: the admission worker reports a job it could not complete (failed / timed-out HIP call): the
+  // rows never arrived, so nothing may be marked resident.
+  const bool lost = fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
   // last kernel of prepare_ids that can change the call's record: publish it (a slot whose seq matches is complete)
   if (ring_slot && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lost && ctl->status == CE_OK) {
+      // the victims are gone (written back) but their slots stay free: undo the plan's share of the free count
+      ctl->n_free = ctl->n_free + ctl->n_miss;
+      ring_slot->status = CE_ERR_HIP;
+      ring_slot->n_free_after = ctl->n_free;
+      __hip_atomic_store(&ctl->status, CE_ERR_HIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __threadfence_system();
     *(volatile long long*)&ring_slot->seq = seq;
   }
-  if (ctl && ctl->status != CE_OK) return;
+  if (lost) return;
+  if (ctl && __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CE_OK) return;
   const long long n = n_ptr ? *n_ptr : n_imm;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -895,22 +1050,40 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, int64_t n,
-                                               const int32_t* __restrict__ idx_map,
-                                               const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out,
-                                               const Ctl* ctl) {
-  // a failed call (overflow / bad id) changes nothing but still hands back well-defined slots (-1):
-  // callers that skip the status check (strict=False) then gather zero rows instead of garbage
-  const bool failed = ctl && ctl->status != CE_OK;
+// _id_to_cached_cuda_id alone (ce_cache_lookup_slots): inverted[idx_map[id]]
+__global__ __launch_bounds__(256) void k_lookup(const int64_t* __restrict__ ids, int64_t n,
+                                                const int32_t* __restrict__ idx_map,
+                                                const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int64_t id = ids[i];
     int64_t slot = -1;
-    if (!failed && (unsigned long long)id < (unsigned long long)N) {
-      const int32_t row = idx_map ? idx_map[id] : (int32_t)id;
-      slot = inverted[row];
-    }
+    if ((unsigned long long)id < (unsigned long long)N) slot = inverted[idx_map ? idx_map[id] : (int32_t)id];
     slots_out[i] = slot;
+  }
+}
+
+// Last kernel of prepare_ids: k_mark left the ROW of every id in `slots` (-1 = bad id); turn it into the slot in
+// place -- one random 4-byte gather per id instead of the two dependent ones of inverted[idx_map[id]] [A.6].
+// A failed call (overflow / bad id) changes nothing but still hands back well-defined slots (-1): callers that skip
+// the status check (strict=False) then gather zero rows instead of garbage.
+__global__ __launch_bounds__(256) void k_slots(int64_t* slots, int64_t n, const int32_t* __restrict__ inverted,
+                                               const Ctl* ctl) {
+  const bool failed = ctl->status != CE_OK;
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; i0 < n; i0 += stride) {
+    int64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      row[u] = i < n ? slots[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i < n) slots[i] = (failed || row[u] < 0) ? -1 : (int64_t)inverted[row[u]];
+    }
   }
 }
 
@@ -919,13 +1092,11 @@ __global__ __launch_bounds__(256) void k_slots(const int64_t* __restrict__ ids, 
 // WAVE the hottest counter alone still took 53 k of them (k_slots 381 us per window).  Here every workgroup owns
 // a contiguous range of lookups and counts them in an LDS hash table (slot -> count, open addressing); only the
 // table's entries go to memory, so a counter sees at most one atomic per workgroup.  Four lookups per thread are
-// in flight to cover the two dependent random loads (idx_map, inverted).
+// in flight to cover the random load.
 constexpr int kSlotsHashBits = 13;
 constexpr int kSlotsHash = 1 << kSlotsHashBits;
-__global__ __launch_bounds__(1024) void k_slots_lfu(const int64_t* __restrict__ ids, int64_t n,
-                                                    const int32_t* __restrict__ idx_map,
-                                                    const int32_t* __restrict__ inverted, int64_t N,
-                                                    int64_t* slots_out, int64_t* freq, const Ctl* ctl) {
+__global__ __launch_bounds__(1024) void k_slots_lfu(int64_t* slots, int64_t n, const int32_t* __restrict__ inverted,
+                                                    int64_t* freq, const Ctl* ctl) {
   __shared__ int hkey[kSlotsHash];
   __shared__ int hcnt[kSlotsHash];
   for (int i = threadIdx.x; i < kSlotsHash; i += blockDim.x) { hkey[i] = -1; hcnt[i] = 0; }
@@ -936,23 +1107,19 @@ __global__ __launch_bounds__(1024) void k_slots_lfu(const int64_t* __restrict__ 
   const int64_t hi = lo + per_block < n ? lo + per_block : n;
   constexpr int U = 4;
   for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)blockDim.x * U) {
-    int32_t row[U];
+    int64_t row[U];
     int slot[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = i0 + (int64_t)u * blockDim.x;
-      row[u] = -1;
-      if (i < hi && !failed) {
-        const int64_t id = ids[i];
-        if ((unsigned long long)id < (unsigned long long)N) row[u] = idx_map ? idx_map[id] : (int32_t)id;
-      }
+      row[u] = (i < hi && !failed) ? slots[i] : -1;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) slot[u] = row[u] >= 0 ? inverted[row[u]] : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = i0 + (int64_t)u * blockDim.x;
-      if (i < hi) slots_out[i] = slot[u];
+      if (i < hi) slots[i] = slot[u];
       if (slot[u] < 0) continue;
       unsigned h = ((unsigned)slot[u] * 2654435761u) >> (32 - kSlotsHashBits);
       bool done = false;
@@ -1190,12 +1357,22 @@ void row_copy_fence();
 
 // waiting for a copy stream without burning a CPU of a quota-limited host and without any packet in a hardware
 // queue: poll hipStreamQuery with short sleeps
-static inline hipError_t stream_wait_polite(hipStream_t st) {
+// seconds a swap worker (or the launch thread waiting for one) gives a copy / a job before it declares it lost:
+// the parked cache-op stream is then released with the job flagged as failed instead of hanging the GPU for ever
+// (what would happen if a copy stream ever shared a hardware queue with the parked stream -- ensure_writeback)
+static double worker_timeout_s() {
+  static const double v = [] { const char* e = getenv("CE_WORKER_TIMEOUT_S"); const double t = e ? atof(e) : 30.0; return t > 0 ? t : 30.0; }();
+  return v;
+}
+static inline hipError_t stream_wait_polite(hipStream_t st, double timeout_s = worker_timeout_s()) {
+  const auto t0 = std::chrono::steady_clock::now();
   for (int spins = 0;; ++spins) {
     const hipError_t e = hipStreamQuery(st);
     if (e != hipErrorNotReady) return e;
     if (spins < 50) std::this_thread::yield();
     else std::this_thread::sleep_for(std::chrono::microseconds(15));
+    if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      return hipErrorNotReady;      // timed out: the caller reports it
   }
 }
 
@@ -1258,7 +1435,9 @@ struct SwapEngine {
   int rowlen = 0, g_log2 = 0, vec = 0, admit_blocks = 0, admit_threads = 1024;      // admit_blocks 0 = by job size
   int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
   int32_t* miss_host_dev = nullptr;
-  unsigned long long* sig = nullptr;               // pinned + mapped: the value the cache-op stream waits for
+  unsigned long long* sig = nullptr;               // pinned + mapped: [0] the value the cache-op stream waits for,
+                                                   // [1] the last admission job that was LOST (k_admit_maps reads it)
+  unsigned long long* sig_dev = nullptr;
   // ---- mailboxes (pinned + mapped): [0], [1] = out staging buffers, [2] = in
   WbMail* mail = nullptr;
   WbMail* mail_dev = nullptr;
@@ -1333,7 +1512,7 @@ struct SwapEngine {
             row_copy_fence();
           });
         }
-        if (e != hipSuccess) fail("D2H copy", e);
+        if (e != hipSuccess) fail(e == hipErrorNotReady ? "write-back copy timed out (CE_WORKER_TIMEOUT_S)" : "D2H copy", e);
       }
       const auto t2 = std::chrono::steady_clock::now();
       CE_TRACE("out job %lld: done", job);
@@ -1452,7 +1631,10 @@ struct SwapEngine {
       // parked wait would never execute (seen as a hang of the full test suite).
       CE_TRACE("in job %lld: rows gathered, copies enqueued", job);
       e = stream_wait_polite(in_stream);
-      if (e != hipSuccess) fail("waiting for the H2D copies", e);
+      if (e != hipSuccess) fail(e == hipErrorNotReady ? "admission timed out (CE_WORKER_TIMEOUT_S)" : "waiting for the H2D copies", e);
+      // a job that did not bring its rows in is flagged BEFORE the stream is released: k_unpack_admitted /
+      // k_admit_maps then admit nothing and the call's record says CE_ERR_HIP
+      if (n > 0 && failed()) __atomic_store_n(sig + 1, (unsigned long long)job, __ATOMIC_RELEASE);
       __atomic_store_n(sig, (unsigned long long)job, __ATOMIC_RELEASE);
       CE_TRACE("in job %lld: released the stream (%s)", job, hipGetErrorString(e));
       const auto t2 = std::chrono::steady_clock::now();
@@ -1469,6 +1651,8 @@ struct SwapEngine {
     }
   }
   long long out_issued_at[8] = {0};      // write-back jobs that must have landed before in-job j gathers
+  hipStream_t tested_stream = nullptr;   // cache-op stream the self-test below has passed on
+  bool tested = false;
 
   int check() {
     std::lock_guard<std::mutex> g(m);
@@ -1478,19 +1662,41 @@ struct SwapEngine {
     }
     return CE_OK;
   }
-  int wait_out(long long upto) {       // blocks until write-back job `upto` has reached the host table
+  // The launch thread never waits for a worker without a deadline: a worker stuck in the runtime (GPU hang, a copy
+  // that never starts) would otherwise block the caller for ever with the cache-op stream parked.  On a timeout the
+  // pending admission is flagged lost and the stream released from here.
+  int give_up(const char* what) {
     {
-      std::unique_lock<std::mutex> g(m);
-      cv_done.wait(g, [&] { return out_done >= upto || out_done >= out_issued; });
+      std::lock_guard<std::mutex> g(m);
+      if (!err) {
+        err = CE_ERR_HIP;
+        snprintf(errmsg, sizeof errmsg, "swap worker: %s did not finish within %.0f s (CE_WORKER_TIMEOUT_S)", what,
+                 2 * worker_timeout_s());
+      }
+    }
+    if (sig) {
+      __atomic_store_n(sig + 1, (unsigned long long)in_issued, __ATOMIC_RELEASE);
+      __atomic_store_n(sig, ~0ull >> 1, __ATOMIC_RELEASE);
     }
     return check();
   }
-  int wait_in(long long upto) {
+  int wait_out(long long upto) {       // blocks until write-back job `upto` has reached the host table
+    bool ok;
     {
       std::unique_lock<std::mutex> g(m);
-      cv_done.wait(g, [&] { return in_done >= upto || in_done >= in_issued; });
+      ok = cv_done.wait_for(g, std::chrono::duration<double>(2 * worker_timeout_s()),
+                            [&] { return out_done >= upto || out_done >= out_issued; });
     }
-    return check();
+    return ok ? check() : give_up("a write-back job");
+  }
+  int wait_in(long long upto) {
+    bool ok;
+    {
+      std::unique_lock<std::mutex> g(m);
+      ok = cv_done.wait_for(g, std::chrono::duration<double>(2 * worker_timeout_s()),
+                            [&] { return in_done >= upto || in_done >= in_issued; });
+    }
+    return ok ? check() : give_up("an admission job");
   }
   void push_out() {
     {
@@ -1545,7 +1751,7 @@ struct ce_cache {
   char* ws;
   ce::Ctl* ctl;
   uint32_t* bitmap;
-  int32_t *blk_unique, *blk_miss, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
+  int32_t *blk_miss, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
   unsigned long long* keys;
   uint32_t* hist;
   ce_call_stats_t* ring;       // pinned host
@@ -1653,7 +1859,6 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->ws = (char*)cfg->workspace;
   h->ctl = (Ctl*)(h->ws + L.ctl);
   h->bitmap = (uint32_t*)(h->ws + L.bitmap);
-  h->blk_unique = (int32_t*)(h->ws + L.blk_unique);
   h->blk_miss = (int32_t*)(h->ws + L.blk_miss);
   h->miss_list = (int32_t*)(h->ws + L.miss_list);
   h->slot_epoch = (int32_t*)(h->ws + L.slot_epoch);
@@ -1877,6 +2082,8 @@ static int ensure_writeback(ce_cache* h) {
     if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
     memset(p, 0, 64);
     w->sig = (unsigned long long*)p;
+    if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
+    w->sig_dev = (unsigned long long*)pd;
     if (hipHostMalloc(&p, idx_bytes, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
     w->miss_host = (int32_t*)p;
     if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
@@ -1954,6 +2161,11 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
   if (freq_vals) h->freq_bound_known = false;      // until ce_cache_set_freq_bound states their maximum
   int rc = before_call(h);
   if (rc) return rc;
+  if (h->wb) {
+    // rows are read zero-copy from the host table: every eviction queued on the worker transport lands first
+    rc = h->wb->wait_out(h->wb->out_issued);
+    if (rc) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
   const ce_cache_config_t& c = h->cfg;
   h->seq += 1;
@@ -1972,8 +2184,8 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
   // preloaded rows must not look "protected" to the first prepare_ids: stamp them as never used
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(n, 256)), dim3(256), 0, s, rows, (const int32_t*)nullptr,
                      (const long long*)nullptr, (long long)n, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, freq_vals, h->slot_epoch, kEpochNever, (const Ctl*)nullptr,
-                     (ce_call_stats_t*)nullptr, 0ll);
+                     c.freq_cnter, freq_vals, h->slot_epoch, kEpochNever, (Ctl*)nullptr,
+                     (ce_call_stats_t*)nullptr, 0ll, (const unsigned long long*)nullptr, 0ll);
   (void)epoch;
   hipLaunchKernelGGL(k_preload_end, dim3(1), dim3(1), 0, s, (long long)n, h->ctl, h->ring_dev + (h->seq % kRing),
                      h->seq);
@@ -2028,6 +2240,46 @@ static int staged_swap(ce_cache* h, hipStream_t s) {
   return CE_OK;
 }
 
+// The worker transport parks the cache-op stream in hipStreamWaitValue64 and relies on its copy streams making
+// progress meanwhile, i.e. on their not sharing a hardware queue with the parked stream (HIP multiplexes streams onto
+// GPU_MAX_HW_QUEUES queues; the copy streams sit in the highest-priority pool for that reason -- ensure_writeback).
+// That is a property of the runtime and of the process's environment, not of this library, so it is TESTED the
+// first time a stream is used: park the stream on a private word, run one small copy on each copy stream, release.
+// Copies that do not finish while the stream is parked mean the transport would hang here: CE_ERR_UNSUPPORTED, and
+// prepare_ids falls back to the zero-copy kernels with a message.  Costs one stream synchronisation, once.
+static int worker_selftest(ce_cache* h, hipStream_t s) {
+  SwapEngine* w = h->wb;
+  if (w->tested && w->tested_stream == s) return CE_OK;
+  CE_HIP_CHECK(hipStreamSynchronize(s));
+  unsigned long long* word = w->sig + 2;
+  __atomic_store_n(word, 0ull, __ATOMIC_RELEASE);
+  CE_HIP_CHECK(hipStreamWaitValue64(s, word, 1, hipStreamWaitValueGte, ~0ull));
+  std::this_thread::sleep_for(std::chrono::milliseconds(2));          // let the wait reach the queue
+  hipError_t e = hipMemcpyAsync(w->rows_host[0], w->stage_dev[0], 64, hipMemcpyDeviceToHost, w->out_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(w->rows_host[1], w->stage_dev[1], 64, hipMemcpyDeviceToHost, w->out_stream2);
+  if (e == hipSuccess) e = hipMemcpyAsync(w->in_stage_dev, w->rows_host[0], 64, hipMemcpyHostToDevice, w->in_stream);
+  bool done = e == hipSuccess;
+  if (done) {
+    for (hipStream_t st : {w->out_stream, w->out_stream2, w->in_stream})
+      if (stream_wait_polite(st, 0.25) != hipSuccess) done = false;
+  }
+  __atomic_store_n(word, 1ull, __ATOMIC_RELEASE);                      // always release
+  CE_HIP_CHECK(hipStreamSynchronize(s));
+  if (e != hipSuccess) {
+    set_error("worker transport self-test: %s", hipGetErrorString(e));
+    return CE_ERR_HIP;
+  }
+  if (!done) {
+    set_error("worker transport self-test failed: copies on the library's copy streams do not run while the cache-op "
+              "stream is parked in hipStreamWaitValue64 (they share a hardware queue with it: GPU_MAX_HW_QUEUES = %s)",
+              getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
+    return CE_ERR_UNSUPPORTED;
+  }
+  w->tested = true;
+  w->tested_stream = s;
+  return CE_OK;
+}
+
 extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                     ce_stream_t stream) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
@@ -2063,12 +2315,25 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
 
   // worker transport: job numbers / staging buffer of this call; the launch thread only waits here when a worker
   // is two calls behind (its buffers and events are about to be reused)
-  const bool worker = c.transport == CE_TRANSPORT_WORKER;
+  bool worker = c.transport == CE_TRANSPORT_WORKER;
   long long out_job = 0, in_job = 0;
   int wbuf = 0;
   if (worker) {
     rc = ensure_writeback(h);
     if (rc) return rc;
+    rc = worker_selftest(h, s);
+    if (rc == CE_ERR_UNSUPPORTED) {
+      // loud, once: the environment cannot run this transport; the zero-copy swap kernel needs nothing from it
+      fprintf(stderr, "[libce_hip] %s -- falling back to the zero-copy transport\n", ce_last_error());
+      rc = h->wb->wait_out(h->wb->out_issued);
+      if (rc) return rc;
+      h->cfg.transport = CE_TRANSPORT_ZEROCOPY;
+      worker = false;
+    } else if (rc) {
+      return rc;
+    }
+  }
+  if (worker) {
     {
       // the stream about to be parked must not live in the copy streams' hardware-queue pool (see ensure_writeback)
       int prio = 0, prio_lo = 0, prio_hi = 0;
@@ -2091,38 +2356,47 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   if (prof) prof->collect(pslot);
 #define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   CE_PHASE();
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, h->blk_miss, (int)L.n_chunks, h->hist);
+  int hot_words_used = 0;
   {
     // Two shapes (rocprofv3, 3.4 M ids per call).  Rows in frequency order (idx_map present): the hot rows sit in
-    // the lowest bitmap words, the LDS window absorbs them, and cold lookups issue their atomicOr directly --
-    // 512 threads x 256 workgroups, 8192-word window: 75 us.  Rows in id order (no idx_map): hot rows are
-    // scattered, every wave would hammer their words (421 us), so equal words of a wave are merged first (135 us).
+    // the lowest bitmap words, the LDS window absorbs them, and cold lookups issue their atomicOr directly.
+    // Rows in id order (no idx_map): hot rows are scattered, every wave would hammer their words (421 us), so
+    // equal words of a wave are merged first.
     const bool ranked = c.idx_map != nullptr;
     static const int mark_hot_env = [] { const char* e = getenv("CE_MARK_HOT"); return e ? atoi(e) : 0; }();
     static const int mark_blocks = [] { const char* e = getenv("CE_MARK_BLOCKS"); return e ? atoi(e) : 256; }();
     static const int mark_threads_env = [] { const char* e = getenv("CE_MARK_THREADS"); return e ? atoi(e) : 0; }();
     static const int mark_merge_env = [] { const char* e = getenv("CE_MARK_MERGE"); return e ? atoi(e) : -1; }();
+    static const int mark_u = [] { const char* e = getenv("CE_MARK_U"); return e ? atoi(e) : 4; }();
     const int mark_hot = mark_hot_env > 0 ? mark_hot_env : (ranked ? 8192 : 2048);
-    const int mark_threads = mark_threads_env > 0 ? mark_threads_env : (ranked ? 512 : 256);
+    const int mark_threads = mark_threads_env > 0 ? std::min(mark_threads_env, 1024) : (ranked ? 512 : 256);
     const bool mark_merge = mark_merge_env >= 0 ? mark_merge_env != 0 : !ranked;
-    const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
+    // whole chunks (k_emit counts the window's rows chunk by chunk), at most kHotChunksMax of them
+    int hot_words = (int)std::min<int64_t>(L.bitmap_words, std::min(mark_hot, kHotChunksMax * (kChunkRows / 32)));
+    if (hot_words < L.bitmap_words) hot_words = hot_words / (kChunkRows / 32) * (kChunkRows / 32);
     if (n > 0) {
-      const dim3 mg(std::min(grid_for(n, 1024), mark_blocks)), mb(mark_threads);
-      if (mark_merge)
-        hipLaunchKernelGGL((k_mark<true>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,
-                           h->word_bits, hot_words, h->bitmap, h->ctl);
-      else
-        hipLaunchKernelGGL((k_mark<false>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,
-                           h->word_bits, hot_words, h->bitmap, h->ctl);
+      hot_words_used = hot_words;
+      const int u = (n >= 65536 && mark_u != 1) ? (mark_u == 2 ? 2 : (mark_u == 8 ? 8 : 4)) : 1;
+      const dim3 mg(std::min(grid_for(n, mark_threads * u), mark_blocks)), mb(mark_threads);
+#define CE_MARK(M, U_)                                                                                          \
+  hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
+                     h->word_bits, hot_words, h->bitmap, h->ctl, slots_out, h->blk_miss)
+      if (mark_merge) { if (u >= 4) CE_MARK(true, 4); else if (u == 2) CE_MARK(true, 2); else CE_MARK(true, 1); }
+      else { if (u == 8) CE_MARK(false, 8); else if (u == 4) CE_MARK(false, 4); else if (u == 2) CE_MARK(false, 2); else CE_MARK(false, 1); }
+#undef CE_MARK
     }
   }
-  hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
-                     c.inverted_cached_idx, N, h->blk_unique, h->blk_miss);
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, h->blk_unique, h->blk_miss, L.n_chunks, C, n, h->ctl, slot,
-                     worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows);
-  hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap,
-                     c.inverted_cached_idx, N, h->blk_miss, h->miss_list, h->slot_epoch, epoch, h->ctl,
-                     worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr, (int)L.stage_rows);
+  {
+    // chunks of k_mark's LDS window (counted by the workgroups of k_emit that scan them); the window is sized in
+    // whole chunks or covers the whole (small) bitmap
+    const int64_t hot_rows = (int64_t)hot_words_used * 32;
+    const int n_hot = (int)std::min<int64_t>(cdiv(hot_rows, kChunkRows), L.n_chunks);
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
+                       h->blk_miss, n_hot, hot_rows, h->miss_list, h->slot_epoch, epoch, h->ctl, C, n, slot,
+                       worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
+                       worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr);
+  }
   if (worker) {
     // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) while this
     // stream selects and stages the victims; it first lets every earlier write-back land
@@ -2156,7 +2430,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   // it from their histograms in its prologue -- select_chain -- so there is no pick kernel at all)
   for (int pass = top_pass; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
-  hipLaunchKernelGGL(k_victims, dim3(cgrid), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
+  hipLaunchKernelGGL(k_victims, dim3((unsigned)cdiv(C, 1024)), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
                      (const uint32_t*)h->hist, top_pass, slot);
   CE_PHASE();
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
@@ -2201,7 +2475,6 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   } else {
     hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                        h->blk_free, h->ctl);
-    hipLaunchKernelGGL(k_free_scan, dim3(1), dim3(1024), 0, s, h->blk_free, L.n_slot_blocks, h->ctl);
     hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                        h->blk_free, h->free_list, h->ctl);
   }
@@ -2215,7 +2488,8 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     if (h->vec) {
       hipLaunchKernelGGL((k_unpack_admitted<f32x4>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const f32x4*)h->in_stage, (f32x4*)c.cache_weight,
-                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+                         h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
+                         in_job);
       if (L.list_cap > L.stage_rows)      // more misses than the staging holds (rare): the rest is read zero-copy
         hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
                            (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
@@ -2223,7 +2497,8 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     } else {
       hipLaunchKernelGGL((k_unpack_admitted<float>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const float*)h->in_stage, (float*)c.cache_weight,
-                         h->rowlen, h->g_log2, (const Ctl*)h->ctl);
+                         h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
+                         in_job);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
                            (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
@@ -2287,16 +2562,16 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
                      (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, (const Ctl*)h->ctl, slot,
-                     (long long)h->seq);
+                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, h->ctl, slot,
+                     (long long)h->seq, worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, in_job);
   CE_PHASE();
   if (n > 0 && lfu) {
     // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
-    hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, ids, n, c.idx_map,
-                       c.inverted_cached_idx, N, slots_out, c.freq_cnter, (const Ctl*)h->ctl);
+    hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, slots_out, n,
+                       c.inverted_cached_idx, c.freq_cnter, (const Ctl*)h->ctl);
   } else if (n > 0) {
-    hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, c.idx_map, c.inverted_cached_idx,
-                       N, slots_out, (const Ctl*)h->ctl);
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, slots_out, n, c.inverted_cached_idx,
+                       (const Ctl*)h->ctl);
   }
   CE_PHASE();
 #undef CE_PHASE
@@ -2365,8 +2640,8 @@ extern "C" int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t 
   if (n == 0) return CE_OK;
   CE_REQUIRE(ids && slots_out && n > 0, CE_ERR_INVALID, "null ids/slots");
   const ce_cache_config_t& c = h->cfg;
-  hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, c.idx_map,
-                     c.inverted_cached_idx, c.num_embeddings, slots_out, (const Ctl*)nullptr);
+  hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, c.idx_map,
+                     c.inverted_cached_idx, c.num_embeddings, slots_out);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }
@@ -2386,7 +2661,7 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
   }
   h->seq += 1;
   const int gpb = 256 >> h->g_log2;
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, h->ctl);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, (int32_t*)nullptr, 0, (uint32_t*)nullptr);
   if (h->vec)
     hipLaunchKernelGGL((k_flush_rows<f32x4>), dim3(grid_for(C, gpb)), dim3(256), 0, s, c.cached_idx_map, C,
                        (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, h->rowlen, h->g_log2);
@@ -2429,6 +2704,8 @@ extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
   if (transport == CE_TRANSPORT_WORKER) return ensure_writeback(h);
   return CE_OK;
 }
+
+extern "C" int32_t ce_cache_get_transport(ce_cache_t* h) { return h ? h->cfg.transport : -1; }
 
 extern "C" int ce_cache_set_profiling(ce_cache_t* h, int32_t on) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");

@@ -49,11 +49,15 @@ def _prep(indices: torch.Tensor, offsets: Optional[torch.Tensor], include_last_o
 class SrcKeys(NamedTuple):
     """Keys of one batch from presort_window(..., offsets=...): row << 32 | grad_out row (ce_bag_presort_window_src).
     They already hold the bag layout they were built for, so embedding_bag(presorted=SrcKeys) checks that the call
-    uses the same one; mode must be 'sum' without per-sample weights."""
+    uses the same one; mode must be 'sum' without per-sample weights.
+    ranges (presort_window(..., ids=...)): the [min, max] id of every 16384-lookup segment of the batch, int64
+    [segments, 2] -- with them the fused-SGD backward updates rows that one lane group owns entirely (flagged in the
+    keys) by plain read-modify-write instead of atomics, after checking that no id can occur in two segments."""
     keys: torch.Tensor
     num_bags: int
     include_last_offset: bool
     hook_features: int
+    ranges: Optional[torch.Tensor] = None
 
 
 class _BagFn(torch.autograd.Function):
@@ -99,6 +103,11 @@ class _BagFn(torch.autograd.Function):
                                                          ptr(offsets), off64, num_bags, int(include_last), ptr(psw),
                                                          mode, hook_features, ptr(grad_out), float(fused.lr),
                                                          ptr(ws), ws.numel(), stream_ptr()))
+                elif isinstance(ctx.presorted, SrcKeys) and ctx.presorted.ranges is not None:
+                    check(lib.ce_bag_backward_sgd_presorted_src_excl(ptr(weight), weight.shape[0], dim, nnz,
+                                                                     ptr(grad_out), float(fused.lr),
+                                                                     ptr(ctx.presorted.keys),
+                                                                     ptr(ctx.presorted.ranges), stream_ptr()))
                 elif isinstance(ctx.presorted, SrcKeys):
                     check(lib.ce_bag_backward_sgd_presorted_src(ptr(weight), weight.shape[0], dim, nnz,
                                                                 ptr(grad_out), float(fused.lr),
@@ -160,7 +169,9 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   mode: str = "mean", sparse: bool = False, per_sample_weights: Optional[torch.Tensor] = None,
                   include_last_offset: bool = False, padding_idx: Optional[int] = None, *,
                   hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None,
-                  presorted: Union[torch.Tensor, SrcKeys, None] = None) -> torch.Tensor:
+                  presorted: Union[torch.Tensor, SrcKeys, None] = None, masked_indices: bool = False) -> torch.Tensor:
+    # masked_indices: the caller already replaced ignored lookups (padding) by -1 -- the kernels skip them; the
+    # sparse=True backward then parks their (zero) gradient rows at index 0 so the COO tensor stays valid
     if max_norm is not None:
         raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
     if mode not in _MODES:
@@ -208,15 +219,23 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
         if (presorted.num_bags, bool(presorted.include_last_offset), int(presorted.hook_features)) != \
                 (num_bags, bool(include_last_offset), int(hook_features)):
             raise ValueError("source-row keys were built for another bag layout "
-                             f"{tuple(presorted[1:])} than this call's {(num_bags, include_last_offset, hook_features)}")
+                             f"{tuple(presorted[1:4])} than this call's {(num_bags, include_last_offset, hook_features)}")
         k = presorted.keys
+        if presorted.ranges is not None:
+            r = presorted.ranges
+            assert r.is_cuda and r.dtype == torch.int64 and r.is_contiguous() and \
+                r.numel() == 2 * (k.numel() // 16384), "ranges must come from presort_window(..., ids=...)"
         assert k.is_cuda and k.dtype == torch.int64 and k.is_contiguous() and \
             k.numel() == lib.ce_bag_presort_len(indices.numel()), "keys must come from presort_window"
     elif presorted is not None:
         assert presorted.is_cuda and presorted.dtype == torch.int64 and presorted.is_contiguous() and \
             presorted.numel() == lib.ce_bag_presort_len(indices.numel()), "presorted must come from presort_slots"
+    if masked_indices and mode != "sum":
+        raise NotImplementedError("masked (padding) lookups are implemented for mode='sum' only (mean would need "
+                                  "the per-bag count of non-padding entries)")
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
-                        int(hook_features), bool(sparse), fused_sgd, presorted, bwd_scale, padding_idx is not None)
+                        int(hook_features), bool(sparse), fused_sgd, presorted, bwd_scale,
+                        padding_idx is not None or bool(masked_indices))
 
 
 def presort_len(n: int) -> int:
@@ -238,7 +257,8 @@ def presort_slots(slots: torch.Tensor, num_rows: int, out: Optional[torch.Tensor
 
 def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.Tensor] = None, *,
                    offsets: Optional[torch.Tensor] = None, include_last_offset: bool = False,
-                   hook_features: int = 0):
+                   hook_features: int = 0, ids: Optional[torch.Tensor] = None,
+                   ranges_out: Optional[torch.Tensor] = None):
     """Grouped keys for the P equal-sized batches of a prefetch window in one launch (ce_bag_presort_window).
     slots: [P, n] int64 (the cache op's output) -> keys [P, presort_len(n)]; row b is what
     embedding_bag(presorted=...) takes for batch b.
@@ -247,7 +267,11 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
     (ce_bag_presort_window_src) for mode='sum' without per-sample weights -- returns a list of P SrcKeys instead,
     which the backward streams over without touching offsets or indices again.  The keys ARE the batch as far as the
     backward is concerned: pass them only to the embedding_bag call that uses the same slots and the same offsets
-    (the bag layout is checked, the contents cannot be)."""
+    (the bag layout is checked, the contents cannot be).
+
+    ids given as well ([P, n] int64: the ids `slots` was computed from, position by position): the keys also mark the
+    rows a single lane group of the backward owns, and every SrcKeys carries the id range of its segments
+    (ce_bag_presort_window_src_excl) -- the fused-SGD backward then updates those rows without atomics."""
     assert slots.dim() == 2 and slots.is_contiguous() and slots.dtype == torch.int64
     P, n = slots.shape
     klen = presort_len(n)
@@ -263,9 +287,21 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
     num_bags = per - 1 if include_last_offset else per
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
-    check(lib.ce_bag_presort_window_src(ptr(slots), n, P, int(num_rows), ptr(offsets),
-                                        int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
-                                        num_bags, int(include_last_offset), int(hook_features), ptr(keys_out),
-                                        stream_ptr()))
     kv = keys_out.view(P, klen)
-    return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features)) for b in range(P)]
+    if ids is None:
+        check(lib.ce_bag_presort_window_src(ptr(slots), n, P, int(num_rows), ptr(offsets),
+                                            int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
+                                            num_bags, int(include_last_offset), int(hook_features), ptr(keys_out),
+                                            stream_ptr()))
+        return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features)) for b in range(P)]
+    assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == P * n
+    segs = klen // 16384
+    if ranges_out is None:
+        ranges_out = torch.empty(P, segs, 2, dtype=torch.int64, device=slots.device)
+    assert ranges_out.is_contiguous() and ranges_out.dtype == torch.int64 and ranges_out.numel() == P * segs * 2
+    check(lib.ce_bag_presort_window_src_excl(ptr(slots), n, P, int(num_rows), ptr(offsets),
+                                             int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
+                                             num_bags, int(include_last_offset), int(hook_features), ptr(ids),
+                                             ptr(keys_out), ptr(ranges_out), stream_ptr()))
+    rv = ranges_out.view(P, segs, 2)
+    return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features), rv[b]) for b in range(P)]

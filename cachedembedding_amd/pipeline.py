@@ -100,11 +100,15 @@ class PrefetchWindow:
         if self.presort:
             C = self.mgr.cuda_row_num
             lay = self._layout or {}
+            # source-row keys: the ids go along, so rows owned by one lane group get plain read-modify-writes
+            def with_ids(t, rows):
+                return dict(ids=t.reshape(-1).long().contiguous().view(rows, -1)) if lay else {}
             if len(set(counts)) == 1:                           # equal batches: one launch for the window
-                keys = presort_window(slots.view(len(counts), counts[0]), C, **lay)
+                keys = presort_window(slots.view(len(counts), counts[0]), C, **lay, **with_ids(cat, len(counts)))
                 self._keys_tmp = [keys[i] for i in range(len(counts))]
             else:
-                self._keys_tmp = [presort_window(p_.view(1, -1), C, **lay)[0] for p_ in parts]
+                self._keys_tmp = [presort_window(p_.view(1, -1), C, **lay, **with_ids(v_, 1))[0]
+                                  for p_, v_ in zip(parts, values)]
         return parts
 
     def prepare(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
@@ -142,6 +146,8 @@ class PrefetchWindow:
             s.record_stream(cur)
         for k in keys or []:
             (k.keys if isinstance(k, SrcKeys) else k).record_stream(cur)
+            if isinstance(k, SrcKeys) and k.ranges is not None:
+                k.ranges.record_stream(cur)
         self.keys = keys
         return slots
 
@@ -177,6 +183,13 @@ class GraphedWindow:
         self._klen = presort_len(self.n)
         self._keys = [torch.full((self.P, self._klen), -1, dtype=torch.int64, device=dev) for _ in range(2)] \
             if self.presort else None
+        # id range of every 16384-lookup segment (source-row keys only): min > max = "no ids seen" until a presort ran
+        self._ranges = None
+        if self.presort and self._layout is not None:
+            self._ranges = [torch.empty(self.P, self._klen // 16384, 2, dtype=torch.int64, device=dev) for _ in range(2)]
+            for r in self._ranges:
+                r[..., 0] = torch.iinfo(torch.int64).min       # "everything": never disjoint -> atomics
+                r[..., 1] = torch.iinfo(torch.int64).max
         self._side = make_side_stream(dev, cache_cus) if overlap else None
         self._events = [None, None]
         self._step_fn = step_fn
@@ -192,8 +205,10 @@ class GraphedWindow:
             self.mgr.prepare_ids(wcat, out=self._bufs[0])
             self._bufs[1].copy_(self._bufs[0])
             if self.presort:
-                self._presort(0)
+                self._presort(0, wcat)
                 self._keys[1].copy_(self._keys[0])
+                if self._ranges is not None:
+                    self._ranges[1].copy_(self._ranges[0])
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -222,15 +237,20 @@ class GraphedWindow:
             lay = self._layout
             per = lay["offsets"].shape[-1]
             step_fn(self._bufs[buf][i], i, SrcKeys(self._keys[buf][i], per - 1 if lay["include_last_offset"] else per,
-                                                   lay["include_last_offset"], lay["hook_features"]))
+                                                   lay["include_last_offset"], lay["hook_features"],
+                                                   self._ranges[buf][i]))
         elif self.presort:
             step_fn(self._bufs[buf][i], i, self._keys[buf][i])
         else:
             step_fn(self._bufs[buf][i], i)
 
-    def _presort(self, buf: int) -> None:
+    def _presort(self, buf: int, ids: torch.Tensor) -> None:
         # one launch for the window: every batch's 16384-lookup segments grouped by row
-        presort_window(self._bufs[buf], self.mgr.cuda_row_num, keys_out=self._keys[buf], **(self._layout or {}))
+        if self._ranges is not None:
+            presort_window(self._bufs[buf], self.mgr.cuda_row_num, keys_out=self._keys[buf], **self._layout,
+                           ids=ids.reshape(self.P, self.n), ranges_out=self._ranges[buf])
+        else:
+            presort_window(self._bufs[buf], self.mgr.cuda_row_num, keys_out=self._keys[buf], **(self._layout or {}))
 
     @torch.no_grad()
     def submit(self, values: Sequence[torch.Tensor], buf: int) -> None:
@@ -245,7 +265,7 @@ class GraphedWindow:
             with torch.cuda.stream(self._side), phase("prefetch cache"):
                 self.mgr.prepare_ids(cat, out=self._bufs[buf])
                 if self.presort:
-                    self._presort(buf)
+                    self._presort(buf, cat)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             cat.record_stream(self._side)
@@ -253,7 +273,7 @@ class GraphedWindow:
         else:
             self.mgr.prepare_ids(cat, out=self._bufs[buf])
             if self.presort:
-                self._presort(buf)
+                self._presort(buf, cat)
             self._events[buf] = None
 
     def run_steps(self, buf: int, first: int, last: int) -> None:

@@ -147,7 +147,10 @@ class SyntheticLoader:
                 self.batches.append(dict(
                     dense=torch.rand(batch_size, num_dense, generator=cpu_gen).pin_memory(),
                     sparse=[vals[i].contiguous().pin_memory(), offsets, batch_size],
-                    labels=torch.randint(0, 2, (batch_size,), generator=cpu_gen).float().pin_memory()))
+                    labels=None))
+                # a learnable target: a function of one dense feature and of the parity of the first sparse id
+                b = self.batches[-1]
+                b["labels"] = ((b["dense"][:, 0] + (vals[i][:batch_size] % 2).float() * 0.5) > 0.75).float().pin_memory()
             done += k
 
     def __len__(self):
@@ -193,8 +196,8 @@ def _window(data_iter, P, device, args, rank, world):
     return (dense, sparse, labels) if dense else None
 
 
-def train(model, optimizer, loader, args, device, rank, world):
-    """recsys/dlrm_main.py:206-297.  Default: the reference's window block (one synchronous prepare_ids per
+def train(model, optimizer, loader, args, device, rank, world, record=None):
+    """recsys/dlrm_main.py:206-297.  record: a list that receives every step's loss (as device scalars: no sync).  Default: the reference's window block (one synchronous prepare_ids per
     prefetch_num batches).  --overlap_cache_op: the cache op of window k+1 runs on a side stream while window k trains
     (pipeline.PrefetchWindow, protect_depth 1, swap traffic through the worker transport when the window is large)."""
     criterion = nn.BCEWithLogitsLoss()
@@ -228,6 +231,8 @@ def train(model, optimizer, loader, args, device, rank, world):
                 loss.backward()
             with phase("optimization"):
                 optimizer.step()
+            if record is not None:
+                record.append(loss.detach())
             done += 1
         elapsed += time.time() - start
         start = time.time()
@@ -285,11 +290,16 @@ def main(argv=None):
     elif args.limit_train_batches:
         loader = _Limit(loader, args.limit_train_batches)
     for epoch in range(args.epochs):
-        done, elapsed, loss = train(model, optimizer, loader, args, device, rank, world)
+        rec = []
+        done, elapsed, loss = train(model, optimizer, loader, args, device, rank, world, record=rec)
         if rank == 0:
             lookups = done * args.batch_size * len(sizes)
+            q = max(1, len(rec) // 4)
+            head = float(torch.stack(rec[:q]).mean()) if rec else float("nan")
+            tail = float(torch.stack(rec[-q:]).mean()) if rec else float("nan")
             print(f"epoch {epoch}: {done} iterations, average throughput: {done / max(elapsed, 1e-9):.2f} it/s, "
-                  f"{lookups / max(elapsed, 1e-9) / 1e6:.1f} M lookups/s, last loss {loss:.4f}")
+                  f"{lookups / max(elapsed, 1e-9) / 1e6:.1f} M lookups/s, last loss {loss:.4f}, "
+                  f"mean loss first quarter {head:.4f} last quarter {tail:.4f}")
             embed.print_comm_stats_()
     if world > 1:
         dist.destroy_process_group()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CE_API_VERSION 2
+#define CE_API_VERSION 3
 
 /* status codes */
 #define CE_OK 0
@@ -60,9 +60,12 @@ extern "C" {
                                     and the cache-op stream waits for them in a hipStreamWaitValue64 while it selects
                                     and stages the victims.  prepare_ids stays
                                     one asynchronous call, but returns before the host table has the evicted rows
-                                    (ce_cache_writeback_wait / ce_cache_flush make it current).  Not capture-safe;
-                                    the stream must not share a hardware queue with work it must not delay
-                                    (GPU_MAX_HW_QUEUES). */
+                                    (ce_cache_writeback_wait / ce_cache_flush make it current).  Not capture-safe.
+                                    The library does not trust the environment for this: the first call on a stream
+                                    self-tests that its copy streams run while that stream is parked (falls back to
+                                    ZEROCOPY with a message otherwise), every wait on a worker has a deadline
+                                    (CE_WORKER_TIMEOUT_S, default 30 s), and an admission that fails or times out
+                                    releases the stream with the call flagged CE_ERR_HIP and nothing admitted. */
 
 typedef void* ce_stream_t; /* hipStream_t */
 typedef struct ce_cache ce_cache_t;
@@ -187,6 +190,26 @@ int ce_bag_backward_sgd_presorted_src(float* weight, int64_t num_rows, int32_t d
                                       const float* grad_out, float lr, const uint64_t* src_keys, ce_stream_t stream);
 int ce_bag_backward_dense_presorted_src(float* grad_weight, int64_t num_rows, int32_t dim, int64_t nnz,
                                         const float* grad_out, const uint64_t* src_keys, ce_stream_t stream);
+/* Owner-exclusive form (API 3).  The fp32 atomics of the fused update retire at ~1 float per clock and L2 channel
+ * (24 us for a Criteo-shaped batch, not overlapped with the gather), so rows that ONE lane group of the backward
+ * can own are taken off them.  ce_bag_presort_window_src_excl additionally (a) sorts every bucket of <= 32 keys by
+ * row and sets bit 31 of the low word of a key that heads a run holding ALL lookups of its row in its segment and
+ * lying inside one 16-position block, and (b) records per segment the [min, max] of `ids` (device int64
+ * [n_batches * nnz_per_batch], the ids `indices` was computed from, position by position; NULL = unknown) in
+ * seg_id_ranges (device int64 [n_batches * segments_per_batch][2]).  ce_bag_backward_sgd_presorted_src_excl takes a
+ * batch's keys and its ranges (seg_id_ranges + b * 2 * segments_per_batch): when the ranges are pairwise disjoint no
+ * id -- hence no row -- occurs in two segments, a flagged run is the only writer of its row in the launch, and it is
+ * applied as old row + folded gradients with one plain store; otherwise (or for unflagged runs) the atomics are
+ * used, so the result never depends on the flags being usable.  Keys with flags are also valid input for the plain
+ * *_presorted_src entry points (they ignore the flag). */
+int ce_bag_presort_window_src_excl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                                   const void* offsets, int32_t offsets_are_i64, int64_t offsets_batch_stride,
+                                   int64_t num_bags, int32_t include_last_offset, int64_t hook_features,
+                                   const int64_t* ids, uint64_t* keys_out, int64_t* seg_id_ranges,
+                                   ce_stream_t stream);
+int ce_bag_backward_sgd_presorted_src_excl(float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                           const float* grad_out, float lr, const uint64_t* src_keys,
+                                           const int64_t* seg_id_ranges, ce_stream_t stream);
 
 /* Deterministic variant of the fused update: lookups are stably radix-sorted by target row
  * (workspace from ce_bag_backward_sgd_sorted_workspace), each row's gradients are summed in
@@ -296,6 +319,11 @@ int ce_cache_flush(ce_cache_t* h, ce_stream_t stream);
 int ce_cache_set_protect_depth(ce_cache_t* h, int32_t depth);
 /* Switching away from / to CE_TRANSPORT_WORKER blocks until the queued write-backs have landed. */
 int ce_cache_set_transport(ce_cache_t* h, int32_t transport);
+/* The transport in force (CE_TRANSPORT_*).  It can differ from what was set: the first prepare_ids on a stream runs a
+ * self-test of the worker transport (do the library's copy streams make progress while that stream is parked in
+ * hipStreamWaitValue64? -- a property of the process's HIP runtime settings, e.g. GPU_MAX_HW_QUEUES) and falls back
+ * to CE_TRANSPORT_ZEROCOPY, with a message on stderr, when they do not. */
+int32_t ce_cache_get_transport(ce_cache_t* h);
 /* Phase timers of prepare_ids (upstream's per-phase Timer / record_function ranges, recsys/dlrm_main.py:258,294):
  * when on, every call brackets its phases with hipEvents on its own stream (no host sync); ce_cache_phase_times
  * blocks until the calls issued so far have finished and returns the accumulated milliseconds per phase

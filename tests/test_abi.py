@@ -22,7 +22,7 @@ def test_build_and_load():
     g.build()
     import cachedembedding_amd as ce
     assert ce.LIB_PATH.exists()
-    assert ce._lib.lib.ce_version() == 2
+    assert ce._lib.lib.ce_version() == 3
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -173,13 +173,16 @@ def test_full_size_batch_properties():
     assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))
 
 
-@pytest.mark.parametrize("presort", [False, True])
+@pytest.mark.parametrize("presort", [False, True, "src", "src_excl", "src_excl_shared"])
 def test_full_size_step_vs_torch_cpu(presort):
     """BASELINE config [2] step at its real shape -- cache of C = 1,779,442 rows x 128, B = 16384, F = 26, long-tail
     slots -- against the calls the reference makes on the CPU (F.embedding_bag, then SGD on the summed gradient):
-    forward bit-exact (L = 1 is a copy), updated cache rows within 1e-5 relative (fp32 sums in another order)."""
+    forward bit-exact (L = 1 is a copy), updated cache rows within 1e-5 relative (fp32 sums in another order).
+    presort: False = the backward sorts 1024-lookup tiles itself, True = segment-grouped keys + tile backward,
+    "src" = source-row keys + the STREAMING backward -- the kernel pair bench.py times (k_bag_presort_seg<true> ->
+    k_bag_bwd_stream)."""
     ce = _ce()
-    from cachedembedding_amd.functional import presort_slots
+    from cachedembedding_amd.functional import presort_slots, presort_window
     B, F, D, C, lr = 16384, 26, 128, 1_779_442, 0.5
     g = torch.Generator().manual_seed(11)
     w = torch.randn(C, D, generator=g)
@@ -187,7 +190,27 @@ def test_full_size_step_vs_torch_cpu(presort):
     off = torch.arange(B * F + 1, dtype=torch.int32)
     go = torch.randn(B, F, D, generator=g) * 0.01
     wc = w.cuda().requires_grad_(True)
-    keys = presort_slots(idx.cuda(), C) if presort else None
+    if presort in ("src_excl", "src_excl_shared"):
+        # owner-exclusive rows (k_bag_presort_seg<true, true> -> k_bag_bwd_stream<EXCL>): ids == slots here.
+        # "src_excl": every feature draws from its own slice of the table, so the segments' id ranges are disjoint and
+        # the plain-store path is live; "src_excl_shared": all features share the rows (ranges overlap) -> the kernel
+        # must notice and keep the atomics
+        if presort == "src_excl":
+            per = C // F
+            idx = (idx % per) + torch.arange(F).repeat_interleave(B) * per
+        keys = presort_window(idx.cuda().view(1, -1), C, offsets=off.cuda(), include_last_offset=True,
+                              hook_features=F, ids=idx.cuda().view(1, -1))[0]
+        assert keys.ranges is not None and keys.ranges.shape == (F, 2)
+        flagged = int(((keys.keys & 0x80000000) != 0).sum())
+        assert flagged > 1000, "the presort marked no owner-exclusive runs"
+        lo, hi = keys.ranges[:, 0].cpu(), keys.ranges[:, 1].cpu()
+        disjoint = bool((hi[:-1] < lo[1:]).all())
+        assert disjoint == (presort == "src_excl")
+    elif presort == "src":
+        keys = presort_window(idx.cuda().view(1, -1), C, offsets=off.cuda(), include_last_offset=True,
+                              hook_features=F)[0]
+    else:
+        keys = presort_slots(idx.cuda(), C) if presort else None
     out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
                            hook_features=F, fused_sgd=ce.FusedSGD(lr), presorted=keys)
     ref_out = torch.nn.functional.embedding_bag(idx, w, off.long(), mode="sum", include_last_offset=True)
@@ -351,11 +374,32 @@ def test_padding_idx_and_scale_grad_by_freq(sparse):
             torch.nn.functional.embedding_bag(idx, ref, off, mode="sum", include_last_offset=True, **kw).backward(go)
             torch.testing.assert_close(got, ref.grad, rtol=1e-4, atol=1e-5)
     # the module: padding in ID space, cache op on
-    emb = ce.CachedEmbeddingBag(N, D, padding_idx=17, sparse=False, _weight=w0.clone(), mode="sum",
+    emb = ce.CachedEmbeddingBag(N, D, padding_idx=17, sparse=sparse, _weight=w0.clone(), mode="sum",
                                 include_last_offset=True, cuda_row_num=N, warmup_ratio=0.5)
     out = emb(idx.cuda(), off.cuda())
     ro = torch.nn.functional.embedding_bag(idx, w0, off, mode="sum", include_last_offset=True, padding_idx=17)
     torch.testing.assert_close(out.detach().cpu(), ro, rtol=1e-5, atol=1e-5)
+    # ... and its gradient (with sparse=True the masked lookups must not reach the COO tensor as index -1):
+    # in slot space, compared row by row with torch's gradient in id space
+    out.backward(go.cuda())
+    gw = emb.cache_weight_mgr.cuda_cached_weight.grad
+    if sparse:
+        assert int(gw._indices().min()) >= 0
+        gw = gw.to_dense()
+    ref = w0.clone().requires_grad_(True)
+    torch.nn.functional.embedding_bag(idx, ref, off, mode="sum", include_last_offset=True, padding_idx=17).backward(go)
+    rows = emb.cache_weight_mgr.cached_idx_map.cpu().long()           # slot -> host row (= id: no frequency map)
+    res = rows >= 0
+    by_id = torch.zeros(N, D).index_add_(0, rows[res], gw.cpu()[res])
+    torch.testing.assert_close(by_id, ref.grad, rtol=1e-4, atol=1e-5)
+    # what the kernels cannot do with padding is refused, not mis-computed
+    emb_mean = ce.CachedEmbeddingBag(N, D, padding_idx=17, sparse=sparse, _weight=w0.clone(), mode="mean",
+                                     include_last_offset=True, cuda_row_num=N)
+    with pytest.raises(NotImplementedError):
+        emb_mean(idx.cuda(), off.cuda())
+    from cachedembedding_amd.functional import presort_slots
+    with pytest.raises(NotImplementedError):
+        emb(idx.cuda(), off.cuda(), presorted=presort_slots(torch.zeros(nnz, dtype=torch.long, device="cuda"), N))
 
 
 @pytest.mark.gpu
@@ -417,6 +461,16 @@ def test_source_row_keys_backward_matches_tile_backward(D, layout):
                 ce.embedding_bag(slots[b], w3, ob, mode="sum", **kw).backward(go)
                 torch.testing.assert_close(w2.grad, w3.grad, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(res["src"], res["plain"], rtol=1e-5, atol=1e-5)
+        # ... and against torch on the CPU: w[slot] -= lr * grad_out[bag of the lookup] for every in-range lookup
+        sl = slots[b].cpu()
+        obc = ob.cpu().long()
+        ends = obc[1:] if kw["include_last_offset"] else torch.cat([obc[1:], torch.tensor([n])])
+        bag_of = torch.repeat_interleave(torch.arange(num_bags), ends - obc[:num_bags])
+        gsrc = go.cpu()
+        gflat = gsrc.transpose(0, 1).reshape(-1, D) if kw["hook_features"] else gsrc.reshape(-1, D)
+        ok = (sl >= 0) & (sl < C)
+        ref = w0.cpu().double().index_add_(0, sl[ok], gflat[bag_of[ok]].double(), alpha=-0.5)
+        torch.testing.assert_close(res["src"].cpu().double(), ref, rtol=1e-5, atol=1e-5)
     # wrong layout / mode are refused, not mis-read
     w = w0.clone().requires_grad_(True)
     ob = offs_d[0] if offs_d.dim() == 2 else offs_d
@@ -425,6 +479,68 @@ def test_source_row_keys_backward_matches_tile_backward(D, layout):
     with pytest.raises(ValueError):
         ce.embedding_bag(slots[0], w, ob, mode="sum", presorted=keys[0]._replace(hook_features=7),
                          include_last_offset=kw["include_last_offset"], hook_features=kw["hook_features"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [16, 128, 256])
+@pytest.mark.parametrize("case", ["disjoint", "shared", "straddle", "hot"])
+def test_owner_exclusive_rows_backward(D, case):
+    """presort_window(..., ids=...) -> flagged keys + segment id ranges -> fused SGD by plain read-modify-write for
+    rows one lane group owns, atomics for the rest, against torch index_add_ in fp64.  disjoint: every 16384-lookup
+    segment has its own id range (the exclusive path is live); shared: the segments share ids (must fall back);
+    straddle: a feature's lookups cross a segment boundary; hot: a few rows collect thousands of lookups (long runs
+    and hot buckets stay on the atomics) next to cold ones."""
+    import cachedembedding_amd as ce
+    from cachedembedding_amd.functional import presort_window
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(D + len(case))
+    P, C = 2, 60000
+    if case == "straddle":
+        B, F = 10000, 5                                     # 50000 lookups: features cross the 16384 boundaries
+    else:
+        B, F = 16384, 3
+    n = B * F
+    per = C // F
+    base = torch.arange(F).repeat_interleave(B) * per
+    u = torch.rand(P, n, generator=g)
+    if case == "hot":
+        local = torch.where(u < 0.5, (u * 8).long(), (torch.rand(P, n, generator=g) * per).long())
+    else:
+        local = (u ** 3 * per).long()
+    slots = (local.clamp_(0, per - 1) + base).contiguous()
+    if case == "shared":
+        slots = (u ** 3 * C).long().clamp_(0, C - 1).contiguous()
+    slots[:, 7] = -1                                        # an ignored lookup
+    ids = slots.clone()
+    ids[:, 7] = 3                                           # its id still counts for the range (conservative)
+    offs = torch.arange(n + 1, dtype=torch.int32)
+    keys = presort_window(slots.to(dev), C, offsets=offs.to(dev), include_last_offset=True, hook_features=F,
+                          ids=ids.to(dev))
+    w0 = torch.randn(C, D, generator=g)
+    for b in range(P):
+        r = keys[b].ranges.cpu()
+        nonempty = r[:, 0] <= r[:, 1]
+        order = torch.argsort(r[nonempty, 0])
+        lo, hi = r[nonempty, 0][order], r[nonempty, 1][order]
+        disjoint = bool((hi[:-1] < lo[1:]).all())
+        assert disjoint == (case in ("disjoint", "hot")), (case, r)
+        go = torch.randn(B, F, D, generator=g) * 0.1
+        w = w0.clone().to(dev).requires_grad_(True)
+        out = ce.embedding_bag(slots[b].to(dev), w, offs.to(dev), mode="sum", include_last_offset=True, sparse=True,
+                               hook_features=F, fused_sgd=ce.FusedSGD(0.5), presorted=keys[b])
+        out.backward(go.to(dev))
+        ok = slots[b] >= 0
+        gflat = go.transpose(0, 1).reshape(-1, D)
+        ref = w0.double().index_add_(0, slots[b][ok], gflat[ok].double(), alpha=-0.5)
+        cnt = torch.bincount(slots[b][ok], minlength=C).double().unsqueeze(1)
+        bound = 1e-5 * ref.abs() + 2e-6 + 3e-7 * cnt.sqrt()
+        assert bool(((w.detach().cpu().double() - ref).abs() <= bound).all())
+        # the flags do not disturb the entry points that ignore them
+        w2 = w0.clone().to(dev).requires_grad_(True)
+        ce.embedding_bag(slots[b].to(dev), w2, offs.to(dev), mode="sum", include_last_offset=True,
+                         hook_features=F, presorted=keys[b]._replace(ranges=None)).backward(go.to(dev))
+        want = torch.zeros(C, D, dtype=torch.float64).index_add_(0, slots[b][ok], gflat[ok].double())
+        torch.testing.assert_close(w2.grad.cpu().double(), want, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu

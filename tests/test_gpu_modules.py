@@ -211,10 +211,66 @@ def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):
     args = ["--dataset", "avazu", "--table_scale", "0.01", "--batch_size", "256", "--embedding_dim", "32",
             "--dense_arch_layer_sizes", "64,32", "--over_arch_layer_sizes", "64,1", "--use_cache", "--cache_ratio", "0.3",
             "--use_freq", "--prefetch_num", "4", "--use_overlap", "--use_sparse_embed_grad", "--limit_train_batches",
-            "24", "--learning_rate", "0.05"] + extra
+            "48", "--learning_rate", "0.2"] + extra
     dm.main(args)
     out = capsys.readouterr().out
-    assert "24 iterations" in out and "it/s" in out and "CUDA->CPU" in out
+    assert "48 iterations" in out and "it/s" in out and "CUDA->CPU" in out
+    import re
+    m = re.search(r"mean loss first quarter ([0-9.]+) last quarter ([0-9.]+)", out)
+    assert m, out
+    first, last = float(m.group(1)), float(m.group(2))
+    assert last < first - 0.01, f"the loss did not go down: {first} -> {last}"
+
+
+def test_toy_dlrm_matches_torch_cpu_trajectory():
+    """SURVEY 8(c) wiring fixture: a toy DLRM (13 -> 64 -> 32 dense, 4 tables, B = 64) trained 20 steps through
+    examples/dlrm_main.py's model and training loop (prefetch window of 4, cached embedding with evictions) against
+    the same model on one fused nn.EmbeddingBag + torch-CPU, captured by tests/golden/make_dlrm_golden.py:
+    per-step pooled [B, F, D] within 1e-5, loss trajectory within 1e-4, final table after flush() within 1e-5."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "examples"))
+    import importlib
+    dm = importlib.import_module("dlrm_main")
+    gold = np.load(ROOT / "tests" / "golden" / "dlrm_toy.npz")
+    sizes = [int(x) for x in gold["sizes"]]
+    steps, B = gold["dense_x"].shape[0], gold["dense_x"].shape[1]
+    D = gold["table"].shape[1]
+    lr = float(gold["lr"])
+    for extra in ([], ["--fused_sgd", "--fold_hook"], ["--overlap_cache_op", "--fused_sgd", "--fold_hook"]):
+        args = dm.parse_args(["--use_cache", "--cache_ratio", "0.4", "--prefetch_num", "4", "--use_sparse_embed_grad",
+                              "--embedding_dim", str(D), "--batch_size", str(B), "--learning_rate", str(lr),
+                              "--dense_arch_layer_sizes", ",".join(str(int(x)) for x in gold["dense_arch"]),
+                              "--over_arch_layer_sizes", ",".join(str(int(x)) for x in gold["over_arch"])] + extra)
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(0)
+        model = dm.HybridParallelDLRM(sizes, args, None, dev)
+        embed = model.sparse_modules.embed
+        embed.flush()                                            # empty cache, then the fixture's table
+        embed.weight.copy_(torch.from_numpy(gold["table"]))
+        model.dense_modules.load_state_dict({k[len("dense."):]: torch.from_numpy(gold[k]) for k in gold.files
+                                             if k.startswith("dense.")})
+        groups = [{"params": list(model.dense_modules.parameters()), "lr": lr}]
+        if args.fused_sgd:
+            embed.set_fused_sgd(lr)
+        else:
+            groups.insert(0, {"params": list(model.sparse_modules.parameters()), "lr": lr})
+        opt = torch.optim.SGD(groups)
+        offsets = torch.arange(len(sizes) * B + 1, dtype=torch.int32)
+        loader = [dict(dense=torch.from_numpy(gold["dense_x"][i]), labels=torch.from_numpy(gold["labels"][i]),
+                       sparse=[torch.from_numpy(gold["values"][i]), offsets, B]) for i in range(steps)]
+        pooled = []
+        hook = model.sparse_modules.register_forward_hook(lambda m, a, out: pooled.append(out.detach().clone()))
+        rec = []
+        done, _, _ = dm.train(model, opt, loader, args, dev, 0, 1, record=rec)
+        hook.remove()
+        assert done == steps and len(pooled) == steps
+        losses = torch.stack(rec).double().cpu().numpy()
+        np.testing.assert_allclose(losses, gold["losses"], rtol=0, atol=1e-4)
+        got = torch.stack(pooled).cpu().numpy()
+        np.testing.assert_allclose(got, gold["pooled"], rtol=1e-5, atol=1e-5)
+        assert sum(embed.cache_weight_mgr.num_write_back_history) >= 0
+        embed.flush()
+        np.testing.assert_allclose(embed.weight.numpy(), gold["final_table"], rtol=1e-5, atol=1e-5)
 
 
 def test_dlrm_trainer_reads_binary_criteo_npy(tmp_path, capsys):
