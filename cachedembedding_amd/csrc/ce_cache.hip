@@ -7,12 +7,12 @@
 // every count the host would need (unique rows, misses, victims) stays in a device-side
 // control block, and the per-call statistics are stored straight into a pinned host ring.
 //
-//   mark      ids -> rows (idx_map) -> bits in a row bitmap (N/8 bytes); the thread whose atomicOr sets a bit first
-//             owns the row: it counts it (unique, missing) and adds it to its 131072-row chunk's miss count;
-//             the row of every id is left in slots_out for the last kernel                  [unique, K2-K4]
-//   emit      every workgroup sums the miss counts of the chunks before its own (that IS the scan), workgroup 0
-//             also does the plan (capacity check, k = miss - free); miss rows in ascending order; hit slots
-//             stamped with the call epoch; bitmap cleared
+//   mark      ids -> rows (idx_map) -> bits in a row bitmap (N/8 bytes); the row of every id is left in
+//             slots_out for the last kernel                                                 [unique, K2/K3]
+//   count     unique / missing rows per 32768-row chunk, and per 64 chunks; miss = inverted[row] < 0   [K4]
+//   emit      every workgroup adds up the counts before its own (that IS the scan), workgroup 0 also does the
+//             plan (capacity check, k = miss - free); miss rows in ascending order; hit slots stamped with the
+//             call epoch; bitmap cleared
 //   keys/hist x<=8/victims      exact k-smallest selection over all slots          [K5]
 //   evict     victims' rows written back to the host table, maps cleared           [K6]
 //   free      first n_miss free slots ascending (ordered compaction)              [K7]
@@ -45,10 +45,15 @@ namespace ce {
 
 constexpr int kChunkShift = 15;
 constexpr int kChunkRows = 1 << kChunkShift;   // rows covered by one 256-thread workgroup of the bitmap scan (uint4/thread)
-constexpr int kHotChunksMax = 8;               // k_mark's LDS window covers at most this many chunks (8192 words)
+constexpr int kCoarseShift = 6;                 // k_count also sums its chunk counts per 64 chunks (k_emit adds those up)
+constexpr int kCoarsePad = 32;                  // ints between two coarse counters: a 128-byte line each (device atomics to one
+                                                // line serialise whatever the address: packed counters cost k_count 15 us)
 constexpr int kSlotsPerBlock = 1024;  // slots covered by one block of the slot-space scans (4/thread)
 constexpr int kRing = 1024;           // pinned host ring of per-call stats
-constexpr int kHistWords = 8 * 256;   // one 256-bin histogram per radix pass
+constexpr int kDigitBits = 11;         // radix select: 11-bit digits (28-bit DATASET keys of a 178 M-row table: 3 passes)
+constexpr int kBins = 1 << kDigitBits;
+constexpr int kLevels = 6;             // 6 x 11 >= 64 bits
+constexpr int kHistWords = kLevels * kBins;   // one histogram per radix pass
 constexpr int32_t kEpochNever = -(1 << 30);
 constexpr int64_t kHistoryKeep = 1 << 16;   // per-call records kept on the host side
 
@@ -58,17 +63,17 @@ struct Ctl {                 // device control block (one per manager)
   long long n_miss;
   long long k_evict;
   long long miss_lookups;
-  unsigned long long sel_prefix;   // (unused since the digits are recomputed from the histograms: select_chain)
-  long long sel_krem;
+  unsigned long long sel_prefix;   // (unused)
+  long long sel_krem;              // k of the current select (set by the plan)
   long long n_eligible;      // slots that may be evicted in this call (resident and not protected)
   int victims_count;
   int status;
   int lost;                  // per call: the admission worker reported that the rows did not arrive (see k_admit_maps)
   int pad_;
-  long long cold_unique;     // per call: unique / missing rows outside k_mark's LDS window (counted by k_mark's owners)
-  long long cold_miss;
-  unsigned long long hot_pub[kHotChunksMax];   // per call: {tag, unique, missing} of the window's chunks, published by
-                                               // the first workgroups of k_emit for all the others
+  // radix select: digits and remaining rank after level q was resolved (written by workgroup 0 of the kernel that
+  // resolves level q -- every workgroup of that kernel computes the same thing for itself --, read by later kernels)
+  unsigned long long sel_prefix_after[8];
+  long long sel_krem_after[8];
 };
 
 struct WbMail {              // pinned host mailbox: how many rows a worker job moves (written by the device)
@@ -77,7 +82,7 @@ struct WbMail {              // pinned host mailbox: how many rows a worker job 
 };
 
 struct Layout {              // byte offsets inside the caller-provided workspace
-  size_t ctl, bitmap, blk_miss, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
+  size_t ctl, bitmap, blk_unique, blk_miss, coarse, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
       stage_idx, stage, stage_idx2, stage2, in_stage, total;
   int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
@@ -94,7 +99,9 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   size_t o = 0;
   L.ctl = o;        o = al(o + sizeof(Ctl));
   L.bitmap = o;     o = al(o + (size_t)L.bitmap_words * 4);
+  L.blk_unique = o; o = al(o + (size_t)(L.n_chunks + 1) * 4);
   L.blk_miss = o;   o = al(o + (size_t)(L.n_chunks + 1) * 4);
+  L.coarse = o;     o = al(o + (size_t)((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad * 4);   // [unique, missing] per 64 chunks
   L.miss_list = o;  o = al(o + (size_t)L.list_cap * 4);
   L.slot_epoch = o; o = al(o + (size_t)C * 4);
   L.keys = o;       o = al(o + (size_t)C * 8);
@@ -152,8 +159,8 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // ----------------------------------------------------------------------------- kernels
 
-// per-call reset: the control block's call fields, the chunk miss counts k_mark adds to, the radix histograms
-__global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* blk_miss, int n_chunks, uint32_t* hist) {
+// per-call reset: the control block's call fields, the coarse chunk sums k_count adds to, the radix histograms
+__global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_coarse2, uint32_t* hist) {
   if (threadIdx.x == 0) {
     ctl->n_unique = 0;
     ctl->n_miss = 0;
@@ -164,12 +171,10 @@ __global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* blk_miss, int 
     ctl->n_eligible = 0;
     ctl->victims_count = 0;
     ctl->status = CE_OK;
-    ctl->cold_unique = 0;
-    ctl->cold_miss = 0;
     ctl->lost = 0;
   }
-  if (blk_miss)
-    for (int i = threadIdx.x; i < n_chunks; i += blockDim.x) blk_miss[i] = 0;
+  if (coarse)
+    for (int i = threadIdx.x; i < n_coarse2; i += blockDim.x) coarse[i] = 0;
   if (hist)
     for (int i = threadIdx.x; i < kHistWords; i += blockDim.x) hist[i] = 0;
 }
@@ -202,37 +207,36 @@ __device__ __forceinline__ uint32_t miss_mask(const int32_t* __restrict__ invert
   return mm;
 }
 
-// ids -> rows -> bitmap, and most of the counting that used to take a second pass over the bitmap (k_count) and a
-// scan kernel (k_plan): outside the LDS window (below) the thread whose atomicOr turns a row's bit on OWNS the row
-// for this call -- it adds 1 to the call's unique count and, if the row is not resident, to the miss count and to
-// the miss count of the row's 32768-row chunk (blk_miss: what k_emit's workgroups sum to find their place in the
-// miss list).
+// ids -> rows -> bits in the row bitmap.
 //
 // Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window sends >100k ids at
 // a 3-row table, so a global atomicOr per id would serialise.  Rows in frequency order (idx_map present): the
-// lowest `hot_words` words live in an LDS window per workgroup and are flushed once at the end with fire-and-forget
-// atomics (who set a bit first cannot be told there: 256 workgroups flush the same words at the same time, and
-// returning atomics for it cost 80 us -- the window's rows are counted by the first workgroups of k_emit instead);
-// a cold id first LOOKS at its word and only issues the atomic when its bit is still clear.  Rows in id order
-// (MERGE): hot rows are scattered, so the lanes of a wave that aim at the same word are merged with ballots first
+// lowest `hot_words` words live in an LDS window per workgroup and are flushed once at the end; a cold id first
+// LOOKS at its word and only issues the (fire-and-forget) atomic when its bit is still clear.  Rows in id order
+// (MERGE): hot rows are scattered, so the lanes of a wave that still aim at the same word are merged with ballots
 // and one lane issues the atomicOr for all of them.
-//
-// U ids per thread are in flight: the kernel is a chain of three dependent random accesses per id (idx_map ->
-// inverted / bitmap word -> atomic), and one id per thread left it latency bound (74 us for 3.4 M ids).
+// (Round 3 tried to count the unique / missing rows here as well -- the thread whose atomicOr sets a bit first owns
+// the row -- so that the bitmap would be scanned once instead of twice: the returning atomics that needs cost 40 us,
+// more than the k_count pass they replaced; ablations in profiles/r03_mark_ablations.txt.)
+// U ids per thread are in flight (a chain of three dependent random accesses per id).
 // rows_out: the row of every id (-1 = bad id), as int64 in the caller's slots buffer -- k_slots turns it into the
 // slot in place, so idx_map is gathered once per id per call.
+#ifdef CE_ABLATIONS
+#define CE_MDBG(x) (dbg & (x))
+#else
+#define CE_MDBG(x) 0
+#endif
 template <bool MERGE, int U>
 __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
                                               const int32_t* __restrict__ idx_map,
                                               const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out,
-                                              int32_t* blk_miss) {
+                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out, int dbg) {
   extern __shared__ uint32_t hot[];
   for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
-  int cold = 0, uniq = 0, miss = 0;
+  int cold = 0;
   // wave-uniform trip count: a wave owns U * 64 consecutive ids per iteration
   for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * U; i0 < n; i0 += stride) {
     int32_t row[U], inv[U];
@@ -260,11 +264,11 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
       inv[u] = 0;
       cur[u] = ~0u;
       if (valid[u]) {
-        rows_out[i] = row[u];
-        inv[u] = inverted[row[u]];
+        if (!CE_MDBG(4)) rows_out[i] = row[u];
+        if (!CE_MDBG(2)) inv[u] = inverted[row[u]];
         const int word = row[u] >> 5;
-        if (word < hot_words) atomicOr(&hot[word], 1u << (row[u] & 31));
-        else cur[u] = *(volatile uint32_t*)(bitmap + word);
+        if (word < hot_words) { if (!CE_MDBG(1)) atomicOr(&hot[word], 1u << (row[u] & 31)); }
+        else if (!CE_MDBG(8)) cur[u] = *(volatile uint32_t*)(bitmap + word);
       }
     }
 #pragma unroll
@@ -273,12 +277,9 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
       const int bidx = row[u] & 31;
       const bool need = valid[u] && (cur[u] & (1u << bidx)) == 0;
       if (valid[u]) cold += inv[u] < 0;
-      bool owner = false;
       if (!MERGE) {
-        if (need) owner = (atomicOr(bitmap + word, 1u << bidx) & (1u << bidx)) == 0;
+        if (need) atomicOr(bitmap + word, 1u << bidx);
       } else if (__any(need)) {
-        // lanes aiming at the same word: one atomicOr by the lowest of them; the lowest lane of every (word, bit)
-        // pair speaks for that row
         unsigned long long pm = __ballot(need);
         if (!need) pm = 0;
         for (int b = 0; b < word_bits; ++b) {
@@ -286,133 +287,134 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
           pm &= ((word >> b) & 1) ? m : ~m;
         }
         uint32_t orbits = 0;
-        unsigned long long same = 0;
 #pragma unroll
         for (int b = 0; b < 32; ++b) {
           const unsigned long long m = __ballot(need && bidx == b);
           if (m & pm) orbits |= (1u << b);
-          if (bidx == b) same = m & pm;
         }
-        const int leader = need ? __ffsll((long long)pm) - 1 : 0;
-        uint32_t old = 0;
-        if (need && leader == lane) old = atomicOr(bitmap + word, orbits);
-        old = __shfl(old, leader);
-        owner = need && (__ffsll((long long)same) - 1) == lane && (old & (1u << bidx)) == 0;
-      }
-      if (owner) {
-        ++uniq;
-        if (inv[u] < 0) {
-          ++miss;
-          atomicAdd(&blk_miss[row[u] >> kChunkShift], 1);
-        }
+        if (need && (__ffsll((long long)pm) - 1) == lane) atomicOr(bitmap + word, orbits);
       }
     }
   }
+  cold = wave_sum(cold);
+  if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
   __syncthreads();
   for (int w = threadIdx.x; w < hot_words; w += blockDim.x) {
     const uint32_t v = hot[w];
     if (v && ((*(volatile uint32_t*)(bitmap + w)) & v) != v) atomicOr(bitmap + w, v);
   }
-  // one atomic per counter and workgroup
-  __shared__ int red[3][16];
-  cold = wave_sum(cold);
-  uniq = wave_sum(uniq);
-  miss = wave_sum(miss);
-  if (lane == 0) {
-    red[0][threadIdx.x >> 6] = cold;
-    red[1][threadIdx.x >> 6] = uniq;
-    red[2][threadIdx.x >> 6] = miss;
+}
+
+// unique / missing rows per 32768-row chunk of the bitmap (one uint4 = 128 rows per thread), and their sums per 64
+// chunks (two device atomics per workgroup on ~85 addresses: k_emit adds those up instead of 5431 chunk counts)
+__global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4,
+                                               const int32_t* __restrict__ inverted, int64_t N,
+                                               int32_t* blk_unique, int32_t* blk_miss, int32_t* coarse) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 q = bitmap4[v];
+  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+  int u = 0, m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!wds[k]) continue;
+    u += __popc(wds[k]);
+    m += __popc(miss_mask(inverted, v * 128 + k * 32, wds[k], N));
+  }
+  __shared__ int su[4], sm[4];
+  u = wave_sum(u);
+  m = wave_sum(m);
+  if ((threadIdx.x & 63) == 0) {
+    su[threadIdx.x >> 6] = u;
+    sm[threadIdx.x >> 6] = m;
   }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    long long t = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[threadIdx.x][k];
-    unsigned long long* dst = (unsigned long long*)(threadIdx.x == 0 ? &ctl->miss_lookups
-                                                                     : threadIdx.x == 1 ? &ctl->cold_unique : &ctl->cold_miss);
-    if (t) atomicAdd(dst, (unsigned long long)t);
+  if (threadIdx.x == 0) {
+    const int tu = su[0] + su[1] + su[2] + su[3], tm = sm[0] + sm[1] + sm[2] + sm[3];
+    blk_unique[blockIdx.x] = tu;
+    blk_miss[blockIdx.x] = tm;
+    if (tu) atomicAdd(&coarse[(2 * (blockIdx.x >> kCoarseShift)) * kCoarsePad], tu);
+    if (tm) atomicAdd(&coarse[(2 * (blockIdx.x >> kCoarseShift) + 1) * kCoarsePad], tm);
   }
 }
 
-// Ordered emission of the missing rows + the plan.  One workgroup of 256 threads per 32768-row chunk of the bitmap
-// (one uint4 = 128 rows per thread).  Its place in the miss list is the number of missing rows in the chunks before
-// it; every workgroup adds those up itself (blk_miss: at most ~20 KB out of L2), so there is neither a scan kernel
-// nor a chain between workgroups.  Two sources: rows outside k_mark's LDS window were counted by their owners in
-// k_mark (cold_unique / cold_miss / blk_miss); the window's own rows (the first n_hot chunks, at most 8) are counted
-// here by the workgroups that scan them anyway, which publish {tag, unique, missing} as ONE 8-byte word each
-// (write-through store, polled with device-scope loads: no fence).  Those workgroups have the lowest indices, so
-// they are resident before any workgroup that waits for them.  With the totals every workgroup derives the same
-// verdict; workgroup 0 also records it: capacity check, k = misses - free slots, the stats record, the mailbox.
+// Ordered emission of the missing rows + the plan.  The bitmap is scanned in 32768-row chunks (one uint4 = 128 rows
+// per thread of a 256-thread workgroup); a workgroup takes kEmitSub chunks, strided by the grid size, with all its
+// loads in flight at once: the whole grid is then resident at the same time (1358 workgroups at N = 178 M) instead of
+// running in 2.7 rounds of short latency-bound workgroups, and the dense chunks of the hot rows (the lowest ones)
+// land in different workgroups.  A chunk's place in the miss list is the number of missing rows in the chunks
+// before it; every workgroup adds that up itself -- k_count's sums per 64 chunks plus the chunk counts of the
+// chunk's own group of 64: ~150 values out of L2 -- so there is neither a scan kernel (k_plan: 13.6 us + a launch)
+// nor a chain between workgroups.  The same sums give every workgroup the call's totals and hence the same verdict;
+// workgroup 0 also records it: capacity check, k = misses - free slots, the stats record, the mailbox.
+constexpr int kEmitSub = 1;      // (4 chunks per workgroup, contiguous or strided, measured SLOWER: 111 / 56 us against 46)
 __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
-                                              const int32_t* __restrict__ blk_miss, int n_hot, int64_t hot_rows,
-                                              int32_t* miss_list, int32_t* slot_epoch, int32_t epoch, Ctl* ctl,
-                                              int64_t C, int64_t n_ids, ce_call_stats_t* ring_slot, WbMail* mail_in,
-                                              long long job, long long in_cap, int32_t* miss_host) {
-  __shared__ int wtot[4], wtot2[4];
-  __shared__ int hot_u_s, hot_m_s[kHotChunksMax];
+                                              const int32_t* __restrict__ blk_miss, const int32_t* __restrict__ coarse,
+                                              int n_chunks, int32_t* miss_list, int32_t* slot_epoch, int32_t epoch,
+                                              Ctl* ctl, int64_t C, int64_t n_ids, ce_call_stats_t* ring_slot,
+                                              WbMail* mail_in, long long job, long long in_cap, int32_t* miss_host) {
+  __shared__ long long red[2 + kEmitSub][4];
+  __shared__ int wsub[kEmitSub][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int bid = (int)blockIdx.x;
+  const int bid = (int)blockIdx.x, G = (int)gridDim.x;
   const int st_in = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int64_t v = (int64_t)bid * 256 + threadIdx.x;
-  const uint4 q = bitmap4[v];
-  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-  // missing rows of this thread's 128 rows (all of them: the list position needs hot and cold alike), and -- in the
-  // window's chunks -- the window's share of unique / missing rows
-  uint32_t mm[4];
-  int m = 0, hu = 0, hm = 0;
+  int chunk[kEmitSub];
+  uint4 q[kEmitSub];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    mm[k] = 0;
-    if (!wds[k]) continue;
-    const int64_t row0 = v * 128 + k * 32;
-    mm[k] = miss_mask(inverted, row0, wds[k], N);
-    m += __popc(mm[k]);
-    if (row0 < hot_rows) {      // a word is hot or cold as a whole (hot_rows is a multiple of 32)
-      hu += __popc(wds[k]);
-      hm += __popc(mm[k]);
-    }
+  for (int j = 0; j < kEmitSub; ++j) {
+    chunk[j] = bid + j * G;
+    q[j] = make_uint4(0, 0, 0, 0);
+    if (chunk[j] < n_chunks) q[j] = bitmap4[(int64_t)chunk[j] * 256 + threadIdx.x];
   }
-  const unsigned long long tag = (unsigned long long)(epoch & 0xffffff);
-  if (bid < n_hot) {
-    const int su = wave_sum(hu), sm = wave_sum(hm);
-    if (lane == 0) { wtot[wv] = su; wtot2[wv] = sm; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned long long u = (unsigned)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
-      const unsigned long long mh = (unsigned)(wtot2[0] + wtot2[1] + wtot2[2] + wtot2[3]);
-      __hip_atomic_store(&ctl->hot_pub[bid], (tag << 40) | (u << 20) | mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-  }
-  // earlier chunks' missing rows outside the window, while the window's workgroups finish
-  int part = 0;
-  for (int i = threadIdx.x; i < bid; i += 256) part += blk_miss[i];
-  if (threadIdx.x < n_hot) {
-    unsigned long long w;
-    do {
-      w = __hip_atomic_load(&ctl->hot_pub[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((w >> 40) != tag) __builtin_amdgcn_s_sleep(2);
-    } while ((w >> 40) != tag);
-    hot_m_s[threadIdx.x] = (int)(w & 0xfffff);
-    const int u = (int)((w >> 20) & 0xfffff);
-    int us = u;
+  // totals, and every chunk's base, from the coarse sums + the chunk counts of the chunk's own group of 64
+  const int n_coarse = (n_chunks >> kCoarseShift) + 1;
+  long long tu_p = 0, tm_p = 0, base_p[kEmitSub];
 #pragma unroll
-    for (int d = 1; d < kHotChunksMax; d <<= 1) {
-      const int o = __shfl_up(us, d);
-      if ((int)threadIdx.x >= d) us += o;
-    }
-    if ((int)threadIdx.x == n_hot - 1) hot_u_s = us;
+  for (int j = 0; j < kEmitSub; ++j) base_p[j] = 0;
+  for (int g = threadIdx.x; g < n_coarse; g += 256) {
+    const int cu = coarse[(2 * g) * kCoarsePad], cm = coarse[(2 * g + 1) * kCoarsePad];
+    tu_p += cu;
+    tm_p += cm;
+#pragma unroll
+    for (int j = 0; j < kEmitSub; ++j)
+      if (g < (chunk[j] >> kCoarseShift)) base_p[j] += cm;
   }
-  part = wave_sum(part);
-  if (lane == 0) wtot[wv] = part;
+#pragma unroll
+  for (int j = 0; j < kEmitSub; ++j) {
+    const int i = ((chunk[j] >> kCoarseShift) << kCoarseShift) + (int)(threadIdx.x & 63);
+    if ((int)(threadIdx.x >> 6) == j && i < chunk[j] && chunk[j] < n_chunks) base_p[j] += blk_miss[i];      // wave j: chunk j
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    tu_p += __shfl_xor(tu_p, d);
+    tm_p += __shfl_xor(tm_p, d);
+#pragma unroll
+    for (int j = 0; j < kEmitSub; ++j) base_p[j] += __shfl_xor(base_p[j], d);
+  }
+  if (lane == 0) {
+    red[0][wv] = tu_p;
+    red[1][wv] = tm_p;
+#pragma unroll
+    for (int j = 0; j < kEmitSub; ++j) red[2 + j][wv] = base_p[j];
+  }
+  uint32_t mm[kEmitSub][4];
+  int m[kEmitSub];
+#pragma unroll
+  for (int j = 0; j < kEmitSub; ++j) {
+    m[j] = 0;
+    const uint32_t wds[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+    const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mm[j][k] = 0;
+      if (wds[k]) {
+        mm[j][k] = miss_mask(inverted, v * 128 + k * 32, wds[k], N);
+        m[j] += __popc(mm[j][k]);
+      }
+    }
+  }
   __syncthreads();
-  int base = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-  long long hot_u = 0, hot_m = 0;
-  if (n_hot > 0) hot_u = hot_u_s;
-  for (int c = 0; c < n_hot; ++c) {
-    hot_m += hot_m_s[c];
-    if (c < bid) base += hot_m_s[c];
-  }
-  const long long tu = ctl->cold_unique + hot_u, tm = ctl->cold_miss + hot_m;
+  const long long tu = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const long long tm = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   // workgroup 0 may already have turned CE_OK into CE_ERR_CAPACITY below: the verdict is the same either way
   const bool ok = st_in == CE_OK && tu <= C;
   if (bid == 0 && threadIdx.x == 0) {
@@ -445,65 +447,85 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
     // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
     // record (k_victims can turn it into a capacity failure): k_admit_maps
   }
-  if (!ok) m = 0;
-  const int inc = wave_incl_scan(m, lane);
+  int inc[kEmitSub];
+#pragma unroll
+  for (int j = 0; j < kEmitSub; ++j) {
+    if (!ok) m[j] = 0;
+    inc[j] = wave_incl_scan(m[j], lane);
+    if (lane == 63) wsub[j][wv] = inc[j];
+  }
   __syncthreads();
-  if (lane == 63) wtot2[wv] = inc;
-  __syncthreads();
-  int pos = base + inc - m;
-  for (int k = 0; k < wv; ++k) pos += wtot2[k];
   if (ok) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t bits = wds[k];
-      if (!bits) continue;
-      const int64_t row0 = v * 128 + k * 32;
-      if (dense_word(bits, row0, N)) {
-        const int4* p = (const int4*)(inverted + row0);
+    for (int j = 0; j < kEmitSub; ++j) {
+      if (chunk[j] >= n_chunks) continue;
+      int pos = (int)(red[2 + j][0] + red[2 + j][1] + red[2 + j][2] + red[2 + j][3]) + inc[j] - m[j];
+      for (int k = 0; k < wv; ++k) pos += wsub[j][k];
+      const uint32_t wds[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+      const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int4 x = p[j];
-          const int32_t sl[4] = {x.x, x.y, x.z, x.w};
+      for (int k = 0; k < 4; ++k) {
+        uint32_t bits = wds[k];
+        if (!bits) continue;
+        const int64_t row0 = v * 128 + k * 32;
+        if (dense_word(bits, row0, N)) {
+          const int4* p = (const int4*)(inverted + row0);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (!((bits >> (4 * j + c)) & 1)) continue;
-            if (sl[c] < 0) {
-              const int32_t mr = (int32_t)(row0 + 4 * j + c);
-              if (miss_host && pos < in_cap) miss_host[pos] = mr;      // the admission worker's copy (pinned host)
-              miss_list[pos++] = mr;
-            } else {
-              slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
+          for (int jj = 0; jj < 8; ++jj) {
+            const int4 x = p[jj];
+            const int32_t sl[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (!((bits >> (4 * jj + c)) & 1)) continue;
+              if (sl[c] < 0) {
+                const int32_t mr = (int32_t)(row0 + 4 * jj + c);
+                if (miss_host && pos < in_cap) miss_host[pos] = mr;      // the admission worker's copy (pinned host)
+                miss_list[pos++] = mr;
+              } else {
+                slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
+              }
             }
           }
+          continue;
         }
-        continue;
-      }
-      // sparse word: the missing rows are known (mm), the resident ones need their slot for the stamp
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const int64_t row = row0 + b;
-        if ((mm[k] >> b) & 1) {
-          if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)row;
-          miss_list[pos++] = (int32_t)row;
-        } else {
-          slot_epoch[inverted[row]] = epoch;        // evict_backlist membership [A.3-3]
+        // sparse word: the missing rows are known (mm), the resident ones need their slot for the stamp
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          const int64_t row = row0 + b;
+          if ((mm[j][k] >> b) & 1) {
+            if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)row;
+            miss_list[pos++] = (int32_t)row;
+          } else {
+            slot_epoch[inverted[row]] = epoch;        // evict_backlist membership [A.3-3]
+          }
         }
       }
     }
   }
-  if (q.x | q.y | q.z | q.w) bitmap4[v] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < kEmitSub; ++j)
+    if (chunk[j] < n_chunks && (q[j].x | q[j].y | q[j].z | q[j].w))
+      bitmap4[(int64_t)chunk[j] * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0);
 }
 
-// selection keys: smaller = evicted first.  Ineligible (empty / protected) = all ones.
+// selection keys: smaller = evicted first.  Ineligible (empty / protected) = all ones.  The histogram of the TOP digit
+// is taken here too (the keys are in registers): one pass over the keys less.
 __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached_idx_map,
                                               const int64_t* __restrict__ freq,
                                               const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
-                                              int32_t epoch, int32_t depth, int slot_bits, int lfu,
+                                              int32_t epoch, int32_t depth, int slot_bits, int lfu, int top_pass,
                                               unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
   if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin)
+  __shared__ uint32_t sh[kBins];
+  for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const int shift = top_pass * kDigitBits;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const unsigned long long fmax = (1ull << (63 - slot_bits)) - 1;
+  // LFU: a counter is clamped so that the key stays inside the digits the select looks at (the host derives
+  // top_pass from an upper bound of the counters; freq_cnter is the caller's tensor, so nothing else guarantees it)
+  const int key_bits = (top_pass + 1) * kDigitBits;
+  const unsigned long long fmax = (1ull << ((key_bits < 63 ? key_bits : 63) - slot_bits)) - 1;
   int elig = 0;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
     const int32_t row = cached_idx_map[s];
@@ -521,9 +543,10 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
       ++elig;
     }
     keys[s] = key;
+    atomicAdd(&sh[(key >> shift) & (kBins - 1)], 1u);
   }
   // evictable slots are counted here, not read off the top-digit histogram: a DATASET key N-1-row can share its
-  // top byte (0xff when N-1 has it, e.g. N = 256, 65536, 2^24) with the all-ones key of an ineligible slot.
+  // top digit with the all-ones key of an ineligible slot.
   // One atomic per WORKGROUP on a grid of at most 512: same-address device atomics serialise at ~7 ns each, and
   // one per wave of a 1738-workgroup grid cost this kernel 50 us.
   __shared__ int wsum[4];
@@ -534,63 +557,84 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
     const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (tot) atomicAdd((unsigned long long*)&ctl->n_eligible, (unsigned long long)tot);
   }
+  uint32_t* const mine = hist + top_pass * kBins;
+  for (int i = threadIdx.x; i < kBins; i += blockDim.x)
+    if (sh[i]) atomicAdd(&mine[i], sh[i]);
 }
 
 // Few, fat workgroups: every workgroup ends with one device atomic per non-empty bin and same-address atomics
 // serialise (~7 ns each), so 1738 workgroups of 256 cost 12 us per pass in the histogram flush alone; 256
 // workgroups of 1024 threads with 4 independent key loads per thread read the 14 MB of keys just as fast.
-// Digits of the k-th smallest key decided so far, from the per-pass histograms hist[q][256] of the passes q > lowest
-// (what the single-thread k_pick kernel between two histogram passes used to compute and leave in ctl): one wave,
-// 4 bins per lane, all levels' bins loaded together, then per level a wave scan and the first lane whose running
-// count reaches k.  Every workgroup of the NEXT kernel recomputes it in its prologue (a few hundred bytes out of
-// L2) -- that removes one launch per pass (5-8 us each: 4 per call at the bench shape, 5-8 for LFU).  The inputs
-// (k in ctl->sel_krem, the histograms) are read-only while it runs, so all workgroups agree.
+// Digits of the k-th smallest key decided so far, from the per-pass histograms hist[q][2048] of the passes q > lowest
+// (what a single-thread pick kernel between two histogram passes would compute): one wave, 32 bins per lane, per
+// level a wave scan, the first lane whose running count reaches k, then that lane's bins handed round with
+// shuffles.  Every workgroup of the NEXT kernel recomputes it in its prologue (8 KB per level out of L2) -- that
+// removes one launch per pass.  The inputs (k in ctl->sel_krem, the histograms) are read-only while it runs, so all
+// workgroups agree.
 struct SelState {
   unsigned long long prefix;
   int krem;
   int fail;      // fewer evictable slots than k: capacity overflow of the overlapped pipeline
 };
-__device__ __forceinline__ SelState select_chain(const uint32_t* __restrict__ hist, int top_pass, int lowest,
-                                                 const Ctl* ctl, int lane) {
+// Resolves ONE level: the digit of the k-th smallest key at level q from that level's histogram, given the digits
+// and the remaining rank of the levels above (from the control block: left there by the kernel before; the top level
+// starts from k itself).  One wave, 32 bins per lane: a wave scan, the first lane whose running count reaches the
+// rank, then that lane's bins handed round with shuffles.  Every workgroup of a kernel does this in its prologue
+// (8 KB out of L2) and workgroup 0 records the result for the next kernel: no pick kernel between two passes, no
+// dependency between workgroups, one histogram read per kernel.
+__device__ __forceinline__ SelState select_level(const uint32_t* __restrict__ hist, int q, int top_pass, Ctl* ctl,
+                                                 int lane, bool record) {
   SelState st;
-  st.prefix = 0;
-  st.krem = (int)ctl->sel_krem;
+  st.prefix = q == top_pass ? 0ull : ctl->sel_prefix_after[q + 1];
+  st.krem = q == top_pass ? (int)ctl->sel_krem : (int)ctl->sel_krem_after[q + 1];
   // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the capacity overflow of
   // the overlapped pipeline (unique(window k u k+1) > cuda_row_num); evictable slots are counted by k_keys
-  st.fail = ctl->n_eligible < (long long)st.krem;
+  st.fail = ctl->n_eligible < ctl->sel_krem;
   uint4 h[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
-    if (q > lowest && q <= top_pass) h[q] = ((const uint4*)(hist + q * 256))[lane];
+  for (int j = 0; j < 8; ++j) h[j] = ((const uint4*)(hist + q * kBins))[lane * 8 + j];
+  int sum = 0;
 #pragma unroll
-  for (int q = 7; q >= 0; --q) {
-    if (q > top_pass || q <= lowest) continue;
-    const int a = (int)h[q].x, b = (int)h[q].y, c = (int)h[q].z, d = (int)h[q].w;
-    const int sum = a + b + c + d;
-    const int inc = wave_incl_scan(sum, lane);
-    const unsigned long long m = __ballot(inc >= st.krem);
-    const int L = m ? __ffsll((long long)m) - 1 : 63;
-    const int r = st.krem - __shfl(inc - sum, L);          // rank inside lane L's four bins
-    const int la = __shfl(a, L), lb = __shfl(b, L), lc = __shfl(c, L);
-    int dd = 3, cum = la + lb + lc;
-    if (r <= la) { dd = 0; cum = 0; }
-    else if (r <= la + lb) { dd = 1; cum = la; }
-    else if (r <= la + lb + lc) { dd = 2; cum = la + lb; }
-    st.prefix |= ((unsigned long long)(4 * L + dd)) << (q * 8);
-    st.krem = r - cum;
+  for (int j = 0; j < 8; ++j) sum += (int)(h[j].x + h[j].y + h[j].z + h[j].w);
+  const int inc = wave_incl_scan(sum, lane);
+  const unsigned long long m = __ballot(inc >= st.krem);
+  const int L = m ? __ffsll((long long)m) - 1 : 63;
+  const int r = st.krem - __shfl(inc - sum, L);          // rank inside lane L's 32 bins
+  int dd = 31, before = 0, cum = 0;
+  bool found = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int vals[4] = {(int)h[j].x, (int)h[j].y, (int)h[j].z, (int)h[j].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int val = __shfl(vals[c], L);
+      if (!found && r <= cum + val) {
+        dd = 4 * j + c;
+        before = cum;
+        found = true;
+      }
+      cum += val;
+    }
+  }
+  if (!found) before = cum - __shfl((int)h[7].w, L);      // (only on the failure path: k beyond the candidates)
+  st.prefix |= ((unsigned long long)(32 * L + dd)) << (q * kDigitBits);
+  st.krem = r - before;
+  if (record && lane == 0) {
+    ctl->sel_prefix_after[q] = st.prefix;
+    ctl->sel_krem_after[q] = st.krem;
   }
   return st;
 }
 
 __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restrict__ keys, int64_t C, int pass,
-                                               int top_pass, uint32_t* hist, const Ctl* ctl) {
+                                               int top_pass, uint32_t* hist, Ctl* ctl) {
   if (ctl->k_evict == 0) return;
-  __shared__ uint32_t sh[256];
+  __shared__ uint32_t sh[kBins];
   __shared__ unsigned long long prefix_s;
   __shared__ int fail_s;
-  if (threadIdx.x < 256) sh[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
   if (threadIdx.x < 64) {
-    const SelState st = select_chain(hist, top_pass, pass, ctl, threadIdx.x);
+    const SelState st = select_level(hist, pass + 1, top_pass, ctl, threadIdx.x, blockIdx.x == 0);
     if (threadIdx.x == 0) {
       prefix_s = st.prefix;
       fail_s = st.fail;
@@ -598,7 +642,7 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
   }
   __syncthreads();
   if (fail_s) return;                  // k_victims records the failure
-  const int shift = pass * 8;
+  const int shift = pass * kDigitBits;
   const unsigned long long prefix = prefix_s;
   constexpr int U = 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
@@ -612,13 +656,15 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t s = s0 + (int64_t)u * blockDim.x;
-      const bool match = (pass == top_pass) || ((key[u] >> (shift + 8)) == (prefix >> (shift + 8)));
-      if (s < C && match) atomicAdd(&sh[(key[u] >> shift) & 255], 1u);
+      // (only passes below the top one get here: shift + kDigitBits <= 55)
+      const bool match = (key[u] >> (shift + kDigitBits)) == (prefix >> (shift + kDigitBits));
+      if (s < C && match) atomicAdd(&sh[(key[u] >> shift) & (kBins - 1)], 1u);
     }
   }
   __syncthreads();
-  uint32_t* const mine = hist + pass * 256;
-  if (threadIdx.x < 256 && sh[threadIdx.x]) atomicAdd(&mine[threadIdx.x], sh[threadIdx.x]);
+  uint32_t* const mine = hist + pass * kBins;
+  for (int i = threadIdx.x; i < kBins; i += blockDim.x)
+    if (sh[i]) atomicAdd(&mine[i], sh[i]);
 }
 
 __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
@@ -626,16 +672,18 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
                                                  int top_pass, ce_call_stats_t* ring_slot) {
   __shared__ unsigned long long prefix_s;
   __shared__ int fail_s, go_s;
-  // this workgroup's 1024 slots (4 per thread, strided by 256): in flight while wave 0 works out the threshold
-  const int64_t s0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-  unsigned long long key[4];
+  // this workgroup's 4096 slots (16 per thread, strided by 256): in flight while wave 0 works out the threshold
+  // (every workgroup recomputes it from the histograms: few, fat workgroups keep that redundant work small)
+  constexpr int KV = 16;
+  const int64_t s0 = (int64_t)blockIdx.x * (256 * KV) + threadIdx.x;
+  unsigned long long key[KV];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < KV; ++u) {
     const int64_t sl = s0 + u * 256;
     key[u] = sl < C ? keys[sl] : ~0ull;
   }
   if (threadIdx.x < 64) {
-    const SelState st = select_chain(hist, top_pass, -1, ctl, threadIdx.x);
+    const SelState st = select_level(hist, 0, top_pass, ctl, threadIdx.x, false);
     if (threadIdx.x == 0) {
       prefix_s = st.prefix;
       fail_s = st.fail;
@@ -666,7 +714,7 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
   __shared__ int base_s;
   int hits = 0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) hits += (key[u] <= T && key[u] != ~0ull);
+  for (int u = 0; u < KV; ++u) hits += (key[u] <= T && key[u] != ~0ull);
   int tot;
   int pos = block_excl_scan_256(hits, &tot);
   if (tot == 0) return;                     // block-uniform
@@ -674,7 +722,7 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
   __syncthreads();
   pos += base_s;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < KV; ++u) {
     if (key[u] <= T && key[u] != ~0ull) {
       if (pos < cap) victims[pos] = (int32_t)(s0 + u * 256);
       ++pos;
@@ -718,12 +766,24 @@ __global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ vict
         }
       }
 #pragma unroll
-      for (int t = 0; t < kSwapRows; ++t)
-        if (dst[t] >= 0 && gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
+      for (int t = 0; t < kSwapRows; ++t) {
+        if (dst[t] < 0) continue;
+        if (gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
+        if (gl == 0) {                      // maps of the victims this kernel moves (k_evict_stage does its own)
+          inverted[dst[t]] = -1;
+          cached_idx_map[victims[i + t]] = -1;
+        }
+      }
     } else {
       for (int t = 0; t < kSwapRows && i + t < k; ++t) {
         const int32_t slot = victims[i + t];
-        copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)cached_idx_map[slot] * rowlen, rowlen, gl, G);
+        const int32_t row = cached_idx_map[slot];
+        copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)row * rowlen, rowlen, gl, G);
+        __builtin_amdgcn_wave_barrier();
+        if (gl == 0) {
+          inverted[row] = -1;
+          cached_idx_map[slot] = -1;
+        }
       }
     }
   }
@@ -736,7 +796,7 @@ constexpr int kStageRowsInFlight = 4;   // rows in flight per lane group of the 
 
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
-                                                     const int32_t* __restrict__ cached_idx_map,
+                                                     int32_t* cached_idx_map, int32_t* inverted,
                                                      const VT* __restrict__ cache, VT* stage, int32_t* stage_rows_idx,
                                                      long long cap, int rowlen, int g_log2, const Ctl* ctl,
                                                      WbMail* mail, long long job) {
@@ -759,7 +819,12 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         if (slot[t] < 0) continue;
-        if (gl == 0) stage_rows_idx[i + t] = cached_idx_map[slot[t]];
+        if (gl == 0) {                      // the victim's host row, then both maps cleared (was k_evict_maps)
+          const int32_t row = cached_idx_map[slot[t]];
+          stage_rows_idx[i + t] = row;
+          inverted[row] = -1;
+          cached_idx_map[slot[t]] = -1;
+        }
         if (gl < rowlen) v[t] = cache[(int64_t)slot[t] * rowlen + gl];
       }
 #pragma unroll
@@ -768,7 +833,12 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
     } else {
       for (int t = 0; t < R && i + t < k; ++t) {
         const int32_t slot = victims[i + t];
-        if (gl == 0) stage_rows_idx[i + t] = cached_idx_map[slot];
+        if (gl == 0) {
+          const int32_t row = cached_idx_map[slot];
+          stage_rows_idx[i + t] = row;
+          inverted[row] = -1;
+          cached_idx_map[slot] = -1;
+        }
         copy_row(cache + (int64_t)slot * rowlen, stage + (i + t) * rowlen, rowlen, gl, G);
       }
     }
@@ -1751,7 +1821,7 @@ struct ce_cache {
   char* ws;
   ce::Ctl* ctl;
   uint32_t* bitmap;
-  int32_t *blk_miss, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
+  int32_t *blk_unique, *blk_miss, *coarse, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
   unsigned long long* keys;
   uint32_t* hist;
   ce_call_stats_t* ring;       // pinned host
@@ -1859,7 +1929,9 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->ws = (char*)cfg->workspace;
   h->ctl = (Ctl*)(h->ws + L.ctl);
   h->bitmap = (uint32_t*)(h->ws + L.bitmap);
+  h->blk_unique = (int32_t*)(h->ws + L.blk_unique);
   h->blk_miss = (int32_t*)(h->ws + L.blk_miss);
+  h->coarse = (int32_t*)(h->ws + L.coarse);
   h->miss_list = (int32_t*)(h->ws + L.miss_list);
   h->slot_epoch = (int32_t*)(h->ws + L.slot_epoch);
   h->keys = (unsigned long long*)(h->ws + L.keys);
@@ -2356,8 +2428,8 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   if (prof) prof->collect(pslot);
 #define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   CE_PHASE();
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, h->blk_miss, (int)L.n_chunks, h->hist);
-  int hot_words_used = 0;
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, h->coarse,
+                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist);
   {
     // Two shapes (rocprofv3, 3.4 M ids per call).  Rows in frequency order (idx_map present): the hot rows sit in
     // the lowest bitmap words, the LDS window absorbs them, and cold lookups issue their atomicOr directly.
@@ -2369,34 +2441,28 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     static const int mark_threads_env = [] { const char* e = getenv("CE_MARK_THREADS"); return e ? atoi(e) : 0; }();
     static const int mark_merge_env = [] { const char* e = getenv("CE_MARK_MERGE"); return e ? atoi(e) : -1; }();
     static const int mark_u = [] { const char* e = getenv("CE_MARK_U"); return e ? atoi(e) : 4; }();
+    static const int mark_dbg = [] { const char* e = getenv("CE_MARK_DEBUG"); return e ? atoi(e) : 0; }();
     const int mark_hot = mark_hot_env > 0 ? mark_hot_env : (ranked ? 8192 : 2048);
     const int mark_threads = mark_threads_env > 0 ? std::min(mark_threads_env, 1024) : (ranked ? 512 : 256);
     const bool mark_merge = mark_merge_env >= 0 ? mark_merge_env != 0 : !ranked;
-    // whole chunks (k_emit counts the window's rows chunk by chunk), at most kHotChunksMax of them
-    int hot_words = (int)std::min<int64_t>(L.bitmap_words, std::min(mark_hot, kHotChunksMax * (kChunkRows / 32)));
-    if (hot_words < L.bitmap_words) hot_words = hot_words / (kChunkRows / 32) * (kChunkRows / 32);
+    const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
     if (n > 0) {
-      hot_words_used = hot_words;
-      const int u = (n >= 65536 && mark_u != 1) ? (mark_u == 2 ? 2 : (mark_u == 8 ? 8 : 4)) : 1;
+      const int u = (n >= 65536 && mark_u != 1) ? (mark_u == 2 ? 2 : 4) : 1;
       const dim3 mg(std::min(grid_for(n, mark_threads * u), mark_blocks)), mb(mark_threads);
 #define CE_MARK(M, U_)                                                                                          \
   hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
-                     h->word_bits, hot_words, h->bitmap, h->ctl, slots_out, h->blk_miss)
-      if (mark_merge) { if (u >= 4) CE_MARK(true, 4); else if (u == 2) CE_MARK(true, 2); else CE_MARK(true, 1); }
-      else { if (u == 8) CE_MARK(false, 8); else if (u == 4) CE_MARK(false, 4); else if (u == 2) CE_MARK(false, 2); else CE_MARK(false, 1); }
+                     h->word_bits, hot_words, h->bitmap, h->ctl, slots_out, mark_dbg)
+      if (mark_merge) { if (u == 4) CE_MARK(true, 4); else if (u == 2) CE_MARK(true, 2); else CE_MARK(true, 1); }
+      else { if (u == 4) CE_MARK(false, 4); else if (u == 2) CE_MARK(false, 2); else CE_MARK(false, 1); }
 #undef CE_MARK
     }
   }
-  {
-    // chunks of k_mark's LDS window (counted by the workgroups of k_emit that scan them); the window is sized in
-    // whole chunks or covers the whole (small) bitmap
-    const int64_t hot_rows = (int64_t)hot_words_used * 32;
-    const int n_hot = (int)std::min<int64_t>(cdiv(hot_rows, kChunkRows), L.n_chunks);
-    hipLaunchKernelGGL(k_emit, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
-                       h->blk_miss, n_hot, hot_rows, h->miss_list, h->slot_epoch, epoch, h->ctl, C, n, slot,
-                       worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
-                       worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr);
-  }
+  hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
+                     c.inverted_cached_idx, N, h->blk_unique, h->blk_miss, h->coarse);
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)cdiv(L.n_chunks, kEmitSub)), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
+                     h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, epoch, h->ctl, C, n, slot,
+                     worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
+                     worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr);
   if (worker) {
     // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) while this
     // stream selects and stages the victims; it first lets every earlier write-back land
@@ -2406,31 +2472,33 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   CE_PHASE();
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
-  hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
-                     epoch, c.protect_depth, h->slot_bits, lfu, h->keys, h->hist, h->ctl);
-  // DATASET keys are < N: the bytes above the highest byte of N-1 are zero for every eligible slot, so the
-  // radix select starts there (4 passes at N = 178 M instead of 8)
-  int top_pass = 7;
+  // DATASET keys are < N: the digits above the highest digit of N-1 are zero for every eligible slot, so the
+  // radix select starts there (3 passes of 11 bits at N = 178 M).  The top pass is taken by k_keys itself.
+  int top_pass = kLevels - 1;
   if (!lfu) {
     top_pass = 0;
-    while (top_pass < 3 && ((uint64_t)(N - 1) >> (8 * (top_pass + 1))) != 0) ++top_pass;
+    while (top_pass < kLevels - 1 && ((uint64_t)(N - 1) >> (kDigitBits * (top_pass + 1))) != 0) ++top_pass;
   } else {
     // LFU keys are freq << slot_bits | slot.  No counter can exceed the largest value ever preloaded plus the ids
-    // seen so far (a call adds at most its own length to a counter), so the bytes above that bound are zero in
-    // every eligible key: 5 passes instead of 8 for the first few thousand calls of benchmark_cache.py's shape.
+    // seen so far (a call adds at most its own length to a counter), so the digits above that bound are zero in
+    // every eligible key.  (k_keys clamps a counter that a caller pushed beyond it -- freq_cnter is the caller's
+    // tensor -- so a key never has bits above the top digit.)
     h->freq_bound += (uint64_t)n;
     const int bits = 64 - __builtin_clzll(h->freq_bound | 1ull) + h->slot_bits;
-    top_pass = h->freq_bound_known ? std::min(7, std::max(0, (bits + 7) / 8 - 1)) : 7;
+    top_pass = h->freq_bound_known ? std::min(kLevels - 1, std::max(0, (bits + kDigitBits - 1) / kDigitBits - 1))
+                                   : kLevels - 1;
   }
+  hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
+                     epoch, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
   // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs; one launch per pass with the LAST
   // workgroup picking the digit: the agent-scope fences it needs write back the L2 of every XCD, 0.22 -> 0.72 ms
   // beside the training kernels.  What works: every workgroup of pass p recomputes the digits of the passes above
-  // it from their histograms in its prologue -- select_chain -- so there is no pick kernel at all)
-  for (int pass = top_pass; pass >= 0; --pass)
+  // level above it from that level's histogram in its prologue -- select_level -- so there is no pick kernel at all)
+  for (int pass = top_pass - 1; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
-  hipLaunchKernelGGL(k_victims, dim3((unsigned)cdiv(C, 1024)), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
+  hipLaunchKernelGGL(k_victims, dim3((unsigned)cdiv(C, 4096)), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
                      (const uint32_t*)h->hist, top_pass, slot);
   CE_PHASE();
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
@@ -2439,11 +2507,12 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     // ---- victims -> HBM staging (fast); rows beyond the staging capacity (rare) are written back directly
     // by k_evict; map clear, free-slot list, admit stay on the caller's stream
     const long long scap = (long long)L.stage_rows;
-    const int sgrid = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    static const int stage_blocks = [] { const char* e = getenv("CE_STAGE_BLOCKS"); return e ? atoi(e) : 512; }();
+    const int sgrid = (int)std::min<int64_t>(stage_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
     WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
     if (h->vec) {
       hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
+                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
@@ -2451,7 +2520,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
                            h->rowlen, h->g_log2, h->ctl);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
+                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
@@ -2463,8 +2532,6 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
       CE_HIP_CHECK(hipEventRecord(h->wb->out_ev[wbuf], s));
       h->wb->push_out();
     }
-    hipLaunchKernelGGL(k_evict_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->victims,
-                       c.cached_idx_map, c.inverted_cached_idx, (int32_t*)nullptr, h->ctl);
   } else {
     rc = staged_swap(h, s);
     if (rc) return rc;
@@ -2484,7 +2551,8 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     // the command processor until the worker's hipStreamWriteValue64 behind the last piece has executed
     const long long scap = (long long)L.stage_rows;
     CE_HIP_CHECK(hipStreamWaitValue64(s, h->wb->sig, (uint64_t)in_job, hipStreamWaitValueGte, ~0ull));
-    const int ugrid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    static const int unpack_blocks = [] { const char* e = getenv("CE_UNPACK_BLOCKS"); return e ? atoi(e) : 1024; }();
+    const int ugrid = (int)std::min<int64_t>(unpack_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
     if (h->vec) {
       hipLaunchKernelGGL((k_unpack_admitted<f32x4>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const f32x4*)h->in_stage, (f32x4*)c.cache_weight,

@@ -53,6 +53,12 @@ def pick_transport(transport: Optional[str], ids_per_call: int) -> Optional[str]
     return transport
 
 
+# Owner-exclusive rows in the fused backward (presort_window(..., ids=...)): measured round 3 -- the presort that
+# marks them costs 4x (208 vs 50 us per window) and the backward gains 2-3 us per batch at best, so
+# the window pipelines only use it when asked to.
+EXCLUSIVE_ROWS = bool(int(__import__("os").environ.get("CE_EXCLUSIVE_ROWS", "0")))
+
+
 class PrefetchWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
                  presort: bool = False, transport: Optional[str] = "auto", bag_layout=None):
@@ -102,7 +108,7 @@ class PrefetchWindow:
             lay = self._layout or {}
             # source-row keys: the ids go along, so rows owned by one lane group get plain read-modify-writes
             def with_ids(t, rows):
-                return dict(ids=t.reshape(-1).long().contiguous().view(rows, -1)) if lay else {}
+                return dict(ids=t.reshape(-1).long().contiguous().view(rows, -1)) if (lay and EXCLUSIVE_ROWS) else {}
             if len(set(counts)) == 1:                           # equal batches: one launch for the window
                 keys = presort_window(slots.view(len(counts), counts[0]), C, **lay, **with_ids(cat, len(counts)))
                 self._keys_tmp = [keys[i] for i in range(len(counts))]
@@ -185,7 +191,7 @@ class GraphedWindow:
             if self.presort else None
         # id range of every 16384-lookup segment (source-row keys only): min > max = "no ids seen" until a presort ran
         self._ranges = None
-        if self.presort and self._layout is not None:
+        if self.presort and self._layout is not None and EXCLUSIVE_ROWS:
             self._ranges = [torch.empty(self.P, self._klen // 16384, 2, dtype=torch.int64, device=dev) for _ in range(2)]
             for r in self._ranges:
                 r[..., 0] = torch.iinfo(torch.int64).min       # "everything": never disjoint -> atomics
@@ -238,7 +244,7 @@ class GraphedWindow:
             per = lay["offsets"].shape[-1]
             step_fn(self._bufs[buf][i], i, SrcKeys(self._keys[buf][i], per - 1 if lay["include_last_offset"] else per,
                                                    lay["include_last_offset"], lay["hook_features"],
-                                                   self._ranges[buf][i]))
+                                                   self._ranges[buf][i] if self._ranges is not None else None))
         elif self.presort:
             step_fn(self._bufs[buf][i], i, self._keys[buf][i])
         else:
