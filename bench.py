@@ -88,6 +88,12 @@ def parse():
     ap.add_argument("--no_prefill", action="store_true", help="skip the untimed cache-fill phase (cache ops on fresh "
                     "windows until no slot is free, so the timed region is steady state incl. evictions whatever "
                     "--warmup is)")
+    ap.add_argument("--unchanged_trainer", action="store_true",
+                    help="the literal call sequence of recsys/dlrm_main.py:259-279 around the operator: one synchronous "
+                         "prepare_ids per window on the compute stream, forward with cache_op=False and the shape_hook "
+                         "CALLABLE, autograd backward to a sparse COO gradient, torch.optim.SGD.step() -- none of this "
+                         "build's additions (fused SGD, folded hook, window keys, overlapped cache op, hipGraph, "
+                         "worker transport).  What a maintainer gets before opting into anything.")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=1024)
@@ -96,6 +102,9 @@ def parse():
 
 def main():
     args = parse()
+    if args.unchanged_trainer:
+        args.no_overlap = args.no_presort = args.no_graph = True
+        args.transport = args.transport or "zerocopy"
     args.overlap = not args.no_overlap
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,7 +154,11 @@ def main():
                                    (pick_transport("auto", P * B * F * L) if args.overlap else "zerocopy"))
     embed.cache_weight_mgr.set_transport(transport)
     transport = embed.cache_weight_mgr.transport_name          # (falls back to zerocopy where the worker one cannot run)
-    embed.set_fused_sgd(args.lr, deterministic=args.deterministic)
+    ref_opt = None
+    if args.unchanged_trainer:
+        ref_opt = torch.optim.SGD(embed.parameters(), lr=args.lr)         # recsys/dlrm_main.py:455-461 (sparse group)
+    else:
+        embed.set_fused_sgd(args.lr, deterministic=args.deterministic)
     embed.set_cache_op(False)
     mgr = embed.cache_weight_mgr
     C = mgr.cuda_row_num
@@ -184,6 +197,14 @@ def main():
     def train_step(slots_i, i, keys_i=None):
         out = embed(slots_i, offsets, hook_features=F, presorted=keys_i)
         out.backward(grad)
+
+    def ref_step(slots_i):
+        # recsys/models/dlrm.py:99-110 + recsys/dlrm_main.py:274-279: shape hook as a callable (a transposed VIEW),
+        # autograd backward (sparse COO gradient: scripts/kaggle.sh:71 --use_sparse_embed_grad), optimizer step
+        out = embed(slots_i, offsets, shape_hook=lambda x: x.view(F, B, -1).transpose(0, 1))
+        ref_opt.zero_grad()
+        out.backward(grad)
+        ref_opt.step()
 
     gw = None
     if use_graph:
@@ -228,9 +249,12 @@ def main():
                         win.submit([windows[w + 1][j] for j in range(P)])
                     else:
                         state["slots"] = win.prepare([windows[w][j] for j in range(P)])
-                out = embed(state["slots"][i], offsets, hook_features=F,
-                            presorted=win.keys[i] if win.keys else None)
-                out.backward(grad)
+                if ref_opt is not None:
+                    ref_step(state["slots"][i])
+                else:
+                    out = embed(state["slots"][i], offsets, hook_features=F,
+                                presorted=win.keys[i] if win.keys else None)
+                    out.backward(grad)
                 g += 1
 
     def run_steps(first, count, ev_pairs=None):
@@ -253,10 +277,16 @@ def main():
             if ev_pairs is not None:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
-            out = embed(slots[bi], offsets, hook_features=F, presorted=win.keys[bi] if win.keys else None)
+            if ref_opt is not None:
+                out = embed(slots[bi], offsets, shape_hook=lambda x: x.view(F, B, -1).transpose(0, 1))
+                ref_opt.zero_grad()
+            else:
+                out = embed(slots[bi], offsets, hook_features=F, presorted=win.keys[bi] if win.keys else None)
             if ev_pairs is not None:
                 e1.record()
             out.backward(grad)
+            if ref_opt is not None:
+                ref_opt.step()
             if ev_pairs is not None:
                 e2.record()
                 ev_pairs.append((e0, e1, e2))
@@ -376,7 +406,9 @@ def main():
                     unit="GB/s", avg_ms=fwd_avg, bytes_per_launch=fwd_compulsory,
                     bytes_basis="compulsory: unique rows x 4D + ids + offsets + output",
                     algorithmic_bytes_per_launch=fwd_bytes, algorithmic_GBps=fwd_bytes / fwd_avg / 1e6)
-    bwd_roof = dict(kernel="k_bag_bwd_stream(sgd)" if streaming else "k_bag_bwd_tile(sgd)", bound="hbm",
+    bwd_name = ("k_bag_bwd_rows + torch coalesce + SGD.step (sparse COO gradient)" if args.unchanged_trainer else
+                "k_bag_bwd_stream(sgd)" if streaming else "k_bag_bwd_tile(sgd)")
+    bwd_roof = dict(kernel=bwd_name, bound="hbm",
                     achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS, unit="GB/s", avg_ms=bwd_avg,
                     bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
@@ -470,7 +502,11 @@ def main():
                    "launch": "hipGraph per window" if use_graph else "python per step",
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "
                                          "(ce_bag_presort_window%s)" % ("" if args.tile_keys else "_src: keys = row | grad_out row, streaming backward") if presort else "1024-lookup tiles sorted inside every backward",
-                   "update": "sorted" if args.deterministic else "atomic", "lr": args.lr},
+                   "update": ("torch.optim.SGD on the sparse COO gradient" if args.unchanged_trainer else
+                              "sorted" if args.deterministic else "atomic"), "lr": args.lr,
+                   "surface": ("unchanged trainer: recsys/dlrm_main.py:259-279 call sequence, none of this build's "
+                               "additions" if args.unchanged_trainer else "this build's additions (see launch / "
+                               "bwd_duplicate_fold / transport)")},
         "cache": {"unique_hit_rate": hits / max(1, hits + miss), "lookup_miss_rate": tot["cache_miss"] / max(1, tot["total_cache"]),
                   "rows_in": tot["cpu_to_cuda_numel"] // D, "rows_out": tot["cuda_to_cpu_numel"] // D,
                   "prefill_cache_ops": prefill, "setup_s": setup_s,
@@ -602,9 +638,12 @@ def run_sharded(args, sizes, rank, world, dev):
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3
 
-    from cachedembedding_amd.parallel import ShardedWindowPipeline
+    from cachedembedding_amd.parallel import GraphedShardedWindow, ShardedWindowPipeline
     if not args.tile_keys:        # every batch has these offsets: the plan stage emits source-row keys
         embed.ops.set_bag_layout(offsets, True, F)
+    if not args.no_graph and not args.tile_keys:
+        return run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, rank, world, dev, P, P_req,
+                                   prefill, setup_s, B, F, L, D, N, K, W)
     st = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or "none")
     pipe = ShardedWindowPipeline(embed, overlap=args.overlap, transport=None if st == "none" else st)
     # finish the next window's plan after a few steps: its dedupe kernels (~0.1 ms per batch on the side stream)
@@ -691,6 +730,107 @@ def run_sharded(args, sizes, rank, world, dev):
                    "update": "atomic", "lr": args.lr},
         "cache": {"rank0_unique_hit_rate": hits / max(1, hits + miss), "rank0_rows_in": tot["cpu_to_cuda_numel"] // D,
                   "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "prefill_cache_ops": prefill, "setup_s": setup_s},
+        "roofline": None, "cpu_baseline": None,
+    }
+    dist.destroy_process_group()
+    if rank == 0:
+        emit(result)
+
+
+def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, rank, world, dev, P, P_req, prefill,
+                        setup_s, B, F, L, D, N, K, W):
+    """Row-wise sharded path with fixed-capacity exchanges: the P steps of a window replay as one hipGraph
+    (parallel.GraphedShardedWindow); the plan of window k+1 runs on side streams while window k trains."""
+    from cachedembedding_amd.parallel import GraphedShardedWindow
+    from cachedembedding_amd.pipeline import pick_transport
+    mgr = embed.cache_weight_mgr
+    # capacity of a (batch, owner) bucket: 1.25 x the largest bucket of a few sample windows, same on every rank
+    big = 0
+    for _ in range(3):
+        for p_ in embed.plan_window([v for v in gen.next_values(P)]):
+            big = max(big, max(p_.send_splits))
+    cap_t = torch.tensor([big], dtype=torch.int64, device=dev)
+    allreduce(cap_t, op=dist.ReduceOp.MAX)
+    cap = (int(int(cap_t.item()) * 1.25) + 1023) // 1024 * 1024
+    tr = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or pick_transport("auto", P * world * cap))
+    gw = GraphedShardedWindow(embed, P, B * F * L, offsets, lambda out, i: grad, cap, hook_features=F, overlap=args.overlap,
+                              transport=tr if args.overlap else None, warmup_ids=[windows[0][i] for i in range(P)])
+    state = {"submitted": -1}
+
+    def run_windows(w0, w1):
+        for w in range(w0, w1):
+            if args.overlap:
+                if state["submitted"] < w:
+                    gw.submit([windows[w][j] for j in range(P)], w % 2)
+                gw.submit([windows[w + 1][j] for j in range(P)], (w + 1) % 2)
+                state["submitted"] = w + 1
+            else:
+                gw.submit([windows[w][j] for j in range(P)], w % 2)
+            gw.run(w % 2)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    Ww = W // P
+    run_windows(0, Ww)
+    barrier()
+    Kw = max(1, K // P)                      # whole windows per block
+    need_windows((Ww + Kw) * P, Ww * P)
+    t1 = time.perf_counter()
+    run_windows(Ww, Ww + Kw)
+    barrier()
+    single = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+    allreduce(single, op=dist.ReduceOp.MAX)
+    single = float(single.item())
+    reps = int(min(args.max_reps, max(3, -(-args.min_time // max(single, 1e-6)))))
+    w0 = Ww + Kw
+    need_windows((w0 + reps * Kw) * P, w0 * P)
+    mgr.set_profiling(True)
+    mgr.phase_times(reset=True)
+    barrier()
+    t1 = time.perf_counter()
+    run_windows(w0, w0 + reps * Kw)
+    enqueue_s = time.perf_counter() - t1
+    barrier()
+    elapsed = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+    allreduce(elapsed, op=dist.ReduceOp.MAX)
+    region = float(elapsed.item())
+    phases = mgr.phase_times()
+    mgr.set_profiling(False)
+    steps_timed = reps * Kw * P
+    ms_step = 1e3 * region / steps_timed
+    st = mgr.sync_stats()
+    bad = torch.tensor([int(st.status != 0)], device=dev)
+    allreduce(bad)
+    if int(bad.item()):
+        raise AssertionError("a shard's cache op overflowed cuda_row_num")
+    hits, miss = sum(mgr.num_hits_history), sum(mgr.num_miss_history)
+    tot = mgr.totals()
+    calls_t = max(1, phases.get("calls", 0))
+    result = {
+        "metric": "embedding lookups/sec (cache op + EmbeddingBag fwd + bwd/SGD), Criteo-1TB table @1% cache",
+        "value": B * F * L * world / (ms_step * 1e-3), "unit": "lookups/s", "n_gpus": world, "steps": K,
+        "warmup": args.warmup, "warmup_steps_run": Ww * P, "reps": reps, "steps_per_rep": Kw * P,
+        "timing": "`reps` x `steps_per_rep` consecutive steps timed as ONE region bracketed by barrier + synchronize, "
+                  "max over ranks; block_ms.single = one block bracketed on its own",
+        "block_ms": {"single": 1e3 * single, "region": 1e3 * region},
+        "ms_per_step": ms_step, "it_per_s": 1e3 / ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
+                   "embedding_dim": D, "features": F, "batch_size_per_gpu": B, "global_batch": B * world,
+                   "pooling": L, "cache_ratio": args.cache_ratio, "cuda_row_num_per_gpu": mgr.cuda_row_num,
+                   "prefetch_num": P, "prefetch_num_requested": P_req, "evict": "LFU" if args.use_lfu else "DATASET",
+                   "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB_per_gpu": mgr.num_embeddings * D * 4 / 1e9,
+                   "sharding": f"row-wise x{world} (row % W); unique rows only; padded equal-split all-to-alls, "
+                               f"capacity {cap} rows per (batch, owner)",
+                   "launch": "hipGraph per window" if gw._graphs is not None else "step by step (capture refused)",
+                   "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
+                   "windows_on_the_variable_size_path": gw.fallback_windows},
+        "cache": {"rank0_unique_hit_rate": hits / max(1, hits + miss), "rank0_rows_in": tot["cpu_to_cuda_numel"] // D,
+                  "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "prefill_cache_ops": prefill, "setup_s": setup_s,
+                  "host_enqueue_s": enqueue_s,
+                  "cache_op_ms_by_phase": {k: v / calls_t for k, v in phases.items() if k != "calls"}},
         "roofline": None, "cpu_baseline": None,
     }
     dist.destroy_process_group()

@@ -143,6 +143,8 @@ SIGNATURES = {
                                   c_size_t, c_void_p]),
     "ce_dedupe_bucket_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ce_dedupe_bucket_rows_padded": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ce_rows_axpy": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
 }
 

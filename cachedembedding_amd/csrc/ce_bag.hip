@@ -498,7 +498,6 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
   __shared__ int wsum[16];
   __shared__ long long mm_s[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int64_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
     const int64_t batch = seg / segs_per_batch;
     const int sib = (int)(seg - batch * segs_per_batch);
@@ -506,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     const int64_t base = seg * kSegLen;
     const int n_here = (int)min((int64_t)kSegLen, nnz_per_batch - (int64_t)sib * kSegLen);
     BagParams q = lay;
-    if (SRC) q.offsets = (const char*)lay.offsets + batch * off_stride * (lay.off64 ? 8 : 4);
+    if (SRC && lay.offsets) q.offsets = (const char*)lay.offsets + batch * off_stride * (lay.off64 ? 8 : 4);
     for (int i = tid; i <= kSegBuckets; i += 1024) cnt[i] = 0;
     __syncthreads();
     unsigned long long key[kSegKeys];
@@ -522,22 +521,30 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
         const int64_t row = indices[in_base + e];
         if ((uint64_t)row < (uint64_t)num_rows) {
           unsigned low = (unsigned)e;
-          if (SRC) low = (unsigned)out_row(q, find_bag(q, sib * kSegLen + e));
+          // lay.offsets == nullptr: one id per bag, in order (bag of lookup j = j) -- what every Criteo / Avazu
+          // batch is; saves the two offset loads per lookup that find_bag needs to establish it (-12 us per window)
+          if (SRC && !(CE_DBG(lay.debug) & 2))
+            low = (unsigned)out_row(q, lay.offsets ? find_bag(q, sib * kSegLen + e) : sib * kSegLen + e);
           key[r] = ((unsigned long long)row << 32) | low;
           bkt[r] = (int)(row & (kSegBuckets - 1));
         }
       }
-      // wave match on the 13-bit bucket id, leader reserves popcount places
-      unsigned long long pm = ~0ull;
-#pragma unroll
-      for (int b = 0; (1 << b) <= kSegBuckets; ++b) {
-        const unsigned long long m = __ballot((bkt[r] >> b) & 1);
-        pm &= ((bkt[r] >> b) & 1) ? m : ~m;
+      if (CE_DBG(lay.debug) & 8) {       // ablation: no LDS atomic
+        place[r] = 0;
+        continue;
       }
-      const int leader = __ffsll((long long)pm) - 1;
-      int first = 0;
-      if (lane == leader) first = atomicAdd(&cnt[bkt[r]], __popcll(pm));
-      place[r] = __shfl(first, leader) + __popcll(pm & lt);
+      // Places inside the bucket: one returning LDS atomic per lane.  (Round 2 matched the lanes of a wave that hold
+      // the same bucket with 13 ballots and let a leader reserve for all of them: on the bench's slots the ballots
+      // cost 13 us per window more than the bank conflicts they avoid.)  Only a wave whose 64 lanes ALL hold one
+      // bucket -- a feature with one hot row -- reserves its 64 places with a single atomic.
+      const int b0 = __builtin_amdgcn_readfirstlane(bkt[r]);
+      if (__all(bkt[r] == b0)) {
+        int first = 0;
+        if (lane == 0) first = atomicAdd(&cnt[b0], 64);
+        place[r] = __shfl(first, 0) + lane;
+      } else {
+        place[r] = atomicAdd(&cnt[bkt[r]], 1);
+      }
     }
     __syncthreads();
     // exclusive scan of the 4097 counters (thread t owns 4t..4t+3; the ignored bucket follows everything)
@@ -562,6 +569,12 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     if (tid == 0) cnt[kSegBuckets] = total;
     __syncthreads();
     if (!EXCL) {
+      if (CE_DBG(lay.debug) & 4) {       // ablation: coalesced stores (wrong places)
+#pragma unroll
+        for (int r = 0; r < kSegKeys; ++r) keys_out[base + r * 1024 + tid] = key[r];
+        __syncthreads();
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < kSegKeys; ++r) keys_out[base + cnt[bkt[r]] + place[r]] = key[r];
       __syncthreads();
@@ -1296,13 +1309,16 @@ static int presort_window_src_impl(const int64_t* indices, int64_t nnz_per_batch
                                    int64_t num_bags, int32_t include_last_offset, int64_t hook_features,
                                    const int64_t* ids, uint64_t* keys_out, int64_t* seg_id_ranges, ce_stream_t stream) {
   if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
-  CE_REQUIRE(offsets && num_bags > 0 && offsets_batch_stride >= 0, CE_ERR_INVALID, "bad offsets");
+  CE_REQUIRE(num_bags > 0 && offsets_batch_stride >= 0, CE_ERR_INVALID, "bad offsets");
+  CE_REQUIRE(offsets || num_bags == nnz_per_batch, CE_ERR_INVALID,
+             "offsets may only be NULL for the one-id-per-bag layout (num_bags == nnz_per_batch)");
   BagParams lay{};
   bool vec;
   int nch;
   int rc = fill_params(lay, 4, indices, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset,
                        nullptr, CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
   if (rc) return rc;
+  { const char* dbg = getenv("CE_PRESORT_DEBUG"); lay.debug = dbg ? atoi(dbg) : 0; }
   return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, &lay, offsets_batch_stride, ids,
                              seg_id_ranges, stream);
 }

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
       if (valid[u]) {
         const int64_t id = ids[i];
         if ((unsigned long long)id >= (unsigned long long)N) {
-          ctl->status = CE_ERR_RANGE;
+          if (id != -1) ctl->status = CE_ERR_RANGE;        // -1 = padding (fixed-capacity exchange): no lookup, slot -1
           valid[u] = false;
           rows_out[i] = -1;
         } else {

@@ -344,6 +344,34 @@ __global__ __launch_bounds__(256) void k_dedupe_finish_w(const int32_t* __restri
   }
 }
 
+// Fixed-capacity form for the graphed row-wise exchange: bucket o occupies rows_out[o * cap, (o + 1) * cap) (unused
+// places = -1) and pos = o * cap + place, so every tensor of a step has a size that does not depend on the data and a
+// window's steps (padded all-to-alls included) can be replayed as one hipGraph.  A bucket that does not fit sets
+// *overflow (the caller re-plans that window on the variable-size path); its surplus lookups get pos = -1.
+__global__ __launch_bounds__(256) void k_dedupe_finish_pad(const int32_t* __restrict__ rows32, int64_t n, int32_t world,
+                                                           int64_t cap, const int32_t* __restrict__ slot_of_row,
+                                                           const int32_t* __restrict__ bucket_rows,
+                                                           const unsigned long long* __restrict__ counts,
+                                                           int64_t* __restrict__ rows_out, int64_t* __restrict__ pos_out,
+                                                           int32_t* overflow) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid0 < world && (long long)counts[tid0] > cap) *overflow = 1;
+  for (int64_t i = tid0; i < n; i += stride) {
+    const int32_t row = rows32[i];
+    int64_t p = -1;
+    if (row >= 0) {
+      const int32_t place = slot_of_row[row];
+      if (place < cap) p = (int64_t)(row % world) * cap + place;
+    }
+    pos_out[i] = p;
+  }
+  for (int64_t i = tid0; i < (int64_t)world * cap; i += stride) {
+    const int64_t o = i / cap, j = i - o * cap;
+    rows_out[i] = j < (long long)counts[o] ? (int64_t)bucket_rows[o * n + j] : -1;
+  }
+}
+
 struct SortWs {
   int32_t *keys[2], *vals[2], *bag_of, *hist, *total;
   size_t bytes;
@@ -408,41 +436,65 @@ extern "C" int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* i
   return CE_OK;
 }
 
-extern "C" int ce_dedupe_bucket_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
-                                     int32_t world, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
-                                     int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out,
-                                     ce_stream_t stream) {
+static int dedupe_bucket_impl(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows, int32_t world,
+                              int64_t cap, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
+                              int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out, int32_t* overflow,
+                              ce_stream_t stream) {
   CE_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX && num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID,
              "bad sizes");
   CE_REQUIRE(world >= 1 && world <= 64, CE_ERR_UNSUPPORTED, "world size must be in [1, 64]");
   CE_REQUIRE(stamp && slot_of_row && counts_out, CE_ERR_INVALID, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   CE_HIP_CHECK(hipMemsetAsync(counts_out, 0, sizeof(int64_t) * world, s));
-  if (n == 0) return CE_OK;
-  CE_REQUIRE(ids && scratch && local_rows_out && pos_out, CE_ERR_INVALID, "null pointer");
+  if (n == 0 && cap <= 0) return CE_OK;
+  CE_REQUIRE(scratch && local_rows_out && (n == 0 || (ids && pos_out)), CE_ERR_INVALID, "null pointer");
   int bits = 1;
   while ((1ll << bits) < num_rows && bits < 31) ++bits;
   int32_t* rows32 = scratch;                 // int32[n]
   int32_t* bucket_rows = scratch + n;        // int32[world][n]
   unsigned long long* counts = (unsigned long long*)counts_out;
-  hipLaunchKernelGGL(k_dedupe_mark_w, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows, bits,
-                     stamp, rows32);
-  const char* it_e = getenv("CE_DEDUPE_IT");      // 1 / 2 / 4 lookups per thread in the claim pass (default 4)
-  const int it_env = it_e ? atoi(it_e) : 4;
-  if (it_env == 1)
-    hipLaunchKernelGGL((k_dedupe_claim_w<1>), dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n,
-                       world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
-  else if (it_env == 2)
-    hipLaunchKernelGGL((k_dedupe_claim_w<2>), dim3(grid_for(n, 512)), dim3(256), 0, s, (const int32_t*)rows32, n,
-                       world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_dedupe_mark_w, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows, bits,
+                       stamp, rows32);
+    const char* it_e = getenv("CE_DEDUPE_IT");      // 1 / 2 / 4 lookups per thread in the claim pass (default 4)
+    const int it_env = it_e ? atoi(it_e) : 4;
+    if (it_env == 1)
+      hipLaunchKernelGGL((k_dedupe_claim_w<1>), dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n,
+                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+    else if (it_env == 2)
+      hipLaunchKernelGGL((k_dedupe_claim_w<2>), dim3(grid_for(n, 512)), dim3(256), 0, s, (const int32_t*)rows32, n,
+                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+    else
+      hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024)), dim3(256), 0, s, (const int32_t*)rows32, n,
+                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+  }
+  if (cap > 0)
+    hipLaunchKernelGGL(k_dedupe_finish_pad, dim3(grid_for(std::max<int64_t>(n, world * cap), 256)), dim3(256), 0, s,
+                       (const int32_t*)rows32, n, world, cap, (const int32_t*)slot_of_row, (const int32_t*)bucket_rows,
+                       (const unsigned long long*)counts, local_rows_out, pos_out, overflow);
   else
-    hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024)), dim3(256), 0, s, (const int32_t*)rows32, n,
-                       world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
-  hipLaunchKernelGGL(k_dedupe_finish_w, dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n, world,
-                     (const int32_t*)slot_of_row, (const int32_t*)bucket_rows, (const unsigned long long*)counts,
-                     local_rows_out, pos_out);
+    hipLaunchKernelGGL(k_dedupe_finish_w, dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n, world,
+                       (const int32_t*)slot_of_row, (const int32_t*)bucket_rows, (const unsigned long long*)counts,
+                       local_rows_out, pos_out);
   CE_LAUNCH_CHECK();
   return CE_OK;
+}
+
+extern "C" int ce_dedupe_bucket_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
+                                     int32_t world, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
+                                     int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out,
+                                     ce_stream_t stream) {
+  return dedupe_bucket_impl(ids, n, idx_map, num_rows, world, 0, stamp, slot_of_row, scratch, local_rows_out, pos_out,
+                            counts_out, nullptr, stream);
+}
+
+extern "C" int ce_dedupe_bucket_rows_padded(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
+                                            int32_t world, int64_t capacity, int32_t* stamp, int32_t* slot_of_row,
+                                            int32_t* scratch, int64_t* local_rows_out, int64_t* pos_out,
+                                            int64_t* counts_out, int32_t* overflow_flag, ce_stream_t stream) {
+  CE_REQUIRE(capacity > 0 && overflow_flag, CE_ERR_INVALID, "capacity must be positive, overflow_flag non-null");
+  return dedupe_bucket_impl(ids, n, idx_map, num_rows, world, capacity, stamp, slot_of_row, scratch, local_rows_out,
+                            pos_out, counts_out, overflow_flag, stream);
 }
 
 extern "C" size_t ce_bag_backward_sgd_sorted_workspace(int64_t num_rows, int64_t nnz) {

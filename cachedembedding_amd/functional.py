@@ -238,6 +238,15 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                         padding_idx is not None or bool(masked_indices))
 
 
+def is_identity_layout(offsets: torch.Tensor, include_last_offset: bool) -> bool:
+    """True when the offsets describe one id per bag, in order (offsets == arange): ONE host comparison, meant for
+    set-up time of a pipeline whose batches all share these offsets."""
+    if offsets.dim() != 1:
+        return False
+    n = offsets.numel()
+    return bool(torch.equal(offsets.long(), torch.arange(n, device=offsets.device)))
+
+
 def presort_len(n: int) -> int:
     """elements of the key tensor presort_slots writes for n lookups (n rounded up to whole 16384-lookup segments)"""
     return int(lib.ce_bag_presort_len(int(n)))
@@ -258,7 +267,7 @@ def presort_slots(slots: torch.Tensor, num_rows: int, out: Optional[torch.Tensor
 def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.Tensor] = None, *,
                    offsets: Optional[torch.Tensor] = None, include_last_offset: bool = False,
                    hook_features: int = 0, ids: Optional[torch.Tensor] = None,
-                   ranges_out: Optional[torch.Tensor] = None):
+                   ranges_out: Optional[torch.Tensor] = None, identity_bags: bool = False):
     """Grouped keys for the P equal-sized batches of a prefetch window in one launch (ce_bag_presort_window).
     slots: [P, n] int64 (the cache op's output) -> keys [P, presort_len(n)]; row b is what
     embedding_bag(presorted=...) takes for batch b.
@@ -271,7 +280,10 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
 
     ids given as well ([P, n] int64: the ids `slots` was computed from, position by position): the keys also mark the
     rows a single lane group of the backward owns, and every SrcKeys carries the id range of its segments
-    (ce_bag_presort_window_src_excl) -- the fused-SGD backward then updates those rows without atomics."""
+    (ce_bag_presort_window_src_excl) -- the fused-SGD backward then updates those rows without atomics.
+
+    identity_bags=True: the caller has checked that `offsets` is arange(n + 1) -- one id per bag, in order, what every
+    Criteo / Avazu batch is (is_identity_layout) -- so the kernel need not read the offsets to establish it."""
     assert slots.dim() == 2 and slots.is_contiguous() and slots.dtype == torch.int64
     P, n = slots.shape
     klen = presort_len(n)
@@ -288,8 +300,11 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
     if hook_features and num_bags % hook_features:
         raise ValueError("hook_features must divide the number of bags")
     kv = keys_out.view(P, klen)
+    if identity_bags:
+        assert num_bags == n, "identity_bags needs one id per bag"
+    off_ptr = None if identity_bags else ptr(offsets)
     if ids is None:
-        check(lib.ce_bag_presort_window_src(ptr(slots), n, P, int(num_rows), ptr(offsets),
+        check(lib.ce_bag_presort_window_src(ptr(slots), n, P, int(num_rows), off_ptr,
                                             int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
                                             num_bags, int(include_last_offset), int(hook_features), ptr(keys_out),
                                             stream_ptr()))
@@ -299,7 +314,7 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
     if ranges_out is None:
         ranges_out = torch.empty(P, segs, 2, dtype=torch.int64, device=slots.device)
     assert ranges_out.is_contiguous() and ranges_out.dtype == torch.int64 and ranges_out.numel() == P * segs * 2
-    check(lib.ce_bag_presort_window_src_excl(ptr(slots), n, P, int(num_rows), ptr(offsets),
+    check(lib.ce_bag_presort_window_src_excl(ptr(slots), n, P, int(num_rows), off_ptr,
                                              int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
                                              num_bags, int(include_last_offset), int(hook_features), ptr(ids),
                                              ptr(keys_out), ptr(ranges_out), stream_ptr()))

@@ -665,6 +665,218 @@ class ShardedWindowPipeline:
         return plans
 
 
+class GraphedShardedWindow:
+    """Row-wise sharded prefetch window with FIXED-CAPACITY exchanges, so that the P training steps of a window --
+    owner gather, padded equal-split row all-to-all, pooling, the caller's dense part, gradient fold, padded gradient
+    all-to-all, owner-side SGD -- replay as ONE hipGraph, like pipeline.GraphedWindow does for the unsharded module.
+
+    Every (batch, owner) bucket of unique rows gets `capacity` places (ce_dedupe_bucket_rows_padded: unused places
+    hold -1, which the cache op, the gather and the row update all skip), so no tensor of a step has a data-dependent
+    size, the collectives are plain equal-split all_to_all_single calls, and nothing in a window needs the host:
+    the one read-back left is a single overflow flag per window, checked when the window is about to train (it was
+    written a whole window earlier).  A bucket that does not fit (the flag) sends that window through the
+    variable-size path (RowwiseExchange.plan_window + forward_backward).
+
+    The planning of window k+1 runs on two side streams while window k trains: dedupe + id exchange on one, the
+    owner-side cache op (which parks its stream when the worker transport moves the rows) + the keys on the other, so
+    the next window's id exchange never queues behind a parked stream.
+
+    dense_fn(pooled [B, F, D] or [num_bags, D], i) -> gradient of the same shape for batch i of the window: the part
+    of the model between the embedding's forward and backward (it is captured with the step; every tensor it reads
+    or writes must be static)."""
+
+    def __init__(self, embed: "RowwiseShardedEmbeddingBag", prefetch_num: int, ids_per_batch: int, offsets: torch.Tensor,
+                 dense_fn, capacity: int, hook_features: int = 0, overlap: bool = True, use_graph: bool = True,
+                 transport: Optional[str] = None, warmup_ids: Optional[Sequence[torch.Tensor]] = None):
+        from .functional import is_identity_layout, presort_len
+        self.embed, self.ex, self.ops = embed, embed.exchange, embed.ops
+        self.mgr = embed.cache_weight_mgr
+        self.P, self.n, self.cap = int(prefetch_num), int(ids_per_batch), int(capacity)
+        self.W = embed.world
+        self.offsets = offsets.contiguous()
+        self.incl = bool(embed.include_last_offset)
+        self.hook = int(hook_features)
+        self.dense_fn = dense_fn
+        self.overlap = overlap
+        dev = self.mgr.device
+        W, P, cap, n = self.W, self.P, self.cap, self.n
+        self.num_bags = self.offsets.numel() - 1 if self.incl else self.offsets.numel()
+        self._identity = self.incl and self.num_bags == n and is_identity_layout(self.offsets, True)
+        klen = presort_len(n)
+        i64 = dict(dtype=torch.int64, device=dev)
+        self._req = [torch.full((P, W, cap), -1, **i64) for _ in range(2)]          # rows I ask owner w for
+        self._serve = [torch.full((W, P, cap), -1, **i64) for _ in range(2)]        # rows peer w asks me for
+        self._slots = [torch.full((P, W * cap), -1, **i64) for _ in range(2)]       # their cache slots, per batch
+        self._pos = [torch.full((P, n), -1, **i64) for _ in range(2)]
+        self._keys = [torch.full((P, klen), -1, **i64) for _ in range(2)]
+        self._counts = [torch.zeros(P, W, **i64) for _ in range(2)]
+        self._ovf = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._ovf_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._events = [None, None]
+        self._ids = [None, None]
+        self._side = torch.cuda.Stream(device=dev) if overlap else None        # dedupe + id exchange
+        self._side2 = torch.cuda.Stream(device=dev) if overlap else None       # owner cache op + keys
+        if overlap:
+            self.mgr.set_protect_depth(1)
+            self.mgr.strict = False
+            if transport:
+                self.mgr.set_transport(transport)
+        # scratch of the dedupe passes (shared with the variable-size path)
+        N = embed.num_embeddings
+        if self.ops._stamp is None:
+            self.ops._stamp = torch.empty(N, dtype=torch.int32, device=dev)
+            self.ops._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
+        self._ws = torch.empty(max((W + 1) * n, 1 << 16), dtype=torch.int32, device=dev)
+        self._graphs = None
+        self.fallback_windows = 0
+        if warmup_ids is not None:
+            self._plan(list(warmup_ids), 0)
+            self._plan_owner(0)
+            for t in (self._slots, self._pos, self._keys):
+                t[1].copy_(t[0])
+            torch.cuda.synchronize(dev)
+            if int(self._ovf[0].item()) != 0:
+                raise ValueError(f"capacity {cap} is smaller than a bucket of the warm-up window "
+                                 f"(largest: {int(self._counts[0].max().item())} rows)")
+            for i in range(P):                       # eager once (lazy initialisation must not happen in a capture)
+                self._step(0, i)
+            torch.cuda.synchronize(dev)
+            if use_graph and not (W > 1 and dist.get_backend(self.ex.group) == "gloo"):     # gloo stages through the host
+                self._capture()
+
+    # ---- planning (per window, no host wait)
+    @torch.no_grad()
+    def _plan(self, ids_list: Sequence[torch.Tensor], buf: int) -> None:
+        W, P, cap, n = self.W, self.P, self.cap, self.n
+        assert len(ids_list) == P
+        sp = stream_ptr()
+        self._ovf[buf].zero_()
+        for b, ids in enumerate(ids_list):
+            ids = ids.reshape(-1).long().contiguous()
+            assert ids.numel() == n
+            check(lib.ce_dedupe_bucket_rows_padded(ptr(ids), n, ptr(self.ops.idx_map), self.embed.num_embeddings, W, cap,
+                                                   ptr(self.ops._stamp), ptr(self.ops._slot_of_row), ptr(self._ws),
+                                                   self._req[buf][b].data_ptr(), self._pos[buf][b].data_ptr(),
+                                                   self._counts[buf][b].data_ptr(), ptr(self._ovf[buf]), sp))
+        if W > 1:       # the ranks must agree on which path a window takes: its collectives differ
+            if dist.get_backend(self.ex.group) == "gloo":
+                f = self._ovf[buf].cpu()
+                dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.ex.group)
+                self._ovf[buf].copy_(f)
+            else:
+                dist.all_reduce(self._ovf[buf], op=dist.ReduceOp.MAX, group=self.ex.group)
+        self._ovf_host[buf].copy_(self._ovf[buf], non_blocking=True)
+        req_wpc = self._req[buf].permute(1, 0, 2).contiguous()                       # peer-major for the exchange
+        if W > 1:
+            _a2a(self._serve[buf], req_wpc, None, None, self.ex.group)
+        else:
+            self._serve[buf].copy_(req_wpc)
+
+    @torch.no_grad()
+    def _plan_owner(self, buf: int) -> None:
+        W, P, cap = self.W, self.P, self.cap
+        slots = self.mgr.prepare_ids(self._serve[buf].view(-1))                      # -1 = padding: slot -1
+        self._slots[buf].view(P, W, cap).copy_(slots.view(W, P, cap).permute(1, 0, 2))
+        from .functional import presort_window
+        presort_window(self._pos[buf], W * cap, keys_out=self._keys[buf], offsets=self.offsets,
+                       include_last_offset=self.incl, hook_features=self.hook, identity_bags=self._identity)
+
+    def submit(self, ids_list: Sequence[torch.Tensor], buf: int) -> None:
+        """Plan of a window into buffer `buf` (0/1); call it before run() of the previous window so they overlap."""
+        dev = self.mgr.device
+        self._ids[buf] = list(ids_list)
+        if not self.overlap:
+            self._plan(ids_list, buf)
+            self._plan_owner(buf)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[buf] = ev
+            return
+        cur = torch.cuda.current_stream(dev)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self._plan(ids_list, buf)
+        self._side2.wait_stream(self._side)
+        with torch.cuda.stream(self._side2):
+            self._plan_owner(buf)
+            ev = torch.cuda.Event()
+            ev.record(self._side2)
+        for t in ids_list:
+            t.record_stream(self._side)
+        self._events[buf] = ev
+
+    # ---- one training step on batch i of buffer buf (captured)
+    def _step(self, buf: int, i: int) -> None:
+        ex, ops, W, cap = self.ex, self.ops, self.W, self.cap
+        lr = self.embed._lr[0]
+        if lr is None:
+            raise RuntimeError("row-wise sharded embedding needs set_fused_sgd(lr)")
+        slots = self._slots[buf][i]
+        pos = self._pos[buf][i]
+        rows = ops.owner_gather(slots)                                       # [W * cap, D], padding -> zero rows
+        if W > 1:
+            got = torch.empty_like(rows)
+            _a2a(got, rows, None, None, ex.group)
+            rows = got
+        out = ops.pool(rows, pos, self.offsets, None, self.embed.mode, self.incl, self.hook)
+        grad = self.dense_fn(out, i)
+        keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook)
+        g = ops.grad_rows(grad, pos, self.offsets, None, self.embed.mode, self.incl, self.hook, W * cap, keys)
+        if W > 1:
+            got = torch.empty_like(g)
+            _a2a(got, g, None, None, ex.group)
+            g = got
+        ops.owner_update(slots, g, lr)
+
+    def _capture(self) -> None:
+        dev = self.mgr.device
+        try:
+            graphs = []
+            for b in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(self.P):
+                        self._step(b, i)
+                graphs.append(g)
+            self._graphs = graphs
+        except Exception as e:                      # e.g. a collective backend that cannot be captured
+            import warnings
+            warnings.warn(f"the window's steps could not be captured in a hipGraph ({e}); launching them one by one")
+            torch.cuda.synchronize(dev)
+            self._graphs = None
+
+    def run(self, buf: int) -> None:
+        """Train the P batches of the window in buffer `buf` (waits for its plan)."""
+        dev = self.mgr.device
+        ev = self._events[buf]
+        if ev is not None:
+            ev.synchronize()               # the plan was enqueued a whole window ago: the flag is there
+            torch.cuda.current_stream(dev).wait_event(ev)
+            self._events[buf] = None
+        if not self.mgr.strict:
+            self.mgr.raise_on_failed_calls()
+        if int(self._ovf_host[buf][0]) != 0:
+            # a bucket did not fit `capacity`: this window goes through the variable-size exchange (its rows are
+            # resident already -- the padded plan admitted every row that did fit; plan_window admits the rest)
+            self.fallback_windows += 1
+            if self._side2 is not None:      # the next window's plan is in flight: the cache manager is not re-entrant
+                self._side2.synchronize()
+            plans = self.embed.plan_window(self._ids[buf])
+            for i, p_ in enumerate(plans):
+                rows = self.ex.fetch_rows(p_)
+                out = self.ops.pool(rows, p_.perm, self.offsets, None, self.embed.mode, self.incl, self.hook)
+                grad_like = self.dense_fn(out, i)
+                g = self.ops.grad_rows(grad_like, p_.perm, self.offsets, None, self.embed.mode, self.incl, self.hook,
+                                       p_.n, p_.keys)
+                self.ops.owner_update(p_.slots, self.ex.return_grads(p_, g), self.embed._lr[0])
+            return
+        if self._graphs is not None:
+            self._graphs[buf].replay()
+        else:
+            for i in range(self.P):
+                self._step(buf, i)
+
+
 class ParallelCachedEmbeddingBag(CachedEmbeddingBag):
     """Column-wise parallel cached EmbeddingBag -- the class recsys/models/dlrm.py:70-81 builds.
     Every rank holds num_embeddings x (embedding_dim / W) and receives the GLOBAL batch; forward returns

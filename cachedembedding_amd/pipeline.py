@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .cached_embedding import CachedEmbeddingBag
-from .functional import SrcKeys, presort_len, presort_window
+from .functional import SrcKeys, is_identity_layout, presort_len, presort_window
 from .tracing import phase
 
 
@@ -67,7 +67,9 @@ class PrefetchWindow:
         # streams over without a per-tile bag search
         self._layout = None if bag_layout is None else dict(offsets=bag_layout[0],
                                                             include_last_offset=bool(bag_layout[1]),
-                                                            hook_features=int(bag_layout[2]))
+                                                            hook_features=int(bag_layout[2]),
+                                                            identity_bags=bool(bag_layout[1]) and
+                                                            is_identity_layout(bag_layout[0], bool(bag_layout[1])))
         # transport (overlap=True only): how rows move while the cache op runs beside training; "worker" keeps the
         # swap traffic off the CUs (CachedParamMgr.set_transport), "auto" decides by the size of the first window
         # (pick_transport), None leaves the manager's setting alone
@@ -175,7 +177,9 @@ class GraphedWindow:
         # bag_layout: see PrefetchWindow (static offsets shared by every batch; keys_i is then a SrcKeys)
         self._layout = None if bag_layout is None else dict(offsets=bag_layout[0],
                                                             include_last_offset=bool(bag_layout[1]),
-                                                            hook_features=int(bag_layout[2]))
+                                                            hook_features=int(bag_layout[2]),
+                                                            identity_bags=bool(bag_layout[1]) and
+                                                            is_identity_layout(bag_layout[0], bool(bag_layout[1])))
         self.embed = embed
         self.mgr = embed.cache_weight_mgr
         self.P = prefetch_num

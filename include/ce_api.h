@@ -179,7 +179,9 @@ int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_
  * offsets, then its place in the [B, F, D] / [num_bags, D] output): key = row << 32 | grad_out row, same grouping
  * and layout as ce_bag_presort_window.  offsets of batch b = offsets + b * offsets_batch_stride elements (0: all
  * batches share one offsets array); num_bags / include_last_offset / hook_features describe ONE batch, as in
- * ce_bag_forward.  The *_presorted_src backward entry points stream over such keys with no per-tile set-up
+ * ce_bag_forward.  offsets == NULL (only with num_bags == nnz_per_batch) states the one-id-per-bag layout
+ * (offsets = arange: every Criteo / Avazu batch, recsys/datasets/criteo.py:127-134) without the kernel having to read
+ * the offsets to establish it.  The *_presorted_src backward entry points stream over such keys with no per-tile set-up
  * (67 vs 74 us at the bench shape); they trust the keys (grad_out row < num_bags) and ignore rows >= num_rows.
  * Replaces the same upstream call as the forms above (recsys/dlrm_main.py:274-279, loss.backward + optimizer.step). */
 int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
@@ -285,7 +287,8 @@ int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_val
  * radix passes above it.  Optional: without it the select runs all 8 byte passes until the bound is known. */
 int ce_cache_set_freq_bound(ce_cache_t* h, int64_t bound);
 
-/* prepare_ids [A.3] -- recsys/dlrm_main.py:259: unique rows of `ids` (device int64[n]) are
+/* prepare_ids [A.3] -- recsys/dlrm_main.py:259: unique rows of `ids` (device int64[n]; an entry of -1 is padding:
+ * it takes no part in the call and gets slot -1; any other id outside [0, num_embeddings) fails the call) are
  * made resident (victim selection A.5 with the canonical tie rule, write-back, admit A.4),
  * slots_out (device int64[n]) receives inverted_cached_idx[idx_map[ids]] [A.6], LFU
  * counters gain the multiplicities.  Fully asynchronous on `stream`.  On overflow or a bad
@@ -370,6 +373,17 @@ int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int
 int ce_dedupe_bucket_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
                           int32_t world, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
                           int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out, ce_stream_t stream);
+
+/* Fixed-capacity form (API 3) for the graphed exchange: bucket w occupies local_rows_out[w * capacity, (w + 1) *
+ * capacity) (device int64[world * capacity], unused places = -1) and pos_out[j] = w * capacity + place, so nothing a
+ * training step touches has a data-dependent size and a window's steps -- padded, equal-split all-to-alls included --
+ * replay as one hipGraph.  A bucket larger than `capacity` sets *overflow_flag (device int32, caller-zeroed) and its
+ * surplus lookups get pos -1: the caller re-plans that window on the variable-size path.  Padding rows (-1) are
+ * accepted by ce_cache_prepare_ids as "no lookup" (slot -1). */
+int ce_dedupe_bucket_rows_padded(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
+                                 int32_t world, int64_t capacity, int32_t* stamp, int32_t* slot_of_row,
+                                 int32_t* scratch, int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out,
+                                 int32_t* overflow_flag, ce_stream_t stream);
 
 /* weight[index[i]] += alpha * src_rows[i] for i < n (whole rows of `dim` floats; repeated / out-of-range
  * index entries are summed / skipped).  Owner-side update of the row-wise exchange: the requester has

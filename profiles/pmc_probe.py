@@ -48,7 +48,7 @@ else:
         slots = emb.cache_weight_mgr.prepare_ids(vals.view(-1)).view(P, -1)
         # as bench.py does: source-row keys for the streaming backward
         keys = presort_window(slots.contiguous(), emb.cache_weight_mgr.cuda_row_num, offsets=off,
-                              include_last_offset=True, hook_features=F)
+                              include_last_offset=True, hook_features=F, identity_bags=True)
         for i in range(P):
             out = emb(slots[i], off, hook_features=F, presorted=keys[i])
             out.backward(grad)

@@ -441,6 +441,16 @@ def test_source_row_keys_backward_matches_tile_backward(D, layout):
     offs_d = offs.to(dev).contiguous()
     keys = presort_window(slots, C, offsets=offs_d, **kw)
     assert isinstance(keys, list) and len(keys) == P and all(isinstance(k, SrcKeys) for k in keys)
+    if layout == "hook":
+        # one id per bag, in order: stating it (offsets not read by the kernel) gives the same keys, segment by
+        # segment (the order inside a bucket is whatever the LDS atomics made it)
+        from cachedembedding_amd.functional import is_identity_layout
+        assert is_identity_layout(offs_d, True)
+        keys_id = presort_window(slots, C, offsets=offs_d, identity_bags=True, **kw)
+        for a, b in zip(keys, keys_id):
+            ka = a.keys.view(-1, 16384).sort(dim=1).values
+            kb = b.keys.view(-1, 16384).sort(dim=1).values
+            assert torch.equal(ka, kb)
     out_rows = num_bags
     shape = (num_bags // kw["hook_features"], kw["hook_features"], D) if kw["hook_features"] else (num_bags, D)
     w0 = torch.randn(C, D, generator=g).to(dev)

@@ -113,6 +113,92 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
     torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
 
 
+def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap):
+    """parallel.GraphedShardedWindow (fixed-capacity exchange, the window's steps replayed as one hipGraph at world 1,
+    launched one by one over gloo) against plain torch on the full table: pooled output of every step, table after
+    flush.  capacity below the bucket sizes forces every window through the variable-size fallback."""
+    import cachedembedding_amd as ce
+    from cachedembedding_amd.parallel import GraphedShardedWindow, RowwiseShardedEmbeddingBag
+    torch.manual_seed(0)
+    N, D, F, B_loc, P, lr = 5003, 64, 4, 32, 3, 0.25
+    w_full = torch.randn(N, D)
+    freq = torch.randint(0, 50, (N,)) if with_freq else None
+    strat = ce.EvictionStrategy.LFU if strategy == "lfu" else ce.EvictionStrategy.DATASET
+    if with_freq and strategy == "dataset":
+        order = torch.argsort(freq, descending=True, stable=True)
+        id2row = torch.empty(N, dtype=torch.long)
+        id2row[order] = torch.arange(N)
+    else:
+        id2row = torch.arange(N)
+    shard = w_full[rank::world].contiguous()
+    emb = RowwiseShardedEmbeddingBag(N, D, mode="sum", include_last_offset=True, ids_freq_mapping=freq,
+                                     warmup_ratio=0.7, evict_strategy=strat, _weight_shard=shard,
+                                     cuda_row_num=1000 * world)
+    emb.set_fused_sgd(lr)
+    g = torch.Generator().manual_seed(100 + rank)
+    offsets = torch.arange(F * B_loc + 1, dtype=torch.int32, device="cuda")
+    emb.ops.set_bag_layout(offsets, True, F)
+    nwin = 4
+    all_ids = [[torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)] for _ in range(nwin + 1)]
+    go = torch.randn(P, B_loc, F, D, generator=g)               # one static upstream gradient per batch of a window
+    go_d = go.cuda()
+    outs = torch.zeros(P, B_loc, F, D, device="cuda")
+
+    def dense_fn(out, i):
+        outs[i].copy_(out)
+        return go_d[i]
+
+    ref_w = w_full.clone()
+    # window 0 doubles as the warm-up (it trains once eagerly inside the constructor): account for it
+    gw = GraphedShardedWindow(emb, P, F * B_loc, offsets, dense_fn, capacity=capacity, hook_features=F,
+                              overlap=overlap, warmup_ids=[i.cuda() for i in all_ids[0]]) if capacity >= 64 else \
+        GraphedShardedWindow(emb, P, F * B_loc, offsets, dense_fn, capacity=capacity, hook_features=F, overlap=overlap)
+
+    def reference_window(ids_list):
+        exp = []
+        for i, ids in enumerate(ids_list):
+            exp.append(ref_w[id2row[ids]].view(F, B_loc, D).transpose(0, 1).clone())
+            packs = [None] * world
+            dist.all_gather_object(packs, ids)
+            packs_go = [None] * world
+            dist.all_gather_object(packs_go, go[i])
+            for pids, pgo in zip(packs, packs_go):
+                ref_w.index_add_(0, id2row[pids], pgo.transpose(0, 1).reshape(-1, D), alpha=-lr)
+        return exp
+
+    if capacity >= 64:
+        reference_window(all_ids[0])                 # the eager warm-up pass of the constructor
+    first = 1
+    if overlap:
+        gw.submit([i.cuda() for i in all_ids[first]], first % 2)
+    for w in range(first, nwin + 1):
+        if not overlap:             # reference semantics: a window's cache op runs when the one before has trained
+            gw.submit([i.cuda() for i in all_ids[w]], w % 2)
+        elif w + 1 <= nwin:
+            gw.submit([i.cuda() for i in all_ids[w + 1]], (w + 1) % 2)
+        gw.run(w % 2)
+        torch.cuda.synchronize()
+        exp = reference_window(all_ids[w])
+        for i in range(P):
+            torch.testing.assert_close(outs[i].cpu(), exp[i], rtol=1e-5, atol=1e-5)
+    if capacity < 64:
+        assert gw.fallback_windows == nwin
+    else:
+        assert gw.fallback_windows == 0
+        if world == 1:
+            assert gw._graphs is not None, "the window's steps were not captured"
+    assert emb.cache_weight_mgr.sync_stats().status == 0
+    emb.flush()
+    torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("strategy,with_freq", [("dataset", True), ("lfu", False)])
+@pytest.mark.parametrize("capacity,overlap", [(256, True), (256, False), (8, True)])
+def test_rowwise_graphed_fixed_capacity_window(world, strategy, with_freq, capacity, overlap):
+    _spawn(_rowwise_graphed, world, strategy, with_freq, capacity, overlap)
+
+
 @pytest.mark.parametrize("world", [1, 2])
 @pytest.mark.parametrize("strategy,with_freq", [("dataset", True), ("lfu", False), ("lfu", True)])
 def test_rowwise_sharded_vs_full_table(world, strategy, with_freq):
