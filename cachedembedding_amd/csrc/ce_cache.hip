@@ -1498,7 +1498,8 @@ struct SwapEngine {
   // over PCIe into in_stage -- no host gather, no staging copy.  The worker thread still orders it (miss list ready,
   // earlier write-backs landed) and releases the parked cache-op stream from the host when the kernel has finished.
   // 16 workgroups x 1024 threads: 28 MB in ~0.6 ms; wider grids finish sooner but slow the training kernels
-  // (8: 0.92 ms admission wait, 2.08 G lookups/s; 16: 0.50 ms, 2.63 G; 32: 0.33 ms, 2.46 G; 64: 0.15 ms, 2.18 G)
+  // (round 2: 8: 0.92 ms admission wait, 2.08 G lookups/s; 16: 0.50 ms, 2.63 G; 32: 0.33 ms, 2.46 G; 64: 0.15 ms, 2.18 G.
+  // round 3, with the shorter cache-op chain: 16: 0.61 ms, 2.70 G; 20: 0.55 ms, 2.72 G; 24: 0.53 ms, 2.67 G; 32: 2.5-2.66 G)
   bool admit_by_kernel = false;
   const int32_t* miss_list_dev = nullptr;
   const void* table_dev = nullptr;
@@ -1627,7 +1628,7 @@ struct SwapEngine {
         // small jobs (prefetch_num 1-2: the cache-op stream is the critical path and waits for every microsecond of
         // this) get 32 workgroups, window-sized jobs 16 (training is the critical path: see the table above).
         // Kaggle 5 % P = 1 (25 k rows): 0.93 -> 1.02 G lookups/s; P = 2: 1.38 -> 1.44 G
-        const int blocks = admit_blocks > 0 ? admit_blocks : (n <= 49152 ? 32 : 16);
+        const int blocks = admit_blocks > 0 ? admit_blocks : (n <= 49152 ? 32 : 20);
         if (vec)
           hipLaunchKernelGGL((k_admit<f32x4>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
                              (const int32_t*)nullptr, (const long long*)nullptr, n, (const f32x4*)table_dev,
