@@ -102,6 +102,7 @@ def parse():
 
 def main():
     args = parse()
+    quiet_stdout()
     if args.unchanged_trainer:
         args.no_overlap = args.no_presort = args.no_graph = True
         args.transport = args.transport or "zerocopy"
@@ -522,15 +523,30 @@ def main():
         emit(result)
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner) goes to
+    stderr; emit() restores the descriptor for the line itself."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(result):
-    """The JSON line must be the LAST thing on stdout: flush whatever C libraries (RCCL's version banner) still
-    hold in stdio buffers first."""
+    """The JSON line must be the only thing on stdout: flush whatever C libraries still hold in stdio buffers
+    (into stderr, see quiet_stdout), then write the line to the real descriptor."""
     import ctypes
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
     sys.stdout.write(json.dumps(result) + "\n")
     sys.stdout.flush()
 

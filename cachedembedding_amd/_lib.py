@@ -129,6 +129,7 @@ SIGNATURES = {
     "ce_cache_set_protect_depth": (c_int, [c_void_p, c_int32]),
     "ce_cache_set_transport": (c_int, [c_void_p, c_int32]),
     "ce_cache_get_transport": (c_int32, [c_void_p]),
+    "ce_cache_set_cache_weight": (c_int, [c_void_p, c_void_p]),
     "ce_cache_set_buffer_rows": (c_int, [c_void_p, c_int64]),
     "ce_cache_set_profiling": (c_int, [c_void_p, c_int32]),
     "ce_cache_phase_count": (c_int32, []),
@@ -145,6 +146,8 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ce_dedupe_bucket_rows_padded": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ce_exchange_local_index": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                        c_void_p, c_void_p]),
     "ce_rows_axpy": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
 }
 

@@ -365,6 +365,30 @@ class CachedParamMgr(torch.nn.Module):
             check(rc)
         self._transport = self._TRANSPORTS[name]
 
+    def reserve_tail(self, rows: int) -> torch.Tensor:
+        """fp32 [rows, D] lying right behind the cache in ONE allocation (the cache moves there, contents kept;
+        `cuda_cached_weight` stays the same Parameter object).  The row-wise exchange receives into it, so that
+        "cache + received rows" is one table for the bag kernels (ce_exchange_local_index).  Blocks until the device
+        is idle; call it before anything that captured the cache's address (hipGraphs)."""
+        rows = int(rows)
+        C, D = self.cuda_row_num, self.embedding_dim
+        full = getattr(self, "_cache_full", None)
+        if full is None or full.shape[0] < C + rows:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize(self.device)
+                full = torch.empty(C + rows, D, device=self.device, dtype=torch.float32)
+                full[:C].copy_(self.cuda_cached_weight.data)
+                full[C:].zero_()
+                check(lib.ce_cache_set_cache_weight(self._handle, full.data_ptr()))
+            self.cuda_cached_weight.data = full[:C]
+            self._cache_full = full
+        return self._cache_full[C:C + rows]
+
+    @property
+    def cache_with_tail(self) -> torch.Tensor:
+        """the allocation `reserve_tail` made: cache rows first, the tail behind them"""
+        return self._cache_full
+
     @property
     def transport_name(self) -> str:
         """the transport in force -- the library falls back from 'worker' to 'zerocopy' (with a message on stderr)

@@ -2776,6 +2776,14 @@ extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
 
 extern "C" int32_t ce_cache_get_transport(ce_cache_t* h) { return h ? h->cfg.transport : -1; }
 
+extern "C" int ce_cache_set_cache_weight(ce_cache_t* h, float* cache_weight) {
+  CE_REQUIRE(h && cache_weight, CE_ERR_INVALID, "null handle / pointer");
+  CE_REQUIRE(!h->vec || ((uintptr_t)cache_weight & 15) == 0, CE_ERR_INVALID, "the cache must keep its 16-byte alignment");
+  CE_HIP_CHECK(hipDeviceSynchronize());       // nothing in flight may still address the old allocation
+  h->cfg.cache_weight = cache_weight;
+  return CE_OK;
+}
+
 extern "C" int ce_cache_set_profiling(ce_cache_t* h, int32_t on) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
   if (on && !h->prof) h->prof = new PhaseProf();

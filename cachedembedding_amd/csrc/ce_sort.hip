@@ -372,6 +372,24 @@ __global__ __launch_bounds__(256) void k_dedupe_finish_pad(const int32_t* __rest
   }
 }
 
+// Requester side of the row-wise exchange, local bypass.  The rows a rank asks ITSELF for never travel: the place
+// of such a lookup is replaced by the cache slot its own owner-side cache op resolved, every other place p becomes
+// tail_base + p, a row of the exchange buffer that lies right behind the cache in the same allocation -- so the
+// pooling and the fused update address "cache + received rows" as ONE table with one index.
+__global__ __launch_bounds__(256) void k_exchange_local_index(const int64_t* __restrict__ pos, int64_t n_per_batch,
+                                                              int64_t total, const int64_t* __restrict__ slots,
+                                                              int64_t slots_batch_stride, int64_t lo, int64_t hi,
+                                                              int64_t tail_base, int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t p = pos[i];
+    int64_t r = -1;
+    if (p >= lo && p < hi) r = slots[(i / n_per_batch) * slots_batch_stride + p];
+    else if (p >= 0) r = tail_base + p;
+    out[i] = r;
+  }
+}
+
 struct SortWs {
   int32_t *keys[2], *vals[2], *bag_of, *hist, *total;
   size_t bytes;
@@ -495,6 +513,20 @@ extern "C" int ce_dedupe_bucket_rows_padded(const int64_t* ids, int64_t n, const
   CE_REQUIRE(capacity > 0 && overflow_flag, CE_ERR_INVALID, "capacity must be positive, overflow_flag non-null");
   return dedupe_bucket_impl(ids, n, idx_map, num_rows, world, capacity, stamp, slot_of_row, scratch, local_rows_out,
                             pos_out, counts_out, overflow_flag, stream);
+}
+
+extern "C" int ce_exchange_local_index(const int64_t* pos, int64_t n_per_batch, int64_t n_batches,
+                                       const int64_t* slots, int64_t slots_batch_stride, int64_t local_lo,
+                                       int64_t local_hi, int64_t tail_base, int64_t* index_out, ce_stream_t stream) {
+  const int64_t total = n_per_batch * n_batches;
+  if (total <= 0) return CE_OK;
+  CE_REQUIRE(pos && index_out && (slots || local_hi <= local_lo), CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(local_lo >= 0 && local_hi <= slots_batch_stride && tail_base >= 0, CE_ERR_INVALID,
+             "the local range must lie inside one batch's slots");
+  hipLaunchKernelGGL(k_exchange_local_index, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                     n_per_batch, total, slots, slots_batch_stride, local_lo, local_hi, tail_base, index_out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
 }
 
 extern "C" size_t ce_bag_backward_sgd_sorted_workspace(int64_t num_rows, int64_t nnz) {

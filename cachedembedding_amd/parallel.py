@@ -347,6 +347,14 @@ class HipShardOps(ShardOps):
                                             _MODES[mode], hook_features, ptr(grad_out.contiguous()), stream_ptr()))
         return g
 
+    def update_table(self, table, grad_out, keys: "SrcKeys", nnz: int, lr: float):
+        """table[row] -= lr * (sum of the gradient rows of its lookups) in place, lookups grouped by `keys`
+        (source-row keys over `table`'s rows): the fused backward + SGD of the unsharded module on a table that
+        holds the cache and, behind it, the exchange buffer (GraphedShardedWindow)."""
+        check(lib.ce_bag_backward_sgd_presorted_src(ptr(table), table.shape[0], self.dim, int(nnz),
+                                                    ptr(grad_out.contiguous()), float(lr), ptr(keys.keys),
+                                                    stream_ptr()))
+
     def owner_update(self, slots, grad_rows, lr):
         n = slots.numel()
         if n == 0:
@@ -677,6 +685,13 @@ class GraphedShardedWindow:
     written a whole window earlier).  A bucket that does not fit (the flag) sends that window through the
     variable-size path (RowwiseExchange.plan_window + forward_backward).
 
+    Local bypass: the receive buffer lies right behind the cache in ONE allocation (CachedParamMgr.reserve_tail) and
+    every lookup's index is either the cache slot of its row -- when this rank owns the row -- or a row of that buffer
+    (ce_exchange_local_index), so pooling and the fused gradient fold + SGD run ONCE over "cache + received rows":
+    rows a rank owns itself are read and updated in place and never pass the exchange buffers (1 / W of the rows; all
+    of them at W = 1, where the step is the unsharded module's).  For the rest the fold leaves -lr * (sum of
+    gradients) in the zeroed buffer, which travels back and is added to the owners' rows.
+
     The planning of window k+1 runs on two side streams while window k trains: dedupe + id exchange on one, the
     owner-side cache op (which parks its stream when the worker transport moves the rows) + the keys on the other, so
     the next window's id exchange never queues behind a parked stream.
@@ -727,12 +742,21 @@ class GraphedShardedWindow:
             self.ops._stamp = torch.empty(N, dtype=torch.int32, device=dev)
             self.ops._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
         self._ws = torch.empty(max((W + 1) * n, 1 << 16), dtype=torch.int32, device=dev)
+        if embed.mode != "sum":
+            raise NotImplementedError("GraphedShardedWindow: mode='sum' only (the fused fold + update)")
+        self.rank = self.ops.rank
+        self._C = self.mgr.cuda_row_num
+        self._tail = self.mgr.reserve_tail(W * cap)                                 # rows received, behind the cache
+        self._table = self.mgr.cache_with_tail[:self._C + W * cap]
+        self._idx = [torch.full((P, n), -1, **i64) for _ in range(2)]               # lookup -> row of _table
+        self._slots_remote = [torch.full((P, W * cap), -1, **i64) for _ in range(2)] if W > 1 else None
+        self._recv = torch.empty(W * cap, embed.embedding_dim, dtype=torch.float32, device=dev) if W > 1 else None
         self._graphs = None
         self.fallback_windows = 0
         if warmup_ids is not None:
             self._plan(list(warmup_ids), 0)
             self._plan_owner(0)
-            for t in (self._slots, self._pos, self._keys):
+            for t in (self._slots, self._pos, self._keys, self._idx) + ((self._slots_remote,) if W > 1 else ()):
                 t[1].copy_(t[0])
             torch.cuda.synchronize(dev)
             if int(self._ovf[0].item()) != 0:
@@ -777,8 +801,14 @@ class GraphedShardedWindow:
         W, P, cap = self.W, self.P, self.cap
         slots = self.mgr.prepare_ids(self._serve[buf].view(-1))                      # -1 = padding: slot -1
         self._slots[buf].view(P, W, cap).copy_(slots.view(W, P, cap).permute(1, 0, 2))
+        r = self.rank
+        check(lib.ce_exchange_local_index(ptr(self._pos[buf]), self.n, P, ptr(self._slots[buf]), W * cap, r * cap,
+                                          (r + 1) * cap, self._C, ptr(self._idx[buf]), stream_ptr()))
+        if W > 1:                      # what the owner side still serves: everything but this rank's own requests
+            self._slots_remote[buf].copy_(self._slots[buf])
+            self._slots_remote[buf].view(P, W, cap)[:, r].fill_(-1)
         from .functional import presort_window
-        presort_window(self._pos[buf], W * cap, keys_out=self._keys[buf], offsets=self.offsets,
+        presort_window(self._idx[buf], self._C + W * cap, keys_out=self._keys[buf], offsets=self.offsets,
                        include_last_offset=self.incl, hook_features=self.hook, identity_bags=self._identity)
 
     def submit(self, ids_list: Sequence[torch.Tensor], buf: int) -> None:
@@ -811,22 +841,19 @@ class GraphedShardedWindow:
         lr = self.embed._lr[0]
         if lr is None:
             raise RuntimeError("row-wise sharded embedding needs set_fused_sgd(lr)")
-        slots = self._slots[buf][i]
-        pos = self._pos[buf][i]
-        rows = ops.owner_gather(slots)                                       # [W * cap, D], padding -> zero rows
+        idx = self._idx[buf][i]
         if W > 1:
-            got = torch.empty_like(rows)
-            _a2a(got, rows, None, None, ex.group)
-            rows = got
-        out = ops.pool(rows, pos, self.offsets, None, self.embed.mode, self.incl, self.hook)
+            rows = ops.owner_gather(self._slots_remote[buf][i])             # [W * cap, D]; padding / own chunk: zeros
+            _a2a(self._tail, rows, None, None, ex.group)
+        out = ops.pool(self._table, idx, self.offsets, None, "sum", self.incl, self.hook)
         grad = self.dense_fn(out, i)
         keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook)
-        g = ops.grad_rows(grad, pos, self.offsets, None, self.embed.mode, self.incl, self.hook, W * cap, keys)
         if W > 1:
-            got = torch.empty_like(g)
-            _a2a(got, g, None, None, ex.group)
-            g = got
-        ops.owner_update(slots, g, lr)
+            self._tail.zero_()
+        ops.update_table(self._table, grad, keys, self.n, lr)               # own rows: SGD in place; tail: -lr * sum g
+        if W > 1:
+            _a2a(self._recv, self._tail, None, None, ex.group)
+            ops.owner_update(self._slots_remote[buf][i], self._recv, -1.0)   # cache row += received delta
 
     def _capture(self) -> None:
         dev = self.mgr.device

@@ -327,6 +327,12 @@ int ce_cache_set_transport(ce_cache_t* h, int32_t transport);
  * hipStreamWaitValue64? -- a property of the process's HIP runtime settings, e.g. GPU_MAX_HW_QUEUES) and falls back
  * to CE_TRANSPORT_ZEROCOPY, with a message on stderr, when they do not. */
 int32_t ce_cache_get_transport(ce_cache_t* h);
+/* Move the cache to another allocation (API 3): `cache_weight` = device fp32 [>= cuda_row_num, D] whose first
+ * cuda_row_num rows the caller has filled with the current cache contents.  Blocks until the device is idle, then
+ * every later call addresses the new rows.  Lets a caller keep extra rows right BEHIND the cache in one allocation
+ * (the row-wise exchange's receive buffer: ce_exchange_local_index).  No upstream counterpart: upstream's
+ * cuda_cached_weight is a torch tensor the caller owns (cache_mgr.py:83-89). */
+int ce_cache_set_cache_weight(ce_cache_t* h, float* cache_weight);
 /* Phase timers of prepare_ids (upstream's per-phase Timer / record_function ranges, recsys/dlrm_main.py:258,294):
  * when on, every call brackets its phases with hipEvents on its own stream (no host sync); ce_cache_phase_times
  * blocks until the calls issued so far have finished and returns the accumulated milliseconds per phase
@@ -384,6 +390,20 @@ int ce_dedupe_bucket_rows_padded(const int64_t* ids, int64_t n, const int32_t* i
                                  int32_t world, int64_t capacity, int32_t* stamp, int32_t* slot_of_row,
                                  int32_t* scratch, int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out,
                                  int32_t* overflow_flag, ce_stream_t stream);
+
+/* Local bypass of the row-wise exchange (API 3).  pos: device int64 [n_batches, n_per_batch], the places
+ * ce_dedupe_bucket_rows_padded returned (bucket * capacity + place, -1 = none); slots: device int64, batch b at
+ * slots + b * slots_batch_stride: the cache slots this rank's owner-side cache op resolved for the rows requested
+ * from it, requester-major.  A rank's request to ITSELF occupies places [local_lo, local_hi) = [rank * capacity,
+ * (rank + 1) * capacity) on both sides, so for those places index_out = slots[b][pos] (the row is read and updated
+ * in the cache, it never passes the exchange buffers); every other place p >= 0 becomes tail_base + p, a row of the
+ * receive buffer the caller keeps tail_base rows behind the cache's first row in the same allocation
+ * (ce_cache_set_cache_weight), so ce_bag_forward / ce_bag_backward_sgd_presorted_src see ONE table of tail_base +
+ * world * capacity rows.  At world 1 the sharded step is then the unsharded one.  No upstream counterpart (upstream
+ * has no row-wise sharding of a cached table). */
+int ce_exchange_local_index(const int64_t* pos, int64_t n_per_batch, int64_t n_batches, const int64_t* slots,
+                            int64_t slots_batch_stride, int64_t local_lo, int64_t local_hi, int64_t tail_base,
+                            int64_t* index_out, ce_stream_t stream);
 
 /* weight[index[i]] += alpha * src_rows[i] for i < n (whole rows of `dim` floats; repeated / out-of-range
  * index entries are summed / skipped).  Owner-side update of the row-wise exchange: the requester has
