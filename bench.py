@@ -70,6 +70,8 @@ def parse():
                     "bag of every lookup per launch) instead of row | grad_out row (streaming backward)")
     ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
                     "hipGraph of the window's P training steps")
+    ap.add_argument("--graph_cache_op", action="store_true", help="zero-copy transport: replay the cache op from a "
+                    "hipGraph of its own instead of launching it kernel by kernel (same speed: DESIGN.md section 4)")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport (= --transport staged)")
     ap.add_argument("--transport", default=None, choices=["worker", "zerocopy", "staged"],
                     help="how rows move between the host table and the cache.  worker (default when the cache op "
@@ -212,8 +214,10 @@ def main():
         from cachedembedding_amd.pipeline import GraphedWindow
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
                            warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort,
-                           transport=None, bag_layout=layout)
-        note("hipGraph of the window's training steps captured")
+                           transport=None, bag_layout=layout,
+                           graph_cache_op=args.graph_cache_op and args.overlap)
+        note("hipGraph of the window's training steps captured" +
+             (" (+ the cache op as a graph of its own)" if gw._plan_graphs is not None else ""))
 
     skip_cache_op = bool(os.environ.get("CE_BENCH_SKIP_CACHE_OP"))      # diagnostic: training kernels only
     state = {"submitted": -1, "slots": None}
@@ -226,7 +230,14 @@ def main():
         g = g0
         while g < g1:
             w, i = divmod(g, P)
-            if use_graph:
+            if use_graph and gw._plan_graphs is not None and i == 0 and g1 - g >= P and not skip_cache_op:
+                # --graph_cache_op: the cache op of window w+1 is a graph replay on the side stream too
+                if state["submitted"] < w:
+                    gw.submit([windows[w][j] for j in range(P)], w % 2)
+                gw.run_and_submit(w % 2, [windows[w + 1][j] for j in range(P)])
+                state["submitted"] = w + 1
+                g += P
+            elif use_graph:
                 if i == 0 and not (skip_cache_op and g0 >= W):
                     if args.overlap:
                         if state["submitted"] < w:

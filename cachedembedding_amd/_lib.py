@@ -130,6 +130,7 @@ SIGNATURES = {
     "ce_cache_set_transport": (c_int, [c_void_p, c_int32]),
     "ce_cache_get_transport": (c_int32, [c_void_p]),
     "ce_cache_set_cache_weight": (c_int, [c_void_p, c_void_p]),
+    "ce_cache_graph_replayed": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "ce_cache_set_buffer_rows": (c_int, [c_void_p, c_int64]),
     "ce_cache_set_profiling": (c_int, [c_void_p, c_int32]),
     "ce_cache_phase_count": (c_int32, []),

@@ -261,7 +261,7 @@ class CachedParamMgr(torch.nn.Module):
             slots = out.view(-1)
         with torch.cuda.device(self.device):
             check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
-        if self.strict:
+        if self.strict and not torch.cuda.is_current_stream_capturing():
             st = CeCallStats()
             rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))
             self._pull_history()
@@ -273,6 +273,12 @@ class CachedParamMgr(torch.nn.Module):
                 raise IndexError(_lib.last_error())
             check(rc)
         return slots.view(shape)
+
+    def graph_replayed(self, n_calls: int, ids_per_call: int) -> None:
+        """Report `n_calls` prepare_ids calls that a hipGraph launched just now on the current stream replayed
+        (prepare_ids issued during a stream capture is recorded into the graph; zero-copy transport only)."""
+        with torch.cuda.device(self.device):
+            check(lib.ce_cache_graph_replayed(self._handle, int(n_calls), int(ids_per_call), stream_ptr()))
 
     def _id_to_cached_cuda_id(self, ids: torch.Tensor) -> torch.Tensor:
         flat = ids.reshape(-1).long().contiguous()

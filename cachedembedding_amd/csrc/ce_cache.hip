@@ -50,6 +50,7 @@ constexpr int kCoarsePad = 32;                  // ints between two coarse count
                                                 // line serialise whatever the address: packed counters cost k_count 15 us)
 constexpr int kSlotsPerBlock = 1024;  // slots covered by one block of the slot-space scans (4/thread)
 constexpr int kRing = 1024;           // pinned host ring of per-call stats
+constexpr unsigned long long kGraphFreqHeadroom = 1ull << 31;   // ids a captured LFU call may see before a new capture
 constexpr int kDigitBits = 11;         // radix select: 11-bit digits (28-bit DATASET keys of a 178 M-row table: 3 passes)
 constexpr int kBins = 1 << kDigitBits;
 constexpr int kLevels = 6;             // 6 x 11 >= 64 bits
@@ -74,7 +75,15 @@ struct Ctl {                 // device control block (one per manager)
   // resolves level q -- every workgroup of that kernel computes the same thing for itself --, read by later kernels)
   unsigned long long sel_prefix_after[8];
   long long sel_krem_after[8];
+  // number of the call in flight (= the host's h->seq).  A launched call brings it along (k_begin stores it); a call
+  // replayed from a captured hipGraph has no per-launch arguments, so there k_begin counts it up itself -- the
+  // epoch of the eviction backlist and the record slot in the stats ring are both derived from it on the device.
+  long long seq;
 };
+
+// call number -> what the kernels need from it (seq_arg != 0: launched with its number; 0: replayed, see Ctl::seq)
+__device__ __forceinline__ long long call_seq(const Ctl* ctl, long long seq_arg) { return seq_arg ? seq_arg : ctl->seq; }
+__device__ __forceinline__ int32_t call_epoch(long long seq) { return (int32_t)(seq & 0x3fffffff); }
 
 struct WbMail {              // pinned host mailbox: how many rows a worker job moves (written by the device)
   long long job;
@@ -160,8 +169,10 @@ __device__ __forceinline__ int wave_sum(int v) {
 // ----------------------------------------------------------------------------- kernels
 
 // per-call reset: the control block's call fields, the coarse chunk sums k_count adds to, the radix histograms
-__global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_coarse2, uint32_t* hist) {
+__global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_coarse2, uint32_t* hist,
+                                               long long seq_arg) {
   if (threadIdx.x == 0) {
+    ctl->seq = seq_arg ? seq_arg : ctl->seq + 1;
     ctl->n_unique = 0;
     ctl->n_miss = 0;
     ctl->k_evict = 0;
@@ -349,9 +360,12 @@ __global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4
 constexpr int kEmitSub = 1;      // (4 chunks per workgroup, contiguous or strided, measured SLOWER: 111 / 56 us against 46)
 __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
                                               const int32_t* __restrict__ blk_miss, const int32_t* __restrict__ coarse,
-                                              int n_chunks, int32_t* miss_list, int32_t* slot_epoch, int32_t epoch,
-                                              Ctl* ctl, int64_t C, int64_t n_ids, ce_call_stats_t* ring_slot,
+                                              int n_chunks, int32_t* miss_list, int32_t* slot_epoch, long long seq_arg,
+                                              Ctl* ctl, int64_t C, int64_t n_ids, ce_call_stats_t* ring,
                                               WbMail* mail_in, long long job, long long in_cap, int32_t* miss_host) {
+  const long long seq_ = call_seq(ctl, seq_arg);
+  const int32_t epoch = call_epoch(seq_);
+  ce_call_stats_t* const ring_slot = ring + (seq_ % kRing);
   __shared__ long long red[2 + kEmitSub][4];
   __shared__ int wsub[kEmitSub][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -514,9 +528,10 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
 __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached_idx_map,
                                               const int64_t* __restrict__ freq,
                                               const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
-                                              int32_t epoch, int32_t depth, int slot_bits, int lfu, int top_pass,
+                                              long long seq_arg, int32_t depth, int slot_bits, int lfu, int top_pass,
                                               unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
   if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin)
+  const int32_t epoch = call_epoch(call_seq(ctl, seq_arg));
   __shared__ uint32_t sh[kBins];
   for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
   __syncthreads();
@@ -669,7 +684,8 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
 
 __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
                                                  int32_t* victims, int64_t cap, Ctl* ctl, const uint32_t* hist,
-                                                 int top_pass, ce_call_stats_t* ring_slot) {
+                                                 int top_pass, ce_call_stats_t* ring, long long seq_arg) {
+  ce_call_stats_t* const ring_slot = ring + (call_seq(ctl, seq_arg) % kRing);
   __shared__ unsigned long long prefix_s;
   __shared__ int fail_s, go_s;
   // this workgroup's 4096 slots (16 per thread, strided by 256): in flight while wave 0 works out the threshold
@@ -1088,9 +1104,13 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ slots, const long long* n_ptr,
                                                     long long n_imm, int32_t* cached_idx_map, int32_t* inverted,
                                                     int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
-                                                    int32_t epoch, Ctl* ctl, ce_call_stats_t* ring_slot,
-                                                    long long seq, const unsigned long long* fail_word,
+                                                    int32_t epoch_imm, Ctl* ctl, ce_call_stats_t* ring,
+                                                    long long seq_arg, const unsigned long long* fail_word,
                                                     long long job) {
+  // ring == NULL (preload): no record to publish, the epoch is the caller's constant
+  const long long seq = ring ? call_seq(ctl, seq_arg) : 0;
+  const int32_t epoch = ring ? call_epoch(seq) : epoch_imm;
+  ce_call_stats_t* const ring_slot = ring ? ring + (seq % kRing) : nullptr;
   // worker transport: the admission worker reports a job it could not complete (failed / timed-out HIP call): the
   // rows never arrived, so nothing may be marked resident.
   const bool lost = fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
@@ -1242,6 +1262,7 @@ __global__ __launch_bounds__(256) void k_flush_maps(int32_t* cached_idx_map, int
 }
 
 __global__ void k_flush_end(int64_t C, Ctl* ctl, ce_call_stats_t* ring_slot, long long seq) {
+  ctl->seq = seq;
   ctl->n_free = C;
   ring_slot->n_ids = 0;
   ring_slot->n_unique = 0;
@@ -1256,6 +1277,7 @@ __global__ void k_flush_end(int64_t C, Ctl* ctl, ce_call_stats_t* ring_slot, lon
 }
 
 __global__ void k_preload_end(long long n, Ctl* ctl, ce_call_stats_t* ring_slot, long long seq) {
+  ctl->seq = seq;
   ctl->n_free -= n;
   ring_slot->n_ids = 0;
   ring_slot->n_unique = n;
@@ -1853,6 +1875,7 @@ struct ce_cache {
   long long hist_base;         // seq of history[0]
   ce::PhaseProf* prof;         // optional per-phase hipEvent timers (ce_cache_set_profiling)
   uint64_t freq_bound;         // LFU: upper bound of any freq_cnter value (shortens the radix select)
+  uint64_t graph_freq_limit;   // LFU: freq_bound the most recently captured call's pass count allows for
   bool freq_bound_known;       // false after a preload with caller-supplied counters until the caller states their max
   long long n_failed;          // finished prepare_ids calls whose status was not CE_OK
   int last_fail_status;
@@ -1968,6 +1991,7 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->hist_base = 1;
   h->prof = nullptr;
   h->freq_bound = 0;
+  h->graph_freq_limit = ~0ull;
   h->freq_bound_known = true;
   h->n_failed = 0;
   h->last_fail_status = CE_OK;
@@ -2359,15 +2383,26 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   CE_REQUIRE(n >= 0 && n <= std::max<int64_t>(h->cfg.max_ids_per_call, 0), CE_ERR_INVALID,
              "n=%lld exceeds max_ids_per_call=%lld", (long long)n, (long long)h->cfg.max_ids_per_call);
   CE_REQUIRE(n == 0 || (ids && slots_out), CE_ERR_INVALID, "null ids/slots");
-  int rc = before_call(h);
-  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  // A call issued while `stream` is being captured becomes part of the caller's hipGraph: it does not run now, so
+  // nothing host-side may depend on it -- no call number (the device counts replays itself, Ctl::seq), no
+  // event, no profiling, no worker hand-shake.  The caller reports every replay with ce_cache_graph_replayed.
+  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+  if (s != nullptr) CE_HIP_CHECK(hipStreamIsCapturing(s, &cap_st));
+  const bool capturing = cap_st == hipStreamCaptureStatusActive;
+  if (capturing) {
+    CE_REQUIRE(h->cfg.transport == CE_TRANSPORT_ZEROCOPY, CE_ERR_UNSUPPORTED,
+               "only the zero-copy transport can be captured in a hipGraph (the others hand rows to host threads)");
+    CE_REQUIRE(!h->prof, CE_ERR_UNSUPPORTED, "switch the phase timers off before capturing a cache op");
+  }
+  int rc = capturing ? CE_OK : before_call(h);
+  if (rc) return rc;
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
   const int64_t N = c.num_embeddings, C = c.cuda_row_num;
-  h->seq += 1;
-  const int32_t epoch = (int32_t)(h->seq & 0x3fffffff);
-  ce_call_stats_t* slot = h->ring_dev + (h->seq % kRing);
+  if (!capturing) h->seq += 1;
+  const long long seq_arg = capturing ? 0ll : (long long)h->seq;     // 0: the device's own count
+  ce_call_stats_t* const ring = h->ring_dev;
   const int lfu = c.evict_strategy == CE_EVICT_LFU;
   const int gpb = 256 >> h->g_log2;
   // swap kernels: small grid (default 2 workgroups per CU's worth of slots is left to training kernels)
@@ -2430,7 +2465,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
 #define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   CE_PHASE();
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, h->coarse,
-                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist);
+                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist, seq_arg);
   {
     // Two shapes (rocprofv3, 3.4 M ids per call).  Rows in frequency order (idx_map present): the hot rows sit in
     // the lowest bitmap words, the LDS window absorbs them, and cold lookups issue their atomicOr directly.
@@ -2461,7 +2496,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss, h->coarse);
   hipLaunchKernelGGL(k_emit, dim3((unsigned)cdiv(L.n_chunks, kEmitSub)), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
-                     h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, epoch, h->ctl, C, n, slot,
+                     h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, ring,
                      worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
                      worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr);
   if (worker) {
@@ -2484,13 +2519,21 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     // seen so far (a call adds at most its own length to a counter), so the digits above that bound are zero in
     // every eligible key.  (k_keys clamps a counter that a caller pushed beyond it -- freq_cnter is the caller's
     // tensor -- so a key never has bits above the top digit.)
-    h->freq_bound += (uint64_t)n;
-    const int bits = 64 - __builtin_clzll(h->freq_bound | 1ull) + h->slot_bits;
+    // (a captured call is replayed an unknown number of times: its pass count allows for kGraphFreqHeadroom more
+    // ids; ce_cache_graph_replayed keeps the bound and asks for a new capture once it is used up)
+    uint64_t bound = h->freq_bound + (uint64_t)n;
+    if (capturing) {
+      bound = h->freq_bound + kGraphFreqHeadroom;
+      h->graph_freq_limit = bound;
+    } else {
+      h->freq_bound = bound;
+    }
+    const int bits = 64 - __builtin_clzll(bound | 1ull) + h->slot_bits;
     top_pass = h->freq_bound_known ? std::min(kLevels - 1, std::max(0, (bits + kDigitBits - 1) / kDigitBits - 1))
                                    : kLevels - 1;
   }
   hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
-                     epoch, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
+                     seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
   // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs; one launch per pass with the LAST
@@ -2500,7 +2543,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   for (int pass = top_pass - 1; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
   hipLaunchKernelGGL(k_victims, dim3((unsigned)cdiv(C, 4096)), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
-                     (const uint32_t*)h->hist, top_pass, slot);
+                     (const uint32_t*)h->hist, top_pass, ring, seq_arg);
   CE_PHASE();
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
   int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
@@ -2538,7 +2581,9 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
     if (rc) return rc;
   }
   CE_PHASE();
-  if (C <= 262144) {
+  // (one workgroup walks 4096 slots per round: beyond a few rounds the pair of wide kernels is faster --
+  // C = 94 k, Avazu at 1 %: 18.3 us against 13.6 us for the pair)
+  if (C <= 16384) {
     hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, h->free_list, h->ctl);
   } else {
     hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
@@ -2631,8 +2676,8 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   }
   hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
                      (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, epoch, h->ctl, slot,
-                     (long long)h->seq, worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, in_job);
+                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl, ring,
+                     seq_arg, worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, in_job);
   CE_PHASE();
   if (n > 0 && lfu) {
     // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
@@ -2646,7 +2691,29 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
 #undef CE_PHASE
   if (prof) prof->pending[pslot] = true;
   CE_LAUNCH_CHECK();
-  CE_HIP_CHECK(hipEventRecord(h->ev, s));
+  if (!capturing) CE_HIP_CHECK(hipEventRecord(h->ev, s));
+  return CE_OK;
+}
+
+extern "C" int ce_cache_graph_replayed(ce_cache_t* h, int64_t n_calls, int64_t ids_per_call, ce_stream_t stream) {
+  CE_REQUIRE(h && n_calls >= 0 && ids_per_call >= 0, CE_ERR_INVALID, "bad arguments");
+  if (n_calls == 0) return CE_OK;
+  CE_REQUIRE(n_calls <= kRing / 4, CE_ERR_INVALID, "report at most %d replayed calls at a time", kRing / 4);
+  // the ring holds kRing records and the replays were launched already: fold what has arrived long before the
+  // device can lap the host
+  if (h->seq + n_calls - h->drained >= kRing / 2) {
+    const int rc = sync_and_drain(h);
+    if (rc) return rc;
+  } else {
+    drain(h);
+  }
+  h->seq += n_calls;
+  CE_HIP_CHECK(hipEventRecord(h->ev, (hipStream_t)stream));
+  if (h->cfg.evict_strategy == CE_EVICT_LFU) {
+    h->freq_bound += (uint64_t)n_calls * (uint64_t)ids_per_call;
+    CE_REQUIRE(h->freq_bound <= h->graph_freq_limit, CE_ERR_UNSUPPORTED,
+               "the captured cache op's LFU key width is used up: capture it again");
+  }
   return CE_OK;
 }
 
@@ -2730,7 +2797,8 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
   }
   h->seq += 1;
   const int gpb = 256 >> h->g_log2;
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, (int32_t*)nullptr, 0, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, (int32_t*)nullptr, 0, (uint32_t*)nullptr,
+                     (long long)h->seq);
   if (h->vec)
     hipLaunchKernelGGL((k_flush_rows<f32x4>), dim3(grid_for(C, gpb)), dim3(256), 0, s, c.cached_idx_map, C,
                        (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, h->rowlen, h->g_log2);

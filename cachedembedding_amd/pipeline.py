@@ -169,11 +169,21 @@ class GraphedWindow:
     alternate so the side-stream cache op of window k+1 can fill its buffer while graph k replays.
 
     step_fn(slots_i, i) runs one training step on batch i of the window; it is recorded once per buffer.
-    All tensors it reads besides `slots_i` must be static (offsets, upstream gradient / dense inputs)."""
+    All tensors it reads besides `slots_i` must be static (offsets, upstream gradient / dense inputs).
+
+    graph_cache_op (overlap=True, zero-copy transport): the cache op + presort of a window are captured too, as a
+    graph of their own that run_and_submit replays on the side stream -- a window then costs the host one copy of the
+    ids into a static buffer and two graph launches instead of ~16 kernel launches (libce_hip counts the call number
+    on the device for replayed calls; CachedParamMgr.graph_replayed keeps the host's books).  Measured (DESIGN.md
+    section 4, Avazu B = 2048 at prefetch_num = 1): the same 0.18 ms per step as launching kernel by kernel -- the cache op
+    there is 14 dependent kernels of 5-30 us, 143 us back to back even inside a graph, i.e. bound by the GPU's
+    kernel-to-kernel latency and not by the host -- so it is off unless asked for.  (The cache op as a second BRANCH
+    of the training graph was measured too: the HIP graph executor runs the branches one after the other with ~70 us
+    between queue switches, 0.66 ms per step.)"""
 
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
                  warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
-                 transport: Optional[str] = "auto", bag_layout=None):
+                 transport: Optional[str] = "auto", bag_layout=None, graph_cache_op: bool = False):
         # bag_layout: see PrefetchWindow (static offsets shared by every batch; keys_i is then a SrcKeys)
         self._layout = None if bag_layout is None else dict(offsets=bag_layout[0],
                                                             include_last_offset=bool(bag_layout[1]),
@@ -241,6 +251,29 @@ class GraphedWindow:
                     self._call(step_fn, b, i)
                 per_step.append(gi)
             self._step_graphs.append(per_step)
+        self._plan_graphs = None
+        self._ids = None
+        if graph_cache_op:
+            if not overlap or self.mgr.transport_name != "zerocopy" or self._ranges is not None:
+                raise ValueError("graph_cache_op needs overlap=True and the zero-copy transport")
+            self._ids = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
+            if warmup_values is not None:
+                for t in self._ids:
+                    t.view(-1).copy_(wcat.reshape(-1))
+            self._capture_plans()
+
+    def _capture_plans(self) -> None:
+        # the cache op + presort that fill buffer b as a graph of their own, replayed on the side stream
+        torch.cuda.synchronize(self.mgr.device)
+        plans = []
+        for b in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.mgr.prepare_ids(self._ids[b], out=self._bufs[b])
+                if self.presort:
+                    self._presort(b, self._ids[b])
+            plans.append(g)
+        self._plan_graphs = plans
 
     def _call(self, step_fn, buf: int, i: int) -> None:
         if self.presort and self._layout is not None:
@@ -297,6 +330,41 @@ class GraphedWindow:
                 self._step_graphs[buf][i].replay()
             else:
                 self._call(self._step_fn, buf, i)
+
+    @torch.no_grad()
+    def run_and_submit(self, buf: int, next_values: Sequence[torch.Tensor]) -> None:
+        """submit(next_values, 1 - buf) + run(buf): the window in buffer `buf` trains while the cache op of the next
+        window fills the other buffer; with graph_cache_op both are graph replays."""
+        if self._plan_graphs is None:
+            self.submit(next_values, 1 - buf)
+            self.run(buf)
+            return
+        cur = torch.cuda.current_stream(self.mgr.device)
+        if self._events[buf] is not None:
+            cur.wait_event(self._events[buf])
+            self._events[buf] = None
+        self.mgr.raise_on_failed_calls()
+        dst = self._ids[1 - buf].view(-1)
+        if len(next_values) == 1:
+            dst.copy_(next_values[0].reshape(-1))
+        else:
+            torch.cat([v.reshape(-1) for v in next_values], out=dst)
+        self._side.wait_stream(cur)
+        recapture = False
+        with torch.cuda.stream(self._side):
+            self._plan_graphs[1 - buf].replay()
+            try:
+                self.mgr.graph_replayed(1, self.P * self.n)
+            except _lib.CeError as e:
+                if e.code != _lib.CE_ERR_UNSUPPORTED:
+                    raise
+                recapture = True                  # LFU: the captured key width is used up (every 2^31 ids)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._graphs[buf].replay()
+        self._events[1 - buf] = ev
+        if recapture:
+            self._capture_plans()
 
     def run(self, buf: int, steps: Optional[int] = None) -> None:
         """Replay the P training steps on the slots in buffer `buf` (waits for its cache op).  steps < P runs

@@ -333,6 +333,16 @@ int32_t ce_cache_get_transport(ce_cache_t* h);
  * (the row-wise exchange's receive buffer: ce_exchange_local_index).  No upstream counterpart: upstream's
  * cuda_cached_weight is a torch tensor the caller owns (cache_mgr.py:83-89). */
 int ce_cache_set_cache_weight(ce_cache_t* h, float* cache_weight);
+/* A cache op inside the caller's hipGraph (API 3).  ce_cache_prepare_ids issued while `stream` is being captured
+ * (hipStreamBeginCapture) records its kernels into that capture instead of running them: zero-copy transport only,
+ * phase timers off; ids / slots_out must stay valid for every replay.  The call number that dates the eviction
+ * backlist and addresses the stats ring is then counted on the device, and the caller reports the replays --
+ * n_calls captured calls of ids_per_call ids each, just launched on `stream` -- right after every hipGraphLaunch:
+ * this keeps the host's call count, the stats history and (LFU) the counter bound in step.  CE_ERR_UNSUPPORTED from it
+ * means an LFU capture has outlived the key width it was captured with (2^31 ids): capture again.  With it the
+ * whole step of a prefetch_num = 1 loop -- cache op of batch k+1 beside forward + backward of batch k -- is ONE graph
+ * launch instead of ~16 kernel launches (recsys/dlrm_main.py:256-279 is the loop this replaces). */
+int ce_cache_graph_replayed(ce_cache_t* h, int64_t n_calls, int64_t ids_per_call, ce_stream_t stream);
 /* Phase timers of prepare_ids (upstream's per-phase Timer / record_function ranges, recsys/dlrm_main.py:258,294):
  * when on, every call brackets its phases with hipEvents on its own stream (no host sync); ce_cache_phase_times
  * blocks until the calls issued so far have finished and returns the accumulated milliseconds per phase

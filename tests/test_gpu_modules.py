@@ -200,6 +200,62 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
     torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("P,lfu,presort", [(4, False, "src"), (1, False, False), (1, True, False), (2, True, "src")])
+def test_cache_op_captured_in_the_window_graph(P, lfu, presort):
+    """GraphedWindow(graph_cache_op=True): the next window's cache op is replayed from a hipGraph of its own beside
+    the graph that trains the current one (zero-copy transport; the call number is counted on the device for
+    replayed calls).  Same training
+    trajectory as a plain full-table EmbeddingBag with SGD, and the same per-call records (hits / misses /
+    write-backs, totals, number of calls) as the kernel-by-kernel pipeline on the same windows."""
+    import cachedembedding_amd as ce
+    from cachedembedding_amd.pipeline import GraphedWindow
+    torch.manual_seed(0)
+    N, D, F, B, lr, nwin = 20000, 64, 4, 64, 0.5, 40
+    w0 = torch.randn(N, D)
+    off = torch.arange(F * B + 1, dtype=torch.int32, device="cuda")
+    layout = (off, True, F) if presort == "src" else None
+    grad = (torch.randn(B, F, D) * 0.1).cuda()
+    g = torch.Generator().manual_seed(5)
+    windows = [[(torch.rand(F * B, generator=g) ** 3 * N).long().clamp_(0, N - 1) for _ in range(P)] for _ in range(nwin)]
+    results = []
+    for full in (True, False):
+        emb = ce.CachedEmbeddingBag(N, D, sparse=True, _weight=w0.clone(), mode="sum", include_last_offset=True,
+                                    cuda_row_num=3 * F * B * P, warmup_ratio=0.5, strict=False,
+                                    evict_strategy=ce.EvictionStrategy.LFU if lfu else ce.EvictionStrategy.DATASET)
+        emb.set_fused_sgd(lr)
+        emb.set_cache_op(False)
+
+        def step(slots, i, keys=None, emb=emb):
+            out = emb(slots, off, hook_features=F, presorted=keys)
+            out.backward(grad)
+
+        gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=[v.cuda() for v in windows[0]],
+                           presort=bool(presort), transport="zerocopy", bag_layout=layout, graph_cache_op=full)
+        assert (gw._plan_graphs is not None) == full
+        gw.submit([v.cuda() for v in windows[0]], 0)
+        for w in range(nwin):
+            if w + 1 < nwin:
+                gw.run_and_submit(w % 2, [v.cuda() for v in windows[w + 1]])
+            else:
+                gw.run(w % 2)
+        torch.cuda.synchronize()
+        mgr = emb.cache_weight_mgr
+        assert mgr.sync_stats().status == 0
+        rec = (list(mgr.num_hits_history), list(mgr.num_miss_history), list(mgr.num_write_back_history), mgr.totals())
+        emb.flush()
+        results.append((emb.weight.clone(), rec))
+    ref = w0.clone()
+    for v in windows[0]:                     # the capture warm-up trained on window 0 once (eager pass)
+        ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+    for w in range(nwin):
+        for v in windows[w]:
+            ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+    torch.testing.assert_close(results[0][0], ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(results[1][0], ref, rtol=1e-4, atol=1e-4)
+    assert results[0][1] == results[1][1]
+    assert results[0][1][3]["calls"] >= nwin
+
+
 @pytest.mark.parametrize("extra", [[], ["--fused_sgd", "--fold_hook", "--use_lfu"], ["--use_cache_mgr_async_copy"],
                                    ["--overlap_cache_op"], ["--overlap_cache_op", "--fused_sgd", "--fold_hook"]])
 def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):

@@ -325,6 +325,60 @@ def test_rows_axpy_matches_index_add():
         torch.testing.assert_close(w, exp, rtol=1e-5, atol=1e-5)   # fp32 sums, atomic order differs
 
 
+def test_exchange_local_index_matches_numpy():
+    """ce_exchange_local_index: places of a rank's own bucket -> the cache slot its owner side resolved, every other
+    place -> a row of the receive buffer behind the cache, no place -> -1."""
+    import numpy as np
+    from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(11)
+    for P, n, W, cap, rank, C in [(3, 1000, 4, 64, 1, 5000), (1, 17, 1, 32, 0, 100), (8, 4099, 2, 512, 1, 1 << 20),
+                                  (2, 300, 8, 16, 7, 77)]:
+        pos = rng.integers(-1, W * cap, size=(P, n)).astype(np.int64)
+        slots = rng.integers(-1, C, size=(P, W * cap)).astype(np.int64)
+        lo, hi = rank * cap, (rank + 1) * cap
+        exp = np.where(pos < 0, -1, np.where((pos >= lo) & (pos < hi),
+                                             np.take_along_axis(slots, np.clip(pos, 0, W * cap - 1), axis=1), C + pos))
+        d_pos, d_slots = torch.from_numpy(pos).cuda(), torch.from_numpy(slots).cuda()
+        out = torch.full((P, n), -7, dtype=torch.int64, device="cuda")
+        check(lib.ce_exchange_local_index(ptr(d_pos), n, P, ptr(d_slots), W * cap, lo, hi, C, ptr(out), stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), exp)
+    # bad ranges are refused
+    assert lib.ce_exchange_local_index(ptr(d_pos), n, P, ptr(d_slots), W * cap, 0, W * cap + 1, C, ptr(out),
+                                       stream_ptr()) != 0
+
+
+def test_reserve_tail_moves_the_cache_and_keeps_its_rows():
+    """CachedParamMgr.reserve_tail: the cache moves into an allocation with extra rows behind it; resident rows,
+    the Parameter object and later cache ops (admission, eviction, flush) are unaffected."""
+    import cachedembedding_amd as ce
+    torch.manual_seed(2)
+    N, D, C = 5000, 32, 400
+    w0 = torch.randn(N, D)
+    emb = ce.CachedEmbeddingBag(N, D, _weight=w0.clone(), mode="sum", include_last_offset=True, cuda_row_num=C)
+    mgr = emb.cache_weight_mgr
+    ids = torch.randint(0, N, (300,), device="cuda")
+    slots = mgr.prepare_ids(ids)
+    param = mgr.cuda_cached_weight
+    before = param.data[slots].clone()
+    tail = mgr.reserve_tail(128)
+    assert mgr.cuda_cached_weight is param and tail.shape == (128, D)
+    assert tail.data_ptr() == param.data_ptr() + C * D * 4                  # right behind the cache
+    assert torch.equal(param.data[slots], before) and torch.equal(before.cpu(), w0[ids.cpu()])
+    assert mgr.reserve_tail(64).data_ptr() == tail.data_ptr()                # a smaller request reuses it
+    tail.fill_(123.0)
+    with torch.no_grad():
+        param.data[slots] += 1.0                                             # "training" on the moved cache
+    ids2 = torch.randint(0, N, (350,), device="cuda")                       # forces evictions of updated rows
+    slots2 = mgr.prepare_ids(ids2)
+    torch.testing.assert_close(param.data[slots2].cpu(),
+                               w0[ids2.cpu()] + torch.isin(ids2, ids).cpu().float().unsqueeze(1), rtol=0, atol=0)
+    emb.flush()
+    exp = w0.clone()
+    exp[ids.cpu().unique()] += 1.0
+    torch.testing.assert_close(emb.weight, exp, rtol=0, atol=0)
+    assert bool((tail == 123.0).all())                                       # no cache op touches the tail
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
 @pytest.mark.parametrize("overlap", [False, True])
 def test_rowwise_sharded_over_rccl(overlap):
