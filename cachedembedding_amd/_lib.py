@@ -147,6 +147,9 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ce_dedupe_bucket_rows_padded": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ce_dedupe_bucket_rows_padded_window": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int64,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p]),
     "ce_exchange_local_index": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                         c_void_p, c_void_p]),
     "ce_rows_axpy": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_float, c_void_p]),

@@ -233,7 +233,11 @@ __global__ __launch_bounds__(256) void k_seg_sgd(SegArgs a) {
 __global__ __launch_bounds__(256) void k_dedupe_mark_w(const int64_t* __restrict__ ids, int64_t n,
                                                        const int32_t* __restrict__ idx_map, int64_t num_rows,
                                                        int row_bits, int32_t* __restrict__ stamp,
-                                                       int32_t* __restrict__ rows32) {
+                                                       int32_t* __restrict__ rows32, int64_t scratch_stride) {
+  // blockIdx.y = batch of a window: every batch has its own ids / stamp array / scratch (see dedupe_bucket_impl)
+  ids += (int64_t)blockIdx.y * n;
+  stamp += (int64_t)blockIdx.y * num_rows;
+  rows32 += (int64_t)blockIdx.y * scratch_stride;
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // wave-uniform trip count (ballots inside)
@@ -262,7 +266,13 @@ __global__ __launch_bounds__(256) void k_dedupe_claim_w(const int32_t* __restric
                                                         int32_t world, const int32_t* __restrict__ stamp,
                                                         int32_t* __restrict__ slot_of_row,
                                                         int32_t* __restrict__ bucket_rows,
-                                                        unsigned long long* counts) {
+                                                        unsigned long long* counts, int64_t num_rows,
+                                                        int64_t scratch_stride) {
+  rows32 += (int64_t)blockIdx.y * scratch_stride;
+  bucket_rows += (int64_t)blockIdx.y * scratch_stride;
+  stamp += (int64_t)blockIdx.y * num_rows;
+  slot_of_row += (int64_t)blockIdx.y * num_rows;
+  counts += (int64_t)blockIdx.y * world;
   __shared__ int wave_cnt[4][64];
   __shared__ unsigned long long blk_base[64];
   const int lane = threadIdx.x & 63;
@@ -353,7 +363,14 @@ __global__ __launch_bounds__(256) void k_dedupe_finish_pad(const int32_t* __rest
                                                            const int32_t* __restrict__ bucket_rows,
                                                            const unsigned long long* __restrict__ counts,
                                                            int64_t* __restrict__ rows_out, int64_t* __restrict__ pos_out,
-                                                           int32_t* overflow) {
+                                                           int32_t* overflow, int64_t num_rows,
+                                                           int64_t scratch_stride) {
+  rows32 += (int64_t)blockIdx.y * scratch_stride;
+  bucket_rows += (int64_t)blockIdx.y * scratch_stride;
+  slot_of_row += (int64_t)blockIdx.y * num_rows;
+  counts += (int64_t)blockIdx.y * world;
+  rows_out += (int64_t)blockIdx.y * world * cap;
+  pos_out += (int64_t)blockIdx.y * n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid0 < world && (long long)counts[tid0] > cap) *overflow = 1;
@@ -454,16 +471,22 @@ extern "C" int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* i
   return CE_OK;
 }
 
+// n_batches > 1 (fixed-capacity form only): the batches of a window in ONE launch per pass, batch b = blockIdx.y with
+// its own ids (ids + b * n), stamp / slot_of_row arrays (+ b * num_rows: the passes of different batches race on a
+// row otherwise), scratch (+ b * (world + 1) * n) and outputs.
 static int dedupe_bucket_impl(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows, int32_t world,
                               int64_t cap, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,
                               int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out, int32_t* overflow,
-                              ce_stream_t stream) {
+                              ce_stream_t stream, int64_t n_batches = 1) {
+  CE_REQUIRE(n_batches >= 1 && n_batches <= 65535 && (n_batches == 1 || cap > 0), CE_ERR_INVALID, "bad batch count");
+  const unsigned nb = (unsigned)n_batches;
+  const int64_t sstride = (int64_t)(world + 1) * n;
   CE_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX && num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID,
              "bad sizes");
   CE_REQUIRE(world >= 1 && world <= 64, CE_ERR_UNSUPPORTED, "world size must be in [1, 64]");
   CE_REQUIRE(stamp && slot_of_row && counts_out, CE_ERR_INVALID, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  CE_HIP_CHECK(hipMemsetAsync(counts_out, 0, sizeof(int64_t) * world, s));
+  CE_HIP_CHECK(hipMemsetAsync(counts_out, 0, sizeof(int64_t) * world * n_batches, s));
   if (n == 0 && cap <= 0) return CE_OK;
   CE_REQUIRE(scratch && local_rows_out && (n == 0 || (ids && pos_out)), CE_ERR_INVALID, "null pointer");
   int bits = 1;
@@ -472,24 +495,24 @@ static int dedupe_bucket_impl(const int64_t* ids, int64_t n, const int32_t* idx_
   int32_t* bucket_rows = scratch + n;        // int32[world][n]
   unsigned long long* counts = (unsigned long long*)counts_out;
   if (n > 0) {
-    hipLaunchKernelGGL(k_dedupe_mark_w, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, idx_map, num_rows, bits,
-                       stamp, rows32);
+    hipLaunchKernelGGL(k_dedupe_mark_w, dim3(grid_for(n, 256), nb), dim3(256), 0, s, ids, n, idx_map, num_rows, bits,
+                       stamp, rows32, sstride);
     const char* it_e = getenv("CE_DEDUPE_IT");      // 1 / 2 / 4 lookups per thread in the claim pass (default 4)
     const int it_env = it_e ? atoi(it_e) : 4;
     if (it_env == 1)
-      hipLaunchKernelGGL((k_dedupe_claim_w<1>), dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n,
-                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+      hipLaunchKernelGGL((k_dedupe_claim_w<1>), dim3(grid_for(n, 256), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
+                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts, num_rows, sstride);
     else if (it_env == 2)
-      hipLaunchKernelGGL((k_dedupe_claim_w<2>), dim3(grid_for(n, 512)), dim3(256), 0, s, (const int32_t*)rows32, n,
-                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+      hipLaunchKernelGGL((k_dedupe_claim_w<2>), dim3(grid_for(n, 512), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
+                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts, num_rows, sstride);
     else
-      hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024)), dim3(256), 0, s, (const int32_t*)rows32, n,
-                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts);
+      hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
+                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts, num_rows, sstride);
   }
   if (cap > 0)
-    hipLaunchKernelGGL(k_dedupe_finish_pad, dim3(grid_for(std::max<int64_t>(n, world * cap), 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_dedupe_finish_pad, dim3(grid_for(std::max<int64_t>(n, world * cap), 256), nb), dim3(256), 0, s,
                        (const int32_t*)rows32, n, world, cap, (const int32_t*)slot_of_row, (const int32_t*)bucket_rows,
-                       (const unsigned long long*)counts, local_rows_out, pos_out, overflow);
+                       (const unsigned long long*)counts, local_rows_out, pos_out, overflow, num_rows, sstride);
   else
     hipLaunchKernelGGL(k_dedupe_finish_w, dim3(grid_for(n, 256)), dim3(256), 0, s, (const int32_t*)rows32, n, world,
                        (const int32_t*)slot_of_row, (const int32_t*)bucket_rows, (const unsigned long long*)counts,
@@ -513,6 +536,17 @@ extern "C" int ce_dedupe_bucket_rows_padded(const int64_t* ids, int64_t n, const
   CE_REQUIRE(capacity > 0 && overflow_flag, CE_ERR_INVALID, "capacity must be positive, overflow_flag non-null");
   return dedupe_bucket_impl(ids, n, idx_map, num_rows, world, capacity, stamp, slot_of_row, scratch, local_rows_out,
                             pos_out, counts_out, overflow_flag, stream);
+}
+
+extern "C" int ce_dedupe_bucket_rows_padded_window(const int64_t* ids, int64_t n, int64_t n_batches,
+                                                   const int32_t* idx_map, int64_t num_rows, int32_t world,
+                                                   int64_t capacity, int32_t* stamp, int32_t* slot_of_row,
+                                                   int32_t* scratch, int64_t* local_rows_out, int64_t* pos_out,
+                                                   int64_t* counts_out, int32_t* overflow_flag, ce_stream_t stream) {
+  CE_REQUIRE(capacity > 0 && overflow_flag, CE_ERR_INVALID, "capacity must be positive, overflow_flag non-null");
+  if (n_batches == 0) return CE_OK;
+  return dedupe_bucket_impl(ids, n, idx_map, num_rows, world, capacity, stamp, slot_of_row, scratch, local_rows_out,
+                            pos_out, counts_out, overflow_flag, stream, n_batches);
 }
 
 extern "C" int ce_exchange_local_index(const int64_t* pos, int64_t n_per_batch, int64_t n_batches,

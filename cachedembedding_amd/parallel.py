@@ -20,6 +20,7 @@ compute as a `ShardOps` object; the product wires in HipShardOps (C ABI, no fall
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -736,12 +737,21 @@ class GraphedShardedWindow:
             self.mgr.strict = False
             if transport:
                 self.mgr.set_transport(transport)
-        # scratch of the dedupe passes (shared with the variable-size path)
+        # scratch of the dedupe passes: one stamp / place array per batch of the window, so that the P batches are
+        # deduped by ONE launch per pass (P * N * 8 bytes: 11 GB for the Criteo-1TB table at P = 8; set
+        # CE_DEDUPE_PER_BATCH=1 to dedupe batch by batch with one pair of arrays instead)
         N = embed.num_embeddings
-        if self.ops._stamp is None:
-            self.ops._stamp = torch.empty(N, dtype=torch.int32, device=dev)
-            self.ops._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
-        self._ws = torch.empty(max((W + 1) * n, 1 << 16), dtype=torch.int32, device=dev)
+        self._window_dedupe = P > 1 and not int(os.environ.get("CE_DEDUPE_PER_BATCH", "0"))
+        if self._window_dedupe:
+            self._stamp = torch.empty(P * N, dtype=torch.int32, device=dev)
+            self._slot_of_row = torch.empty(P * N, dtype=torch.int32, device=dev)
+            self._ids_win = torch.empty(P, n, **i64)
+        else:
+            if self.ops._stamp is None:
+                self.ops._stamp = torch.empty(N, dtype=torch.int32, device=dev)
+                self.ops._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
+            self._stamp, self._slot_of_row = self.ops._stamp, self.ops._slot_of_row
+        self._ws = torch.empty(max(P * (W + 1) * n, 1 << 16), dtype=torch.int32, device=dev)
         if embed.mode != "sum":
             raise NotImplementedError("GraphedShardedWindow: mode='sum' only (the fused fold + update)")
         self.rank = self.ops.rank
@@ -775,13 +785,32 @@ class GraphedShardedWindow:
         assert len(ids_list) == P
         sp = stream_ptr()
         self._ovf[buf].zero_()
-        for b, ids in enumerate(ids_list):
-            ids = ids.reshape(-1).long().contiguous()
-            assert ids.numel() == n
-            check(lib.ce_dedupe_bucket_rows_padded(ptr(ids), n, ptr(self.ops.idx_map), self.embed.num_embeddings, W, cap,
-                                                   ptr(self.ops._stamp), ptr(self.ops._slot_of_row), ptr(self._ws),
-                                                   self._req[buf][b].data_ptr(), self._pos[buf][b].data_ptr(),
-                                                   self._counts[buf][b].data_ptr(), ptr(self._ovf[buf]), sp))
+        if self._window_dedupe:
+            # the window's ids as one [P, n] block: as they are when the batches are rows of one tensor, copied otherwise
+            first = ids_list[0]
+            win = None
+            if first.dtype == torch.int64 and all(
+                    t.dtype == torch.int64 and t.is_contiguous() and t.numel() == n and
+                    t.data_ptr() == first.data_ptr() + 8 * n * b for b, t in enumerate(ids_list)):
+                win = first
+            else:
+                for b, t in enumerate(ids_list):
+                    assert t.numel() == n
+                    self._ids_win[b].copy_(t.reshape(-1))
+                win = self._ids_win
+            check(lib.ce_dedupe_bucket_rows_padded_window(win.data_ptr(), n, P, ptr(self.ops.idx_map),
+                                                          self.embed.num_embeddings, W, cap, ptr(self._stamp),
+                                                          ptr(self._slot_of_row), ptr(self._ws),
+                                                          ptr(self._req[buf]), ptr(self._pos[buf]),
+                                                          ptr(self._counts[buf]), ptr(self._ovf[buf]), sp))
+        else:
+            for b, ids in enumerate(ids_list):
+                ids = ids.reshape(-1).long().contiguous()
+                assert ids.numel() == n
+                check(lib.ce_dedupe_bucket_rows_padded(ptr(ids), n, ptr(self.ops.idx_map), self.embed.num_embeddings, W,
+                                                       cap, ptr(self._stamp), ptr(self._slot_of_row), ptr(self._ws),
+                                                       self._req[buf][b].data_ptr(), self._pos[buf][b].data_ptr(),
+                                                       self._counts[buf][b].data_ptr(), ptr(self._ovf[buf]), sp))
         if W > 1:       # the ranks must agree on which path a window takes: its collectives differ
             if dist.get_backend(self.ex.group) == "gloo":
                 f = self._ovf[buf].cpu()

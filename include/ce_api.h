@@ -401,6 +401,16 @@ int ce_dedupe_bucket_rows_padded(const int64_t* ids, int64_t n, const int32_t* i
                                  int32_t* scratch, int64_t* local_rows_out, int64_t* pos_out, int64_t* counts_out,
                                  int32_t* overflow_flag, ce_stream_t stream);
 
+/* The same for the n_batches batches of a window in one launch per pass (3 launches instead of 3 per batch): ids =
+ * device int64 [n_batches, n] contiguous, outputs [n_batches, world * capacity] / [n_batches, n] / [n_batches, world];
+ * stamp and slot_of_row = device int32 [n_batches * num_rows] EACH (one array per batch: concurrent batches would race
+ * on a row's entry), scratch = device int32 [n_batches * (world + 1) * n]; one overflow flag for the window. */
+int ce_dedupe_bucket_rows_padded_window(const int64_t* ids, int64_t n, int64_t n_batches, const int32_t* idx_map,
+                                        int64_t num_rows, int32_t world, int64_t capacity, int32_t* stamp,
+                                        int32_t* slot_of_row, int32_t* scratch, int64_t* local_rows_out,
+                                        int64_t* pos_out, int64_t* counts_out, int32_t* overflow_flag,
+                                        ce_stream_t stream);
+
 /* Local bypass of the row-wise exchange (API 3).  pos: device int64 [n_batches, n_per_batch], the places
  * ce_dedupe_bucket_rows_padded returned (bucket * capacity + place, -1 = none); slots: device int64, batch b at
  * slots + b * slots_batch_stride: the cache slots this rank's owner-side cache op resolved for the rows requested

@@ -20,6 +20,7 @@ python profiles/probe_sdma.py > gpurun_out/probe_sdma.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_seq -o r03 -- python $R/bench.py --no_cpu_baseline --no_overlap --no_graph --transport zerocopy > $R/gpurun_out/prof_seq.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ov -o r03 -- python $R/bench.py --no_cpu_baseline > $R/gpurun_out/prof_ov.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sh -o r03 -- python $R/bench.py --no_cpu_baseline --force_sharded --transport zerocopy > $R/gpurun_out/prof_sh.log 2>&1
 mkdir -p $R/gpurun_out/pmc
 for m in calib bench; do for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc/${m}_$c -o p -- python $R/profiles/pmc_probe.py $m > $R/gpurun_out/pmc/${m}_$c.log 2>&1
@@ -27,9 +28,12 @@ done; done
 cd $R
 python profiles/rocpd_summary.py gpurun_out/prof_seq/r03_results.db 40 > gpurun_out/stats_seq.txt
 python profiles/rocpd_summary.py gpurun_out/prof_ov/r03_results.db 40 > gpurun_out/stats_ov.txt
+python profiles/rocpd_summary.py gpurun_out/prof_sh/r03_results.db 45 > gpurun_out/stats_sharded_w1.txt
 python profiles/rocpd_timeline.py gpurun_out/prof_seq/r03_results.db -4 > gpurun_out/timeline_seq.txt
 python profiles/rocpd_timeline.py gpurun_out/prof_ov/r03_results.db -4 > gpurun_out/timeline_ov.txt
 python profiles/pmc_summary.py gpurun_out/pmc --json gpurun_out/traffic.json > gpurun_out/pmc_hbm_traffic.txt 2>&1
-rm -rf gpurun_out/prof_ov gpurun_out/prof_seq
+rm -rf gpurun_out/prof_ov gpurun_out/prof_seq gpurun_out/prof_sh
 find gpurun_out/pmc -name "*kernel_trace.csv" -size +20M -delete
 du -sh gpurun_out
+bash profiles/config_matrix.sh > gpurun_out/config_matrix.md 2>&1
+python bench.py --no_cpu_baseline --workload avazu --cache_ratio 0.01 --use_lfu --batch_size 2048 --embedding_dim 32 --prefetch_num 1 --graph_cache_op 2>/dev/null | tail -1 > gpurun_out/bench_avazu_p1_graph_cache_op.json

@@ -308,6 +308,63 @@ def test_dedupe_bucket_rows_properties(it, monkeypatch):
             assert torch.equal(rows[p] * W + owner_of_pos[p], r)
 
 
+@pytest.mark.parametrize("P", [1, 3, 8])
+def test_dedupe_bucket_rows_padded_window_properties(P):
+    """ce_dedupe_bucket_rows_padded (P = 1 per call) and its window form (the P batches in one launch per pass, one
+    stamp array per batch): bucket w of batch b holds exactly the rows owner w has in that batch, each once, padded with
+    -1 to the capacity; every lookup's place points at its own row; a bucket beyond the capacity raises the flag."""
+    from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
+    torch.manual_seed(P)
+    for n, W, N, cap in [(4097, 4, 100000, 2048), (50000, 3, 977, 512), (425984, 8, 3_000_000, 16384), (300, 1, 64, 64),
+                         (1000, 2, 5000, 100)]:
+        ids = (torch.rand(P, n, device="cuda").pow(4) * N).long().clamp_(0, N - 1)
+        ids[0, 3] = -1
+        ids[P - 1, 7] = N
+        idx_map = torch.randperm(N, device="cuda").int()
+        stamp = torch.randint(0, 2**31 - 1, (P * N,), dtype=torch.int32, device="cuda")
+        slot = torch.empty(P * N, dtype=torch.int32, device="cuda")
+        scratch = torch.empty(P * (W + 1) * n, dtype=torch.int32, device="cuda")
+        rows = torch.full((P, W * cap), -7, dtype=torch.int64, device="cuda")
+        pos = torch.full((P, n), -7, dtype=torch.int64, device="cuda")
+        counts = torch.full((P, W), -7, dtype=torch.int64, device="cuda")
+        ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for _rep in (1, 2):
+            ovf.zero_()
+            if P == 1:
+                check(lib.ce_dedupe_bucket_rows_padded(ptr(ids), n, ptr(idx_map), N, W, cap, ptr(stamp), ptr(slot),
+                                                       ptr(scratch), ptr(rows), ptr(pos), ptr(counts), ptr(ovf),
+                                                       stream_ptr()))
+            else:
+                check(lib.ce_dedupe_bucket_rows_padded_window(ptr(ids), n, P, ptr(idx_map), N, W, cap, ptr(stamp),
+                                                              ptr(slot), ptr(scratch), ptr(rows), ptr(pos), ptr(counts),
+                                                              ptr(ovf), stream_ptr()))
+            over = False
+            for b in range(P):
+                ok = (ids[b] >= 0) & (ids[b] < N)
+                r = idx_map[ids[b][ok]].long()
+                uniq = torch.unique(r)
+                exp_counts = torch.bincount(uniq % W, minlength=W)
+                assert torch.equal(counts[b], exp_counts)
+                over = over or bool((exp_counts > cap).any())
+                assert bool((pos[b][~ok] == -1).all())
+                for w in range(W):
+                    seg = rows[b, w * cap:(w + 1) * cap]
+                    c = min(int(exp_counts[w]), cap)
+                    assert bool((seg[c:] == -1).all())
+                    mine = uniq[uniq % W == w] // W
+                    if c == mine.numel():
+                        assert torch.equal(torch.sort(seg[:c]).values, torch.sort(mine).values)
+                    else:       # overflowing bucket: a subset of the owner's rows, each once
+                        assert torch.unique(seg[:c]).numel() == c and bool(torch.isin(seg[:c], mine).all())
+                p = pos[b][ok]
+                placed = p >= 0
+                assert bool((p[placed] < W * cap).all())
+                assert torch.equal(rows[b][p[placed]] * W + p[placed] // cap, r[placed])
+                if not bool((exp_counts > cap).any()):
+                    assert bool(placed.all())
+            assert bool(ovf.item()) == over
+
+
 def test_rows_axpy_matches_index_add():
     from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
     torch.manual_seed(3)
