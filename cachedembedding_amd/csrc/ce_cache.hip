@@ -218,6 +218,38 @@ __device__ __forceinline__ uint32_t miss_mask(const int32_t* __restrict__ invert
   return mm;
 }
 
+// The same, and every resident row's slot gets the call's stamp on the way (k_emit: the slot is in hand here, a second
+// pass over the map just for the stamps was k_emit's tail).
+__device__ __forceinline__ uint32_t miss_mask_stamp(const int32_t* __restrict__ inverted, int64_t row0, uint32_t bits,
+                                                    int64_t N, int32_t* slot_epoch, int32_t epoch) {
+  uint32_t mm = 0;
+  if (dense_word(bits, row0, N)) {
+    const int4* p = (const int4*)(inverted + row0);
+    int4 x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = p[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int32_t sl[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (!((bits >> (4 * j + c)) & 1)) continue;
+        if (sl[c] < 0) mm |= 1u << (4 * j + c);
+        else slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
+      }
+    }
+    return mm;
+  }
+  while (bits) {
+    const int b = __ffs(bits) - 1;
+    bits &= bits - 1;
+    const int32_t sl = inverted[row0 + b];
+    if (sl < 0) mm |= 1u << b;
+    else slot_epoch[sl] = epoch;
+  }
+  return mm;
+}
+
 // ids -> rows -> bits in the row bitmap.
 //
 // Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window sends >100k ids at
@@ -410,22 +442,6 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
 #pragma unroll
     for (int j = 0; j < kEmitSub; ++j) red[2 + j][wv] = base_p[j];
   }
-  uint32_t mm[kEmitSub][4];
-  int m[kEmitSub];
-#pragma unroll
-  for (int j = 0; j < kEmitSub; ++j) {
-    m[j] = 0;
-    const uint32_t wds[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-    const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      mm[j][k] = 0;
-      if (wds[k]) {
-        mm[j][k] = miss_mask(inverted, v * 128 + k * 32, wds[k], N);
-        m[j] += __popc(mm[j][k]);
-      }
-    }
-  }
   __syncthreads();
   const long long tu = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   const long long tm = red[1][0] + red[1][1] + red[1][2] + red[1][3];
@@ -461,10 +477,23 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
     // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
     // record (k_victims can turn it into a capacity failure): k_admit_maps
   }
-  int inc[kEmitSub];
+  // ONE pass over the map entries of the rows seen: which of them are missing, and the call's stamp on the slots of
+  // the others (a failed call stamps nothing and emits nothing)
+  uint32_t mm[kEmitSub][4];
+  int m[kEmitSub], inc[kEmitSub];
 #pragma unroll
   for (int j = 0; j < kEmitSub; ++j) {
-    if (!ok) m[j] = 0;
+    m[j] = 0;
+    const uint32_t wds[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+    const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mm[j][k] = 0;
+      if (ok && wds[k]) {
+        mm[j][k] = miss_mask_stamp(inverted, v * 128 + k * 32, wds[k], N, slot_epoch, epoch);
+        m[j] += __popc(mm[j][k]);
+      }
+    }
     inc[j] = wave_incl_scan(m[j], lane);
     if (lane == 63) wsub[j][wv] = inc[j];
   }
@@ -475,44 +504,16 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
       if (chunk[j] >= n_chunks) continue;
       int pos = (int)(red[2 + j][0] + red[2 + j][1] + red[2 + j][2] + red[2 + j][3]) + inc[j] - m[j];
       for (int k = 0; k < wv; ++k) pos += wsub[j][k];
-      const uint32_t wds[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
       const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        uint32_t bits = wds[k];
-        if (!bits) continue;
+        uint32_t bits = mm[j][k];
         const int64_t row0 = v * 128 + k * 32;
-        if (dense_word(bits, row0, N)) {
-          const int4* p = (const int4*)(inverted + row0);
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            const int4 x = p[jj];
-            const int32_t sl[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (!((bits >> (4 * jj + c)) & 1)) continue;
-              if (sl[c] < 0) {
-                const int32_t mr = (int32_t)(row0 + 4 * jj + c);
-                if (miss_host && pos < in_cap) miss_host[pos] = mr;      // the admission worker's copy (pinned host)
-                miss_list[pos++] = mr;
-              } else {
-                slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
-              }
-            }
-          }
-          continue;
-        }
-        // sparse word: the missing rows are known (mm), the resident ones need their slot for the stamp
         while (bits) {
           const int b = __ffs(bits) - 1;
           bits &= bits - 1;
-          const int64_t row = row0 + b;
-          if ((mm[j][k] >> b) & 1) {
-            if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)row;
-            miss_list[pos++] = (int32_t)row;
-          } else {
-            slot_epoch[inverted[row]] = epoch;        // evict_backlist membership [A.3-3]
-          }
+          if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)(row0 + b);      // the admission worker's copy
+          miss_list[pos++] = (int32_t)(row0 + b);
         }
       }
     }
