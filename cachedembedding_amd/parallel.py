@@ -886,11 +886,21 @@ class GraphedShardedWindow:
 
     def _capture(self) -> None:
         dev = self.mgr.device
+        mode = {}
+        if self.W > 1:
+            # the process group's watchdog thread polls events of finished collectives: let it drain (it would
+            # invalidate a capture in the default "global" error mode) and keep other threads' calls out of the capture
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=self.ex.group)
+            torch.cuda.synchronize(dev)
+            import time
+            time.sleep(0.5)
+            mode = dict(capture_error_mode="thread_local")
         try:
             graphs = []
             for b in range(2):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, **mode):
                     for i in range(self.P):
                         self._step(b, i)
                 graphs.append(g)
