@@ -41,12 +41,19 @@ def _digest() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    # two stamps: csrc/.build_stamp is TRACKED (the digest of the sources a commit's numbers were measured on:
+    # profiles/traffic.json refers to it); csrc/build/lib.stamp lies with the objects, untracked like the library itself,
+    # and is what says which sources the library on disk was built from -- a `git checkout` can put an old tracked
+    # stamp back beside a newer library, and the next build() must not take that library for current
     stamp = PKG / "csrc" / ".build_stamp"
+    objdir = PKG / "csrc" / "build"
+    lib_stamp = objdir / "lib.stamp"
     dig = _digest()
-    if LIB.exists() and not force and stamp.exists() and stamp.read_text().strip() == dig:
+    if LIB.exists() and not force and lib_stamp.exists() and lib_stamp.read_text().strip() == dig:
+        if not stamp.exists() or stamp.read_text().strip() != dig:
+            stamp.write_text(dig)
         return LIB
     hipcc = _hipcc()
-    objdir = PKG / "csrc" / "build"
     objdir.mkdir(exist_ok=True)
     objs = []
     procs = []
@@ -72,6 +79,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     stamp.write_text(dig)
+    lib_stamp.write_text(dig)
     return LIB
 
 

@@ -172,6 +172,107 @@ __global__ __launch_bounds__(256) void k_bwd_flag(const f32x4* __restrict__ GO, 
   }
 }
 
+// ---- two passes: (A) gather + fold; a flagged run (its row occurs nowhere else in the launch, the run lies inside one
+// lane group's share) leaves its folded, scaled gradient in a scratch row (plain 512-byte store, scratch rows in key
+// order: a nearly sequential write stream) instead of touching W; everything else keeps the atomics.  (B) every
+// flagged run head: W[row] += scratch row, a plain read-modify-write with nothing else going on.
+// SIDX: 0 = scratch row = key position (sparse over nnz rows), 1 = compact index from cidx[position]
+template <int R, int NTG, int SIDX>
+__global__ __launch_bounds__(256) void k_bwd_2pA(const f32x4* __restrict__ GO, float* __restrict__ W, const u64* __restrict__ keys,
+                                                 const int* __restrict__ cidx, f32x4* __restrict__ scratch, int64_t total, float alpha) {
+  __shared__ u64 lk[8 * 128];
+  const int tid = threadIdx.x, grp = tid >> 5, gl = tid & 31;
+  const int g = blockIdx.x * 8 + grp;
+  const int64_t all = (int64_t)gridDim.x * 8;
+  const int64_t share = ((total + all - 1) / all + 15) / 16 * 16;
+  const int64_t s0 = g * share, s1 = s0 + share < total ? s0 + share : total;
+  if (s0 >= s1) return;
+  u64* mylk = lk + grp * 128;
+  f32x4 acc = {0, 0, 0, 0};
+  uint32_t cur = 0xffffffffu;
+  int64_t cur_pos = -1;          // >= 0: the run in flight is a flagged one, its head sits at this position
+  auto flush = [&]() {
+    if (cur == 0xffffffffu) return;
+    if (cur_pos >= 0) scratch[(SIDX ? (int64_t)cidx[cur_pos] : cur_pos) * 32 + gl] = acc;
+    else flush_atomic(W + (int64_t)cur * 128, acc, gl);
+  };
+  for (int64_t c0 = s0; c0 < s1; c0 += 128) {
+    for (int k = gl; k < 128; k += 32) mylk[k] = c0 + k < s1 ? keys[c0 + k] : ~0ull;
+    const int64_t c1 = s1 < c0 + 128 ? s1 : c0 + 128;
+    for (int64_t q = c0; q < c1; q += R) {
+      f32x4 v[R];
+      uint32_t rw[R];
+      uint32_t isw = 0;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        const u64 k = mylk[(int)(q - c0) + t];
+        const bool on = k != ~0ull;
+        rw[t] = on ? (uint32_t)(k >> 32) : 0xffffffffu;
+        const uint32_t low = (uint32_t)k;
+        if (on && (low >> 31)) isw |= 1u << t;
+        const int64_t src = (int64_t)(low & 0x7fffffffu);
+        const f32x4* p = GO + src * 32 + gl;
+        v[t] = f32x4{0, 0, 0, 0};
+        if (on) v[t] = NTG ? __builtin_nontemporal_load(p) : *p;
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        if (rw[t] != 0xffffffffu) {
+          if (rw[t] != cur || ((isw >> t) & 1)) {
+            flush();
+            acc = f32x4{0, 0, 0, 0};
+            cur = rw[t];
+            cur_pos = ((isw >> t) & 1) ? q + t : -1;
+          }
+          acc = acc + v[t] * alpha;
+        }
+      }
+    }
+  }
+  flush();
+}
+
+template <int RB, int SIDX>
+__global__ __launch_bounds__(256) void k_bwd_2pB(float* __restrict__ W, const u64* __restrict__ keys, const int* __restrict__ cidx,
+                                                 const f32x4* __restrict__ scratch, int64_t total) {
+  const int tid = threadIdx.x, grp = tid >> 5, gl = tid & 31;
+  const int64_t all = (int64_t)gridDim.x * 8;
+  const int64_t g = (int64_t)blockIdx.x * 8 + grp;
+  const int64_t share = ((total + all - 1) / all + 31) / 32 * 32;
+  const int64_t s0 = g * share, s1 = s0 + share < total ? s0 + share : total;
+  f32x4* WV = (f32x4*)W;
+  for (int64_t c0 = s0; c0 < s1; c0 += 32) {
+    const u64 k = c0 + gl < s1 ? keys[c0 + gl] : ~0ull;
+    const bool fl = k != ~0ull && (((uint32_t)k) >> 31);
+    uint32_t m = (uint32_t)__ballot(fl) >> 0;       // lanes 0..31 or 32..63 of the wave: take this group's half
+    unsigned long long mb = __ballot(fl);
+    m = (uint32_t)(mb >> ((tid & 32) ? 32 : 0));
+    while (m) {
+      f32x4 d[RB], w[RB];
+      int64_t row[RB];
+      int n = 0;
+#pragma unroll
+      for (int t = 0; t < RB; ++t) {
+        row[t] = -1;
+        if (m) {
+          const int b = __ffs(m) - 1;
+          m &= m - 1;
+          const u64 kk = __shfl(k, (tid & 32) + b);
+          row[t] = (int64_t)(kk >> 32);
+          const int64_t si = SIDX ? (int64_t)cidx[c0 + b] : c0 + b;
+          d[t] = scratch[si * 32 + gl];
+          w[t] = WV[row[t] * 32 + gl];
+          ++n;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < RB; ++t)
+        if (row[t] >= 0) WV[row[t] * 32 + gl] = w[t] + d[t];
+    }
+  }
+}
+
 // decoupled flush: waves 0-2 of a workgroup only gather and fold (their vmcnt never holds a store or an atomic), wave 3
 // only applies finished rows, handed over through 2-slot LDS rings (one per producer lane group)
 template <int R, int NTG, int STORE>
@@ -581,6 +682,17 @@ int main(int argc, char** argv) {
   u64* d_flag;
   CK(hipMalloc(&d_flag, T0 * 8));
   CK(hipMemcpy(d_flag, k_flag.data(), T0 * 8, hipMemcpyHostToDevice));
+  // compact index of every flagged run head (two-pass scratch)
+  std::vector<int> h_cidx(T0, -1);
+  {
+    int c = 0;
+    for (int64_t i = 0; i < T0; ++i) if (k_flag[i] & 0x80000000ull) h_cidx[i] = c++;
+  }
+  int* d_cidx;
+  CK(hipMalloc(&d_cidx, T0 * 4));
+  CK(hipMemcpy(d_cidx, h_cidx.data(), T0 * 4, hipMemcpyHostToDevice));
+  f32x4* scratch;
+  CK(hipMalloc(&scratch, (size_t)T0 * 512));
 
   f32x4* go;
   float *W, *W0;
@@ -639,6 +751,21 @@ int main(int argc, char** argv) {
     maxd = 0;
     for (size_t i = 0; i < a.size(); ++i) maxd = std::max(maxd, (double)fabsf(a[i] - b[i]));
     printf("flag vs atomic kernel: max |diff| = %.3g\n", maxd);
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      CK(hipMemcpy(W, W0, C * 512, hipMemcpyDeviceToDevice));
+      if (sidx) {
+        hipLaunchKernelGGL((k_bwd_2pA<16, 1, 1>), dim3(grid), dim3(256), 0, 0, go, W, d_flag, d_cidx, scratch, T0, alpha);
+        hipLaunchKernelGGL((k_bwd_2pB<4, 1>), dim3(grid), dim3(256), 0, 0, W, d_flag, d_cidx, scratch, T0);
+      } else {
+        hipLaunchKernelGGL((k_bwd_2pA<16, 1, 0>), dim3(grid), dim3(256), 0, 0, go, W, d_flag, d_cidx, scratch, T0, alpha);
+        hipLaunchKernelGGL((k_bwd_2pB<4, 0>), dim3(grid), dim3(256), 0, 0, W, d_flag, d_cidx, scratch, T0);
+      }
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(b.data(), W, b.size() * 4, hipMemcpyDeviceToHost));
+      maxd = 0;
+      for (size_t i = 0; i < a.size(); ++i) maxd = std::max(maxd, (double)fabsf(a[i] - b[i]));
+      printf("two-pass (scratch %s) vs atomic kernel: max |diff| = %.3g\n", sidx ? "compact" : "by position", maxd);
+    }
     CK(hipMemcpy(W, W0, C * 512, hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL((k_bwd_split<16, 1, 0>), dim3(683), dim3(256), 0, 0, go, W, d_cur, T0, alpha);
     CK(hipDeviceSynchronize());
@@ -710,6 +837,19 @@ int main(int argc, char** argv) {
     float t = time_it(nop, [&] { hipLaunchKernelGGL((k_bwd_pipe3<NTG, HIDE>), dim3(GRID), dim3(256), 0, 0, go, W, d_cur, T0, alpha); }); \
     printf("%-34s R= 8 grid=%5d : %6.1f us\n", NAME, GRID, t);                                            \
   }
+#define RUN2P(NAME, NTG, SIDX, RB, GRID, GRIDB)                                                                \
+  {                                                                                                           \
+    float ta = time_it(nop, [&] { hipLaunchKernelGGL((k_bwd_2pA<16, NTG, SIDX>), dim3(GRID), dim3(256), 0, 0, go, W, d_flag, d_cidx, scratch, T0, alpha); }); \
+    float tb = time_it(nop, [&] { hipLaunchKernelGGL((k_bwd_2pB<RB, SIDX>), dim3(GRIDB), dim3(256), 0, 0, W, d_flag, d_cidx, scratch, T0); }); \
+    float tab = time_it(nop, [&] { hipLaunchKernelGGL((k_bwd_2pA<16, NTG, SIDX>), dim3(GRID), dim3(256), 0, 0, go, W, d_flag, d_cidx, scratch, T0, alpha); \
+                                   hipLaunchKernelGGL((k_bwd_2pB<RB, SIDX>), dim3(GRIDB), dim3(256), 0, 0, W, d_flag, d_cidx, scratch, T0); }); \
+    printf("%-34s gridA=%5d gridB=%5d : A %6.1f  B %6.1f  A+B %6.1f us\n", NAME, GRID, GRIDB, ta, tb, tab);      \
+  }
+    RUN2P("2pass nt, scratch by position, RB4", 1, 0, 4, grid, grid);
+    RUN2P("2pass nt, scratch compact, RB4", 1, 1, 4, grid, grid);
+    RUN2P("2pass nt, compact, RB8, B 2x grid", 1, 1, 8, grid, 2 * grid);
+    RUN2P("2pass nt, compact, RB2, B 4x grid", 1, 1, 2, grid, 4 * grid);
+    RUN2P("2pass plain, compact, RB4", 0, 1, 4, grid, grid);
     RUNP3("pipe3 (3 x 8 rows, asm atomics, nt)", 1, 1, grid);
     RUNP3("pipe3 (3 x 8 rows, asm atomics, pl)", 0, 1, grid);
     RUNP3("pipe3 (3 x 8 rows, C++ atomics, nt)", 1, 0, grid);
