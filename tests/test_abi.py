@@ -25,6 +25,25 @@ def test_build_and_load():
     assert ce._lib.lib.ce_version() == 3
 
 
+def test_library_on_disk_is_the_one_the_sources_describe():
+    """build() decides "up to date" from the stamp that lies with the objects (untracked, like the library), not from the
+    tracked csrc/.build_stamp -- a checkout can put an old tracked stamp back beside a newer library."""
+    from cachedembedding_amd import build as b
+    b.build()
+    tracked = b.PKG / "csrc" / ".build_stamp"
+    own = b.PKG / "csrc" / "build" / "lib.stamp"
+    assert own.read_text().strip() == b._digest() == tracked.read_text().strip()
+    before = b.LIB.stat().st_mtime_ns
+    saved = own.read_text()
+    try:
+        own.write_text("0" * 64)                 # "the library was built from something else"
+        b.build()
+        assert b.LIB.stat().st_mtime_ns > before and own.read_text().strip() == b._digest()
+    finally:
+        if own.read_text().strip() != b._digest():
+            own.write_text(saved)
+
+
 def test_every_declared_symbol_is_exported_and_bound():
     from cachedembedding_amd import _lib
     names = declared_functions()
