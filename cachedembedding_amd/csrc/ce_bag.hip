@@ -63,7 +63,9 @@ static int bag_policy() {
   return v;
 }
 
+// offsets == nullptr: the caller states one id per bag, in order (offsets = arange; ce_bag_forward, the presorts)
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
+  if (p.offsets == nullptr) return i;
   return p.off64 ? (int)((const int64_t*)p.offsets)[i] : ((const int32_t*)p.offsets)[i];
 }
 __device__ __forceinline__ int bag_end(const BagParams& p, int b) {
@@ -1067,7 +1069,9 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
                               int32_t include_last_offset, const float* per_sample_weights, int32_t mode,
                               int64_t hook_features, float* out, ce_stream_t stream) {
   if (num_bags == 0) return CE_OK;
-  CE_REQUIRE(weight && out && offsets && (indices || nnz == 0), CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(weight && out && (indices || nnz == 0), CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(offsets || num_bags == nnz, CE_ERR_INVALID,
+             "offsets == NULL states one id per bag (offsets = arange): num_bags must equal nnz");
   BagParams p{};
   bool vec;
   int nch;

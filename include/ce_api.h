@@ -109,6 +109,8 @@ int ce_host_fill_uniform(float* dst, int64_t n, float lo, float hi, uint64_t see
  * sparse_embedding_shape_hook (recsys/models/dlrm.py:26-27) into the store: bags are
  * feature-major (bag = f*B + b, B = num_bags/F) and out is written as [B, F, dim].
  * include_last_offset == 0: offsets has num_bags entries and the last bag ends at nnz.
+ * offsets == NULL (only with num_bags == nnz) states the one-id-per-bag layout (offsets = arange: every Criteo /
+ * Avazu batch, recsys/datasets/criteo.py:127-134): the kernel then reads no offsets at all.
  */
 int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim,
                    const int64_t* indices, int64_t nnz,

@@ -83,6 +83,48 @@ def test_single_id_bags_bit_exact(D, nb):
     assert torch.equal(out.cpu(), w[idx])
 
 
+@pytest.mark.parametrize("include_last", [True, False])
+@pytest.mark.parametrize("F,B,D", [(0, 777, 128), (4, 300, 64), (26, 512, 128), (0, 65, 100)])
+def test_forward_without_offsets_is_the_one_id_per_bag_layout(F, B, D, include_last):
+    """ce_bag_forward(offsets=NULL) = the same call with offsets = arange (one id per bag): bit-exact, with the shape
+    hook, per-sample weights and ignored (-1) indices; NULL with num_bags != nnz is refused.  (Measured: the forward is
+    no faster for it -- 55.7-56.4 us either way -- so the Python surface keeps passing the offsets it is given.)"""
+    ce = _ce()
+    from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
+    n = max(F, 1) * B
+    g = torch.Generator().manual_seed(n)
+    w = torch.randn(3000, D, generator=g).cuda()
+    idx = torch.randint(0, 3000, (n,), generator=g).cuda()
+    idx[5] = -1
+    psw = torch.rand(n, generator=g).cuda()
+    off = torch.arange(n + 1 if include_last else n, dtype=torch.int32).cuda()
+    for weights in (None, psw):
+        outs = []
+        for o in (off, None):
+            out = torch.full((n, D), 7.0, device="cuda")
+            check(lib.ce_bag_forward(ptr(w), 3000, D, ptr(idx), n, ptr(o), 0, n, int(include_last), ptr(weights), 0, F,
+                                     ptr(out), stream_ptr()))
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+    assert lib.ce_bag_forward(ptr(w), 3000, D, ptr(idx), n, None, 0, n - 1, int(include_last), None, 0, 0, ptr(out),
+                              stream_ptr()) != 0
+    ok = idx.clamp(min=0)
+    ref = w[ok] * (idx >= 0).unsqueeze(1)
+    if F:
+        ref = ref.view(F, B, D).transpose(0, 1).contiguous()
+    got = ce.embedding_bag(idx, w, off, mode="sum", include_last_offset=include_last, hook_features=F)
+    assert torch.equal(got.reshape(ref.shape), ref)
+    if n > 10:
+        # the same tensor object, no longer arange: bag 2 takes two ids, bag 3 none
+        off[3] = 4
+        ref2 = ref.clone().view(-1, D) if not F else None
+        got2 = ce.embedding_bag(idx, w, off, mode="sum", include_last_offset=include_last, hook_features=0)
+        exp = (w[ok] * (idx >= 0).unsqueeze(1)).clone()
+        exp[2] = exp[2] + exp[3]
+        exp[3] = 0
+        torch.testing.assert_close(got2, exp, rtol=0, atol=0)
+
+
 def test_empty_inputs():
     ce = _ce()
     w = torch.randn(10, 16).cuda()
