@@ -445,6 +445,16 @@ class CachedParamMgr(torch.nn.Module):
                 raise IndexError(f"cache op #{sq.value}: an id is outside [0, {self.num_embeddings})")
             raise _lib.CeError(st.value, f"cache op #{sq.value} failed")
 
+    def acknowledge_failures(self) -> int:
+        """Mark the calls that have failed so far as seen (they will not make raise_on_failed_calls raise) and return
+        how many there are -- for a caller that PROBES with calls it expects to overflow (bench.py sizing the
+        prefetch window of a shard cache) and has read their records itself."""
+        n, st, sq = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+        self.sync_stats()                                           # every call issued so far has finished
+        check(lib.ce_cache_failures(self._handle, ctypes.byref(n), ctypes.byref(st), ctypes.byref(sq)))
+        self._failures_seen = n.value
+        return n.value
+
     def cuda_weight_data(self, slot: int) -> torch.Tensor:
         return self.cuda_cached_weight.data[slot]
 

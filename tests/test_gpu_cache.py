@@ -243,6 +243,27 @@ def test_non_strict_overflow_yields_minus_one_slots_and_zero_rows():
     assert emb.cache_weight_mgr.sync_stats().status == 3     # CE_ERR_CAPACITY
 
 
+def test_probing_overflows_can_be_acknowledged():
+    """A caller that sizes its window with calls it expects to overflow (bench.py on a shard cache) reads their records
+    itself; acknowledge_failures() keeps them from surfacing later in raise_on_failed_calls, which still reports every
+    failure that happens afterwards."""
+    ce = _ce()
+    emb = ce.CachedEmbeddingBag(1000, 16, sparse=True, _weight=torch.randn(1000, 16), mode="sum",
+                                include_last_offset=True, cuda_row_num=20, strict=False)
+    mgr = emb.cache_weight_mgr
+    mgr.prepare_ids(torch.arange(100, 140, device="cuda"))            # overflows: 40 unique rows, 20 slots
+    assert mgr.sync_stats().status == 3 and mgr.sync_stats().n_unique == 40
+    assert mgr.acknowledge_failures() == 1
+    mgr.prepare_ids(torch.arange(100, 110, device="cuda"))            # fits
+    torch.cuda.synchronize()
+    mgr.raise_on_failed_calls()                                        # nothing new: does not raise
+    mgr.prepare_ids(torch.arange(200, 260, device="cuda"))            # overflows again
+    torch.cuda.synchronize()
+    mgr.sync_stats()
+    with pytest.raises(AssertionError, match="needed more unique rows"):
+        mgr.raise_on_failed_calls()
+
+
 @pytest.mark.parametrize("N", [256, 65536, 1 << 24])
 def test_dataset_keys_sharing_the_top_byte_with_ineligible_slots(N):
     """N - 1 has 0xff in its top byte, so the DATASET keys N-1-row of the hottest rows (row < 256^t) share the top
