@@ -70,6 +70,10 @@ def parse():
                     "bag of every lookup per launch) instead of row | grad_out row (streaming backward)")
     ap.add_argument("--no_graph", action="store_true", help="launch every step from Python instead of replaying a "
                     "hipGraph of the window's P training steps")
+    ap.add_argument("--plan_ahead", type=int, default=int(os.environ.get("CE_BENCH_PLAN_AHEAD", "0")), choices=[0, 1, 2],
+                    help="windows the cache op may run ahead of training (2: three slot buffers, protect_depth 2; pays "
+                    "when the cache op of a window takes longer than the window trains).  0 = 2 for prefetch_num 1 "
+                    "(Kaggle P = 1: 1.17 -> 1.25 G, LFU 1.19 -> 1.38 G), else 1")
     ap.add_argument("--graph_cache_op", action="store_true", help="zero-copy transport: replay the cache op from a "
                     "hipGraph of its own instead of launching it kernel by kernel (same speed: DESIGN.md section 4)")
     ap.add_argument("--async_copy", action="store_true", help="staged hipMemcpyAsync transport (= --transport staged)")
@@ -109,6 +113,8 @@ def main():
         args.no_overlap = args.no_presort = args.no_graph = True
         args.transport = args.transport or "zerocopy"
     args.overlap = not args.no_overlap
+    if args.plan_ahead == 0:
+        args.plan_ahead = 2 if (args.prefetch_num == 1 and args.overlap) else 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,7 +187,7 @@ def main():
     windows = []
 
     def need_windows(n_steps, first_step=0):
-        while len(windows) * P < n_steps + P:          # + one look-ahead window for the overlapped cache op
+        while len(windows) * P < n_steps + P * args.plan_ahead:   # + the look-ahead windows of the overlapped cache op
             windows.append(gen.next_values(P))          # each [P, F*B*L]
         for w in range(max(0, first_step // P - 2)):   # windows long done: give the HBM back
             windows[w] = None
@@ -215,7 +221,8 @@ def main():
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
                            warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort,
                            transport=None, bag_layout=layout,
-                           graph_cache_op=args.graph_cache_op and args.overlap)
+                           graph_cache_op=args.graph_cache_op and args.overlap,
+                           plan_ahead=args.plan_ahead if args.overlap else 1)
         note("hipGraph of the window's training steps captured" +
              (" (+ the cache op as a graph of its own)" if gw._plan_graphs is not None else ""))
 
@@ -238,19 +245,19 @@ def main():
                 state["submitted"] = w + 1
                 g += P
             elif use_graph:
+                nb, ahead = gw.nbuf, gw.plan_ahead
                 if i == 0 and not (skip_cache_op and g0 >= W):
                     if args.overlap:
-                        if state["submitted"] < w:
-                            gw.submit([windows[w][j] for j in range(P)], w % 2)
-                        gw.submit([windows[w + 1][j] for j in range(P)], (w + 1) % 2)
-                        state["submitted"] = w + 1
+                        for w2 in range(max(state["submitted"] + 1, w), w + ahead + 1):
+                            gw.submit([windows[w2][j] for j in range(P)], w2 % nb)
+                            state["submitted"] = w2
                     else:
-                        gw.submit([windows[w][j] for j in range(P)], w % 2)
+                        gw.submit([windows[w][j] for j in range(P)], w % nb)
                 n = min(P - i, g1 - g)
                 if i == 0 and n == P:
-                    gw.run(w % 2)
+                    gw.run(w % nb)
                 else:
-                    gw.run_steps(w % 2, i, i + n)
+                    gw.run_steps(w % nb, i, i + n)
                 g += n
             else:
                 if i == 0 or state["slots"] is None:
@@ -511,6 +518,7 @@ def main():
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
                    "transport": transport, "overlap": bool(args.overlap),
+                   "plan_ahead_windows": (gw.plan_ahead if gw is not None else 1) if args.overlap else 0,
                    "launch": "hipGraph per window" if use_graph else "python per step",
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "
                                          "(ce_bag_presort_window%s)" % ("" if args.tile_keys else "_src: keys = row | grad_out row, streaming backward") if presort else "1024-lookup tiles sorted inside every backward",

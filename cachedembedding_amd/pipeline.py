@@ -183,8 +183,18 @@ class GraphedWindow:
 
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
                  warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
-                 transport: Optional[str] = "auto", bag_layout=None, graph_cache_op: bool = False):
+                 transport: Optional[str] = "auto", bag_layout=None, graph_cache_op: bool = False,
+                 plan_ahead: int = 1):
+        # plan_ahead (overlap=True): how many windows the cache op may run ahead of training.  1: the cache op of window
+        # k+1 starts when window k-1 has trained (two slot buffers, protect_depth 1).  2: it starts when window k-2 has
+        # -- three buffers, protect_depth 2, unique(three consecutive windows) must fit the cache, and the ids handed to
+        # submit() must be COMPLETE when it is called (submit no longer waits for the compute stream, which would put
+        # the cache op behind the training already enqueued there).  That takes the wait for the previous window's
+        # training out of a chain that is longer than a training step: prefetch_num = 1.
         # bag_layout: see PrefetchWindow (static offsets shared by every batch; keys_i is then a SrcKeys)
+        assert plan_ahead in (1, 2) and (plan_ahead == 1 or overlap)
+        self.plan_ahead = plan_ahead
+        nbuf = self.nbuf = plan_ahead + 1
         self._layout = None if bag_layout is None else dict(offsets=bag_layout[0],
                                                             include_last_offset=bool(bag_layout[1]),
                                                             hook_features=int(bag_layout[2]),
@@ -196,25 +206,27 @@ class GraphedWindow:
         self.n = ids_per_batch
         self.overlap = overlap
         dev = self.mgr.device
-        self._bufs = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
+        self._bufs = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(nbuf)]
         # presort=True: step_fn(slots_i, i, keys_i); the segment-grouped keys of the window (ce_bag_presort_window)
         # are produced behind the cache op into a static buffer next to the slots
         self.presort = presort
         self._klen = presort_len(self.n)
-        self._keys = [torch.full((self.P, self._klen), -1, dtype=torch.int64, device=dev) for _ in range(2)] \
+        self._keys = [torch.full((self.P, self._klen), -1, dtype=torch.int64, device=dev) for _ in range(nbuf)] \
             if self.presort else None
         # id range of every 16384-lookup segment (source-row keys only): min > max = "no ids seen" until a presort ran
         self._ranges = None
         if self.presort and self._layout is not None and EXCLUSIVE_ROWS:
-            self._ranges = [torch.empty(self.P, self._klen // 16384, 2, dtype=torch.int64, device=dev) for _ in range(2)]
+            self._ranges = [torch.empty(self.P, self._klen // 16384, 2, dtype=torch.int64, device=dev)
+                            for _ in range(nbuf)]
             for r in self._ranges:
                 r[..., 0] = torch.iinfo(torch.int64).min       # "everything": never disjoint -> atomics
                 r[..., 1] = torch.iinfo(torch.int64).max
         self._side = make_side_stream(dev, cache_cus) if overlap else None
-        self._events = [None, None]
+        self._events = [None] * nbuf
+        self._read_done = [None] * nbuf        # event behind the last training run that read buffer b
         self._step_fn = step_fn
         if overlap:
-            self.mgr.set_protect_depth(1)
+            self.mgr.set_protect_depth(plan_ahead)
             self.mgr.strict = False
             transport = pick_transport(transport, prefetch_num * ids_per_batch)
             if transport:
@@ -223,12 +235,14 @@ class GraphedWindow:
         if warmup_values is not None:
             wcat = torch.cat(list(warmup_values))
             self.mgr.prepare_ids(wcat, out=self._bufs[0])
-            self._bufs[1].copy_(self._bufs[0])
+            for b in range(1, nbuf):
+                self._bufs[b].copy_(self._bufs[0])
             if self.presort:
                 self._presort(0, wcat)
-                self._keys[1].copy_(self._keys[0])
-                if self._ranges is not None:
-                    self._ranges[1].copy_(self._ranges[0])
+                for b in range(1, nbuf):
+                    self._keys[b].copy_(self._keys[0])
+                    if self._ranges is not None:
+                        self._ranges[b].copy_(self._ranges[0])
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -238,7 +252,7 @@ class GraphedWindow:
         torch.cuda.synchronize(dev)
         self._graphs = []
         self._step_graphs = []          # [buf][i]: batch i alone (windows a caller trains in part)
-        for b in range(2):
+        for b in range(nbuf):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for i in range(self.P):
@@ -254,8 +268,8 @@ class GraphedWindow:
         self._plan_graphs = None
         self._ids = None
         if graph_cache_op:
-            if not overlap or self.mgr.transport_name != "zerocopy" or self._ranges is not None:
-                raise ValueError("graph_cache_op needs overlap=True and the zero-copy transport")
+            if not overlap or self.mgr.transport_name != "zerocopy" or self._ranges is not None or plan_ahead != 1:
+                raise ValueError("graph_cache_op needs overlap=True, plan_ahead=1 and the zero-copy transport")
             self._ids = [torch.zeros(self.P, self.n, dtype=torch.int64, device=dev) for _ in range(2)]
             if warmup_values is not None:
                 for t in self._ids:
@@ -300,6 +314,22 @@ class GraphedWindow:
         """Cache op of a window into slot buffer `buf` (0/1), on the side stream when overlap=True.
         Call it BEFORE run() of the previous window so the two overlap: the side stream only waits for the
         work already enqueued on the compute stream (the graph that last read `buf`)."""
+        if self.overlap and self.plan_ahead > 1:
+            # the ids are complete (the caller's promise): only the last training run that read this buffer is waited for
+            with torch.cuda.stream(self._side), phase("prefetch cache"):
+                if self._read_done[buf] is not None:
+                    self._side.wait_event(self._read_done[buf])
+                cat = values[0] if len(values) == 1 else torch.cat(list(values))
+                assert cat.numel() == self.P * self.n
+                self.mgr.prepare_ids(cat, out=self._bufs[buf])
+                if self.presort:
+                    self._presort(buf, cat)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            for v in values:
+                v.record_stream(self._side)
+            self._events[buf] = ev
+            return
         cat = values[0] if len(values) == 1 else torch.cat(list(values))
         assert cat.numel() == self.P * self.n
         if self.overlap:
@@ -330,11 +360,16 @@ class GraphedWindow:
                 self._step_graphs[buf][i].replay()
             else:
                 self._call(self._step_fn, buf, i)
+        if self.plan_ahead > 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.mgr.device))
+            self._read_done[buf] = ev
 
     @torch.no_grad()
     def run_and_submit(self, buf: int, next_values: Sequence[torch.Tensor]) -> None:
         """submit(next_values, 1 - buf) + run(buf): the window in buffer `buf` trains while the cache op of the next
         window fills the other buffer; with graph_cache_op both are graph replays."""
+        assert self.nbuf == 2, "run_and_submit alternates two buffers (plan_ahead = 1)"
         if self._plan_graphs is None:
             self.submit(next_values, 1 - buf)
             self.run(buf)
@@ -378,3 +413,7 @@ class GraphedWindow:
             self._graphs[buf].replay()
         else:
             self.run_steps(buf, 0, steps)
+        if self.plan_ahead > 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.mgr.device))
+            self._read_done[buf] = ev

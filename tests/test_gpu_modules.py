@@ -200,6 +200,55 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
     torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("P,lfu,presort,transport", [(1, False, False, "worker"), (1, True, False, "zerocopy"),
+                                                    (3, False, "src", "worker")])
+def test_cache_op_two_windows_ahead(P, lfu, presort, transport):
+    """GraphedWindow(plan_ahead=2): three slot buffers, protect_depth 2, the cache op of window k+2 only waits for the
+    training of window k-1 (the last reader of its buffer).  Same training trajectory as a plain full-table
+    EmbeddingBag with SGD, and no row of a window that still trains is evicted (the table after flush says so)."""
+    import cachedembedding_amd as ce
+    from cachedembedding_amd.pipeline import GraphedWindow
+    torch.manual_seed(0)
+    N, D, F, B, lr, nwin = 20000, 64, 4, 64, 0.5, 30
+    w0 = torch.randn(N, D)
+    off = torch.arange(F * B + 1, dtype=torch.int32, device="cuda")
+    layout = (off, True, F) if presort == "src" else None
+    grad = (torch.randn(B, F, D) * 0.1).cuda()
+    g = torch.Generator().manual_seed(7)
+    windows = [[(torch.rand(F * B, generator=g) ** 3 * N).long().clamp_(0, N - 1).cuda() for _ in range(P)]
+               for _ in range(nwin)]
+    emb = ce.CachedEmbeddingBag(N, D, sparse=True, _weight=w0.clone(), mode="sum", include_last_offset=True,
+                                cuda_row_num=4 * F * B * P, warmup_ratio=0.5, strict=False,
+                                evict_strategy=ce.EvictionStrategy.LFU if lfu else ce.EvictionStrategy.DATASET)
+    emb.set_fused_sgd(lr)
+    emb.set_cache_op(False)
+
+    def step(slots, i, keys=None):
+        out = emb(slots, off, hook_features=F, presorted=keys)
+        out.backward(grad)
+
+    gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=windows[0], presort=bool(presort),
+                       transport=transport, bag_layout=layout, plan_ahead=2)
+    assert gw.nbuf == 3
+    torch.cuda.synchronize()
+    submitted = -1
+    for w in range(nwin):
+        for w2 in range(submitted + 1, min(nwin, w + 3)):
+            gw.submit(windows[w2], w2 % 3)
+            submitted = w2
+        gw.run(w % 3)
+    torch.cuda.synchronize()
+    assert emb.cache_weight_mgr.sync_stats().status == 0
+    emb.flush()
+    ref = w0.clone()
+    for v in windows[0]:                     # the capture warm-up trained on window 0 once (eager pass)
+        ref.index_add_(0, v.cpu(), grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+    for w in range(nwin):
+        for v in windows[w]:
+            ref.index_add_(0, v.cpu(), grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+    torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("P,lfu,presort", [(4, False, "src"), (1, False, False), (1, True, False), (2, True, "src")])
 def test_cache_op_captured_in_the_window_graph(P, lfu, presort):
     """GraphedWindow(graph_cache_op=True): the next window's cache op is replayed from a hipGraph of its own beside
