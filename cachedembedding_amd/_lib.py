@@ -152,6 +152,15 @@ SIGNATURES = {
                                                     c_void_p, c_void_p]),
     "ce_exchange_local_index": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                         c_void_p, c_void_p]),
+    "ce_bag_forward_max": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_int32,
+                                   c_int64, c_void_p, c_void_p, c_void_p]),
+    "ce_bag_backward_max": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                    c_float, c_void_p]),
+    "ce_bag_backward_psw": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_int32,
+                                    c_int64, c_void_p, c_void_p, c_void_p]),
+    "ce_rows_renorm_workspace": (c_size_t, [c_int64]),
+    "ce_rows_renorm": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_float, c_float, c_void_p, c_size_t,
+                               c_void_p]),
     "ce_rows_axpy": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
 }
 

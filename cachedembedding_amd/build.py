@@ -12,7 +12,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libce_hip.so"
-SOURCES = ["ce_host.hip", "ce_bag.hip", "ce_cache.hip", "ce_sort.hip", "ce_rowcopy.cpp"]
+SOURCES = ["ce_host.hip", "ce_bag.hip", "ce_bag_extra.hip", "ce_cache.hip", "ce_sort.hip", "ce_rowcopy.cpp"]
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++"]       # plain C++ sources (host only)
 HEADERS = [ROOT / "include" / "ce_api.h", CSRC / "ce_common.h"]
 ARCH = "gfx950"

@@ -143,7 +143,66 @@ class _BagFn(torch.autograd.Function):
                 check(lib.ce_bag_backward_dense(ptr(gw), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
                                                 num_bags, int(include_last), ptr(psw), mode, hook_features,
                                                 ptr(grad_out), stream_ptr()))
-        return gw, None, None, None, None, None, None, None, None, None, None, None
+        gpsw = None
+        if ctx.needs_input_grad[3]:
+            # d loss / d per_sample_weights[j] = <grad_out[bag of j], weight[indices[j]]>; with the fused update the rows
+            # have moved already, which is what the optimizer-step-after-backward order of a trainer would not do:
+            # refuse that combination rather than hand back a gradient against the updated rows
+            if fused is not None and fused.lr is not None:
+                raise NotImplementedError("gradient w.r.t. per_sample_weights with the fused SGD update")
+            gpsw = torch.empty(nnz, device=weight.device, dtype=torch.float32)
+            check(lib.ce_bag_backward_psw(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
+                                          num_bags, int(include_last), hook_features, ptr(grad_out), ptr(gpsw),
+                                          stream_ptr()))
+        return gw, None, None, gpsw, None, None, None, None, None, None, None, None
+
+
+class _BagMaxFn(torch.autograd.Function):
+    """mode='max' (ce_bag_forward_max / ce_bag_backward_max): dense gradient or the fused SGD update."""
+
+    @staticmethod
+    def forward(ctx, weight, indices, offsets, include_last, hook_features, fused):
+        _lib.require_gpu()
+        assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+        num_bags = offsets.numel() - 1 if include_last else offsets.numel()
+        dim = weight.shape[1]
+        shape = (num_bags // hook_features, hook_features, dim) if hook_features else (num_bags, dim)
+        out = torch.empty(shape, device=weight.device, dtype=torch.float32)
+        pos = torch.empty(num_bags, dim, device=weight.device, dtype=torch.int32)
+        check(lib.ce_bag_forward_max(ptr(weight), weight.shape[0], dim, ptr(indices), indices.numel(), ptr(offsets),
+                                     int(offsets.dtype == torch.int64), num_bags, int(include_last), hook_features,
+                                     ptr(out), ptr(pos), stream_ptr()))
+        ctx.save_for_backward(indices, pos)
+        ctx.weight = weight
+        ctx.args = (num_bags, hook_features, fused)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        indices, pos = ctx.saved_tensors
+        weight = ctx.weight
+        num_bags, hook_features, fused = ctx.args
+        grad_out = grad_out.contiguous()
+        dim = weight.shape[1]
+        if fused is not None and fused.lr is not None:
+            with torch.no_grad():
+                check(lib.ce_bag_backward_max(ptr(weight), weight.shape[0], dim, ptr(indices), indices.numel(), num_bags,
+                                              hook_features, ptr(grad_out), ptr(pos), -float(fused.lr), stream_ptr()))
+            return None, None, None, None, None, None
+        gw = torch.zeros_like(weight)
+        check(lib.ce_bag_backward_max(ptr(gw), weight.shape[0], dim, ptr(indices), indices.numel(), num_bags,
+                                      hook_features, ptr(grad_out), ptr(pos), 1.0, stream_ptr()))
+        return gw, None, None, None, None, None
+
+
+def renorm_rows_(weight: torch.Tensor, indices: torch.Tensor, max_norm: float, norm_type: float = 2.0) -> None:
+    """torch.embedding_renorm_ on the rows `indices` names (out-of-range entries are skipped), in place."""
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+    idx = indices.reshape(-1).long().contiguous()
+    ws = torch.empty(lib.ce_rows_renorm_workspace(weight.shape[0]), dtype=torch.uint8, device=weight.device)
+    with torch.no_grad():
+        check(lib.ce_rows_renorm(ptr(weight), weight.shape[0], weight.shape[1], ptr(idx), idx.numel(), float(max_norm),
+                                 float(norm_type), ptr(ws), ws.numel(), stream_ptr()))
 
 
 class FusedSGD:
@@ -172,18 +231,34 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   presorted: Union[torch.Tensor, SrcKeys, None] = None, masked_indices: bool = False) -> torch.Tensor:
     # masked_indices: the caller already replaced ignored lookups (padding) by -1 -- the kernels skip them; the
     # sparse=True backward then parks their (zero) gradient rows at index 0 so the COO tensor stays valid
-    if max_norm is not None:
-        raise NotImplementedError("max_norm renormalisation is not implemented by the HIP path")
-    if mode not in _MODES:
-        raise NotImplementedError(f"mode={mode!r}: only 'sum' and 'mean' are implemented")
+    if mode not in _MODES and mode != "max":
+        raise NotImplementedError(f"mode={mode!r}: 'sum', 'mean' and 'max' are implemented")
     if per_sample_weights is not None:
         if mode != "sum":
             raise NotImplementedError("embedding_bag: per_sample_weights was not None. per_sample_weights is "
                                       f"only supported for mode='sum' (got mode='{mode}').")
-        if per_sample_weights.requires_grad:
-            raise NotImplementedError("gradient w.r.t. per_sample_weights is not implemented")
-        per_sample_weights = per_sample_weights.reshape(-1).float().contiguous()
+        if per_sample_weights.dtype != torch.float32 or not per_sample_weights.is_contiguous() or \
+                per_sample_weights.dim() != 1:
+            per_sample_weights = per_sample_weights.reshape(-1).float().contiguous()     # (keeps the autograd link)
     indices, offsets, include_last_offset, num_bags = _prep(indices, offsets, include_last_offset)
+    if max_norm is not None:
+        # F.embedding_bag renormalises the rows the input names, in place, before it looks them up
+        renorm_rows_(weight.detach(), indices, max_norm, norm_type)
+    if mode == "max":
+        # torch: no per_sample_weights (above), no sparse gradient, no scale_grad_by_freq for 'max'
+        if sparse:
+            raise RuntimeError("embedding_bag: sparse gradients are not supported with mode='max'")
+        if scale_grad_by_freq:
+            raise RuntimeError("embedding_bag: scale_grad_by_freq is not supported with mode='max'")
+        if presorted is not None:
+            raise NotImplementedError("presorted keys serve the sum / mean backward only")
+        if hook_features and num_bags % hook_features:
+            raise ValueError("hook_features must divide the number of bags")
+        if padding_idx is not None:
+            if padding_idx < 0:
+                padding_idx += weight.shape[0]
+            indices = torch.where(indices == padding_idx, torch.full_like(indices, -1), indices)
+        return _BagMaxFn.apply(weight, indices, offsets, bool(include_last_offset), int(hook_features), fused_sgd)
     if per_sample_weights is not None and per_sample_weights.numel() != indices.numel():
         raise ValueError("per_sample_weights must have the same number of elements as input")
     bwd_scale = None

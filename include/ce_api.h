@@ -427,6 +427,33 @@ int ce_exchange_local_index(const int64_t* pos, int64_t n_per_batch, int64_t n_b
                             int64_t slots_batch_stride, int64_t local_lo, int64_t local_hi, int64_t tail_base,
                             int64_t* index_out, ce_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * The F.embedding_bag arguments the reference forwards (recsys/models/dlrm.py:99-110 -> upstream A.7) and none of its
+ * scripts sets (API 3).  Plain kernels (any dim, one wave per bag / row), off the benchmarked path.
+ *
+ * mode = 'max': out[bag][d] = max over the bag's rows (0 for a bag without valid rows), written like ce_bag_forward
+ * (hook_features folds the shape hook).  max_pos (device int32 [num_bags, dim], may be NULL for inference) receives the
+ * lookup that supplied each maximum (-1: none; the first of equal maxima, as torch's CPU kernel).  ce_bag_backward_max
+ * routes the gradient there: dst[indices[max_pos[bag][d]]][d] += alpha * grad_out[bag][d] -- alpha 1 into a zeroed
+ * grad_weight, alpha -lr straight into the weight (fused SGD). */
+int ce_bag_forward_max(const float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
+                       const void* offsets, int32_t offsets_are_i64, int64_t num_bags, int32_t include_last_offset,
+                       int64_t hook_features, float* out, int32_t* max_pos, ce_stream_t stream);
+int ce_bag_backward_max(float* dst, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
+                        int64_t num_bags, int64_t hook_features, const float* grad_out, const int32_t* max_pos,
+                        float alpha, ce_stream_t stream);
+/* Gradient w.r.t. per_sample_weights (mode 'sum'): grad_psw[j] = < grad_out[bag of j], weight[indices[j]] >, 0 for an
+ * ignored lookup.  grad_psw: device fp32 [nnz]. */
+int ce_bag_backward_psw(const float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t nnz,
+                        const void* offsets, int32_t offsets_are_i64, int64_t num_bags, int32_t include_last_offset,
+                        int64_t hook_features, const float* grad_out, float* grad_psw, ce_stream_t stream);
+/* max_norm / norm_type (torch.embedding_renorm_, applied by F.embedding_bag before the lookup): every row an index
+ * names is scaled by max_norm / (norm + 1e-7) if its norm_type-norm exceeds max_norm -- once, however often it is named.
+ * workspace: device memory of ce_rows_renorm_workspace(num_rows) bytes (a bitmap of the named rows). */
+size_t ce_rows_renorm_workspace(int64_t num_rows);
+int ce_rows_renorm(float* weight, int64_t num_rows, int32_t dim, const int64_t* indices, int64_t n, float max_norm,
+                   float norm_type, void* workspace, size_t workspace_bytes, ce_stream_t stream);
+
 /* weight[index[i]] += alpha * src_rows[i] for i < n (whole rows of `dim` floats; repeated / out-of-range
  * index entries are summed / skipped).  Owner-side update of the row-wise exchange: the requester has
  * already folded a batch's duplicates, so each received gradient row is applied as is (alpha = -lr). */

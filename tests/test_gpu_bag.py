@@ -149,7 +149,7 @@ def test_2d_input_and_errors():
     with pytest.raises(ValueError):
         ce.embedding_bag(idx.cuda(), w.cuda(), torch.arange(3).cuda())
     with pytest.raises(NotImplementedError):
-        ce.embedding_bag(idx.cuda(), w.cuda(), mode="max")
+        ce.embedding_bag(idx.cuda(), w.cuda(), mode="min")
 
 
 @pytest.mark.parametrize("F,B,D", [(26, 512, 128), (13, 100, 32), (3, 7, 64)])
@@ -625,3 +625,86 @@ def test_hooked_forward_with_ragged_bags_of_total_length_num_bags(D):
         wr = w.clone().requires_grad_(True)
         torch.nn.functional.embedding_bag(idx, wr, off[:-1], mode="sum").view(F, B, D).transpose(0, 1).backward(go)
         torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("D", [128, 33, 64])
+@pytest.mark.parametrize("fused", [False, True])
+def test_mode_max_matches_torch(D, fused):
+    """mode='max' (an F.embedding_bag argument the reference forwards, recsys/models/dlrm.py:99-110): forward, the
+    gradient routed to the rows that supplied the maxima, and the fused SGD form, against torch on the CPU -- ragged
+    bags, an empty bag, a padding index."""
+    ce = _ce()
+    g = torch.Generator().manual_seed(D)
+    R, nb = 500, 200
+    w = torch.randn(R, D, generator=g)
+    lens = torch.randint(0, 7, (nb,), generator=g)
+    lens[3] = 0
+    off = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    idx = torch.randint(0, R, (int(off[-1]),), generator=g)
+    go = torch.randn(nb, D, generator=g)
+    wr = w.clone().requires_grad_(True)
+    ref = torch.nn.functional.embedding_bag(idx, wr, off, mode="max", include_last_offset=True, padding_idx=7)
+    ref.backward(go)
+    wc = w.cuda().requires_grad_(True)
+    fs = ce.FusedSGD(0.25) if fused else None
+    out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="max", include_last_offset=True, padding_idx=7,
+                           fused_sgd=fs)
+    torch.testing.assert_close(out.cpu(), ref, rtol=0, atol=0)
+    out.backward(go.cuda())
+    if fused:
+        assert wc.grad is None
+        torch.testing.assert_close(wc.detach().cpu(), w - 0.25 * wr.grad, rtol=1e-6, atol=1e-6)
+    else:
+        torch.testing.assert_close(wc.grad.cpu(), wr.grad, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="max", include_last_offset=True, sparse=True)
+    # folded shape hook: feature-major bags -> [B, F, D]
+    F_, B_ = 4, 50
+    out_h = ce.embedding_bag(idx.cuda(), w.cuda(), off.cuda(), mode="max", include_last_offset=True, padding_idx=7,
+                             hook_features=F_)
+    torch.testing.assert_close(out_h.cpu(), ref.detach().view(F_, B_, D).transpose(0, 1).contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("D", [128, 20])
+def test_per_sample_weights_gradient_matches_torch(D):
+    ce = _ce()
+    g = torch.Generator().manual_seed(D + 1)
+    R, nb = 300, 150
+    w = torch.randn(R, D, generator=g)
+    lens = torch.randint(0, 6, (nb,), generator=g)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    idx = torch.randint(0, R, (int(off[-1]),), generator=g)
+    psw = torch.rand(idx.numel(), generator=g)
+    go = torch.randn(nb, D, generator=g)
+    wr, pr = w.clone().requires_grad_(True), psw.clone().requires_grad_(True)
+    torch.nn.functional.embedding_bag(idx, wr, off, mode="sum", include_last_offset=True,
+                                      per_sample_weights=pr).backward(go)
+    wc, pc = w.cuda().requires_grad_(True), psw.cuda().requires_grad_(True)
+    ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True,
+                     per_sample_weights=pc).backward(go.cuda())
+    torch.testing.assert_close(pc.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(wc.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("norm_type", [2.0, 1.0, 3.0, float("inf")])
+@pytest.mark.parametrize("D", [128, 17])
+def test_max_norm_renormalises_the_named_rows_like_torch(D, norm_type):
+    """max_norm / norm_type: the rows the input names are scaled in place before the lookup (torch.embedding_renorm_),
+    once however often they are named; all other rows stay as they are."""
+    ce = _ce()
+    g = torch.Generator().manual_seed(int(D * 10 + min(norm_type, 9)))
+    R, nb = 400, 120
+    w = torch.randn(R, D, generator=g) * 0.3
+    idx = torch.randint(0, R // 2, (nb * 3,), generator=g)          # many duplicates, half of the table untouched
+    off = torch.arange(0, nb * 3 + 1, 3)
+    max_norm = float(torch.linalg.vector_norm(w[:R // 2], ord=norm_type, dim=1).median())   # about half the rows shrink
+    wr = w.clone()
+    ref = torch.nn.functional.embedding_bag(idx, wr, off, mode="sum", include_last_offset=True, max_norm=max_norm,
+                                            norm_type=norm_type)
+    wc = w.cuda()
+    out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, max_norm=max_norm,
+                           norm_type=norm_type)
+    assert not torch.equal(wr, w), "the case must renormalise something"
+    torch.testing.assert_close(wc.cpu(), wr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(wc.cpu()[R // 2:], w[R // 2:])

@@ -207,6 +207,36 @@ def test_module_equivalence_with_plain_embedding_bag(strategy, mode):
     torch.testing.assert_close(model.weight, ref.weight.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode,max_norm", [("max", None), ("sum", 4.0), ("max", 4.0), ("mean", 3.0)])
+def test_module_with_max_mode_and_max_norm_matches_plain_embedding_bag(mode, max_norm):
+    """The F.embedding_bag arguments the reference's module forwards (mode='max', max_norm / norm_type) through the
+    cache: same outputs as nn.EmbeddingBag over several SGD steps, and after flush() the host table equals the reference
+    weight -- max_norm rescales the CACHED rows in place, the write-back carries them home."""
+    ce = _ce()
+    torch.manual_seed(9)
+    N, D = 600, 32
+    w0 = torch.randn(N, D)
+    model = ce.CachedEmbeddingBag(N, D, sparse=False, _weight=w0.clone(), mode=mode, include_last_offset=True,
+                                  cache_ratio=0.15, max_norm=max_norm, norm_type=2.0)
+    ref = torch.nn.EmbeddingBag.from_pretrained(w0.clone(), freeze=False, mode=mode, include_last_offset=True,
+                                                sparse=False, max_norm=max_norm)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    for step in range(8):
+        lens = torch.randint(0, 5, (20,))
+        off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
+        ids = torch.randint(0, N, (int(off[-1]),))
+        go = torch.randn(20, D)
+        out = model(ids.cuda(), off.cuda())
+        rout = ref(ids, off)
+        torch.testing.assert_close(out.cpu(), rout, rtol=1e-5, atol=1e-5)
+        opt.zero_grad(); ropt.zero_grad()
+        out.backward(go.cuda()); rout.backward(go)
+        opt.step(); ropt.step()
+    model.flush()
+    torch.testing.assert_close(model.weight, ref.weight.detach(), rtol=1e-5, atol=1e-5)
+
+
 def test_window_prepare_then_cache_op_false_forwards():
     """_train's window semantics (recsys/dlrm_main.py:245-269): one prepare_ids over P concatenated
     batches, torch.chunk the slots, forward each batch with cache_op=False."""
