@@ -100,9 +100,6 @@ class CachedEmbeddingBag(nn.Module):
                 ids = input
                 input = self.cache_weight_mgr.prepare_ids(ids)
                 if self.padding_idx is not None:
-                    if self.mode == "mean":
-                        raise NotImplementedError("padding_idx is implemented for mode='sum' and 'max' (mean would "
-                                                  "need the per-bag count of non-padding entries)")
                     if presorted is not None:
                         raise NotImplementedError("padding_idx cannot be combined with presorted keys: they were "
                                                   "built from slots that still hold the padding lookups")

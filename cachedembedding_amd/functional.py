@@ -262,10 +262,31 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
     if per_sample_weights is not None and per_sample_weights.numel() != indices.numel():
         raise ValueError("per_sample_weights must have the same number of elements as input")
     bwd_scale = None
+    if mode == "mean" and (padding_idx is not None or masked_indices or scale_grad_by_freq):
+        # 'mean' over the NON-padding entries of a bag (torch excludes padding from the sum and from the count), and
+        # 'mean' with scale_grad_by_freq: the kernels' mean divides by the bag length, so these run as a 'sum' with
+        # per-lookup weights 1 / (valid entries of the bag) -- a handful of torch ops, off the benchmarked path
+        if presorted is not None:
+            raise NotImplementedError("padding_idx / scale_grad_by_freq with mode='mean' cannot be combined with "
+                                      "presorted keys")
+        if padding_idx is not None:
+            pi = padding_idx + weight.shape[0] if padding_idx < 0 else padding_idx
+            indices = torch.where(indices == pi, torch.full_like(indices, -1), indices)
+            padding_idx = None
+            masked_indices = True
+        nnz = indices.numel()
+        ends = offsets[1:] if include_last_offset else torch.cat(
+            [offsets[1:], torch.full((1,), nnz, dtype=offsets.dtype, device=offsets.device)])
+        lens = (ends - offsets[:num_bags]).long()
+        bag_of = torch.repeat_interleave(torch.arange(num_bags, device=indices.device), lens, output_size=nnz)
+        valid = ((indices >= 0) & (indices < weight.shape[0])).to(torch.float32)
+        cnt = torch.zeros(num_bags, device=indices.device, dtype=torch.float32).index_add_(0, bag_of, valid)
+        per_sample_weights = valid / cnt.clamp_(min=1.0)[bag_of]
+        mode = "sum"
     if scale_grad_by_freq:
         # torch: the gradient of a row is divided by the number of times the row occurs in the mini-batch
         if mode != "sum":
-            raise NotImplementedError("scale_grad_by_freq is implemented for mode='sum' only")
+            raise NotImplementedError("scale_grad_by_freq is implemented for mode='sum' and 'mean'")
         if presorted is not None:
             raise NotImplementedError("scale_grad_by_freq cannot be combined with presorted keys")
         _, inv, cnt = torch.unique(indices, return_inverse=True, return_counts=True)

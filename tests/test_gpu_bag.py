@@ -434,11 +434,30 @@ def test_padding_idx_and_scale_grad_by_freq(sparse):
     res = rows >= 0
     by_id = torch.zeros(N, D).index_add_(0, rows[res], gw.cpu()[res])
     torch.testing.assert_close(by_id, ref.grad, rtol=1e-4, atol=1e-5)
-    # what the kernels cannot do with padding is refused, not mis-computed
+    # mode='mean' with a padding id: the mean over the NON-padding entries of every bag (torch's rule), forward and
+    # gradient, functional and through the module; with scale_grad_by_freq against the closed form
+    for kw in (dict(padding_idx=17), dict(scale_grad_by_freq=True), dict(padding_idx=17, scale_grad_by_freq=True)):
+        wc = w0.clone().cuda().requires_grad_(True)
+        out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="mean", include_last_offset=True, sparse=sparse, **kw)
+        out.backward(go.cuda())
+        ref = w0.clone().requires_grad_(True)
+        ro = torch.nn.functional.embedding_bag(idx, ref, off, mode="mean", include_last_offset=True,
+                                               padding_idx=kw.get("padding_idx"))
+        torch.testing.assert_close(out.detach().cpu(), ro.detach(), rtol=1e-5, atol=1e-5)
+        got = wc.grad.to_dense().cpu() if sparse else wc.grad.cpu()
+        keep = idx != 17 if "padding_idx" in kw else torch.ones_like(idx, dtype=torch.bool)
+        nvalid = torch.zeros(nb).index_add_(0, bag, keep.float()).clamp_(min=1)
+        scale = (1.0 / cnt[idx]) if kw.get("scale_grad_by_freq") else torch.ones(nnz)
+        want = torch.zeros(N, D).index_add_(0, idx[keep], go[bag[keep]] * (scale[keep] / nvalid[bag[keep]]).unsqueeze(1))
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+        if "scale_grad_by_freq" not in kw:
+            ro.backward(go)
+            torch.testing.assert_close(got, ref.grad, rtol=1e-4, atol=1e-5)
     emb_mean = ce.CachedEmbeddingBag(N, D, padding_idx=17, sparse=sparse, _weight=w0.clone(), mode="mean",
                                      include_last_offset=True, cuda_row_num=N)
-    with pytest.raises(NotImplementedError):
-        emb_mean(idx.cuda(), off.cuda())
+    torch.testing.assert_close(emb_mean(idx.cuda(), off.cuda()).detach().cpu(),
+                               torch.nn.functional.embedding_bag(idx, w0, off, mode="mean", include_last_offset=True,
+                                                                 padding_idx=17), rtol=1e-5, atol=1e-5)
     from cachedembedding_amd.functional import presort_slots
     with pytest.raises(NotImplementedError):
         emb(idx.cuda(), off.cuda(), presorted=presort_slots(torch.zeros(nnz, dtype=torch.long, device="cuda"), N))
