@@ -445,3 +445,26 @@ def test_rowwise_sharded_over_rccl(overlap):
     world = min(torch.cuda.device_count(), 4)
     _spawn(_rowwise, world, "dataset", True, overlap, backend="nccl")
     _spawn(_rowwise, 2, "lfu", False, overlap, backend="nccl")
+
+
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--use_lfu"])])
+def test_bench_multi_rank_path_with_ranks_sharing_the_gpu(ranks, extra):
+    """`bench.py --gpus N` is launched by the driver as `torch.distributed.run --nproc-per-node N`; no multi-GPU box is
+    available to the tests, so the same command runs with N ranks SHARING cuda:0 over gloo (--share_gpu) on a
+    scaled-down table: window sizing (prefetch_num is lowered until the shard cache holds it -- the probing calls
+    overflow on purpose), capacity choice, the fixed-capacity plan, the steps and the timed region all execute, and
+    rank 0 prints ONE JSON line with the whole-job rate."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(ranks), "--share_gpu",
+           "--table_scale", "0.02", "--batch_size", "4096", "--steps", "16", "--warmup", "8", "--no_cpu_baseline",
+           "--min_time", "0.05"] + extra
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 4096 * ranks
