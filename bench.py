@@ -114,7 +114,7 @@ def main():
         args.transport = args.transport or "zerocopy"
     args.overlap = not args.no_overlap
     if args.plan_ahead == 0:
-        args.plan_ahead = 2 if (args.prefetch_num == 1 and args.overlap) else 1
+        args.plan_ahead = 2 if (args.prefetch_num == 1 and args.overlap and not args.graph_cache_op) else 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -335,6 +335,8 @@ def main():
     g = W
     need_windows(g + K, g)
     barrier()
+    mgr.sync_stats()
+    tot_blk0 = mgr.totals()
     t1 = time.perf_counter()
     run_range(g, g + K)
     barrier()
@@ -342,6 +344,8 @@ def main():
     g += K
     phases = mgr.phase_times()
     mgr.set_profiling(False)
+    mgr.sync_stats()
+    tot_blk1 = mgr.totals()                  # rows moved by the calls the phase timers saw
     reps = int(min(args.max_reps, max(3, -(-args.min_time // max(single, 1e-6)))))
     need_windows(g + reps * K, g)
     tot0 = mgr.totals()
@@ -466,10 +470,11 @@ def main():
     # the PCIe row swap of the cache op (k_swap), timed inside the timed blocks by the library's phase events
     # (side stream, i.e. while training kernels run beside it).  Bytes: rows admitted (+ rows written back when the
     # kernel carries both directions) x 4D; peak: PCIe Gen5 x16, ~63 GB/s per direction.
-    calls_t = max(1, phases.get("calls", 0))
-    rows_in_t = (tot["cpu_to_cuda_numel"] - tot0["cpu_to_cuda_numel"]) // D
-    rows_out_t = (tot["cuda_to_cpu_numel"] - tot0["cuda_to_cpu_numel"]) // D
-    swap_ms = phases.get("admit_swap", 0.0) / calls_t
+    # (both from the separately bracketed block: that is where the phase timers ran)
+    swap_ms = phases.get("admit_swap", 0.0) / max(1, phases.get("calls", 0))
+    rows_in_t = (tot_blk1["cpu_to_cuda_numel"] - tot_blk0["cpu_to_cuda_numel"]) // D
+    rows_out_t = (tot_blk1["cuda_to_cpu_numel"] - tot_blk0["cuda_to_cpu_numel"]) // D
+    calls_t = max(1, tot_blk1["calls"] - tot_blk0["calls"])
     wbs = mgr.writeback_stats()
     if transport == "worker" and wbs["in_jobs"]:
         # write-back = SDMA copies + host scatter, admission = a 16-workgroup kernel on the worker's private stream
@@ -497,14 +502,16 @@ def main():
     swap_roof.update(launches_per_step=1.0 / P, rows_in_per_launch=rows_in_t / calls_t,
                      rows_out_per_launch=rows_out_t / calls_t, traffic=None,
                      note="timed in the pipeline (cache-op stream) by hipEvents around the phase")
-    swap_roof["frac"] = swap_roof["achieved"] / swap_roof["peak"]
+    if swap_roof["avg_ms"] <= 0:          # no phase timers ran (cache op replayed from a hipGraph): no rate to quote
+        swap_roof["achieved"] = None
+    swap_roof["frac"] = None if swap_roof["achieved"] is None else swap_roof["achieved"] / swap_roof["peak"]
     # `roofline` = the kernel with the largest share of a step's GPU time (a step = 1 fwd + 1 bwd + 1/P swap)
     for r, per_step in ((fwd_roof, 1.0), (bwd_roof, 1.0), (swap_roof, 1.0 / P)):
         r["ms_per_step_share"] = r["avg_ms"] * per_step
     cands = (fwd_roof, bwd_roof) if transport == "worker" else (fwd_roof, bwd_roof, swap_roof)
     ranked = sorted(cands, key=lambda r: -r["ms_per_step_share"])
     dominant, other = ranked[0], ranked[1:] + ([swap_roof] if transport == "worker" else [])
-    cache_phases = {k: v / calls_t for k, v in phases.items() if k != "calls"}
+    cache_phases = {k: v / max(1, phases.get("calls", 0)) for k, v in phases.items() if k != "calls"}
 
     result = {
         "metric": "embedding lookups/sec (cache op + EmbeddingBag fwd + bwd/SGD), Criteo-1TB table @1% cache",
