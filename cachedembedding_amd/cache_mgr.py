@@ -259,8 +259,11 @@ class CachedParamMgr(torch.nn.Module):
         else:
             assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == flat.numel()
             slots = out.view(-1)
-        with torch.cuda.device(self.device):
+        if torch.cuda.current_device() == self.device.index:      # (the device guard costs ~5 us: only when needed)
             check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+        else:
+            with torch.cuda.device(self.device):
+                check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
         if self.strict and not torch.cuda.is_current_stream_capturing():
             st = CeCallStats()
             rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))

@@ -25,12 +25,23 @@ for _p in (os.environ.get("ROCTX_LIB"), "libroctx64.so", "/opt/rocm/lib/libroctx
         _roctx = None
 
 
+_NAMES: dict = {}
+
+
 @contextlib.contextmanager
 def phase(name: str):
+    # (the torch range only while a torch profiler is collecting: record_function costs microseconds per use even
+    # when nobody listens, and this brackets every cache op of a prefetch_num = 1 loop)
     if _roctx is not None:
-        _roctx.roctxRangePushA(name.encode())
+        b = _NAMES.get(name)
+        if b is None:
+            b = _NAMES[name] = name.encode()
+        _roctx.roctxRangePushA(b)
     try:
-        with torch.profiler.record_function(name):
+        if torch.autograd._profiler_enabled():
+            with torch.profiler.record_function(name):
+                yield
+        else:
             yield
     finally:
         if _roctx is not None:
