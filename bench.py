@@ -875,7 +875,8 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB_per_gpu": mgr.num_embeddings * D * 4 / 1e9,
                    "sharding": f"row-wise x{world} (row % W); unique rows only; padded equal-split all-to-alls, "
                                f"capacity {cap} rows per (batch, owner)",
-                   "launch": "hipGraph per window" if gw._graphs is not None else "step by step (capture refused)",
+                   "launch": "hipGraph per window" if gw._graphs is not None else
+                             "fixed-capacity steps launched one by one (world > 1: CE_SHARDED_GRAPH=1 captures them)",
                    "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
                    "windows_on_the_variable_size_path": gw.fallback_windows},
         "cache": {"rank0_unique_hit_rate": hits / max(1, hits + miss), "rank0_rows_in": tot["cpu_to_cuda_numel"] // D,
