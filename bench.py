@@ -347,6 +347,7 @@ def main():
     mgr.sync_stats()
     tot_blk1 = mgr.totals()                  # rows moved by the calls the phase timers saw
     reps = int(min(args.max_reps, max(3, -(-args.min_time // max(single, 1e-6)))))
+    reps = min(reps, ids_budget_reps(K, B * F * L))     # the region's ids are generated up front and stay in HBM
     need_windows(g + reps * K, g)
     tot0 = mgr.totals()
     barrier()
@@ -567,6 +568,12 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
+def ids_budget_reps(steps_per_rep: int, ids_per_step: int) -> int:
+    """repetitions whose pre-generated ids (int64, resident for the whole timed region) fit a quarter of the free HBM"""
+    free, _ = torch.cuda.mem_get_info()
+    return max(3, int(0.25 * free) // max(1, steps_per_rep * ids_per_step * 8))
+
+
 def emit(result):
     """The JSON line must be the only thing on stdout: flush whatever C libraries still hold in stdio buffers
     (into stderr, see quiet_stdout), then write the line to the real descriptor."""
@@ -732,6 +739,7 @@ def run_sharded(args, sizes, rank, world, dev):
     allreduce(single, op=dist.ReduceOp.MAX)
     single = float(single.item())
     reps = int(min(args.max_reps, max(3, -(-args.min_time // max(single, 1e-6)))))
+    reps = min(reps, ids_budget_reps(Kw, B * F * L))
     g0 = W + Kw
     need_windows(g0 + reps * Kw, g0)
     barrier()
@@ -839,6 +847,7 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
     phases = mgr.phase_times()
     mgr.set_profiling(False)
     reps = int(min(args.max_reps, max(3, -(-args.min_time // max(single, 1e-6)))))
+    reps = min(reps, ids_budget_reps(Kw * P, B * F * L))
     w0 = Ww + Kw
     need_windows((w0 + reps * Kw) * P, w0 * P)
     barrier()
