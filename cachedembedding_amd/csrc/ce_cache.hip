@@ -29,6 +29,7 @@
 // pinned staging + hipMemcpyAsync with host worker threads doing the table gather/scatter.
 #include <sched.h>
 #include <stdlib.h>
+#include <sys/prctl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1457,6 +1458,11 @@ static double worker_timeout_s() {
   static const double v = [] { const char* e = getenv("CE_WORKER_TIMEOUT_S"); const double t = e ? atof(e) : 30.0; return t > 0 ? t : 30.0; }();
   return v;
 }
+// The workers wait with short sleeps (no queue packets, see run_in).  A thread's default timer slack is 50 us, so
+// sleep_for(15 us) returns after ~65 us: at prefetch_num 1 a write-back job is a few hundred microseconds of which
+// those overshoots were a third (Kaggle 5 % P = 1: 0.327 ms per job).  Worker threads ask for 1 us of slack.
+static inline void tight_timer_slack() { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); }
+
 static inline hipError_t stream_wait_polite(hipStream_t st, double timeout_s = worker_timeout_s()) {
   const auto t0 = std::chrono::steady_clock::now();
   for (int spins = 0;; ++spins) {
@@ -1562,6 +1568,7 @@ struct SwapEngine {
 
   void run_out() {
     (void)hipSetDevice(device);
+    tight_timer_slack();
     for (;;) {
       long long job;
       {
@@ -1624,6 +1631,7 @@ struct SwapEngine {
 
   void run_in() {
     (void)hipSetDevice(device);
+    tight_timer_slack();
     for (;;) {
       long long job, need_out;
       {
