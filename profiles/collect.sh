@@ -37,3 +37,7 @@ find gpurun_out/pmc -name "*kernel_trace.csv" -size +20M -delete
 du -sh gpurun_out
 bash profiles/config_matrix.sh > gpurun_out/config_matrix.md 2>&1
 python bench.py --no_cpu_baseline --workload avazu --cache_ratio 0.01 --use_lfu --batch_size 2048 --embedding_dim 32 --prefetch_num 1 --graph_cache_op 2>/dev/null | tail -1 > gpurun_out/bench_avazu_p1_graph_cache_op.json
+# the default lines once more, now that profiles/traffic.json carries this build's digest (roofline.traffic)
+cp gpurun_out/traffic.json profiles/traffic.json
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -3 gpurun_out/bench_default.err
+python bench.py --steps 20 --warmup 5 --no_cpu_baseline > gpurun_out/bench_driver_args.json 2>/dev/null
