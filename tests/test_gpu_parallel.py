@@ -113,14 +113,14 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
     torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
 
 
-def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap):
+def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=(5003, 64, 4, 32, 3, 1000)):
     """parallel.GraphedShardedWindow (fixed-capacity exchange, the window's steps replayed as one hipGraph at world 1,
     launched one by one over gloo) against plain torch on the full table: pooled output of every step, table after
     flush.  capacity below the bucket sizes forces every window through the variable-size fallback."""
     import cachedembedding_amd as ce
     from cachedembedding_amd.parallel import GraphedShardedWindow, RowwiseShardedEmbeddingBag
     torch.manual_seed(0)
-    N, D, F, B_loc, P, lr = 5003, 64, 4, 32, 3, 0.25
+    (N, D, F, B_loc, P, C_rank), lr = sizes, 0.25
     w_full = torch.randn(N, D)
     freq = torch.randint(0, 50, (N,)) if with_freq else None
     strat = ce.EvictionStrategy.LFU if strategy == "lfu" else ce.EvictionStrategy.DATASET
@@ -133,13 +133,17 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap):
     shard = w_full[rank::world].contiguous()
     emb = RowwiseShardedEmbeddingBag(N, D, mode="sum", include_last_offset=True, ids_freq_mapping=freq,
                                      warmup_ratio=0.7, evict_strategy=strat, _weight_shard=shard,
-                                     cuda_row_num=1000 * world)
+                                     cuda_row_num=C_rank * world)
     emb.set_fused_sgd(lr)
     g = torch.Generator().manual_seed(100 + rank)
     offsets = torch.arange(F * B_loc + 1, dtype=torch.int32, device="cuda")
     emb.ops.set_bag_layout(offsets, True, F)
     nwin = 4
-    all_ids = [[torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)] for _ in range(nwin + 1)]
+    if N > 100000:       # bench-shaped: skewed ids, ~10 % distinct rows per batch
+        all_ids = [[(torch.rand(F * B_loc, generator=g) ** 5 * N).long().clamp_(0, N - 1) for _ in range(P)]
+                   for _ in range(nwin + 1)]
+    else:
+        all_ids = [[torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)] for _ in range(nwin + 1)]
     go = torch.randn(P, B_loc, F, D, generator=g)               # one static upstream gradient per batch of a window
     go_d = go.cuda()
     outs = torch.zeros(P, B_loc, F, D, device="cuda")
@@ -180,7 +184,10 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap):
         torch.cuda.synchronize()
         exp = reference_window(all_ids[w])
         for i in range(P):
-            torch.testing.assert_close(outs[i].cpu(), exp[i], rtol=1e-5, atol=1e-5)
+            # (bench shape: a hot row collects thousands of fp32 atomic updates per window, in an order torch's
+            # index_add_ does not share -- the sums agree to fp32 round-off of their size, not to 1e-5)
+            tol = dict(rtol=1e-5, atol=1e-5) if N <= 100000 else dict(rtol=1e-3, atol=2e-2)
+            torch.testing.assert_close(outs[i].cpu(), exp[i], **tol)
     if capacity < 64:
         assert gw.fallback_windows == nwin
     else:
@@ -189,7 +196,10 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap):
             assert gw._graphs is not None, "the window's steps were not captured"
     assert emb.cache_weight_mgr.sync_stats().status == 0
     emb.flush()
-    torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
+    tol = dict(rtol=1e-4, atol=1e-5) if N <= 100000 else dict(rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(emb.weight, ref_w[rank::world], **tol)
+    if N > 100000 and rank == 0:
+        print("max |table - reference| =", float((emb.weight - ref_w[rank::world]).abs().max()), flush=True)
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -197,6 +207,14 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap):
 @pytest.mark.parametrize("capacity,overlap", [(256, True), (256, False), (8, True)])
 def test_rowwise_graphed_fixed_capacity_window(world, strategy, with_freq, capacity, overlap):
     _spawn(_rowwise_graphed, world, strategy, with_freq, capacity, overlap)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_rowwise_graphed_window_at_the_benchmarked_batch_shape(world):
+    """the same check with the bench's batch shape: 26 features x 16384 samples per rank, D = 128, skewed ids, two
+    batches per window (window dedupe: one launch per pass for both), buckets of up to 262144 rows, against torch's
+    index_add_ on the full 2 M-row table"""
+    _spawn(_rowwise_graphed, world, "dataset", True, 262144, True, (2_000_003, 128, 26, 16384, 2, 1_200_000 // world))
 
 
 @pytest.mark.parametrize("world", [1, 2])
