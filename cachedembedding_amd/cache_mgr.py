@@ -250,15 +250,15 @@ class CachedParamMgr(torch.nn.Module):
         a captured hipGraph reads (pipeline.GraphedWindow)."""
         assert ids.is_cuda, "ids must live on the GPU (recsys/dlrm_main.py:250 moves the batch first)"
         shape = ids.shape
-        flat = ids.reshape(-1)
-        if flat.dtype != torch.int64:
-            flat = flat.long()
-        flat = flat.contiguous()
+        # (every tensor method below is microseconds of a prefetch_num = 1 step that the launch thread bounds: the common
+        # case -- flat int64 ids -- takes none of them)
+        flat = ids if (ids.dim() == 1 and ids.dtype == torch.int64 and ids.is_contiguous()) \
+            else ids.reshape(-1).long().contiguous()
         if out is None:
             slots = torch.empty_like(flat)
         else:
             assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == flat.numel()
-            slots = out.view(-1)
+            slots = out if out.dim() == 1 else out.view(-1)
         if torch.cuda.current_device() == self.device.index:      # (the device guard costs ~5 us: only when needed)
             check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
         else:
@@ -275,7 +275,7 @@ class CachedParamMgr(torch.nn.Module):
             if rc == _lib.CE_ERR_RANGE:
                 raise IndexError(_lib.last_error())
             check(rc)
-        return slots.view(shape)
+        return slots if slots.shape == shape else slots.view(shape)
 
     def graph_replayed(self, n_calls: int, ids_per_call: int) -> None:
         """Report `n_calls` prepare_ids calls that a hipGraph launched just now on the current stream replayed
