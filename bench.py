@@ -433,7 +433,9 @@ def main():
                     unit="GB/s", avg_ms=fwd_avg, bytes_per_launch=fwd_compulsory,
                     bytes_basis="compulsory: unique rows x 4D + ids + offsets + output",
                     algorithmic_bytes_per_launch=fwd_bytes, algorithmic_GBps=fwd_bytes / fwd_avg / 1e6)
-    bwd_name = ("k_bag_bwd_rows + torch coalesce + SGD.step (sparse COO gradient)" if args.unchanged_trainer else
+    from cachedembedding_amd.functional import COALESCED_SPARSE_GRAD
+    bwd_name = (("dedupe + fold into a COALESCED sparse COO gradient + SGD.step" if COALESCED_SPARSE_GRAD else
+                 "k_bag_bwd_rows + torch coalesce + SGD.step (sparse COO gradient)") if args.unchanged_trainer else
                 "k_bag_bwd_stream(sgd)" if streaming else "k_bag_bwd_tile(sgd)")
     bwd_roof = dict(kernel=bwd_name, bound="hbm",
                     achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS, unit="GB/s", avg_ms=bwd_avg,

@@ -121,6 +121,29 @@ class _BagFn(torch.autograd.Function):
                     check(lib.ce_bag_backward_sgd(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets),
                                                   off64, num_bags, int(include_last), ptr(psw), mode, hook_features,
                                                   ptr(grad_out), float(fused.lr), stream_ptr()))
+        elif sparse and COALESCED_SPARSE_GRAD and nnz > 0:
+            # sparse=True (scripts/kaggle.sh:71 --use_sparse_embed_grad): the COO gradient is handed over COALESCED --
+            # unique rows (ce_dedupe_bucket_rows), ascending, each with the sum of its lookups' gradient rows (the dense
+            # backward kernel over the unique positions) -- so torch.optim.SGD's grad.coalesce() (a sort of every lookup
+            # and a segmented sum over nnz x D floats, most of an unchanged trainer's step) has nothing left to do.
+            # One host read (the number of unique rows), as coalesce() has too.
+            dev = weight.device
+            R = weight.shape[0]
+            ws = _sparse_ws(R, nnz, dev)
+            urows = torch.empty(nnz, dtype=torch.int64, device=dev)
+            pos = torch.empty(nnz, dtype=torch.int64, device=dev)
+            cnt = torch.empty(1, dtype=torch.int64, device=dev)
+            check(lib.ce_dedupe_bucket_rows(ptr(indices), nnz, None, R, 1, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(urows),
+                                            ptr(pos), ptr(cnt), stream_ptr()))
+            n_u = int(cnt.item())
+            folded = torch.zeros(max(n_u, 1), dim, device=dev, dtype=torch.float32)
+            if n_u:
+                check(lib.ce_bag_backward_dense(ptr(folded), n_u, dim, ptr(pos), nnz, ptr(offsets), off64, num_bags,
+                                                int(include_last), ptr(psw), mode, hook_features, ptr(grad_out),
+                                                stream_ptr()))
+            order = torch.argsort(urows[:n_u])
+            gw = torch.sparse_coo_tensor(urows[:n_u][order].view(1, -1), folded[:n_u][order], weight.shape,
+                                         is_coalesced=True, check_invariants=False)
         elif sparse:
             rows = torch.empty(nnz, dim, device=weight.device, dtype=torch.float32)
             check(lib.ce_bag_backward_rows(ptr(rows), None, dim, nnz, ptr(offsets), off64, num_bags, int(include_last),
@@ -155,6 +178,23 @@ class _BagFn(torch.autograd.Function):
                                           num_bags, int(include_last), hook_features, ptr(grad_out), ptr(gpsw),
                                           stream_ptr()))
         return gw, None, None, gpsw, None, None, None, None, None, None, None, None
+
+
+# sparse=True: hand torch a coalesced COO gradient (CE_SPARSE_GRAD=rows restores one value row per lookup)
+COALESCED_SPARSE_GRAD = __import__("os").environ.get("CE_SPARSE_GRAD", "coalesced") != "rows"
+_SPARSE_WS: dict = {}
+
+
+def _sparse_ws(num_rows: int, nnz: int, device):
+    """scratch of ce_dedupe_bucket_rows for the coalesced sparse gradient: two int32[num_rows] + int32[2 * nnz]"""
+    key = (str(device), num_rows)
+    ws = _SPARSE_WS.get(key)
+    if ws is None or ws[2].numel() < 2 * nnz:
+        ws = (torch.empty(num_rows, dtype=torch.int32, device=device),
+              torch.empty(num_rows, dtype=torch.int32, device=device),
+              torch.empty(max(2 * nnz, 1 << 16), dtype=torch.int32, device=device))
+        _SPARSE_WS[key] = ws
+    return ws
 
 
 class _BagMaxFn(torch.autograd.Function):
