@@ -121,12 +121,13 @@ class _BagFn(torch.autograd.Function):
                     check(lib.ce_bag_backward_sgd(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets),
                                                   off64, num_bags, int(include_last), ptr(psw), mode, hook_features,
                                                   ptr(grad_out), float(fused.lr), stream_ptr()))
-        elif sparse and COALESCED_SPARSE_GRAD and nnz > 0:
+        elif sparse and COALESCED_SPARSE_GRAD and nnz > 0 and not torch.cuda.is_current_stream_capturing():
             # sparse=True (scripts/kaggle.sh:71 --use_sparse_embed_grad): the COO gradient is handed over COALESCED --
             # unique rows (ce_dedupe_bucket_rows), ascending, each with the sum of its lookups' gradient rows (the dense
             # backward kernel over the unique positions) -- so torch.optim.SGD's grad.coalesce() (a sort of every lookup
             # and a segmented sum over nnz x D floats, most of an unchanged trainer's step) has nothing left to do.
-            # One host read (the number of unique rows), as coalesce() has too.
+            # One host read (the number of unique rows), as coalesce() has too -- which is why a backward that is being
+            # captured into a hipGraph takes the one-row-per-lookup form below instead.
             dev = weight.device
             R = weight.shape[0]
             ws = _sparse_ws(R, nnz, dev)
