@@ -101,6 +101,10 @@ def parse():
                          "build's additions (fused SGD, folded hook, window keys, overlapped cache op, hipGraph, "
                          "worker transport).  What a maintainer gets before opting into anything.")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_verify", action="store_true",
+                    help="skip the end-of-run check: after the timed region the cache is flushed and EVERY row the run "
+                         "looked up is compared, in the host table, with w0[row] - lr * (sum of the gradient rows of its "
+                         "lookups) accumulated in fp64 (oracle/closed_form.py; `verified` in the JSON line)")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=1024)
     return ap.parse_args()
@@ -195,6 +199,27 @@ def main():
     need_windows(W + K)
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
+    # ... with zero mean over the batch, per feature and element.  The reference draws a fresh randn every iteration;
+    # ONE tensor reused for thousands of steps at lr = 1 otherwise pushes the rows of the 3-row tables (a third of every
+    # batch each) linearly to |w| ~ 460, where one fp32 ulp is 3e-5 and ANY summation order -- torch's included --
+    # accumulates noise of that size (measured: DESIGN.md section 4c).  Centred, a hot row performs the random walk a real
+    # gradient stream gives it (|w| ~ 5 after 3000 steps).  Same kernels, same traffic.
+    grad -= grad.mean(dim=0, keepdim=True)
+    # every step that trains is entered in a ledger (a reference to its ids, nothing else) so that the table the run
+    # leaves behind can be checked against the closed form of SGD once the timed region is over
+    verify = not args.no_verify and not os.environ.get("CE_BENCH_SKIP_CACHE_OP")
+    ledger = None
+    if verify:
+        from oracle.closed_form import SgdLedger       # checker only: nothing of it runs before the timing is done
+        ledger = SgdLedger(N, D, args.lr, mgr._idx_map)
+        gflat = grad.transpose(0, 1).reshape(F * B, D).contiguous()       # gradient row of lookup j (bag j = f * B + b)
+        if L > 1:
+            gflat = gflat.repeat_interleave(L, dim=0)
+
+    def trained(w, i0, i1):
+        if ledger is not None:
+            for i in range(i0, i1):
+                ledger.record(windows[w][i], gflat)
     # grouping the window's slots costs one workgroup per 16384-lookup segment on the cache-op stream: with only a
     # few segments per batch (B = 2048 shapes) that is ~30 us of latency for a backward of ~18 us -- leave those to
     # the backward's own 1024-lookup tile sort
@@ -223,6 +248,7 @@ def main():
                            transport=None, bag_layout=layout,
                            graph_cache_op=args.graph_cache_op and args.overlap,
                            plan_ahead=args.plan_ahead if args.overlap else 1)
+        trained(0, 0, P)          # GraphedWindow ran the window it was given once, eagerly, before capturing
         note("hipGraph of the window's training steps captured" +
              (" (+ the cache op as a graph of its own)" if gw._plan_graphs is not None else ""))
 
@@ -243,6 +269,7 @@ def main():
                     gw.submit([windows[w][j] for j in range(P)], w % 2)
                 gw.run_and_submit(w % 2, [windows[w + 1][j] for j in range(P)])
                 state["submitted"] = w + 1
+                trained(w, 0, P)
                 g += P
             elif use_graph:
                 nb, ahead = gw.nbuf, gw.plan_ahead
@@ -258,6 +285,7 @@ def main():
                     gw.run(w % nb)
                 else:
                     gw.run_steps(w % nb, i, i + n)
+                trained(w, i, i + n)
                 g += n
             else:
                 if i == 0 or state["slots"] is None:
@@ -274,6 +302,7 @@ def main():
                     out = embed(state["slots"][i], offsets, hook_features=F,
                                 presorted=win.keys[i] if win.keys else None)
                     out.backward(grad)
+                trained(w, i, i + 1)
                 g += 1
 
     def run_steps(first, count, ev_pairs=None):
@@ -306,6 +335,7 @@ def main():
             out.backward(grad)
             if ref_opt is not None:
                 ref_opt.step()
+            trained(wi, bi, bi + 1)
             if ev_pairs is not None:
                 e2.record()
                 ev_pairs.append((e0, e1, e2))
@@ -315,6 +345,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def box_probe():
+        """streaming read / fill rate of THIS box, this minute (218 MB = the forward's output; 20 launches each)"""
+        import ctypes
+        from cachedembedding_amd import _lib
+        nbytes = B * F * D * 4 if B * F * D * 4 >= (64 << 20) else (218 << 20)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rd, fl = ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib.ce_box_probe(buf.data_ptr(), nbytes, 20, ctypes.byref(rd), ctypes.byref(fl),
+                                         _lib.stream_ptr()))
+        return {"read_GBps": rd.value, "fill_GBps": fl.value}
+
+    barrier()
+    box = {"what": "ce_box_probe: 20 streaming reads, then 20 fills, of a buffer the size of the forward's output "
+                   "(>= 64 MB), hipEvent-bracketed; `before` the warm-up, `after` the timed region",
+           "before": box_probe()}
     barrier()
     tw = time.perf_counter()
     run_range(0, W)
@@ -366,6 +411,29 @@ def main():
     st = mgr.sync_stats()
     if st.status != 0:
         raise AssertionError(f"cache op failed with status {st.status}: unique rows of a window exceed cuda_row_num={C}")
+    box["after"] = box_probe()
+    # cache-op phase timers: the K-step block above holds K / P cache ops (3 at the driver's --steps 20); average over
+    # >= 16 of them in a block of its own, outside both timed brackets
+    n_prof = max(0, 16 - phases.get("calls", 0))
+    if n_prof and not skip_cache_op:
+        gp = ((g + P - 1) // P) * P
+        need_windows(gp + n_prof * P, gp)
+        mgr.set_profiling(True)
+        mgr.phase_times(reset=True)
+        barrier()
+        mgr.sync_stats()
+        tot_p0 = mgr.totals()
+        run_range(gp, gp + n_prof * P)
+        barrier()
+        ph2 = mgr.phase_times()
+        mgr.set_profiling(False)
+        mgr.sync_stats()
+        tot_p1 = mgr.totals()
+        g = gp + n_prof * P
+        for k_, v_ in ph2.items():
+            phases[k_] = phases.get(k_, 0) + v_
+        for k_ in tot_blk1:
+            tot_blk1[k_] += tot_p1[k_] - tot_p0[k_]
 
     lookups = K * B * F * L
     value = lookups / elapsed
@@ -409,14 +477,63 @@ def main():
     if args.overlap:
         win = PrefetchWindow(embed, P, overlap=True, presort=presort, transport=None, bag_layout=layout)
         fwd_pipe, bwd_pipe = event_pass(ev_first + 4 * P)
+        if win._pending is not None:
+            win.collect()
         torch.cuda.synchronize()
+    # Pass C: the two bag kernels launched BACK TO BACK through the C ABI (4 rounds over the P batches of one fresh
+    # window, no autograd, no allocation between launches), ONE event pair around each block of 4 * P launches: the
+    # launch queue never runs dry, so the average is kernel time, not kernel time + a host gap (the eager brackets of
+    # pass A read ~10 % above rocprofv3's figure).  `avg_ms` of the roofline is this number when the streaming backward
+    # is in use; the eager bracket stays as `avg_ms_eager_bracket`.
+    fwd_eager, bwd_eager = fwd_avg, bwd_avg
+    b2b_launches = 0
+    if presort and layout is not None and ref_opt is None and not args.deterministic:
+        from cachedembedding_amd import _lib
+        wi_b = ev_first // P + 8
+        need_windows(ev_first + 9 * P)
+        win = PrefetchWindow(embed, P, overlap=False, presort=presort, transport=None, bag_layout=layout)
+        mgr.set_protect_depth(0)
+        slots_b = win.prepare([windows[wi_b][i] for i in range(P)])
+        keys_b = win.keys
+        out_b = torch.empty(B, F, D, device=dev)
+        cw = mgr.cuda_cached_weight
+        rounds = 4
+        off64 = int(offsets.dtype == torch.int64)
+        nb_ = offsets.numel() - 1 if embed.include_last_offset else offsets.numel()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        sp = _lib.stream_ptr()
+        torch.cuda.synchronize()
+        from cachedembedding_amd.functional import FORWARD_FROM_KEYS
+        fwd_from_keys = bool(FORWARD_FROM_KEYS and keys_b[0].identity)         # what embed() launches for these keys
+        ev[0].record()
+        for _ in range(rounds):
+            for i in range(P):
+                if fwd_from_keys:
+                    _lib.check(_lib.lib.ce_bag_forward_src_keys(cw.data_ptr(), C, D, slots_b[i].numel(),
+                                                                keys_b[i].keys.data_ptr(), out_b.data_ptr(), sp))
+                else:
+                    _lib.check(_lib.lib.ce_bag_forward(cw.data_ptr(), C, D, slots_b[i].data_ptr(), slots_b[i].numel(),
+                                                       offsets.data_ptr(), off64, nb_, int(embed.include_last_offset),
+                                                       None, _lib.CE_MODE_SUM, F, out_b.data_ptr(), sp))
+        ev[1].record()
+        for _ in range(rounds):
+            for i in range(P):
+                _lib.check(_lib.lib.ce_bag_backward_sgd_presorted_src(cw.data_ptr(), C, D, slots_b[i].numel(),
+                                                                      grad.data_ptr(), float(args.lr),
+                                                                      keys_b[i].keys.data_ptr(), sp))
+                trained(wi_b, i, i + 1)
+        ev[2].record()
+        torch.cuda.synchronize()
+        b2b_launches = rounds * P
+        fwd_avg, bwd_avg = ev[0].elapsed_time(ev[1]) / b2b_launches, ev[1].elapsed_time(ev[2]) / b2b_launches
     row_b = 4 * D
     fwd_bytes = B * F * (L * (row_b + 8) + 8 + row_b)            # 1040 B/lookup at D=128, L=1
     # backward: per bag read the gradient row (4D) + offset (8), per lookup the slot (8); per UNIQUE
     # target row of the batch a read-modify-write (2 * 4D).  Unique rows counted on the measured batches.
     with torch.no_grad():
-        wi0 = ev_first // P + 3          # a window of the event pass: its rows are still resident
-        uniq = [int(torch.unique(mgr._id_to_cached_cuda_id(windows[wi0][i])).numel()) for i in range(P)]
+        wi0 = ev_first // P + 3          # a window of the event pass
+        im = mgr._idx_map                # distinct ROWS of a batch (= distinct slots while they are resident)
+        uniq = [int(torch.unique(windows[wi0][i] if im is None else im[windows[wi0][i]]).numel()) for i in range(P)]
     uniq_avg = sum(uniq) / len(uniq)
     streaming = presort and layout is not None
     if streaming:      # the key (8 B) replaces slot + offset: gradient row + key per lookup, RMW per unique row
@@ -429,7 +546,7 @@ def main():
     # HBM peak on skewed ids and is NOT a roofline fraction.
     off_b = offsets.element_size()
     fwd_compulsory = uniq_avg * row_b + B * F * L * 8 + (B * F + 1) * off_b + B * F * row_b
-    fwd_roof = dict(kernel="k_bag_fwd", bound="hbm", achieved=fwd_compulsory / fwd_avg / 1e6, peak=HBM_PEAK_GBPS,
+    fwd_roof = dict(kernel="k_bag_fwd_keys" if (b2b_launches and fwd_from_keys) else "k_bag_fwd", bound="hbm", achieved=fwd_compulsory / fwd_avg / 1e6, peak=HBM_PEAK_GBPS,
                     unit="GB/s", avg_ms=fwd_avg, bytes_per_launch=fwd_compulsory,
                     bytes_basis="compulsory: unique rows x 4D + ids + offsets + output",
                     algorithmic_bytes_per_launch=fwd_bytes, algorithmic_GBps=fwd_bytes / fwd_avg / 1e6)
@@ -441,6 +558,10 @@ def main():
                     achieved=bwd_bytes / bwd_avg / 1e6, peak=HBM_PEAK_GBPS, unit="GB/s", avg_ms=bwd_avg,
                     bytes_per_launch=bwd_bytes)
     bwd_roof["unique_rows_per_batch"] = uniq_avg
+    fwd_roof["avg_ms_eager_bracket"], bwd_roof["avg_ms_eager_bracket"] = fwd_eager, bwd_eager
+    for r in (fwd_roof, bwd_roof):
+        r["avg_ms_basis"] = (f"{b2b_launches} launches back to back through the C ABI between one hipEvent pair" if b2b_launches
+                             else "mean of per-launch hipEvent brackets around eager launches")
     bwd_roof["event_samples_dropped_as_host_stalls"] = dropped[0]
     fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
     for r in (fwd_roof, bwd_roof):
@@ -524,8 +645,12 @@ def main():
                   "region of `steps` steps alone is a few ms and measures pipeline fill/drain); ms_per_step = region / "
                   "(reps * steps); block_ms.single = one `steps`-step block bracketed on its own",
         "block_ms": {"single": 1e3 * single, "region": 1e3 * region},
-        "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed,
+        "it_per_s_scope": "embedding operator only (cache op + EmbeddingBag forward + backward/SGD), no dense part: "
+                          "the whole-model it/s of examples/dlrm_main.py at this configuration is in profiles/ "
+                          "(r04_dlrm_main_criteo1tb.json)",
+        "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "box": box,
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
                    "embedding_dim": D, "features": F, "batch_size": B, "pooling": L, "cache_ratio": args.cache_ratio,
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
@@ -551,10 +676,54 @@ def main():
         "roofline_other": other,
     }
 
+    if ledger is not None:
+        result["verified"] = verify_table(ledger, embed, args, N, D, dev, note)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(embed, gen, args, B, F, L, D)
     if rank == 0:
         emit(result)
+
+
+def verify_table(ledger, embed, args, N, D, dev, note):
+    """The table the run leaves behind against the closed form of SGD (oracle/closed_form.py): flush the cache, then
+    for EVERY row any trained step looked up -- warm-up, both timed brackets, the profiling block and the per-kernel
+    passes included -- host_table[row] vs w0[row] - lr * sum of its lookups' gradient rows (fp64), per element within
+    1e-5 * |ref| + 2e-6 + 3e-7 * sqrt(lookups of the row); rows no step looked up must still hold w0 bit for bit
+    (sample).  w0 is regenerated from the seed (ce_host_fill_uniform is counter-based), the rows are read back through
+    the table's device mapping."""
+    from cachedembedding_amd import _lib
+    t0 = time.time()
+    mgr = embed.cache_weight_mgr
+    torch.cuda.synchronize()
+    mgr.flush()                               # every cached row home (waits for the queued write-backs first)
+    torch.cuda.synchronize()
+    lo, hi = -1.0 / N, 1.0 / N                # CachedEmbeddingBag's initialisation (A.7), seed = --seed
+    table_dev = mgr._table.dev_ptr
+
+    def initial_rows(rows):
+        out = torch.empty(rows.numel(), D, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.ce_host_fill_uniform_rows(rows.data_ptr(), rows.numel(), D, lo, hi, args.seed,
+                                                      out.data_ptr(), _lib.stream_ptr()))
+        return out
+
+    def current_rows(rows):
+        out = torch.empty(rows.numel(), D, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.ce_host_rows_gather(table_dev, N, D, rows.data_ptr(), rows.numel(), out.data_ptr(),
+                                                _lib.stream_ptr()))
+        return out
+
+    res = ledger.check(initial_rows, current_rows, hot_rows=256)
+    res["pass"] = res["bound_violations"] == 0 and res.get("untouched_mismatch", 0) == 0
+    res["seconds"] = time.time() - t0
+    res["what"] = ("after the timed region: cache flushed; every row any trained step looked up compared in the host "
+                   "table with w0 - lr * (fp64 sum of its lookups' gradient rows); untouched rows (sample) bit-equal "
+                   "to w0; hot rows also against the reference's fp32 step-by-step arithmetic")
+    note(f"verified {res['rows']} rows / {res['lookups']} lookups / {res['steps']} steps in {res['seconds']:.1f}s: "
+         f"{res['bound_violations']} bound violations, max err/bound {res['max_err_over_bound']:.3f}, "
+         f"untouched mismatches {res.get('untouched_mismatch')}")
+    if not res["pass"]:
+        print("[bench] VERIFICATION FAILED: the host table is not what SGD should have produced", file=sys.stderr, flush=True)
+    return res
 
 
 _REAL_STDOUT = None

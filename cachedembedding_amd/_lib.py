@@ -84,6 +84,9 @@ SIGNATURES = {
     "ce_host_register": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "ce_host_unregister": (c_int, [c_void_p]),
     "ce_host_fill_uniform": (c_int, [c_void_p, c_int64, c_float, c_float, c_uint64, c_int]),
+    "ce_host_fill_uniform_rows": (c_int, [c_void_p, c_int64, c_int32, c_float, c_float, c_uint64, c_void_p, c_void_p]),
+    "ce_host_rows_gather": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ce_box_probe": (c_int, [c_void_p, c_size_t, c_int32, POINTER(c_double), POINTER(c_double), c_void_p]),
     "ce_bag_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
                                c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_dense": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
@@ -102,6 +105,7 @@ SIGNATURES = {
     "ce_bag_presort_window": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "ce_bag_presort_window_src": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_int64, c_int64,
                                           c_int32, c_int64, c_void_p, c_void_p]),
+    "ce_bag_forward_src_keys": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "ce_bag_backward_sgd_presorted_src": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_float, c_void_p,
                                                   c_void_p]),
     "ce_bag_presort_window_src_excl": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_int64,
@@ -120,6 +124,7 @@ SIGNATURES = {
     "ce_cache_preload": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ce_cache_set_freq_bound": (c_int, [c_void_p, c_int64]),
     "ce_cache_prepare_ids": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ce_cache_prepare_ids_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ce_cache_last_stats": (c_int, [c_void_p, POINTER(CeCallStats)]),
     "ce_cache_totals": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                                 POINTER(c_int64), POINTER(c_int64)]),

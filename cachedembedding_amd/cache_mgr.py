@@ -245,9 +245,14 @@ class CachedParamMgr(torch.nn.Module):
 
     # ------------------------------------------------------------------ A.3
     @torch.no_grad()
-    def prepare_ids(self, ids: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def prepare_ids(self, ids: torch.Tensor, out: Optional[torch.Tensor] = None, padded: bool = False) -> torch.Tensor:
         """`out` (int64, same numel, contiguous) lets a caller keep the slots in a static buffer, e.g. one
-        a captured hipGraph reads (pipeline.GraphedWindow)."""
+        a captured hipGraph reads (pipeline.GraphedWindow).  The buffer is SCRATCH for the whole cache op, not only
+        written at its end (the call parks every id's row there first): no other stream may read it until the call has
+        finished, and it must not alias `ids`.
+        padded=True (ce_cache_prepare_ids_padded): entries of -1 are padding -- no lookup, slot -1 -- as the
+        fixed-capacity row-wise exchange produces them.  Without it a -1 is a bad id like any other: IndexError under
+        strict=True, a failed call (raise_on_failed_calls) otherwise -- as upstream's idx_map.index_select raises."""
         assert ids.is_cuda, "ids must live on the GPU (recsys/dlrm_main.py:250 moves the batch first)"
         shape = ids.shape
         # (every tensor method below is microseconds of a prefetch_num = 1 step that the launch thread bounds: the common
@@ -259,11 +264,12 @@ class CachedParamMgr(torch.nn.Module):
         else:
             assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == flat.numel()
             slots = out if out.dim() == 1 else out.view(-1)
+        fn = lib.ce_cache_prepare_ids_padded if padded else lib.ce_cache_prepare_ids
         if torch.cuda.current_device() == self.device.index:      # (the device guard costs ~5 us: only when needed)
-            check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+            check(fn(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
         else:
             with torch.cuda.device(self.device):
-                check(lib.ce_cache_prepare_ids(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+                check(fn(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
         if self.strict and not torch.cuda.is_current_stream_capturing():
             st = CeCallStats()
             rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))
@@ -378,7 +384,10 @@ class CachedParamMgr(torch.nn.Module):
         """fp32 [rows, D] lying right behind the cache in ONE allocation (the cache moves there, contents kept;
         `cuda_cached_weight` stays the same Parameter object).  The row-wise exchange receives into it, so that
         "cache + received rows" is one table for the bag kernels (ce_exchange_local_index).  Blocks until the device
-        is idle; call it before anything that captured the cache's address (hipGraphs)."""
+        is idle; call it before anything that captured the cache's address (hipGraphs) -- every address taken earlier
+        goes stale.  `cuda_cached_weight.data` is from then on a VIEW of the larger (C + rows) storage: torch.save of a
+        state_dict that holds it serialises the whole storage, tail included (clone the parameter before saving, or
+        save the host table after flush(), which is what a checkpoint of this module is anyway)."""
         rows = int(rows)
         C, D = self.cuda_row_num, self.embedding_dim
         full = getattr(self, "_cache_full", None)

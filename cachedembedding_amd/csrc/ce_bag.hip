@@ -521,14 +521,18 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
       bkt[r] = kSegBuckets;
       if (e < n_here) {
         const int64_t row = indices[in_base + e];
-        if ((uint64_t)row < (uint64_t)num_rows) {
+        const bool valid = (uint64_t)row < (uint64_t)num_rows;
+        if (valid || SRC) {
           unsigned low = (unsigned)e;
           // lay.offsets == nullptr: one id per bag, in order (bag of lookup j = j) -- what every Criteo / Avazu
           // batch is; saves the two offset loads per lookup that find_bag needs to establish it (-12 us per window)
           if (SRC && !(CE_DBG(lay.debug) & 2))
             low = (unsigned)out_row(q, lay.offsets ? find_bag(q, sib * kSegLen + e) : sib * kSegLen + e);
-          key[r] = ((unsigned long long)row << 32) | low;
-          bkt[r] = (int)(row & (kSegBuckets - 1));
+          // SRC: an ignored lookup (slot -1 / out of range) keeps its output row under the row 0xffffffff -- the
+          // backward skips it like padding (row >= num_rows), the key-driven forward writes its zero row; it goes to
+          // the last bucket with the padding
+          key[r] = ((unsigned long long)(valid ? (uint32_t)row : 0xffffffffu) << 32) | low;
+          if (valid) bkt[r] = (int)(row & (kSegBuckets - 1));
         }
       }
       if (CE_DBG(lay.debug) & 8) {       // ablation: no LDS atomic
@@ -921,6 +925,84 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
   }
 }
 
+// Forward from the window's source-row keys (one id per bag, mode sum, no per-sample weights: out[bag] = W[slot], a
+// row copy per lookup).  The keys of a batch hold, per lookup, the cache row and the row of the [B, F, D] output it
+// lands in, GROUPED BY ROW inside every 16384-lookup segment -- so a lane group that walks its share of the key array
+// loads a cache row ONCE per run of equal rows and stores it to every output row of the run: ~50 k row loads per
+// Criteo batch instead of 425,984 (the other 375 k were L2 / Infinity-Cache hits, but every one of them crossed the
+// fabric: the gather-shaped forward ran at the speed of a COPY of its output, 52 us; this one is bound by the FILL of
+// its output).  Same walk as k_bag_bwd_stream: contiguous equal shares, keys staged through a group-private LDS slice,
+// R keys per step -- the loads of the step's run heads in flight together, one wait, then the stores.
+// An ignored lookup (row 0xffffffff, see k_bag_presort_seg) gets a zero row; padding keys (~0) are skipped.
+template <typename VT, int NCH, int R, int NTS>
+__global__ __launch_bounds__(256, 4) void k_bag_fwd_keys(BagParams p, int64_t total) {      // 4 waves per SIMD: <= 128 VGPRs
+  __shared__ unsigned long long lk[256 * (R > 4 ? R : 4)];
+  const int tid = threadIdx.x;
+  const int G = 1 << p.g_log2;
+  const int ngroups = 256 >> p.g_log2;
+  const int grp = tid >> p.g_log2;
+  const int gl = tid & (G - 1);
+  const int rowlen = p.rowlen;
+  const VT* __restrict__ W = (const VT*)p.weight;
+  VT* __restrict__ O = (VT*)p.dst;
+  const unsigned long long* __restrict__ keys = p.presorted;
+  const int64_t all_groups = (int64_t)gridDim.x * ngroups;
+  const int64_t round = R > 16 ? R : 16;
+  const int64_t share = ((total + all_groups - 1) / all_groups + round - 1) / round * round;
+  const int64_t s0 = ((int64_t)blockIdx.x * ngroups + grp) * share;
+  const int64_t s1 = min(total, s0 + share);
+  if (s0 >= s1) return;
+  const int kc = 4 * G > R ? 4 * G : R;
+  unsigned long long* mylk = lk + grp * kc;
+  VT prev[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) prev[c] = vzero<VT>();
+  uint32_t prev_row = 0xffffffffu;          // "ignored": a zero row, which is what prev holds
+  for (int64_t c0 = s0; c0 < s1; c0 += kc) {
+    for (int k = gl; k < kc; k += G) mylk[k] = c0 + k < s1 ? keys[c0 + k] : ~0ull;
+    const int64_t c1 = min(s1, c0 + kc);
+    for (int64_t q = c0; q < c1; q += R) {
+      VT v[R][NCH];
+      uint32_t heads = 0;
+      uint32_t last = prev_row;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        const unsigned long long k = mylk[(int)(q - c0) + t];
+        const bool on = k != ~0ull;
+        const uint32_t rw = (uint32_t)(k >> 32);
+        const bool head = on && rw != last;
+        if (on) last = rw;
+        if (head) heads |= 1u << t;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = gl + c * G;
+          v[t][c] = vzero<VT>();
+          if (head && ch < rowlen && rw < p.num_rows) v[t][c] = W[(int64_t)rw * rowlen + ch];
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): every head of the step has arrived
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        // (the output row comes out of LDS again rather than out of 16 more registers: the kernel sits at the
+        // 128-VGPR line that separates 4 waves per SIMD from 3)
+        const unsigned long long k = mylk[(int)(q - c0) + t];
+        if (k == ~0ull) continue;              // padding (group-uniform)
+        if ((heads >> t) & 1) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) prev[c] = v[t][c];       // a new run: its row stays in `prev` until the next head
+        }
+        const int64_t orow = (int64_t)(uint32_t)k;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = gl + c * G;
+          if (ch < rowlen) store_out<NTS>(&O[orow * rowlen + ch], prev[c]);
+        }
+      }
+      prev_row = last;
+    }
+  }
+}
+
 // dst[index[i]] += alpha * src[i] for whole rows (the owner-side SGD of the row-wise exchange: `src` holds one
 // already-folded gradient row per requested row, so there is nothing to sort or fold; rows requested by several
 // peers repeat, hence atomics).  Lane group per row, U rows in flight, lane-block transposed atomics as above.
@@ -1272,6 +1354,46 @@ extern "C" int ce_bag_backward_dense_presorted_src(float* grad_weight, int64_t n
                                                    ce_stream_t stream) {
   return launch_bwd_stream(grad_weight, num_rows, dim, nnz, grad_out, 1.f, (const unsigned long long*)src_keys, nullptr,
                            (hipStream_t)stream);
+}
+
+extern "C" int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
+                                       const uint64_t* src_keys, float* out, ce_stream_t stream) {
+  if (nnz == 0) return CE_OK;
+  CE_REQUIRE(weight && src_keys && out, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  BagParams p{};
+  bool vec;
+  int nch;
+  int rc = fill_params(p, dim, nullptr, nnz, nullptr, 0, 0, 1, nullptr, CE_MODE_SUM, 0, &vec, &nch, weight, out, nullptr);
+  if (rc) return rc;
+  p.weight = weight;
+  p.dst = out;
+  p.num_rows = (uint32_t)num_rows;
+  p.presorted = (const unsigned long long*)src_keys;
+  const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
+  // 8 workgroups per CU (measured at the bench shape, three runs each: 4/CU 2.59-2.82 G lookups/s and 72-74 us per
+  // launch beside the cache op, 8/CU 2.79-2.97 G and 64-66 us; the slot-driven forward 2.56-2.76 G and 72-76 us)
+  static const int per_cu = [] { const char* e = getenv("CE_FWDK_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
+  static const int r_env = [] { const char* e = getenv("CE_FWDK_R"); return e ? atoi(e) : 16; }();
+  const int ngroups = 256 >> p.g_log2;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));
+  dim3 g(grid), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int nts = (p.policy & 1) ? 1 : 0;
+#define CE_FWK(VT, N, R)                                                                    \
+  do {                                                                                      \
+    if (nts) hipLaunchKernelGGL((k_bag_fwd_keys<VT, N, R, 1>), g, b, 0, s, p, total);       \
+    else hipLaunchKernelGGL((k_bag_fwd_keys<VT, N, R, 0>), g, b, 0, s, p, total);           \
+  } while (0)
+  if (vec) {
+    if (nch == 1) { if (r_env == 8) CE_FWK(f32x4, 1, 8); else if (r_env == 32) CE_FWK(f32x4, 1, 32); else CE_FWK(f32x4, 1, 16); }
+    else if (nch == 2) CE_FWK(f32x4, 2, 8); else CE_FWK(f32x4, 4, 4);
+  } else {
+    if (nch == 1) CE_FWK(float, 1, 16); else if (nch == 2) CE_FWK(float, 2, 8); else CE_FWK(float, 4, 4);
+  }
+#undef CE_FWK
+  CE_LAUNCH_CHECK();
+  return CE_OK;
 }
 
 extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }

@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256) void k_bag_fwd_max(XParams p, const float* __r
         const int64_t ri = p.indices[j];
         if ((uint64_t)ri >= (uint64_t)p.num_rows || d >= p.dim) continue;
         const float v = W[ri * p.dim + d];
+        // NaN: exactly torch's CPU kernel -- the bag's first row is taken as it is, a later row only if `v > best`;
+        // so a NaN in the first row stays, a NaN further on never wins (tests/test_gpu_bag.py pins this against torch)
         if (pos < 0 || v > best) { best = v; pos = j; }
       }
       if (d < p.dim) {

@@ -274,7 +274,8 @@ template <bool MERGE, int U>
 __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
                                               const int32_t* __restrict__ idx_map,
                                               const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out, int dbg) {
+                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out, int dbg,
+                                              int allow_pad) {
   extern __shared__ uint32_t hot[];
   for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
   __syncthreads();
@@ -294,7 +295,9 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
       if (valid[u]) {
         const int64_t id = ids[i];
         if ((unsigned long long)id >= (unsigned long long)N) {
-          if (id != -1) ctl->status = CE_ERR_RANGE;        // -1 = padding (fixed-capacity exchange): no lookup, slot -1
+          // ce_cache_prepare_ids_padded only: -1 = padding (fixed-capacity exchange), no lookup, slot -1.  On the
+          // plain entry point a -1 is a bad id like any other (upstream's idx_map.index_select raises on it).
+          if (!(allow_pad && id == -1)) ctl->status = CE_ERR_RANGE;
           valid[u] = false;
           rows_out[i] = -1;
         } else {
@@ -2386,8 +2389,8 @@ static int worker_selftest(ce_cache* h, hipStream_t s) {
   return CE_OK;
 }
 
-extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
-                                    ce_stream_t stream) {
+static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out, ce_stream_t stream,
+                            int allow_pad) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
   CE_REQUIRE(n >= 0 && n <= std::max<int64_t>(h->cfg.max_ids_per_call, 0), CE_ERR_INVALID,
              "n=%lld exceeds max_ids_per_call=%lld", (long long)n, (long long)h->cfg.max_ids_per_call);
@@ -2496,7 +2499,7 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
       const dim3 mg(std::min(grid_for(n, mark_threads * u), mark_blocks)), mb(mark_threads);
 #define CE_MARK(M, U_)                                                                                          \
   hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
-                     h->word_bits, hot_words, h->bitmap, h->ctl, slots_out, mark_dbg)
+                     h->word_bits, hot_words, h->bitmap, h->ctl, slots_out, mark_dbg, allow_pad)
       if (mark_merge) { if (u == 4) CE_MARK(true, 4); else if (u == 2) CE_MARK(true, 2); else CE_MARK(true, 1); }
       else { if (u == 4) CE_MARK(false, 4); else if (u == 2) CE_MARK(false, 2); else CE_MARK(false, 1); }
 #undef CE_MARK
@@ -2702,6 +2705,16 @@ extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n
   CE_LAUNCH_CHECK();
   if (!capturing) CE_HIP_CHECK(hipEventRecord(h->ev, s));
   return CE_OK;
+}
+
+extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                    ce_stream_t stream) {
+  return prepare_ids_impl(h, ids, n, slots_out, stream, 0);
+}
+
+extern "C" int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                           ce_stream_t stream) {
+  return prepare_ids_impl(h, ids, n, slots_out, stream, 1);
 }
 
 extern "C" int ce_cache_graph_replayed(ce_cache_t* h, int64_t n_calls, int64_t ids_per_call, ce_stream_t stream) {

@@ -124,6 +124,163 @@ extern "C" int ce_host_fill_uniform(float* dst, int64_t n, float lo, float hi, u
   return CE_OK;
 }
 
+// ---- rows of the host table by number: regenerated from the seed, or read back through the device mapping ----------
+
+namespace ce {
+
+// lo + span * u with TWO roundings, like the host loop (x86-64 without FMA): the device compiler would contract it
+__device__ __forceinline__ float mul_then_add(float lo, float span, float u) {
+#pragma clang fp contract(off)
+  const float t = span * u;
+  return lo + t;
+}
+
+// the values ce_host_fill_uniform gave rows[i] (same counter-based generator, same two roundings: the host code is
+// compiled without FMA contraction, so multiply and add stay separate here)
+__global__ __launch_bounds__(256) void k_fill_uniform_rows(const int64_t* __restrict__ rows, int64_t n, int dim,
+                                                           float lo, float span, uint64_t seed_mul, float* out) {
+  const int64_t total = n * dim;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t i = e / dim;
+    const int d = (int)(e - i * dim);
+    uint64_t x = seed_mul + (uint64_t)(rows[i] * dim + d);
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+    out[e] = mul_then_add(lo, span, u);
+  }
+}
+
+// out[i] = table[rows[i]] over the device mapping of the pinned table (PCIe reads; lane group per row, R in flight)
+template <typename VT>
+__global__ __launch_bounds__(256) void k_host_rows_gather(const VT* __restrict__ table, int64_t num_rows,
+                                                          const int64_t* __restrict__ rows, int64_t n, int rowlen,
+                                                          int g_log2, VT* __restrict__ out) {
+  constexpr int R = 8;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
+    for (int c0 = 0; c0 < rowlen; c0 += G) {
+      VT v[R];
+      const int ch = c0 + gl;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        v[t] = vzero<VT>();
+        if (i + t < n && ch < rowlen) {
+          const int64_t r = rows[i + t];
+          if ((uint64_t)r < (uint64_t)num_rows) v[t] = table[r * rowlen + ch];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if (i + t < n && ch < rowlen) out[(i + t) * rowlen + ch] = v[t];
+    }
+  }
+}
+
+// box probe: a streaming read and a fill of `n4` 16-byte words
+__global__ __launch_bounds__(256) void k_probe_read(const f32x4* __restrict__ src, int64_t n4, f32x4* sink) {
+  constexpr int U = 8;
+  f32x4 acc = {0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * 256 * U;
+  for (int64_t i = (int64_t)blockIdx.x * 256 * U + threadIdx.x; i < n4; i += stride) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + u * 256;
+      v[u] = f32x4{0, 0, 0, 0};
+      if (j < n4) v[u] = __builtin_nontemporal_load(src + j);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+  }
+  if (acc.x == 12345.678f) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_probe_fill(f32x4* __restrict__ dst, int64_t n4, float val) {
+  constexpr int U = 8;
+  const f32x4 v = {val, val, val, val};
+  const int64_t stride = (int64_t)gridDim.x * 256 * U;
+  for (int64_t i = (int64_t)blockIdx.x * 256 * U + threadIdx.x; i < n4; i += stride) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + u * 256;
+      if (j < n4) dst[j] = v;
+    }
+  }
+}
+
+}  // namespace ce
+
+extern "C" int ce_host_fill_uniform_rows(const int64_t* rows, int64_t n, int32_t dim, float lo, float hi,
+                                         uint64_t seed, float* out, ce_stream_t stream) {
+  if (n == 0) return CE_OK;
+  CE_REQUIRE(rows && out && n > 0 && dim > 0, CE_ERR_INVALID, "bad arguments");
+  hipLaunchKernelGGL(k_fill_uniform_rows, dim3(grid_for(n * dim, 256 * 4)), dim3(256), 0, (hipStream_t)stream, rows, n,
+                     (int)dim, lo, hi - lo, seed * 0xD6E8FEB86659FD93ull, out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_host_rows_gather(const float* table_dev, int64_t num_rows, int32_t dim, const int64_t* rows,
+                                   int64_t n, float* out, ce_stream_t stream) {
+  if (n == 0) return CE_OK;
+  CE_REQUIRE(table_dev && rows && out && n > 0 && dim > 0 && num_rows > 0, CE_ERR_INVALID, "bad arguments");
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  const bool vec = (dim % 4 == 0) && al16(table_dev) && al16(out);
+  const int rowlen = vec ? dim / 4 : dim;
+  int g = 1, gl2 = 0;
+  while (g < rowlen && g < 64) { g <<= 1; ++gl2; }
+  const int grid = grid_for(n, (256 >> gl2) * 8);
+  if (vec)
+    hipLaunchKernelGGL((k_host_rows_gather<f32x4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)table_dev, num_rows, rows, n, rowlen, gl2, (f32x4*)out);
+  else
+    hipLaunchKernelGGL((k_host_rows_gather<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, table_dev,
+                       num_rows, rows, n, rowlen, gl2, out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_box_probe(void* scratch, size_t bytes, int32_t reps, double* read_GBps, double* fill_GBps,
+                            ce_stream_t stream) {
+  CE_REQUIRE(scratch && bytes >= (1u << 20) && reps > 0 && read_GBps && fill_GBps, CE_ERR_INVALID, "bad arguments");
+  CE_REQUIRE((((uintptr_t)scratch) & 15) == 0, CE_ERR_INVALID, "scratch must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n4 = (int64_t)(bytes / 16);
+  hipEvent_t e0, e1, e2;
+  CE_HIP_CHECK(hipEventCreate(&e0));
+  CE_HIP_CHECK(hipEventCreate(&e1));
+  CE_HIP_CHECK(hipEventCreate(&e2));
+  const dim3 grid(kNumCU * 8), block(256);
+  // one untimed launch of each first (page-table walks, clocks), then `reps` back to back between two events
+  hipLaunchKernelGGL(k_probe_fill, grid, block, 0, s, (f32x4*)scratch, n4, 0.f);
+  hipLaunchKernelGGL(k_probe_read, grid, block, 0, s, (const f32x4*)scratch, n4, (f32x4*)scratch);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(k_probe_read, grid, block, 0, s, (const f32x4*)scratch, n4, (f32x4*)scratch);
+  (void)hipEventRecord(e1, s);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_probe_fill, grid, block, 0, s, (f32x4*)scratch, n4, 0.f);
+  (void)hipEventRecord(e2, s);
+  hipError_t e = hipEventSynchronize(e2);
+  float ms_r = 0, ms_f = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms_r, e0, e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms_f, e1, e2);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  if (e != hipSuccess) {
+    set_error("box probe failed: %s", hipGetErrorString(e));
+    return CE_ERR_HIP;
+  }
+  *read_GBps = (double)n4 * 16 * reps / (ms_r * 1e-3) / 1e9;
+  *fill_GBps = (double)n4 * 16 * reps / (ms_f * 1e-3) / 1e9;
+  return CE_OK;
+}
+
 extern "C" int ce_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words, ce_stream_t* out) {
   CE_REQUIRE(out && words >= 0 && (words == 0 || cu_mask), CE_ERR_INVALID, "bad arguments");
   hipStream_t s = nullptr;

@@ -58,6 +58,9 @@ class SrcKeys(NamedTuple):
     include_last_offset: bool
     hook_features: int
     ranges: Optional[torch.Tensor] = None
+    # the keys were built for the one-id-per-bag layout (presort_window(identity_bags=True)): the FORWARD can then run
+    # from them as well (ce_bag_forward_src_keys: a cache row is loaded once per run of equal rows)
+    identity: bool = False
 
 
 class _BagFn(torch.autograd.Function):
@@ -66,6 +69,11 @@ class _BagFn(torch.autograd.Function):
                 bwd_scale=None, masked=False):
         _lib.require_gpu()
         assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+        if psw is not None and ctx.needs_input_grad[3] and fused is not None and fused.lr is not None:
+            # d loss / d per_sample_weights[j] = <grad_out[bag of j], weight[indices[j]]> needs the rows as the forward
+            # saw them, and the fused update moves them inside backward: refused HERE, before any kernel has run (a
+            # refusal inside backward would leave the caller with an exception AND an updated table)
+            raise NotImplementedError("gradient w.r.t. per_sample_weights with the fused SGD update")
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
         dim = weight.shape[1]
         if hook_features:
@@ -73,9 +81,15 @@ class _BagFn(torch.autograd.Function):
                               dtype=torch.float32)
         else:
             out = torch.empty(num_bags, dim, device=weight.device, dtype=torch.float32)
-        check(lib.ce_bag_forward(ptr(weight), weight.shape[0], dim, ptr(indices), indices.numel(), ptr(offsets),
-                                 int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw), mode,
-                                 hook_features, ptr(out), stream_ptr()))
+        if FORWARD_FROM_KEYS and isinstance(presorted, SrcKeys) and presorted.identity and psw is None \
+                and mode == _lib.CE_MODE_SUM and num_bags == indices.numel():
+            # one id per bag: out[bag] = W[slot], and the window's keys hold (slot, output row) grouped by slot
+            check(lib.ce_bag_forward_src_keys(ptr(weight), weight.shape[0], dim, indices.numel(), ptr(presorted.keys),
+                                              ptr(out), stream_ptr()))
+        else:
+            check(lib.ce_bag_forward(ptr(weight), weight.shape[0], dim, ptr(indices), indices.numel(), ptr(offsets),
+                                     int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw), mode,
+                                     hook_features, ptr(out), stream_ptr()))
         # bwd_scale (scale_grad_by_freq): per-lookup factor of the backward only; it takes the place of psw there
         ctx.save_for_backward(indices, offsets, psw if bwd_scale is None else bwd_scale.contiguous())
         ctx.weight = weight
@@ -128,15 +142,19 @@ class _BagFn(torch.autograd.Function):
             # and a segmented sum over nnz x D floats, most of an unchanged trainer's step) has nothing left to do.
             # One host read (the number of unique rows), as coalesce() has too -- which is why a backward that is being
             # captured into a hipGraph takes the one-row-per-lookup form below instead.
+            # The dedupe scratch (two int32[rows] + int32[2 nnz]; nothing in it needs initialising) comes from the
+            # caching allocator per call, so its lifetime is ordered on the stream this backward runs on: two
+            # same-sized tables running their backwards on two streams do not share it.
             dev = weight.device
             R = weight.shape[0]
-            ws = _sparse_ws(R, nnz, dev)
+            ws = (torch.empty(R, dtype=torch.int32, device=dev), torch.empty(R, dtype=torch.int32, device=dev),
+                  torch.empty(max(2 * nnz, 1 << 16), dtype=torch.int32, device=dev))
             urows = torch.empty(nnz, dtype=torch.int64, device=dev)
             pos = torch.empty(nnz, dtype=torch.int64, device=dev)
             cnt = torch.empty(1, dtype=torch.int64, device=dev)
             check(lib.ce_dedupe_bucket_rows(ptr(indices), nnz, None, R, 1, ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(urows),
                                             ptr(pos), ptr(cnt), stream_ptr()))
-            n_u = int(cnt.item())
+            n_u = int(cnt.item())           # the ONE host sync of this path (torch's coalesce() has the same one)
             folded = torch.zeros(max(n_u, 1), dim, device=dev, dtype=torch.float32)
             if n_u:
                 check(lib.ce_bag_backward_dense(ptr(folded), n_u, dim, ptr(pos), nnz, ptr(offsets), off64, num_bags,
@@ -169,11 +187,8 @@ class _BagFn(torch.autograd.Function):
                                                 ptr(grad_out), stream_ptr()))
         gpsw = None
         if ctx.needs_input_grad[3]:
-            # d loss / d per_sample_weights[j] = <grad_out[bag of j], weight[indices[j]]>; with the fused update the rows
-            # have moved already, which is what the optimizer-step-after-backward order of a trainer would not do:
-            # refuse that combination rather than hand back a gradient against the updated rows
-            if fused is not None and fused.lr is not None:
-                raise NotImplementedError("gradient w.r.t. per_sample_weights with the fused SGD update")
+            # d loss / d per_sample_weights[j] = <grad_out[bag of j], weight[indices[j]]> (the combination with the
+            # fused update was refused in forward)
             gpsw = torch.empty(nnz, device=weight.device, dtype=torch.float32)
             check(lib.ce_bag_backward_psw(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
                                           num_bags, int(include_last), hook_features, ptr(grad_out), ptr(gpsw),
@@ -181,21 +196,11 @@ class _BagFn(torch.autograd.Function):
         return gw, None, None, gpsw, None, None, None, None, None, None, None, None
 
 
+# forward from the window's source-row keys when they were built for the one-id-per-bag layout (CE_FWD_KEYS=0: always
+# the gather-shaped kernel over slots + offsets)
+FORWARD_FROM_KEYS = __import__("os").environ.get("CE_FWD_KEYS", "1") != "0"
 # sparse=True: hand torch a coalesced COO gradient (CE_SPARSE_GRAD=rows restores one value row per lookup)
 COALESCED_SPARSE_GRAD = __import__("os").environ.get("CE_SPARSE_GRAD", "coalesced") != "rows"
-_SPARSE_WS: dict = {}
-
-
-def _sparse_ws(num_rows: int, nnz: int, device):
-    """scratch of ce_dedupe_bucket_rows for the coalesced sparse gradient: two int32[num_rows] + int32[2 * nnz]"""
-    key = (str(device), num_rows)
-    ws = _SPARSE_WS.get(key)
-    if ws is None or ws[2].numel() < 2 * nnz:
-        ws = (torch.empty(num_rows, dtype=torch.int32, device=device),
-              torch.empty(num_rows, dtype=torch.int32, device=device),
-              torch.empty(max(2 * nnz, 1 << 16), dtype=torch.int32, device=device))
-        _SPARSE_WS[key] = ws
-    return ws
 
 
 class _BagMaxFn(torch.autograd.Function):
@@ -445,7 +450,8 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
                                             int(offsets.dtype == torch.int64), per if offsets.dim() == 2 else 0,
                                             num_bags, int(include_last_offset), int(hook_features), ptr(keys_out),
                                             stream_ptr()))
-        return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features)) for b in range(P)]
+        return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features), None, bool(identity_bags))
+                for b in range(P)]
     assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == P * n
     segs = klen // 16384
     if ranges_out is None:
@@ -456,4 +462,5 @@ def presort_window(slots: torch.Tensor, num_rows: int, keys_out: Optional[torch.
                                              num_bags, int(include_last_offset), int(hook_features), ptr(ids),
                                              ptr(keys_out), ptr(ranges_out), stream_ptr()))
     rv = ranges_out.view(P, segs, 2)
-    return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features), rv[b]) for b in range(P)]
+    return [SrcKeys(kv[b], num_bags, bool(include_last_offset), int(hook_features), rv[b], bool(identity_bags))
+            for b in range(P)]

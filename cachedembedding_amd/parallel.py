@@ -835,7 +835,7 @@ class GraphedShardedWindow:
     @torch.no_grad()
     def _plan_owner(self, buf: int) -> None:
         W, P, cap = self.W, self.P, self.cap
-        slots = self.mgr.prepare_ids(self._serve[buf].view(-1))                      # -1 = padding: slot -1
+        slots = self.mgr.prepare_ids(self._serve[buf].view(-1), padded=True)         # -1 = padding: slot -1
         self._slots[buf].view(P, W, cap).copy_(slots.view(W, P, cap).permute(1, 0, 2))
         r = self.rank
         check(lib.ce_exchange_local_index(ptr(self._pos[buf]), self.n, P, ptr(self._slots[buf]), W * cap, r * cap,

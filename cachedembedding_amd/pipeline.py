@@ -295,7 +295,8 @@ class GraphedWindow:
             per = lay["offsets"].shape[-1]
             step_fn(self._bufs[buf][i], i, SrcKeys(self._keys[buf][i], per - 1 if lay["include_last_offset"] else per,
                                                    lay["include_last_offset"], lay["hook_features"],
-                                                   self._ranges[buf][i] if self._ranges is not None else None))
+                                                   self._ranges[buf][i] if self._ranges is not None else None,
+                                                   bool(lay["identity_bags"])))
         elif self.presort:
             step_fn(self._bufs[buf][i], i, self._keys[buf][i])
         else:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CE_API_VERSION 3
+#define CE_API_VERSION 4
 
 /* status codes */
 #define CE_OK 0
@@ -99,6 +99,22 @@ int ce_host_unregister(void* host_ptr);
 /* weight init of CachedEmbeddingBag: uniform_(-1/N, 1/N) (A.7); counter-based RNG so the
  * result is independent of `threads`. */
 int ce_host_fill_uniform(float* dst, int64_t n, float lo, float hi, uint64_t seed, int threads);
+/* The values ce_host_fill_uniform(dst, N * dim, lo, hi, seed, .) gave the rows `rows[0..n)` of an [N, dim] table,
+ * regenerated on the device into out[n, dim] (bit-identical: the generator is counter-based).  What a checker needs to
+ * state "row r still holds its initial value" / "row r = initial value - lr * sum of its gradients" for a 91 GB table
+ * without keeping a second copy of it. */
+int ce_host_fill_uniform_rows(const int64_t* rows, int64_t n, int32_t dim, float lo, float hi, uint64_t seed,
+                              float* out, ce_stream_t stream);
+/* out[i] = table[rows[i]] (i < n) read through the device mapping `table_dev` of a pinned host table (the *dev_ptr of
+ * ce_host_alloc / ce_host_register); rows outside [0, num_rows) give zeros.  `rows` and `out` are device memory.
+ * (CachedParamMgr.cpu_weight_data for many rows at once; a PCIe-bound read.) */
+int ce_host_rows_gather(const float* table_dev, int64_t num_rows, int32_t dim, const int64_t* rows, int64_t n,
+                        float* out, ce_stream_t stream);
+/* Memory-system probe of the box the process runs on: `reps` streaming reads, then `reps` fills, of `bytes` of
+ * device scratch, each block of launches bracketed by hipEvents on `stream` (blocks until done).  A bench line carries
+ * the two rates so that a reader can tell a slow box from slow code (allocations of the same GPU model differ by
+ * several per cent). */
+int ce_box_probe(void* scratch, size_t bytes, int32_t reps, double* read_GBps, double* fill_GBps, ce_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K12: F.embedding_bag(slots, cuda_cached_weight, offsets, mode, per_sample_weights,
@@ -190,6 +206,14 @@ int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int
                               const void* offsets, int32_t offsets_are_i64, int64_t offsets_batch_stride,
                               int64_t num_bags, int32_t include_last_offset, int64_t hook_features,
                               uint64_t* keys_out, ce_stream_t stream);
+/* K12 from the same keys, for the one-id-per-bag layout (every Criteo / Avazu batch; mode sum, no per-sample
+ * weights): out[low word of key] = weight[high word of key], a zero row for an ignored lookup.  The keys are grouped by
+ * row, so a cache row is LOADED once per run of equal rows and stored to every output row of the run (~50 k row loads
+ * per Criteo batch instead of 425,984): the forward becomes a fill of its output instead of a copy.  `out` is
+ * [nnz, dim] (or [B, F, dim] when the keys were built with hook_features = F); only valid for keys built from a layout
+ * in which every bag holds exactly one lookup. */
+int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, int32_t dim, int64_t nnz, const uint64_t* src_keys,
+                            float* out, ce_stream_t stream);
 int ce_bag_backward_sgd_presorted_src(float* weight, int64_t num_rows, int32_t dim, int64_t nnz,
                                       const float* grad_out, float lr, const uint64_t* src_keys, ce_stream_t stream);
 int ce_bag_backward_dense_presorted_src(float* grad_weight, int64_t num_rows, int32_t dim, int64_t nnz,
@@ -289,14 +313,23 @@ int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_t* freq_val
  * radix passes above it.  Optional: without it the select runs all 8 byte passes until the bound is known. */
 int ce_cache_set_freq_bound(ce_cache_t* h, int64_t bound);
 
-/* prepare_ids [A.3] -- recsys/dlrm_main.py:259: unique rows of `ids` (device int64[n]; an entry of -1 is padding:
- * it takes no part in the call and gets slot -1; any other id outside [0, num_embeddings) fails the call) are
+/* prepare_ids [A.3] -- recsys/dlrm_main.py:259: unique rows of `ids` (device int64[n]; any id outside
+ * [0, num_embeddings) -- -1 included -- fails the call with CE_ERR_RANGE, as upstream's idx_map.index_select raises) are
  * made resident (victim selection A.5 with the canonical tie rule, write-back, admit A.4),
  * slots_out (device int64[n]) receives inverted_cached_idx[idx_map[ids]] [A.6], LFU
  * counters gain the multiplicities.  Fully asynchronous on `stream`.  On overflow or a bad
- * id the call leaves every piece of state untouched and flags the status in its stats. */
+ * id the call leaves every piece of state untouched and flags the status in its stats.
+ * slots_out is SCRATCH from the call's first kernel on (the row of every id is parked there and converted to its slot
+ * in place by the last kernel): nothing may read or write it on another stream until the call has finished, and it
+ * must not alias `ids`. */
 int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                          ce_stream_t stream);
+/* The same, for callers whose id lists are PADDED to a fixed capacity (the row-wise exchange's fixed-size buckets):
+ * an entry of -1 is padding -- it takes no part in the call and gets slot -1.  Every other id outside the table still
+ * fails the call.  Opt-in on purpose: on the plain entry point a -1 sentinel leaking out of a data pipeline must fail
+ * loudly, not train on zero rows. */
+int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                ce_stream_t stream);
 
 /* Blocks until the most recent prepare_ids/preload/flush has finished on the device and
  * returns that call's statistics; returns its status (CE_ERR_CAPACITY ...). */

@@ -1,0 +1,212 @@
+"""CLOSED-FORM SGD CHECKER (test infrastructure -- a checker, never the thing measured or shipped).
+
+What plain SGD leaves in an embedding table is known in closed form when no other optimiser state exists
+(`torch.optim.SGD(lr)` without momentum / weight decay on the sparse group: recsys/dlrm_main.py:455-461, stepped
+at :279 after the backward of :274-278):
+
+    table[row] = table0[row] - lr * sum over every trained lookup j with row(id_j) == row of grad_out[bag(j)]
+
+where row(id) = idx_map[id] and, with one id per bag in feature-major order (recsys/datasets/
+criteo.py:127-134), bag(j) = j.  The order of the additions is the only freedom the reference leaves (fp32,
+`index_add_`-style coalescing inside a step, steps in sequence), so the check is against the sum accumulated in
+fp64, with a per-element bound on what fp32 accumulation in ANY order may differ by.
+
+`SgdLedger` records which batches were trained (references to the id tensors, nothing is copied) and, once the
+run has been flushed to the host table, compares every row the run touched -- wherever the cache put it in the
+meantime, however often it was evicted and re-admitted -- with that closed form.  It talks to the table through
+two callables (initial rows, current rows), so it is independent of the library it checks.  The arithmetic is
+torch on the device that holds the ids (sizes: a Criteo-1TB run touches ~10^7 rows of 128 floats).
+
+For the rows that sum the most gradients it also replays the REFERENCE's own arithmetic -- fp32, step by step:
+coalesce the step's gradient rows, then w += -lr * g -- and holds it to the same bound: a bound torch's fp32
+result violated would not be a statement about the kernels.
+
+Parity note: this is arithmetic that follows from the reference's optimiser configuration, not a golden vector
+of the reference; the bag kernels are pinned against torch-CPU elsewhere (tests/test_gpu_bag.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+# per-element bound of tests/test_gpu_bag.py::test_full_size_step_vs_torch_cpu:
+#   |got - ref64| <= REL * |ref64| + ATOL + SQRT * sqrt(n)        n = lookups summed into the row
+REL, ATOL, SQRT = 1e-5, 2e-6, 3e-7
+
+
+class SgdLedger:
+    def __init__(self, num_rows: int, dim: int, lr: float, idx_map: Optional[torch.Tensor] = None):
+        """idx_map: id -> table row (int32/int64 [num_ids] on the device) or None for the identity."""
+        self.N, self.D, self.lr = int(num_rows), int(dim), float(lr)
+        self.idx_map = idx_map
+        self.entries: List[tuple] = []            # (ids [n] int64, grad rows [n, D] fp32 in lookup order), training order
+
+    def record(self, ids: torch.Tensor, grad_rows: torch.Tensor) -> None:
+        """one trained batch: lookup j read row(ids[j]) and received grad_rows[j]"""
+        assert ids.dim() == 1 and grad_rows.shape == (ids.numel(), self.D)
+        self.entries.append((ids, grad_rows))
+
+    def __len__(self) -> int:
+        return len(self.entries)
+
+    def _rows(self, ids: torch.Tensor) -> torch.Tensor:
+        ok = (ids >= 0) & (ids < (self.idx_map.numel() if self.idx_map is not None else self.N))
+        safe = torch.where(ok, ids, torch.zeros_like(ids))
+        rows = self.idx_map[safe].long() if self.idx_map is not None else safe
+        return torch.where(ok, rows, torch.full_like(rows, -1))           # padding / bad ids: no lookup
+
+    @torch.no_grad()
+    def check(self, initial_rows: Callable[[torch.Tensor], torch.Tensor],
+              current_rows: Callable[[torch.Tensor], torch.Tensor], hot_rows: int = 2048,
+              untouched_sample: int = 1 << 20, max_chunk_rows: Optional[int] = None, seed: int = 7) -> dict:
+        """initial_rows(rows int64 [k]) / current_rows(rows) -> fp32 [k, D] on the same device.
+        Returns counts and the worst cases; `bound_violations == 0` and `untouched_mismatch == 0` is a pass."""
+        assert self.entries, "nothing was recorded"
+        import time
+        dev = self.entries[0][0].device
+
+        def now():
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            return time.time()
+        t_start = now()
+        N, D, lr = self.N, self.D, self.lr
+        # ---- which rows did the run touch, and how many lookups did each get
+        mark = torch.zeros(N, dtype=torch.bool, device=dev)
+        seen = {}
+        for ids, _ in self.entries:
+            if id(ids) in seen:
+                continue
+            seen[id(ids)] = True
+            r = self._rows(ids)
+            mark[r[r >= 0]] = True
+        touched = mark.nonzero(as_tuple=False).view(-1)
+        T = int(touched.numel())
+        compact = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        compact[touched] = torch.arange(T, dtype=torch.int32, device=dev)
+        del mark
+        cis = {}                                         # id(ids) -> compact index per lookup (-1: no lookup)
+
+        def ci_of(ids):
+            """index among the touched rows of every lookup of the batch; T (a dummy row) for padding / bad ids"""
+            c = cis.get(id(ids))
+            if c is None:
+                r = self._rows(ids)
+                c = torch.where(r >= 0, compact[r.clamp(min=0)].long(), torch.full_like(r, T))
+                cis[id(ids)] = c
+            return c
+
+        n_lookups = torch.zeros(T + 1, dtype=torch.int64, device=dev)        # [T] = the dummy row of non-lookups
+        for ids, _ in self.entries:
+            n_lookups += torch.bincount(ci_of(ids), minlength=T + 1)
+        n_lookups = n_lookups[:T]
+        g64t = {}
+
+        def grad64t(g):
+            v = g64t.get(id(g))
+            if v is None:
+                v = g64t[id(g)] = g.double().t().contiguous()          # [D, n]: the scan below runs along the last dim
+            return v
+
+        def step_sums(ids, g):
+            """the step's gradient COALESCED in fp64: (touched-row index [U], sum of the gradient rows of its lookups
+            [U, D]).  Sorted + prefix sums along the contiguous dimension rather than index_add_: a Criteo batch sends
+            ~9000 lookups at one row, and 9000 fp64 atomics on one address (compare-and-swap loops) cost 100 ms per step;
+            a scan along the OUTER dimension is a serial loop per column (170 ms per step)."""
+            c = ci_of(ids)
+            order = torch.argsort(c)
+            uniq, counts = torch.unique_consecutive(c[order], return_counts=True)
+            ends = counts.cumsum(0)
+            cum = grad64t(g).index_select(1, order).cumsum_(1)
+            sums = cum.index_select(1, ends - 1)
+            sums[:, 1:] -= cum.index_select(1, ends[:-1] - 1)
+            return uniq, sums.t()
+
+        gs = torch.stack([g.float().pow(2).mean() for g in {id(g): g for _, g in self.entries}.values()]).mean().sqrt()
+        grad_rms = float(gs)
+        free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 8 << 30
+        chunk = max(1, min(T, int(0.35 * free) // (48 * D)))
+        if max_chunk_rows:
+            chunk = min(chunk, int(max_chunk_rows))
+        res = dict(rows=T, lookups=int(n_lookups.sum()), steps=len(self.entries), bound_violations=0, max_err=0.0,
+                   max_err_over_bound=0.0, rows_violating=0, chunks=0)
+        worst = None
+        t_marked = now()
+        K = min(int(hot_rows), T)
+        hot = torch.topk(n_lookups, K).indices if K > 0 else None
+        hot_e64 = torch.zeros(K, D, dtype=torch.float64, device=dev) if K > 0 else None
+        # ---- every touched row against the fp64 closed form
+        for c0 in range(0, T, chunk):
+            c1 = min(T, c0 + chunk)
+            rows = touched[c0:c1]
+            w0 = initial_rows(rows)
+            exp = torch.cat([w0.double(), torch.zeros(1, D, dtype=torch.float64, device=dev)])   # + the dummy row
+            for ids, g in self.entries:
+                uniq, sums = step_sums(ids, g)
+                if c0 == 0 and c1 == T:
+                    exp.index_add_(0, uniq, sums, alpha=-lr)          # (uniq[-1] may be the dummy row T)
+                else:
+                    sel = (uniq >= c0) & (uniq < c1)
+                    exp.index_add_(0, uniq[sel] - c0, sums[sel], alpha=-lr)
+            exp = exp[:c1 - c0]
+            if K > 0:
+                inch = (hot >= c0) & (hot < c1)
+                hot_e64[inch] = exp[hot[inch] - c0]
+            got = current_rows(rows).double()
+            err = (got - exp).abs_()
+            del got
+            bound = exp.abs().mul_(REL).add_(ATOL).add_(n_lookups[c0:c1].double().sqrt_().mul_(SQRT).unsqueeze(1))
+            ratio = err / bound
+            bad = ratio > 1.0
+            res["bound_violations"] += int(bad.sum())
+            res["rows_violating"] += int(bad.any(dim=1).sum())
+            res["max_err"] = max(res["max_err"], float(err.max()))
+            mr = float(ratio.max())
+            if mr >= res["max_err_over_bound"]:
+                res["max_err_over_bound"] = mr
+                k = int(ratio.max(dim=1).values.argmax())
+                worst = dict(row=int(rows[k]), lookups=int(n_lookups[c0 + k]), err=float(err[k].max()),
+                             ref_abs_max=float(exp[k].abs().max()))
+            res["chunks"] += 1
+            del err, bound, ratio, bad, exp, w0
+        res["worst"] = worst
+        res["bound"] = f"|table - ref64| <= {REL:g}*|ref64| + {ATOL:g} + {SQRT:g}*sqrt(lookups of the row), per element"
+        res["grad_rms"] = grad_rms
+        t_main = now()
+        # ---- the reference's own fp32 arithmetic on the rows that sum the most gradients, held to the same bound
+        if K > 0:
+            hot_of = torch.full((T + 1,), -1, dtype=torch.int64, device=dev)
+            hot_of[hot] = torch.arange(K, device=dev)
+            rows = touched[hot]
+            w32 = initial_rows(rows).clone()
+            for ids, g in self.entries:                    # training order
+                hk = hot_of[ci_of(ids)]
+                sel = hk >= 0
+                # torch.optim.SGD on a sparse gradient: grad.coalesce() (torch's own segmented fp32 sum), then
+                # param.add_(grad, alpha=-lr)
+                step = torch.sparse_coo_tensor(hk[sel].view(1, -1), g[sel].float(), (K, D)).coalesce()
+                w32.index_add_(0, step.indices()[0], step.values(), alpha=-lr)
+            e64 = hot_e64
+            bound = e64.abs() * REL + ATOL + n_lookups[hot].double().sqrt().mul(SQRT).unsqueeze(1)
+            got = current_rows(rows).double()
+            scale = e64.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
+            res["hot_rows_checked"] = K
+            res["hot_rows_min_lookups"] = int(n_lookups[hot].min())
+            res["hot_rows_max_lookups"] = int(n_lookups[hot].max())
+            res["hot_rows_max_abs_value"] = float(e64.abs().max())
+            res["hot_torch_fp32_max_err_over_bound"] = float(((w32.double() - e64).abs() / bound).max())
+            res["hot_table_max_err_over_bound"] = float(((got - e64).abs() / bound).max())
+            res["hot_table_vs_torch_fp32_max_diff_rel_to_row_max"] = float(((got - w32.double()).abs() / scale).max())
+        t_hot = now()
+        res["seconds_by_part"] = {"mark_and_count": t_marked - t_start, "closed_form_fp64": t_main - t_marked,
+                                  "hot_rows_torch_fp32": t_hot - t_main}
+        # ---- rows the run never looked up still hold their initial value, bit for bit
+        if untouched_sample > 0:
+            gen = torch.Generator(device=dev).manual_seed(seed)
+            cand = torch.randint(0, N, (int(untouched_sample),), device=dev, generator=gen)
+            cand = cand[compact[cand] < 0]
+            a, b = initial_rows(cand), current_rows(cand)
+            res["untouched_sampled"] = int(cand.numel())
+            res["untouched_mismatch"] = int((a.view(torch.int32) != b.view(torch.int32)).any(dim=1).sum())
+        return res

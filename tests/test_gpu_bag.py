@@ -215,14 +215,15 @@ def test_full_size_batch_properties():
     assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))
 
 
-@pytest.mark.parametrize("presort", [False, True, "src", "src_excl", "src_excl_shared"])
+@pytest.mark.parametrize("presort", [False, True, "src", "src_identity", "src_excl", "src_excl_shared"])
 def test_full_size_step_vs_torch_cpu(presort):
     """BASELINE config [2] step at its real shape -- cache of C = 1,779,442 rows x 128, B = 16384, F = 26, long-tail
     slots -- against the calls the reference makes on the CPU (F.embedding_bag, then SGD on the summed gradient):
     forward bit-exact (L = 1 is a copy), updated cache rows within 1e-5 relative (fp32 sums in another order).
     presort: False = the backward sorts 1024-lookup tiles itself, True = segment-grouped keys + tile backward,
-    "src" = source-row keys + the STREAMING backward -- the kernel pair bench.py times (k_bag_presort_seg<true> ->
-    k_bag_bwd_stream)."""
+    "src" = source-row keys + the STREAMING backward (k_bag_presort_seg<true> -> k_bag_bwd_stream);
+    "src_identity" = the same keys built with the one-id-per-bag layout stated, so that the FORWARD runs from them too
+    (k_bag_fwd_keys) -- the kernel triple bench.py times."""
     ce = _ce()
     from cachedembedding_amd.functional import presort_slots, presort_window
     B, F, D, C, lr = 16384, 26, 128, 1_779_442, 0.5
@@ -248,9 +249,10 @@ def test_full_size_step_vs_torch_cpu(presort):
         lo, hi = keys.ranges[:, 0].cpu(), keys.ranges[:, 1].cpu()
         disjoint = bool((hi[:-1] < lo[1:]).all())
         assert disjoint == (presort == "src_excl")
-    elif presort == "src":
+    elif presort in ("src", "src_identity"):
         keys = presort_window(idx.cuda().view(1, -1), C, offsets=off.cuda(), include_last_offset=True,
-                              hook_features=F)[0]
+                              hook_features=F, identity_bags=presort == "src_identity")[0]
+        assert keys.identity == (presort == "src_identity")
     else:
         keys = presort_slots(idx.cuda(), C) if presort else None
     out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="sum", include_last_offset=True, sparse=True,
@@ -703,6 +705,129 @@ def test_per_sample_weights_gradient_matches_torch(D):
                      per_sample_weights=pc).backward(go.cuda())
     torch.testing.assert_close(pc.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(wc.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("D", [128, 64, 32, 20, 260, 4])
+@pytest.mark.parametrize("hook", [True, False])
+def test_forward_from_source_row_keys_equals_the_gather_forward(D, hook):
+    """ce_bag_forward_src_keys (one id per bag: a cache row loaded once per run of equal rows, stored to every output
+    row of the run) against the slot-driven forward and against torch, BIT-exact (L = 1 is a copy); ignored lookups
+    (slot -1 / beyond the table) must come out as zero rows, batch sizes that are no multiple of a segment included."""
+    ce = _ce()
+    from cachedembedding_amd.functional import presort_window
+    g = torch.Generator().manual_seed(D * 2 + hook)
+    C = 5000
+    F, B = (13, 3001) if hook else (1, 40_000)
+    n = F * B
+    w = torch.randn(C, D, generator=g)
+    idx = (torch.rand(n, generator=g) ** 4 * C).long().clamp_(0, C - 1)
+    idx[::97] = -1
+    idx[5::211] = C + 3
+    off = torch.arange(n + 1, dtype=torch.int32)
+    keys = presort_window(idx.cuda().view(1, -1), C, offsets=off.cuda(), include_last_offset=True,
+                          hook_features=F if hook else 0, identity_bags=True)[0]
+    assert keys.identity
+    wc = w.cuda()
+    kw = dict(mode="sum", include_last_offset=True, hook_features=F if hook else 0)
+    by_keys = ce.embedding_bag(idx.cuda(), wc, off.cuda(), presorted=keys, **kw)
+    by_slots = ce.embedding_bag(idx.cuda(), wc, off.cuda(), presorted=keys._replace(identity=False), **kw)
+    assert torch.equal(by_keys, by_slots)
+    safe = idx.clone()
+    bad = (idx < 0) | (idx >= C)
+    safe[bad] = 0
+    ref = w[safe]
+    ref[bad] = 0
+    if hook:
+        ref = ref.view(F, B, D).transpose(0, 1)
+    assert torch.equal(by_keys.cpu(), ref)
+    # and the backward through the same keys still ignores those lookups
+    wg = w.cuda().requires_grad_(True)
+    out = ce.embedding_bag(idx.cuda(), wg, off.cuda(), presorted=keys, fused_sgd=ce.FusedSGD(0.5), **kw)
+    go = torch.randn(out.shape, generator=g) * 0.01
+    out.backward(go.cuda())
+    gflat = go.transpose(0, 1).reshape(-1, D) if hook else go
+    want = w.double().index_add_(0, safe[~bad], gflat[~bad].double(), alpha=-0.5)
+    cnt = torch.bincount(safe[~bad], minlength=C).double().unsqueeze(1)          # row 0 sums thousands of gradients
+    bound = 1e-5 * want.abs() + 2e-6 + 3e-7 * cnt.sqrt()
+    assert bool(((wg.detach().cpu().double() - want).abs() <= bound).all())
+
+
+def test_per_sample_weights_gradient_with_fused_sgd_is_refused_before_the_table_moves():
+    """the combination used to raise inside backward AFTER the fused kernel had updated the rows."""
+    ce = _ce()
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(64, 16, generator=g)
+    idx = torch.randint(0, 64, (40,), generator=g).cuda()
+    off = torch.arange(0, 41, 4).cuda()
+    wc = w.cuda().requires_grad_(True)
+    pc = torch.rand(40, generator=g).cuda().requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="per_sample_weights"):
+        ce.embedding_bag(idx, wc, off, mode="sum", include_last_offset=True, per_sample_weights=pc,
+                         fused_sgd=ce.FusedSGD(0.5))
+    assert torch.equal(wc.detach().cpu(), w)
+    # weights that need no gradient are fine with the fused update
+    out = ce.embedding_bag(idx, wc, off, mode="sum", include_last_offset=True, per_sample_weights=pc.detach(),
+                           fused_sgd=ce.FusedSGD(0.5))
+    out.backward(torch.ones_like(out))
+    assert not torch.equal(wc.detach().cpu(), w)
+
+
+def test_mode_max_treats_nan_like_torch():
+    """ADVICE r3 asked for NaN to win every comparison "as torch does".  torch's CPU kernel (the oracle here) does not:
+    it takes the bag's first row as it is and a later row only if `v > best`, so a NaN in the FIRST row of a bag stays
+    and a NaN further on never wins.  The kernel keeps exactly that (bit-parity with the reference path is the
+    contract); this pins it, forward values and gradient routing."""
+    ce = _ce()
+    g = torch.Generator().manual_seed(2)
+    R, D, nb = 50, 24, 12
+    w = torch.randn(R, D, generator=g)
+    w[7, 3] = float("nan")
+    w[9] = float("nan")
+    idx = torch.randint(0, R, (nb * 4,), generator=g)
+    idx[(idx == 7) | (idx == 9)] = 11
+    idx[0:4] = torch.tensor([1, 7, 2, 3])        # NaN in the middle of a bag: never wins
+    idx[4:8] = torch.tensor([9, 9, 9, 9])        # nothing but NaN rows
+    idx[8:12] = torch.tensor([7, 4, 9, 5])       # NaN first: stays
+    idx[12:16] = torch.tensor([4, 5, 9, 6])      # a whole NaN row in the middle
+    off = torch.arange(0, nb * 4 + 1, 4)
+    wr = w.clone().requires_grad_(True)
+    ref = torch.nn.functional.embedding_bag(idx, wr, off, mode="max", include_last_offset=True)
+    wc = w.cuda().requires_grad_(True)
+    out = ce.embedding_bag(idx.cuda(), wc, off.cuda(), mode="max", include_last_offset=True)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=0, atol=0, equal_nan=True)
+    assert bool(torch.isnan(ref[1]).all()) and bool(torch.isnan(ref[2, 3])) and not bool(torch.isnan(ref[0]).any())
+    go = torch.randn(nb, D, generator=g)
+    ref.backward(go)
+    out.backward(go.cuda())
+    torch.testing.assert_close(wc.grad.cpu(), wr.grad, rtol=1e-6, atol=1e-6)
+
+
+def test_coalesced_sparse_backward_of_two_same_sized_tables_on_two_streams():
+    """the dedupe scratch of the coalesced COO gradient was a module-global keyed by (device, rows), shared
+    by every same-sized table whatever stream its backward ran on."""
+    ce = _ce()
+    g = torch.Generator().manual_seed(8)
+    R, D, n = 20_000, 32, 60_000
+    off = torch.arange(n + 1, device="cuda")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    tabs, idxs, gos, outs = [], [], [], []
+    for k in range(2):
+        tabs.append(torch.randn(R, D, generator=g).cuda().requires_grad_(True))
+        idxs.append((torch.rand(n, generator=g) ** 3 * R).long().clamp_(0, R - 1).cuda())
+        gos.append(torch.randn(n, D, generator=g).cuda())
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for k in range(2):
+            tabs[k].grad = None
+            with torch.cuda.stream(streams[k]):
+                out = ce.embedding_bag(idxs[k], tabs[k], off, mode="sum", include_last_offset=True, sparse=True)
+                out.backward(gos[k])
+        torch.cuda.synchronize()
+        for k in range(2):
+            gw = tabs[k].grad
+            assert gw.is_sparse and gw.is_coalesced()
+            ref = torch.zeros(R, D, device="cuda").index_add_(0, idxs[k], gos[k])
+            torch.testing.assert_close(gw.to_dense(), ref, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("norm_type", [2.0, 1.0, 3.0, float("inf")])

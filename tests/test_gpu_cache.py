@@ -142,6 +142,53 @@ def test_capacity_overflow_is_assertion_and_state_untouched():
         ce.CachedParamMgr(w, 0)
 
 
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+def test_minus_one_is_a_bad_id_unless_the_call_is_padded(strategy):
+    """a -1 sentinel leaking out of a data pipeline must fail like upstream's idx_map.index_select does
+    (IndexError under strict, a failed call otherwise, state untouched); only ce_cache_prepare_ids_padded -- the
+    fixed-capacity row-wise exchange -- treats it as padding (no lookup, slot -1), other bad ids still fail there."""
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
+    rng = np.random.default_rng(5)
+    N, C, D = 3000, 200, 8
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    freq = rng.integers(0, 100, N)
+    mgr = _mk(ce, w, C, strategy, freq, 0.5)
+    ora = OracleCachedParamMgr(w.copy(), C, LFU if strategy == "lfu" else DATASET)
+    ora.reorder(freq, 0.5)
+    before = mgr.cached_idx_map.clone()
+    free = mgr.cuda_available_row_num
+    with pytest.raises(IndexError):
+        mgr.prepare_ids(torch.tensor([-1], device="cuda"))
+    with pytest.raises(IndexError):
+        mgr.prepare_ids(torch.tensor([5, 17, -1, 9], device="cuda"))
+    assert torch.equal(before, mgr.cached_idx_map) and mgr.cuda_available_row_num == free
+    mgr.strict = False
+    s = mgr.prepare_ids(torch.tensor([5, -1, 9], device="cuda"))
+    assert (s == -1).all()                                        # a failed call hands back -1 everywhere
+    mgr.sync_stats()
+    with pytest.raises(IndexError):
+        mgr.raise_on_failed_calls()                               # what the overlapped pipelines poll once per window
+    mgr.strict = True
+    assert torch.equal(before, mgr.cached_idx_map)
+    # padded: -1 takes no part, everything else as the oracle says
+    for it in range(4):
+        ids = rng.integers(0, N, 150)
+        pad = rng.random(150) < 0.3
+        padded = np.where(pad, -1, ids)
+        s = mgr.prepare_ids(torch.from_numpy(padded).cuda(), padded=True).cpu().numpy()
+        want = ora.prepare_ids(ids[~pad])
+        assert (s[pad] == -1).all() and np.array_equal(s[~pad], want)
+        _state_equal(mgr, ora, strategy == "lfu")
+    with pytest.raises(IndexError):
+        mgr.prepare_ids(torch.tensor([5, -2, 9], device="cuda"), padded=True)
+    with pytest.raises(IndexError):
+        mgr.prepare_ids(torch.tensor([5, N, -1], device="cuda"), padded=True)
+    s = mgr.prepare_ids(torch.full((64,), -1, device="cuda"), padded=True)          # nothing but padding
+    assert (s == -1).all()
+    _state_equal(mgr, ora, strategy == "lfu")
+
+
 def test_empty_and_duplicate_only_calls():
     ce = _ce()
     mgr = ce.CachedParamMgr(torch.randn(100, 4), 10, evict_strategy=ce.EvictionStrategy.LFU)
