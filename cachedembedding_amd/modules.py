@@ -151,7 +151,9 @@ class FusedSparseModules(nn.Module):
         dist_on = torch.distributed.is_initialized()
         self.kjt_collector = KJTAllToAll(group) if (is_dist_dataloader and dist_on) else None
 
-    def forward(self, sparse_features: Union[List, Any], cache_op: bool = True) -> torch.Tensor:
+    def forward(self, sparse_features: Union[List, Any], cache_op: bool = True, presorted=None) -> torch.Tensor:
+        # presorted (an addition; fold_hook=True, cache_op=False): the window keys of this batch from
+        # pipeline.PrefetchWindow(presort=True, bag_layout=...) -- forward and fused backward then run from them
         self.embed.set_cache_op(cache_op)
         if isinstance(sparse_features, list):
             values, offsets, batch_size = sparse_features[0], sparse_features[1], sparse_features[2]
@@ -166,5 +168,6 @@ class FusedSparseModules(nn.Module):
             batch_size = batch_size * self.kjt_collector.world_size
         F = self.sparse_feature_num
         if self.fold_hook:
-            return self.embed(values, offsets, hook_features=F)
+            return self.embed(values, offsets, hook_features=F, presorted=presorted)
+        assert presorted is None, "window keys need fold_hook=True"
         return self.embed(values, offsets, shape_hook=lambda x: self.shape_hook(x, F, batch_size))

@@ -972,8 +972,9 @@ class ParallelCachedEmbeddingBag(CachedEmbeddingBag):
                          warmup_ratio, buffer_size, pin_weight, evict_strategy, **kw)
 
     def forward(self, indices, offsets=None, per_sample_weights=None, shape_hook=None, scatter_dim=0, gather_dim=-1,
-                *, hook_features: int = 0):
-        out = super().forward(indices, offsets, per_sample_weights, shape_hook, hook_features=hook_features)
+                *, hook_features: int = 0, presorted=None):
+        out = super().forward(indices, offsets, per_sample_weights, shape_hook, hook_features=hook_features,
+                              presorted=presorted)
         if self.world_size == 1:
             return out
         sizes = None

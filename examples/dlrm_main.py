@@ -74,6 +74,13 @@ def parse_args(argv=None):
     # additions of this build
     p.add_argument("--fused_sgd", action="store_true", help="apply the embedding SGD inside backward")
     p.add_argument("--fold_hook", action="store_true", help="write [B,F,D] from the gather kernel")
+    p.add_argument("--window_keys", action="store_true",
+                   help="the window's cache op also groups every batch's slots by row (source-row keys): the forward "
+                        "loads a cache row once per run, the fused backward streams over the keys (needs --fused_sgd "
+                        "--fold_hook; one id per bag)")
+    p.add_argument("--warmup_batches", type=int, default=16, help="iterations before the throughput clock starts "
+                   "(library initialisation, GEMM algorithm search, pipeline fill)")
+    p.add_argument("--json_out", type=str, default=None, help="write the run's numbers as one JSON object")
     return p.parse_args(argv)
 
 
@@ -124,8 +131,8 @@ class HybridParallelDLRM(nn.Module):
         self.dense_modules = dense
         self.dense_device = self.sparse_device = device
 
-    def forward(self, dense, sparse, cache_op: bool = True):
-        emb = self.sparse_modules(sparse, cache_op=cache_op)     # [B(/W), F, D]
+    def forward(self, dense, sparse, cache_op: bool = True, presorted=None):
+        emb = self.sparse_modules(sparse, cache_op=cache_op, presorted=presorted)     # [B(/W), F, D]
         return self.dense_modules(dense, emb)
 
 
@@ -204,8 +211,16 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
     data_iter = FiniteDataIter(loader, device) if args.use_overlap else iter(loader)
     P = args.prefetch_num
     embed = model.sparse_modules.embed
-    win = PrefetchWindow(embed, P, overlap=args.overlap_cache_op)
+    layout = None
+    if args.window_keys:
+        if not (args.fused_sgd and args.fold_hook) or world > 1:
+            raise ValueError("--window_keys needs --fused_sgd --fold_hook (one process)")
+        F = model.sparse_modules.sparse_feature_num
+        offsets = torch.arange(F * args.batch_size + 1, dtype=torch.int32, device=device)     # one id per bag (KJT lengths = 1)
+        layout = (offsets, True, F)
+    win = PrefetchWindow(embed, P, overlap=args.overlap_cache_op, presort=layout is not None, bag_layout=layout)
     elapsed, done, loss = 0.0, 0, None
+    steady = {"t0": None, "done0": 0}
     model.train()
     start = time.time()
     cur = _window(data_iter, P, device, args, rank, world)
@@ -224,7 +239,8 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
         for k in range(len(dense_l)):
             sparse_l[k][0] = slots[k]
             with phase("forward pass"):                       # the reference's ranges: recsys/dlrm_main.py:268-278
-                logits = model(dense_l[k], sparse_l[k], cache_op=False).squeeze(-1)
+                logits = model(dense_l[k], sparse_l[k], cache_op=False,
+                               presorted=win.keys[k] if layout is not None else None).squeeze(-1)
                 loss = criterion(logits, labels_l[k])
             with phase("backward pass"):
                 optimizer.zero_grad()
@@ -236,8 +252,18 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
             done += 1
         elapsed += time.time() - start
         start = time.time()
+        if steady["t0"] is None and done >= args.warmup_batches:
+            torch.cuda.synchronize()                          # the throughput clock starts on an idle GPU
+            steady["t0"], steady["done0"] = time.time(), done
+            start = steady["t0"]
         cur = nxt if args.overlap_cache_op else _window(data_iter, P, device, args, rank, world)
     torch.cuda.synchronize()
+    t_end = time.time()
+    if steady["t0"] is not None and done > steady["done0"]:
+        train.steady_it_per_s = (done - steady["done0"]) / (t_end - steady["t0"])
+        train.steady_iterations = done - steady["done0"]
+    else:
+        train.steady_it_per_s, train.steady_iterations = float("nan"), 0
     return done, elapsed, float(loss.detach()) if done else float("nan")
 
 
@@ -300,7 +326,28 @@ def main(argv=None):
             print(f"epoch {epoch}: {done} iterations, average throughput: {done / max(elapsed, 1e-9):.2f} it/s, "
                   f"{lookups / max(elapsed, 1e-9) / 1e6:.1f} M lookups/s, last loss {loss:.4f}, "
                   f"mean loss first quarter {head:.4f} last quarter {tail:.4f}")
+            print(f"         steady state (after {args.warmup_batches} iterations, GPU-synchronised at both ends): "
+                  f"{train.steady_it_per_s:.2f} it/s over {train.steady_iterations} iterations, "
+                  f"{train.steady_it_per_s * args.batch_size * len(sizes) / 1e6:.1f} M lookups/s")
             embed.print_comm_stats_()
+            if args.json_out:
+                import json
+                mgr = embed.cache_weight_mgr
+                Path(args.json_out).write_text(json.dumps({
+                    "script": "examples/dlrm_main.py", "dataset": args.dataset, "table_scale": args.table_scale,
+                    "num_embeddings": int(sum(sizes)), "embedding_dim": args.embedding_dim, "features": len(sizes),
+                    "batch_size": args.batch_size, "prefetch_num": args.prefetch_num, "cache_ratio": args.cache_ratio,
+                    "cuda_row_num": int(mgr.cuda_row_num), "dense_arch": args.dense_arch_layer_sizes,
+                    "over_arch": args.over_arch_layer_sizes, "dtype": "f32", "data": "synthetic",
+                    "surface": {k: bool(getattr(args, k)) for k in ("use_overlap", "overlap_cache_op", "fused_sgd",
+                                                                    "fold_hook", "window_keys",
+                                                                    "use_sparse_embed_grad", "use_lfu", "use_freq")},
+                    "transport": mgr.transport_name, "iterations": done, "warmup_iterations": args.warmup_batches,
+                    "it_per_s": train.steady_it_per_s, "it_per_s_scope": "whole model: data iterator + cache op + "
+                    "embedding forward + dense forward + loss + backward + optimizer step",
+                    "lookups_per_s": train.steady_it_per_s * args.batch_size * len(sizes),
+                    "ms_per_iteration": 1e3 / train.steady_it_per_s, "it_per_s_whole_run_host_clock": done / max(elapsed, 1e-9),
+                    "loss_first_quarter": head, "loss_last_quarter": tail}, indent=1))
     if world > 1:
         dist.destroy_process_group()
 
