@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="criteo_1tb", choices=["criteo_1tb", "criteo_kaggle", "avazu", "custom"])
+    ap.add_argument("--workload", default="criteo_1tb", choices=["criteo_1tb", "criteo_kaggle", "avazu", "custom", "flat_178m"])
     ap.add_argument("--batch_size", type=int, default=16384)
     ap.add_argument("--embedding_dim", type=int, default=128)
     ap.add_argument("--cache_ratio", type=float, default=0.01)
@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--warmup_ratio", type=float, default=0.7)
     ap.add_argument("--dist", default="power_law", choices=["power_law", "uniform"])
     ap.add_argument("--skew", type=float, default=0.25)
+    ap.add_argument("--uniform_frac", type=float, default=0.0, help="share of the power-law lookups whose id is drawn "
+                    "uniformly instead (reuse sweep: ~0.36 gives ~25 %% distinct rows per Criteo batch)")
     ap.add_argument("--table_scale", type=float, default=1.0, help="shrink every table (hosts that cannot pin 91 GB)")
     ap.add_argument("--lr", type=float, default=1.0)
     ap.add_argument("--no_overlap", action="store_true",
@@ -154,7 +156,8 @@ def main():
             print(f"[bench +{time.time() - t0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     t0 = time.time()
-    gen = synthetic.SyntheticKJT(sizes, B, L, args.dist, args.skew, seed=args.seed + rank, device=dev)
+    gen = synthetic.SyntheticKJT(sizes, B, L, args.dist, args.skew, seed=args.seed + rank, device=dev,
+                                 uniform_frac=args.uniform_frac)
     freq = None if args.no_freq else gen.id_freq_map(sample_batches=4 * P)
     note(f"id_freq_map over {N} rows built")
     strategy = ce.EvictionStrategy.LFU if args.use_lfu else ce.EvictionStrategy.DATASET
@@ -654,7 +657,8 @@ def main():
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,
                    "embedding_dim": D, "features": F, "batch_size": B, "pooling": L, "cache_ratio": args.cache_ratio,
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
-                   "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB": N * D * 4 / 1e9,
+                   "id_dist": f"{args.dist}(s={args.skew})" + (f" + {args.uniform_frac:g} uniform" if args.uniform_frac else ""),
+                   "distinct_rows_per_batch_frac": uniq_avg / (B * F * L), "host_table_GB": N * D * 4 / 1e9,
                    "transport": transport, "overlap": bool(args.overlap),
                    "plan_ahead_windows": (gw.plan_ahead if gw is not None else 1) if args.overlap else 0,
                    "launch": "hipGraph per window" if use_graph else "python per step",

@@ -25,7 +25,12 @@ AVAZU = [7, 7, 4737, 7745, 26, 8552, 559, 36, 2686408, 6729486, 8251, 5, 4]
 CUSTOM_POWER_LAW = [int(3e7), int(1e7), int(2e7), int(1e7), int(1e7), int(3e6), int(8e6), int(1e7), int(1e6),
                     int(1e6), int(1e6), int(1e6), int(5e6), 4000, 250, 250]
 
-TABLES = {"criteo_1tb": CRITEO_1TB, "criteo_kaggle": CRITEO_KAGGLE, "avazu": AVAZU, "custom": CUSTOM_POWER_LAW}
+# 26 equal tables with the Criteo-1TB row total: with uniform ids a batch of 16384 samples then holds (almost) no row
+# twice -- the no-reuse end of the reuse sweep (profiles/r04_reuse_sweep.md), where counted and algorithmic bytes agree
+FLAT_178M = [6_844_011] * 25 + [6_844_000]
+
+TABLES = {"criteo_1tb": CRITEO_1TB, "criteo_kaggle": CRITEO_KAGGLE, "avazu": AVAZU, "custom": CUSTOM_POWER_LAW,
+          "flat_178m": FLAT_178M}
 
 
 def scale_tables(sizes: Sequence[int], scale: float) -> List[int]:
@@ -46,7 +51,10 @@ class SparseBatch:
 
 class SyntheticKJT:
     def __init__(self, table_sizes: Sequence[int], batch_size: int, pooling: int = 1, dist: str = "power_law",
-                 s: float = 0.25, seed: int = 1024, device="cuda"):
+                 s: float = 0.25, seed: int = 1024, device="cuda", uniform_frac: float = 0.0):
+        # uniform_frac (dist = "power_law"): this share of the lookups draws its id uniformly from the table instead --
+        # a knob between the long-tail generator's ~9 % distinct rows per Criteo batch and the uniform one's ~54 %
+        self.uniform_frac = float(uniform_frac)
         self.sizes = list(table_sizes)
         self.F = len(self.sizes)
         self.B = batch_size
@@ -71,6 +79,10 @@ class SyntheticKJT:
             lo = self._lo.unsqueeze(1)
             x = u * (1.0 - lo) + lo
             ids = torch.floor(1.0 / (x ** (1.0 / self.s))).long() - 1
+            if self.uniform_frac > 0.0:
+                pick = torch.rand(self.F, n_per_table, device=self.device, generator=self.gen) < self.uniform_frac
+                u2 = torch.rand(self.F, n_per_table, dtype=torch.float64, device=self.device, generator=self.gen)
+                ids = torch.where(pick, torch.floor(u2 * self._sizes_i.unsqueeze(1).double()).long(), ids)
         return torch.minimum(ids.clamp_(min=0), self._sizes_i.unsqueeze(1) - 1)
 
     def next_values(self, batches: int = 1) -> torch.Tensor:

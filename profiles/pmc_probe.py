@@ -18,6 +18,8 @@ from cachedembedding_amd import synthetic  # noqa: E402
 from cachedembedding_amd.functional import presort_window  # noqa: E402
 
 mode = sys.argv[1]
+# bench mode, optional: workload dist skew uniform_frac prefetch_num  (the reuse sweep: profiles/reuse_sweep.sh)
+workload, dist_, skew, ufrac, P_arg = (sys.argv[2:7] + ["criteo_1tb", "power_law", "0.25", "0", "8"][len(sys.argv[2:7]):])
 B, F, D = 16384, 26, 128
 dev = torch.device("cuda", 0)
 off = torch.arange(B * F + 1, dtype=torch.int32, device=dev)
@@ -33,17 +35,17 @@ if mode == "calib":
         out.backward(grad)
     torch.cuda.synchronize()
 else:
-    sizes = synthetic.TABLES["criteo_1tb"]
+    sizes = synthetic.TABLES[workload]
     N = sum(sizes)
-    gen = synthetic.SyntheticKJT(sizes, B, 1, "power_law", 0.25, seed=1024, device=dev)
+    gen = synthetic.SyntheticKJT(sizes, B, 1, dist_, float(skew), seed=1024, device=dev, uniform_frac=float(ufrac))
     freq = gen.id_freq_map(32)
     emb = ce.CachedEmbeddingBag(N, D, sparse=True, mode="sum", include_last_offset=True, cache_ratio=0.01,
                                 ids_freq_mapping=freq, warmup_ratio=0.7, strict=False)
     emb.set_fused_sgd(1.0)
     emb.set_cache_op(False)
     grad = torch.randn(B, F, D, device=dev) * 1e-3
-    P = 8
-    for win in range(14):
+    P = int(P_arg)
+    for win in range(max(14, 112 // P)):
         vals = gen.next_values(P)
         slots = emb.cache_weight_mgr.prepare_ids(vals.view(-1)).view(P, -1)
         # as bench.py does: source-row keys for the streaming backward
@@ -53,4 +55,6 @@ else:
             out = emb(slots[i], off, hook_features=F, presorted=keys[i])
             out.backward(grad)
     torch.cuda.synchronize()
+    st = emb.cache_weight_mgr.sync_stats()
+    assert st.status == 0, "a cache op of the probe overflowed: lower prefetch_num"
 print("done", mode)

@@ -21,9 +21,10 @@ for mode in ("calib", "bench"):
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != counter:
                     continue
-                for k in ("k_bag_bwd_tile", "k_bag_bwd_stream", "k_bag_fwd", "k_rows_axpy"):
-                    if k in r["Kernel_Name"]:
+                for k in ("k_bag_bwd_tile", "k_bag_bwd_stream", "k_bag_fwd_keys", "k_bag_fwd", "k_rows_axpy"):
+                    if k + "<" in r["Kernel_Name"] or k + "(" in r["Kernel_Name"]:      # (k_bag_fwd is a prefix of k_bag_fwd_keys)
                         vals[k].append(float(r["Counter_Value"]))
+                        break
         parts = []
         for k, v in sorted(vals.items()):
             v = v[2:] if len(v) > 4 else v
@@ -35,7 +36,8 @@ if json_out:
     import json
     repo = Path(__file__).resolve().parents[1]
     stamp = (repo / "cachedembedding_amd" / "csrc" / ".build_stamp").read_text().strip()
-    names = {"k_bag_fwd": "k_bag_fwd", "k_bag_bwd_stream": "k_bag_bwd_stream(sgd)", "k_bag_bwd_tile": "k_bag_bwd_tile(sgd)"}
+    names = {"k_bag_fwd": "k_bag_fwd", "k_bag_fwd_keys": "k_bag_fwd_keys", "k_bag_bwd_stream": "k_bag_bwd_stream(sgd)",
+             "k_bag_bwd_tile": "k_bag_bwd_tile(sgd)"}
     entry = {}
     for k, label in names.items():
         f, w = avgs.get(("bench", "FETCH_SIZE", k)), avgs.get(("bench", "WRITE_SIZE", k))
