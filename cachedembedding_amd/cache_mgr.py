@@ -270,6 +270,11 @@ class CachedParamMgr(torch.nn.Module):
         else:
             with torch.cuda.device(self.device):
                 check(fn(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+        self._strict_check()
+        return slots if slots.shape == shape else slots.view(shape)
+
+    def _strict_check(self) -> None:
+        """strict=True: wait for the call just issued and raise what upstream raises (one tiny sync)"""
         if self.strict and not torch.cuda.is_current_stream_capturing():
             st = CeCallStats()
             rc = lib.ce_cache_last_stats(self._handle, ctypes.byref(st))
@@ -281,7 +286,43 @@ class CachedParamMgr(torch.nn.Module):
             if rc == _lib.CE_ERR_RANGE:
                 raise IndexError(_lib.last_error())
             check(rc)
-        return slots if slots.shape == shape else slots.view(shape)
+
+    @torch.no_grad()
+    def prepare_ids_keys(self, ids: torch.Tensor, out: torch.Tensor, keys_out: torch.Tensor, *,
+                         offsets: Optional[torch.Tensor] = None, include_last_offset: bool = False,
+                         hook_features: int = 0, identity_bags: bool = False) -> torch.Tensor:
+        """prepare_ids for a prefetch window of P equal batches (ids [P, n] int64) that also leaves the window's keys in
+        keys_out ([P, presort_len(n)] int64) -- functional.presort_window's keys, written by the cache op's last kernel
+        together with the slots instead of by a launch of its own (ce_cache_prepare_ids_keys).  offsets given: source-row
+        keys (see presort_window).  `out` ([P, n] int64) receives the slots and is scratch during the call, as in
+        prepare_ids.  Returns `out`."""
+        assert ids.is_cuda and ids.dim() == 2 and ids.dtype == torch.int64 and ids.is_contiguous()
+        P, n = ids.shape
+        assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == P * n
+        klen = int(lib.ce_bag_presort_len(n))
+        assert keys_out.is_cuda and keys_out.dtype == torch.int64 and keys_out.is_contiguous() and \
+            keys_out.numel() == P * klen
+        src, off_ptr, off64, stride, num_bags = 0, 0, 0, 0, n
+        if offsets is not None:
+            assert offsets.is_cuda and offsets.dtype in (torch.int32, torch.int64) and offsets.is_contiguous()
+            assert offsets.dim() == 1 or (offsets.dim() == 2 and offsets.shape[0] == P)
+            per = offsets.shape[-1]
+            num_bags = per - 1 if include_last_offset else per
+            if hook_features and num_bags % hook_features:
+                raise ValueError("hook_features must divide the number of bags")
+            if identity_bags:
+                assert num_bags == n, "identity_bags needs one id per bag"
+            src, off_ptr = 1, (0 if identity_bags else ptr(offsets))
+            off64, stride = int(offsets.dtype == torch.int64), (per if offsets.dim() == 2 else 0)
+        args = (self._handle, ptr(ids), P, n, ptr(out), src, off_ptr, off64, stride, num_bags, int(include_last_offset),
+                int(hook_features), ptr(keys_out))
+        if torch.cuda.current_device() == self.device.index:
+            check(lib.ce_cache_prepare_ids_keys(*args, stream_ptr()))
+        else:
+            with torch.cuda.device(self.device):
+                check(lib.ce_cache_prepare_ids_keys(*args, stream_ptr()))
+        self._strict_check()
+        return out
 
     def graph_replayed(self, n_calls: int, ids_per_call: int) -> None:
         """Report `n_calls` prepare_ids calls that a hipGraph launched just now on the current stream replayed

@@ -489,12 +489,17 @@ constexpr int kSegBuckets = CE_SEG_BUCKETS;
 constexpr int kExclRun = 32;
 constexpr unsigned kExclFlag = 0x80000000u;
 
-template <bool SRC, bool EXCL>
+// ROWS (the cache op's fused form, presort_window_from_rows): slots_io holds the table ROW of every lookup; its slot
+// is inverted[row] (one random 4-byte gather per lookup, all 16 of a thread in flight before anything else happens)
+// and is written back in place.
+template <bool SRC, bool EXCL, bool ROWS>
 __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz_per_batch,
                                                          int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
                                                          unsigned long long* __restrict__ keys_out, BagParams lay,
                                                          int64_t off_stride, const int64_t* __restrict__ ids,
-                                                         int64_t* __restrict__ ids_minmax) {
+                                                         int64_t* __restrict__ ids_minmax, int64_t* slots_io,
+                                                         const int32_t* __restrict__ inverted,
+                                                         const int* __restrict__ status) {
   __shared__ unsigned long long lk[EXCL ? kSegLen : (kSegBuckets + 2) / 2];   // EXCL: the segment's keys by position
   int* const cnt = (int*)lk;                            // [kSegBuckets + 1] bucket counters ([kSegBuckets] = ignored)
   __shared__ int wsum[16];
@@ -512,6 +517,23 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     __syncthreads();
     unsigned long long key[kSegKeys];
     int place[kSegKeys], bkt[kSegKeys];                  // place inside the bucket (a bucket can hold the whole segment)
+    int32_t slot_r[ROWS ? kSegKeys : 1];
+    if (ROWS) {
+      const bool failed = *status != CE_OK;              // a failed cache op hands back -1 everywhere
+      int32_t row_r[kSegKeys];
+#pragma unroll
+      for (int r = 0; r < kSegKeys; ++r) {
+        const int e = r * 1024 + tid;
+        row_r[r] = e < n_here ? (int32_t)slots_io[in_base + e] : -1;
+      }
+#pragma unroll
+      for (int r = 0; r < kSegKeys; ++r) slot_r[r] = (row_r[r] >= 0 && !failed) ? inverted[row_r[r]] : -1;
+#pragma unroll
+      for (int r = 0; r < kSegKeys; ++r) {
+        const int e = r * 1024 + tid;
+        if (e < n_here) slots_io[in_base + e] = (int64_t)slot_r[r];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < kSegKeys; ++r) {
       // lane-interleaved ownership: lookup e = r * 1024 + tid (coalesced loads; the order inside a row's group
@@ -520,7 +542,7 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
       key[r] = ~0ull;
       bkt[r] = kSegBuckets;
       if (e < n_here) {
-        const int64_t row = indices[in_base + e];
+        const int64_t row = ROWS ? (int64_t)slot_r[ROWS ? r : 0] : indices[in_base + e];
         const bool valid = (uint64_t)row < (uint64_t)num_rows;
         if (valid || SRC) {
           unsigned low = (unsigned)e;
@@ -1409,21 +1431,60 @@ static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, in
   const int64_t nseg = spb * n_batches;
   CE_REQUIRE(spb < (int64_t)INT32_MAX && nseg < (int64_t)INT32_MAX, CE_ERR_INVALID, "too many segments");
   const dim3 grid((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), block(1024);
+  int64_t* const no_io = nullptr;
+  const int32_t* const no_inv = nullptr;
+  const int* const no_st = nullptr;
   if (lay && ids_minmax)
-    hipLaunchKernelGGL((k_bag_presort_seg<true, true>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+    hipLaunchKernelGGL((k_bag_presort_seg<true, true, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride, ids,
-                       ids_minmax);
+                       ids_minmax, no_io, no_inv, no_st);
   else if (lay)
-    hipLaunchKernelGGL((k_bag_presort_seg<true, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+    hipLaunchKernelGGL((k_bag_presort_seg<true, false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride,
-                       (const int64_t*)nullptr, (int64_t*)nullptr);
+                       (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
   else
-    hipLaunchKernelGGL((k_bag_presort_seg<false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+    hipLaunchKernelGGL((k_bag_presort_seg<false, false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{}, 0ll,
-                       (const int64_t*)nullptr, (int64_t*)nullptr);
+                       (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }
+
+namespace ce {
+int presort_window_from_rows(int64_t* slots_io, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                             const int32_t* inverted, const int* status, int32_t src_keys, const void* offsets,
+                             int32_t offsets_are_i64, int64_t offsets_batch_stride, int64_t num_bags,
+                             int32_t include_last_offset, int64_t hook_features, uint64_t* keys_out, hipStream_t stream) {
+  if (nnz_per_batch == 0 || n_batches == 0) return CE_OK;
+  CE_REQUIRE(slots_io && keys_out && inverted && status && nnz_per_batch > 0 && n_batches > 0, CE_ERR_INVALID, "bad arguments");
+  CE_REQUIRE(nnz_per_batch < (int64_t)INT32_MAX - kSegLen, CE_ERR_INVALID, "batch too large");
+  CE_REQUIRE(num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID, "num_rows out of range");
+  const int64_t spb = cdiv(nnz_per_batch, kSegLen);
+  const int64_t nseg = spb * n_batches;
+  CE_REQUIRE(spb < (int64_t)INT32_MAX && nseg < (int64_t)INT32_MAX, CE_ERR_INVALID, "too many segments");
+  const dim3 grid((unsigned)std::min<int64_t>(nseg, kMaxBlocks)), block(1024);
+  if (src_keys) {
+    CE_REQUIRE(num_bags > 0 && offsets_batch_stride >= 0, CE_ERR_INVALID, "bad offsets");
+    CE_REQUIRE(offsets || num_bags == nnz_per_batch, CE_ERR_INVALID,
+               "offsets may only be NULL for the one-id-per-bag layout (num_bags == nnz_per_batch)");
+    BagParams lay{};
+    bool vec;
+    int nch;
+    int rc = fill_params(lay, 4, nullptr, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset, nullptr,
+                         CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_bag_presort_seg<true, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
+                       nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
+                       offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
+  } else {
+    hipLaunchKernelGGL((k_bag_presort_seg<false, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
+                       nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{},
+                       0ll, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
+  }
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+}  // namespace ce
 
 extern "C" int ce_bag_presort_window(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches,
                                      int64_t num_rows, uint64_t* keys_out, ce_stream_t stream) {

@@ -72,6 +72,7 @@ struct Ctl {                 // device control block (one per manager)
   int status;
   int lost;                  // per call: the admission worker reported that the rows did not arrive (see k_admit_maps)
   int pad_;
+  long long n_free_start;    // per call: n_free when the call began (k_begin; read-only for the rest of the call)
   // radix select: digits and remaining rank after level q was resolved (written by workgroup 0 of the kernel that
   // resolves level q -- every workgroup of that kernel computes the same thing for itself --, read by later kernels)
   unsigned long long sel_prefix_after[8];
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_
     ctl->victims_count = 0;
     ctl->status = CE_OK;
     ctl->lost = 0;
+    ctl->n_free_start = ctl->n_free;
   }
   if (coarse)
     for (int i = threadIdx.x; i < n_coarse2; i += blockDim.x) coarse[i] = 0;
@@ -398,7 +400,8 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
                                               const int32_t* __restrict__ blk_miss, const int32_t* __restrict__ coarse,
                                               int n_chunks, int32_t* miss_list, int32_t* slot_epoch, long long seq_arg,
                                               Ctl* ctl, int64_t C, int64_t n_ids, ce_call_stats_t* ring,
-                                              WbMail* mail_in, long long job, long long in_cap, int32_t* miss_host) {
+                                              WbMail* mail_in, long long job, long long in_cap, int32_t* miss_host,
+                                              int assume_free0) {
   const long long seq_ = call_seq(ctl, seq_arg);
   const int32_t epoch = call_epoch(seq_);
   ce_call_stats_t* const ring_slot = ring + (seq_ % kRing);
@@ -449,11 +452,17 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
   __syncthreads();
   const long long tu = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   const long long tm = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  // assume_free0: the host launched the call in its steady-state form (no free-list scan: the slots to fill are the
+  // victims, see k_evict_stage) because the last record it has seen said "no free slot left".  Nothing but a flush or
+  // a lost admission raises the count again and the host knows of both -- but a call launched before the record of
+  // a lost admission arrived must not pair missing rows with a stale list: it fails, state untouched.
+  const bool stale = assume_free0 && ctl->n_free_start != 0;
   // workgroup 0 may already have turned CE_OK into CE_ERR_CAPACITY below: the verdict is the same either way
-  const bool ok = st_in == CE_OK && tu <= C;
+  const bool ok = st_in == CE_OK && tu <= C && !stale;
   if (bid == 0 && threadIdx.x == 0) {
     int status = st_in;
     if (status == CE_OK && tu > C) status = CE_ERR_CAPACITY;
+    if (status == CE_OK && stale) status = CE_ERR_HIP;
     long long k = 0;
     if (status == CE_OK) {
       k = tm - ctl->n_free;
@@ -687,9 +696,13 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
     if (sh[i]) atomicAdd(&mine[i], sh[i]);
 }
 
+// blk_vic (steady-state calls only): victims among this workgroup's 4096 slots -- k_evict_stage's free-list
+// workgroups turn them into the ascending list of slots to fill without another scan of cached_idx_map; the
+// threshold key goes to ctl->sel_prefix_after[0] for them.
 __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
                                                  int32_t* victims, int64_t cap, Ctl* ctl, const uint32_t* hist,
-                                                 int top_pass, ce_call_stats_t* ring, long long seq_arg) {
+                                                 int top_pass, ce_call_stats_t* ring, long long seq_arg,
+                                                 int32_t* blk_vic) {
   ce_call_stats_t* const ring_slot = ring + (call_seq(ctl, seq_arg) % kRing);
   __shared__ unsigned long long prefix_s;
   __shared__ int fail_s, go_s;
@@ -703,8 +716,9 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
     const int64_t sl = s0 + u * 256;
     key[u] = sl < C ? keys[sl] : ~0ull;
   }
+  if (blk_vic && threadIdx.x == 0) blk_vic[blockIdx.x] = 0;
   if (threadIdx.x < 64) {
-    const SelState st = select_level(hist, 0, top_pass, ctl, threadIdx.x, false);
+    const SelState st = select_level(hist, 0, top_pass, ctl, threadIdx.x, blk_vic != nullptr && blockIdx.x == 0);
     if (threadIdx.x == 0) {
       prefix_s = st.prefix;
       fail_s = st.fail;
@@ -739,7 +753,10 @@ __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __res
   int tot;
   int pos = block_excl_scan_256(hits, &tot);
   if (tot == 0) return;                     // block-uniform
-  if (threadIdx.x == 0) base_s = atomicAdd(&ctl->victims_count, tot);
+  if (threadIdx.x == 0) {
+    base_s = atomicAdd(&ctl->victims_count, tot);
+    if (blk_vic) blk_vic[blockIdx.x] = tot;
+  }
   __syncthreads();
   pos += base_s;
 #pragma unroll
@@ -815,12 +832,68 @@ __global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ vict
 // written back directly by k_evict (`first` = staging capacity).
 constexpr int kStageRowsInFlight = 4;   // rows in flight per lane group of the HBM-to-HBM row movers
 
+// Steady state (the call began with no free slot: every missing row takes a victim's place): the free-slot list IS
+// the victim list in ascending slot order.  Workgroup j of this role owns the 4096 slots k_victims' workgroup j
+// counted (blk_vic[j]), adds up the counts before its own (<= a few hundred values out of L2), finds its victims again
+// from the keys (key <= the threshold k_victims recorded) and writes their slots at base + rank: no scan of
+// cached_idx_map, no launch of its own -- it rides in k_evict_stage's grid (which clears cached_idx_map meanwhile:
+// nothing here reads it).
+__device__ __forceinline__ void free_list_from_victims(const unsigned long long* __restrict__ keys, int64_t C,
+                                                       const int32_t* __restrict__ blk_vic, int32_t* free_list,
+                                                       const Ctl* ctl, int j) {
+  if (ctl->status != CE_OK || ctl->k_evict == 0) return;
+  const unsigned long long T = ctl->sel_prefix_after[0];
+  const long long need = ctl->n_miss;
+  __shared__ int part_s[4];
+  __shared__ unsigned long long mask_s[64];
+  __shared__ int pre_s[65];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int part = 0;
+  for (int i = threadIdx.x; i < j; i += 256) part += blk_vic[i];
+  part = wave_sum(part);
+  if (lane == 0) part_s[wv] = part;
+  // victims among 64 consecutive slots -> one 64-bit mask (wave wv takes the 64-slot groups wv, wv + 4, ...)
+  const int64_t s0 = (int64_t)j * 4096;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int g = wv + 4 * u;
+    const int64_t sl = s0 + (int64_t)g * 64 + lane;
+    const unsigned long long key = sl < C ? keys[sl] : ~0ull;
+    const unsigned long long m = __ballot(key <= T && key != ~0ull);
+    if (lane == 0) mask_s[g] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = __popcll(mask_s[threadIdx.x]);
+    const int inc = wave_incl_scan(c, lane);
+    pre_s[threadIdx.x] = inc - c;
+  }
+  __syncthreads();
+  const long long base = (long long)part_s[0] + part_s[1] + part_s[2] + part_s[3];
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int g = wv + 4 * u;
+    const unsigned long long m = mask_s[g];
+    if ((m >> lane) & 1) {
+      const long long pos = base + pre_s[g] + __popcll(m & lt);
+      if (pos < need) free_list[pos] = (int32_t)(s0 + (int64_t)g * 64 + lane);
+    }
+  }
+}
+
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
                                                      int32_t* cached_idx_map, int32_t* inverted,
                                                      const VT* __restrict__ cache, VT* stage, int32_t* stage_rows_idx,
                                                      long long cap, int rowlen, int g_log2, const Ctl* ctl,
-                                                     WbMail* mail, long long job) {
+                                                     WbMail* mail, long long job, int stage_grid,
+                                                     const unsigned long long* __restrict__ keys, int64_t C,
+                                                     const int32_t* __restrict__ blk_vic, int32_t* free_list) {
+  if ((int)blockIdx.x >= stage_grid) {       // (only launched with these workgroups in the steady-state form)
+    free_list_from_victims(keys, C, blk_vic, free_list, ctl, (int)blockIdx.x - stage_grid);
+    return;
+  }
   long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
   if (k > cap) k = cap;
   if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // read by the worker after this kernel's event
@@ -829,7 +902,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
   }
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  const int64_t gstride = ((int64_t)stage_grid * blockDim.x) >> g_log2;
   constexpr int R = kStageRowsInFlight;
   for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < k; i += gstride * R) {
     if (rowlen <= G) {          // R rows in flight per lane group (one row at a time left this kernel latency bound)
@@ -1892,6 +1965,11 @@ struct ce_cache {
   long long n_failed;          // finished prepare_ids calls whose status was not CE_OK
   int last_fail_status;
   long long last_fail_seq;
+  // "the cache has no free slot left": true once a finished prepare_ids record issued after the last flush says so,
+  // until the next flush or failed call.  Calls launched while it holds take the steady-state form (free slots = this
+  // call's victims: no free-list scan, see free_list_from_victims); the device re-checks the premise (k_emit).
+  bool free_zero;
+  long long free_reset_seq;    // records up to this call number say nothing about the present
 };
 
 using namespace ce;
@@ -1913,6 +1991,10 @@ static void drain(ce_cache* h) {
       h->n_failed += 1;
       h->last_fail_status = r.status;
       h->last_fail_seq = s;
+      h->free_zero = false;            // (a lost admission gives its slots back: n_free > 0 again)
+      h->free_reset_seq = h->seq;
+    } else if (r.kind == CE_CALL_PREPARE && s > h->free_reset_seq) {
+      h->free_zero = r.n_free_after == 0;
     }
     if (r.status == CE_OK && r.kind != CE_CALL_PRELOAD) {   // warm-up preload is not counted upstream either
       h->cpu_to_cuda_numel += r.n_miss * h->cfg.embedding_dim;
@@ -2008,6 +2090,8 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->n_failed = 0;
   h->last_fail_status = CE_OK;
   h->last_fail_seq = 0;
+  h->free_zero = false;
+  h->free_reset_seq = 0;
   h->stage2 = (float*)(h->ws + L.stage2);
   h->stage_idx2 = (int32_t*)(h->ws + L.stage_idx2);
   h->in_stage = (float*)(h->ws + L.in_stage);
@@ -2389,8 +2473,20 @@ static int worker_selftest(ce_cache* h, hipStream_t s) {
   return CE_OK;
 }
 
+// the window's keys, written by the call's last kernel (ce_cache_prepare_ids_keys)
+struct KeysTail {
+  int64_t n_batches, nnz_per_batch;
+  int32_t src_keys;
+  const void* offsets;
+  int32_t offsets_are_i64;
+  int64_t offsets_batch_stride, num_bags;
+  int32_t include_last_offset;
+  int64_t hook_features;
+  uint64_t* keys_out;
+};
+
 static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out, ce_stream_t stream,
-                            int allow_pad) {
+                            int allow_pad, const KeysTail* tail = nullptr) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
   CE_REQUIRE(n >= 0 && n <= std::max<int64_t>(h->cfg.max_ids_per_call, 0), CE_ERR_INVALID,
              "n=%lld exceeds max_ids_per_call=%lld", (long long)n, (long long)h->cfg.max_ids_per_call);
@@ -2470,6 +2566,9 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     if (rc == CE_OK) rc = h->wb->wait_in(in_job - 2);
     if (rc) return rc;
   }
+  // steady-state form (see ce_cache::free_zero): the slots to fill are this call's victims
+  const bool steady = h->free_zero && !capturing && (c.transport == CE_TRANSPORT_ZEROCOPY || worker);
+  const int n_vblocks = (int)cdiv(C, 4096);
   PhaseProf* const prof = h->prof;
   const int pslot = (int)(h->seq % kProfDepth);
   int pmark = 0;
@@ -2510,7 +2609,7 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   hipLaunchKernelGGL(k_emit, dim3((unsigned)cdiv(L.n_chunks, kEmitSub)), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
                      h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, ring,
                      worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
-                     worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr);
+                     worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr, steady ? 1 : 0);
   if (worker) {
     // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) while this
     // stream selects and stages the victims; it first lets every earlier write-back land
@@ -2554,8 +2653,8 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   // level above it from that level's histogram in its prologue -- select_level -- so there is no pick kernel at all)
   for (int pass = top_pass - 1; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
-  hipLaunchKernelGGL(k_victims, dim3((unsigned)cdiv(C, 4096)), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
-                     (const uint32_t*)h->hist, top_pass, ring, seq_arg);
+  hipLaunchKernelGGL(k_victims, dim3((unsigned)n_vblocks), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
+                     (const uint32_t*)h->hist, top_pass, ring, seq_arg, steady ? h->blk_free : (int32_t*)nullptr);
   CE_PHASE();
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
   int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
@@ -2566,18 +2665,21 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     static const int stage_blocks = [] { const char* e = getenv("CE_STAGE_BLOCKS"); return e ? atoi(e) : 512; }();
     const int sgrid = (int)std::min<int64_t>(stage_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
     WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
+    const dim3 sg(sgrid + (steady ? n_vblocks : 0));        // + the free-list workgroups of the steady-state form
     if (h->vec) {
-      hipLaunchKernelGGL((k_evict_stage<f32x4>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
+      hipLaunchKernelGGL((k_evict_stage<f32x4>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
-                         h->ctl, mail, out_job);
+                         h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
+                         h->free_list);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                            c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
                            h->rowlen, h->g_log2, h->ctl);
     } else {
-      hipLaunchKernelGGL((k_evict_stage<float>), dim3(sgrid), dim3(256), 0, s, h->victims, c.cached_idx_map,
+      hipLaunchKernelGGL((k_evict_stage<float>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
-                         h->ctl, mail, out_job);
+                         h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
+                         h->free_list);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                            c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
@@ -2595,7 +2697,9 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   CE_PHASE();
   // (one workgroup walks 4096 slots per round: beyond a few rounds the pair of wide kernels is faster --
   // C = 94 k, Avazu at 1 %: 18.3 us against 13.6 us for the pair)
-  if (C <= 16384) {
+  if (steady) {
+    // (the list was written by k_evict_stage's free-list workgroups)
+  } else if (C <= 16384) {
     hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, h->free_list, h->ctl);
   } else {
     hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
@@ -2695,6 +2799,21 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
     hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, slots_out, n,
                        c.inverted_cached_idx, c.freq_cnter, (const Ctl*)h->ctl);
+    if (tail) {
+      rc = tail->src_keys
+               ? ce_bag_presort_window_src(slots_out, tail->nnz_per_batch, tail->n_batches, C, tail->offsets,
+                                           tail->offsets_are_i64, tail->offsets_batch_stride, tail->num_bags,
+                                           tail->include_last_offset, tail->hook_features, tail->keys_out, stream)
+               : ce_bag_presort_window(slots_out, tail->nnz_per_batch, tail->n_batches, C, tail->keys_out, stream);
+      if (rc) return rc;
+    }
+  } else if (n > 0 && tail) {
+    // rows -> slots AND the window's keys in one pass (k_slots would write 8 bytes per id for the presort to read back)
+    rc = presort_window_from_rows(slots_out, tail->nnz_per_batch, tail->n_batches, C, c.inverted_cached_idx,
+                                  &h->ctl->status, tail->src_keys, tail->offsets, tail->offsets_are_i64,
+                                  tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset,
+                                  tail->hook_features, tail->keys_out, s);
+    if (rc) return rc;
   } else if (n > 0) {
     hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, slots_out, n, c.inverted_cached_idx,
                        (const Ctl*)h->ctl);
@@ -2710,6 +2829,17 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
 extern "C" int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                     ce_stream_t stream) {
   return prepare_ids_impl(h, ids, n, slots_out, stream, 0);
+}
+
+extern "C" int ce_cache_prepare_ids_keys(ce_cache_t* h, const int64_t* ids, int64_t n_batches, int64_t nnz_per_batch,
+                                         int64_t* slots_out, int32_t src_keys, const void* offsets,
+                                         int32_t offsets_are_i64, int64_t offsets_batch_stride, int64_t num_bags,
+                                         int32_t include_last_offset, int64_t hook_features, uint64_t* keys_out,
+                                         ce_stream_t stream) {
+  CE_REQUIRE(n_batches > 0 && nnz_per_batch > 0 && keys_out, CE_ERR_INVALID, "bad window shape / null keys_out");
+  KeysTail t{n_batches, nnz_per_batch, src_keys, offsets, offsets_are_i64, offsets_batch_stride, num_bags,
+             include_last_offset, hook_features, keys_out};
+  return prepare_ids_impl(h, ids, n_batches * nnz_per_batch, slots_out, stream, 0, &t);
 }
 
 extern "C" int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
@@ -2818,6 +2948,8 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
     if (rc) return rc;
   }
   h->seq += 1;
+  h->free_zero = false;            // every slot is free again once this has run
+  h->free_reset_seq = h->seq;
   const int gpb = 256 >> h->g_log2;
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, (int32_t*)nullptr, 0, (uint32_t*)nullptr,
                      (long long)h->seq);

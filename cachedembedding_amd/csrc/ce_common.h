@@ -49,6 +49,16 @@ static inline int grid_for(int64_t work_items, int per_block) {
   return (int)b;
 }
 
+// ce_bag.hip, for the cache manager (ce_cache.hip): the window presort with the cache op's last step folded in.
+// slots_io holds the ROW of every id (what k_mark left there; -1 = no lookup); the kernel turns it into the slot in
+// place (inverted[row]; -1 everywhere when *status != CE_OK) and writes the window's keys in the same pass -- instead
+// of k_slots writing 8 bytes per id that the presort reads straight back.  lay_* as ce_bag_presort_window_src;
+// src_keys == 0: keys = row << 32 | lookup in segment (ce_bag_presort_window).
+int presort_window_from_rows(int64_t* slots_io, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
+                             const int32_t* inverted, const int* status, int32_t src_keys, const void* offsets,
+                             int32_t offsets_are_i64, int64_t offsets_batch_stride, int64_t num_bags,
+                             int32_t include_last_offset, int64_t hook_features, uint64_t* keys_out, hipStream_t stream);
+
 // lanes cooperating on one embedding row: 16 B per lane, power of two, at most one wave
 static inline int group_lanes_for_dim(int dim) {
   int v = (dim + 3) / 4;

@@ -57,6 +57,9 @@ def pick_transport(transport: Optional[str], ids_per_call: int) -> Optional[str]
 # marks them costs 4x (208 vs 50 us per window) and the backward gains 2-3 us per batch at best, so
 # the window pipelines only use it when asked to.
 EXCLUSIVE_ROWS = bool(int(__import__("os").environ.get("CE_EXCLUSIVE_ROWS", "0")))
+# the window's keys written by the cache op's last kernel (ce_cache_prepare_ids_keys) instead of by a presort launch
+# behind it (CE_FUSED_WINDOW_KEYS=0: two calls)
+FUSED_WINDOW_KEYS = bool(int(__import__("os").environ.get("CE_FUSED_WINDOW_KEYS", "1")))
 
 
 class PrefetchWindow:
@@ -100,14 +103,30 @@ class PrefetchWindow:
         if self._auto:
             self._auto = False
             self.mgr.set_transport(pick_transport("auto", int(cat.numel())))
+        lay = self._layout or {}
+        fused = (self.presort and FUSED_WINDOW_KEYS and len(set(counts)) == 1 and counts[0] > 0
+                 and not (lay and EXCLUSIVE_ROWS) and cat.dim() == 1 and cat.dtype == torch.int64)
         with phase("prefetch cache"):                      # the reference's range name (recsys/dlrm_main.py:258)
-            slots = self.mgr.prepare_ids(cat)
+            if fused:       # slots and the window's keys out of one call
+                P_, n_ = len(counts), counts[0]
+                slots = torch.empty(P_ * n_, dtype=torch.int64, device=cat.device)
+                kbuf = torch.empty(P_, presort_len(n_), dtype=torch.int64, device=cat.device)
+                self.mgr.prepare_ids_keys(cat.view(P_, n_), slots, kbuf, **lay)
+            else:
+                slots = self.mgr.prepare_ids(cat)
         # split by per-batch id counts (torch.chunk in the reference is only right for equal sizes, B#13)
         parts = list(torch.split(slots, counts))
         self._keys_tmp = None
-        if self.presort:
+        if fused:
+            if lay:
+                per = lay["offsets"].shape[-1]
+                nb_ = per - 1 if lay["include_last_offset"] else per
+                self._keys_tmp = [SrcKeys(kbuf[i], nb_, lay["include_last_offset"], lay["hook_features"], None,
+                                          bool(lay["identity_bags"])) for i in range(P_)]
+            else:
+                self._keys_tmp = [kbuf[i] for i in range(P_)]
+        elif self.presort:
             C = self.mgr.cuda_row_num
-            lay = self._layout or {}
             # source-row keys: the ids go along, so rows owned by one lane group get plain read-modify-writes
             def with_ids(t, rows):
                 return dict(ids=t.reshape(-1).long().contiguous().view(rows, -1)) if (lay and EXCLUSIVE_ROWS) else {}
@@ -234,11 +253,10 @@ class GraphedWindow:
         # eager warm-up on real slots (lazy initialisation must not happen during capture), then capture
         if warmup_values is not None:
             wcat = torch.cat(list(warmup_values))
-            self.mgr.prepare_ids(wcat, out=self._bufs[0])
+            self._cache_op(wcat, 0)
             for b in range(1, nbuf):
                 self._bufs[b].copy_(self._bufs[0])
             if self.presort:
-                self._presort(0, wcat)
                 for b in range(1, nbuf):
                     self._keys[b].copy_(self._keys[0])
                     if self._ranges is not None:
@@ -283,9 +301,7 @@ class GraphedWindow:
         for b in range(2):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.mgr.prepare_ids(self._ids[b], out=self._bufs[b])
-                if self.presort:
-                    self._presort(b, self._ids[b])
+                self._cache_op(self._ids[b].view(-1), b)
             plans.append(g)
         self._plan_graphs = plans
 
@@ -301,6 +317,15 @@ class GraphedWindow:
             step_fn(self._bufs[buf][i], i, self._keys[buf][i])
         else:
             step_fn(self._bufs[buf][i], i)
+
+    def _cache_op(self, cat: torch.Tensor, buf: int) -> None:
+        """cache op of a window into slot buffer `buf`, and its keys when the window is presorted"""
+        if self.presort and FUSED_WINDOW_KEYS and self._ranges is None and cat.dtype == torch.int64 and cat.is_contiguous():
+            self.mgr.prepare_ids_keys(cat.view(self.P, self.n), self._bufs[buf], self._keys[buf], **(self._layout or {}))
+            return
+        self.mgr.prepare_ids(cat, out=self._bufs[buf])
+        if self.presort:
+            self._presort(buf, cat)
 
     def _presort(self, buf: int, ids: torch.Tensor) -> None:
         # one launch for the window: every batch's 16384-lookup segments grouped by row
@@ -322,9 +347,7 @@ class GraphedWindow:
                     self._side.wait_event(self._read_done[buf])
                 cat = values[0] if len(values) == 1 else torch.cat(list(values))
                 assert cat.numel() == self.P * self.n
-                self.mgr.prepare_ids(cat, out=self._bufs[buf])
-                if self.presort:
-                    self._presort(buf, cat)
+                self._cache_op(cat, buf)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             for v in values:
@@ -337,17 +360,13 @@ class GraphedWindow:
             cur = torch.cuda.current_stream(self.mgr.device)
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side), phase("prefetch cache"):
-                self.mgr.prepare_ids(cat, out=self._bufs[buf])
-                if self.presort:
-                    self._presort(buf, cat)
+                self._cache_op(cat, buf)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             cat.record_stream(self._side)
             self._events[buf] = ev
         else:
-            self.mgr.prepare_ids(cat, out=self._bufs[buf])
-            if self.presort:
-                self._presort(buf, cat)
+            self._cache_op(cat, buf)
             self._events[buf] = None
 
     def run_steps(self, buf: int, first: int, last: int) -> None:

@@ -324,6 +324,17 @@ int ce_cache_set_freq_bound(ce_cache_t* h, int64_t bound);
  * must not alias `ids`. */
 int ce_cache_prepare_ids(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                          ce_stream_t stream);
+/* prepare_ids for a prefetch window of n_batches equal batches (ids = [n_batches, nnz_per_batch]) that also leaves
+ * the window's keys in keys_out (device uint64[n_batches * ce_bag_presort_len(nnz_per_batch)]): what
+ * ce_cache_prepare_ids followed by ce_bag_presort_window (src_keys == 0) or ce_bag_presort_window_src (src_keys != 0;
+ * the offsets / num_bags / include_last_offset / hook_features arguments as there) produce, but the call's last kernel
+ * converts the rows to slots AND writes the keys in ONE pass instead of writing 8 bytes of slot per id for the presort
+ * to read straight back (the reference's `_train` window block, recsys/dlrm_main.py:243-262, plus this build's
+ * window presort).  slots_out is still filled.  Capturable like ce_cache_prepare_ids. */
+int ce_cache_prepare_ids_keys(ce_cache_t* h, const int64_t* ids, int64_t n_batches, int64_t nnz_per_batch,
+                              int64_t* slots_out, int32_t src_keys, const void* offsets, int32_t offsets_are_i64,
+                              int64_t offsets_batch_stride, int64_t num_bags, int32_t include_last_offset,
+                              int64_t hook_features, uint64_t* keys_out, ce_stream_t stream);
 /* The same, for callers whose id lists are PADDED to a fixed capacity (the row-wise exchange's fixed-size buckets):
  * an entry of -1 is padding -- it takes no part in the call and gets slot -1.  Every other id outside the table still
  * fails the call.  Opt-in on purpose: on the plain entry point a -1 sentinel leaking out of a data pipeline must fail

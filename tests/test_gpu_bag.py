@@ -814,7 +814,7 @@ def test_coalesced_sparse_backward_of_two_same_sized_tables_on_two_streams():
     for k in range(2):
         tabs.append(torch.randn(R, D, generator=g).cuda().requires_grad_(True))
         idxs.append((torch.rand(n, generator=g) ** 3 * R).long().clamp_(0, R - 1).cuda())
-        gos.append(torch.randn(n, D, generator=g).cuda())
+        gos.append((torch.randn(n, D, generator=g) * 0.01).cuda())       # (row 0 sums ~2000 of them in fp32)
     torch.cuda.synchronize()
     for rep in range(5):
         for k in range(2):
@@ -827,7 +827,7 @@ def test_coalesced_sparse_backward_of_two_same_sized_tables_on_two_streams():
             gw = tabs[k].grad
             assert gw.is_sparse
             ref = torch.zeros(R, D, device="cuda").index_add_(0, idxs[k], gos[k])
-            torch.testing.assert_close(gw.to_dense(), ref, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(gw.to_dense(), ref, rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("norm_type", [2.0, 1.0, 3.0, float("inf")])

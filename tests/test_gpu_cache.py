@@ -189,6 +189,53 @@ def test_minus_one_is_a_bad_id_unless_the_call_is_padded(strategy):
     _state_equal(mgr, ora, strategy == "lfu")
 
 
+@pytest.mark.parametrize("strategy", ["dataset", "lfu"])
+@pytest.mark.parametrize("src", [True, False])
+def test_prepare_ids_keys_equals_prepare_ids_then_presort(strategy, src):
+    """ce_cache_prepare_ids_keys (the cache op's last kernel writes slots AND window keys) against the two calls it
+    replaces, on two managers fed the same stream: slots and cache state identical, keys identical per 16384-lookup
+    segment up to the order inside a segment (it depends on an atomic race in either form); also a window that overflows
+    (non-strict): slots -1, no live key."""
+    ce = _ce()
+    from cachedembedding_amd.functional import presort_len, presort_window
+    rng = np.random.default_rng(3)
+    N, C, D, P, n, F = 200_000, 60_000, 8, 3, 40_000, 4
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    freq = rng.integers(0, 100, N)
+    a, b = _mk(ce, w, C, strategy, freq, 0.6), _mk(ce, w, C, strategy, freq, 0.6)
+    off = torch.arange(n + 1, dtype=torch.int32, device="cuda")
+    lay = dict(offsets=off, include_last_offset=True, hook_features=F, identity_bags=True) if src else {}
+    klen = presort_len(n)
+    for it in range(5):
+        ids = torch.from_numpy((rng.random((P, n)) ** 6 * N).astype(np.int64)).cuda()       # ~35 k unique rows
+        slots_a = a.prepare_ids(ids.view(-1)).view(P, n)
+        keys_a = presort_window(slots_a.contiguous(), C, **lay)
+        keys_a = torch.stack([k.keys for k in keys_a]) if src else keys_a
+        slots_b = torch.empty(P, n, dtype=torch.int64, device="cuda")
+        keys_b = torch.empty(P, klen, dtype=torch.int64, device="cuda")
+        b.prepare_ids_keys(ids, slots_b, keys_b, **lay)
+        assert torch.equal(slots_a, slots_b)
+        ka = keys_a.view(P, -1, 16384).sort(dim=2).values
+        kb = keys_b.view(P, -1, 16384).sort(dim=2).values
+        assert torch.equal(ka, kb)
+        assert torch.equal(a.cached_idx_map, b.cached_idx_map) and torch.equal(a.inverted_cached_idx, b.inverted_cached_idx)
+        if strategy == "lfu":
+            assert torch.equal(a.freq_cnter, b.freq_cnter)
+    assert a.num_miss_history == b.num_miss_history and a.num_write_back_history == b.num_write_back_history
+    assert sum(b.num_write_back_history) > 0
+    # a window with more unique rows than the cache holds
+    b.strict = False
+    ids = torch.arange(P * n, device="cuda").view(P, n) % N
+    b.prepare_ids_keys(ids, slots_b, keys_b, **lay)
+    torch.cuda.synchronize()
+    assert bool((slots_b == -1).all())
+    hi = (keys_b.view(-1) >> 32) & 0xffffffff
+    assert bool((hi == 0xffffffff).all()), "a failed window must not leave live keys"
+    b.sync_stats()
+    with pytest.raises(AssertionError):
+        b.raise_on_failed_calls()
+
+
 def test_empty_and_duplicate_only_calls():
     ce = _ce()
     mgr = ce.CachedParamMgr(torch.randn(100, 4), 10, evict_strategy=ce.EvictionStrategy.LFU)
