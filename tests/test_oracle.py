@@ -232,3 +232,73 @@ def test_torch_literal_oracle_lfu_known_answer(init_freq):
     for ids in LFU_SCRIPT:
         t.prepare_ids(torch.tensor(ids))
     assert t.num_hits_history[-6:] == [3, 0, 1, 0, 1, 1]
+
+
+def _replay_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("replay_reference", GOLD / "replay_reference.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_parity_pin_kit_skips_cleanly_without_colossalai(capsys):
+    """tests/golden/replay_reference.py: the one command that pins the cache path against the real upstream manager;
+    without an importable ColossalAI (this container, the GPU box) it says so and exits 0."""
+    rr = _replay_module()
+    assert rr.upstream() is None
+    assert rr.lfu_known_answer() is None
+    assert rr.main([]) == 0
+    assert "SKIPPED" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_lfu_freq", "lfu"),
+                                           ("cache_lfu_nofreq", "lfu")])
+def test_parity_pin_kit_comparison_logic(name, strategy):
+    """the replay + diff logic on a manager with upstream's attribute names (the op-sequence-literal torch restatement):
+    identical -> every call exact; victims swapped among LFU ties -> reported as tie order; a wrong victim -> a real
+    difference"""
+    from oracle.cache_oracle_torch import TorchCachedParamMgr
+    rr = _replay_module()
+    z = np.load(GOLD / f"{name}.npz")
+
+    def factory(tamper=None):
+        def make(weight, C, freq, warmup):
+            m = TorchCachedParamMgr(torch.from_numpy(weight.copy()), C, LFU if strategy == "lfu" else DATASET)
+            m.reorder(None if freq is None else torch.from_numpy(freq), warmup)
+            m._calls = 0
+            return m
+
+        def prepare(m, ids):
+            out = m.prepare_ids(torch.from_numpy(ids)).numpy()
+            m._calls += 1
+            if tamper is not None and m._calls == 6:
+                tamper(m)
+            return out
+
+        def touch(m, slots):
+            m.cuda_cached_weight[torch.from_numpy(np.unique(slots))] += 0.5
+
+        return make, prepare, touch
+
+    rep = rr.replay(strategy, z, factory())
+    assert rep["exact"] == rep["calls"] and rep["different"] == 0 and rep["histories_equal"], rep
+
+    def swap_two_slots(m):                       # same resident rows, other slots
+        a, b = (m.cached_idx_map >= 0).nonzero().view(-1)[:2].tolist()
+        ra, rb = int(m.cached_idx_map[a]), int(m.cached_idx_map[b])
+        m.cached_idx_map[a], m.cached_idx_map[b] = rb, ra
+        m.inverted_cached_idx[ra], m.inverted_cached_idx[rb] = b, a
+
+    rep = rr.replay(strategy, z, factory(swap_two_slots))
+    assert rep["exact"] == 5 and rep["slot_pairing_only"] >= 1 and rep["different"] == 0, rep
+
+    def evict_a_wrong_row(m):                    # a resident row replaced by one that is not
+        s = int((m.cached_idx_map >= 0).nonzero().view(-1)[0])
+        old = int(m.cached_idx_map[s])
+        new = int((m.inverted_cached_idx < 0).nonzero().view(-1)[0])
+        m.cached_idx_map[s] = new
+        m.inverted_cached_idx[old], m.inverted_cached_idx[new] = -1, s
+
+    rep = rr.replay(strategy, z, factory(evict_a_wrong_row))
+    assert rep["different"] == 1, rep
