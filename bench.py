@@ -103,6 +103,10 @@ def parse():
                          "build's additions (fused SGD, folded hook, window keys, overlapped cache op, hipGraph, "
                          "worker transport).  What a maintainer gets before opting into anything.")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--verify_sharded", action="store_true",
+                    help="row-wise sharded runs at N > 1: the same end-of-run check per shard (every rank gathers all "
+                         "ranks' ids of every trained step: steps x N x 3.4 MB of HBM per rank).  On by default for "
+                         "--force_sharded at N = 1, where it costs what the unsharded check costs")
     ap.add_argument("--no_verify", action="store_true",
                     help="skip the end-of-run check: after the timed region the cache is flushed and EVERY row the run "
                          "looked up is compared, in the host table, with w0[row] - lr * (sum of the gradient rows of its "
@@ -860,15 +864,18 @@ def run_sharded(args, sizes, rank, world, dev):
         W = (W // P + 1) * P          # whole windows of warm-up: the timed regions start on a window
     windows = []
 
+    keep_ids = not args.no_verify and (world == 1 or args.verify_sharded)      # the end-of-run check reads them again
+
     def need_windows(n_steps, first_step=0):
         while len(windows) * P < n_steps + P:
             windows.append(gen.next_values(P))
-        for w in range(max(0, first_step // P - 2)):
+        for w in range(max(0, first_step // P - 2) if not keep_ids else 0):
             windows[w] = None
 
     need_windows(W + K)
     offsets = gen.offsets
     grad = torch.randn(B, F, D, device=dev) * 1e-3
+    grad -= grad.mean(dim=0, keepdim=True)          # zero mean over the batch: see the unsharded path
 
     from cachedembedding_amd.parallel import GraphedShardedWindow, ShardedWindowPipeline
     if not args.tile_keys:        # every batch has these offsets: the plan stage emits source-row keys
@@ -977,18 +984,26 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
     from cachedembedding_amd.parallel import GraphedShardedWindow
     from cachedembedding_amd.pipeline import pick_transport
     mgr = embed.cache_weight_mgr
-    # capacity of a (batch, owner) bucket: 1.25 x the largest bucket of a few sample windows, same on every rank
-    big = 0
+    # capacity of a (batch, owner) bucket, same on every rank: every place beyond a bucket's rows is padding that
+    # travels in both row all-to-alls of every step, so it is fitted to the distribution of the bucket sizes of a few
+    # sample windows -- the largest seen or mean + 4.5 sigma, whichever is larger (round 3: 1.25 x the largest, 20 %
+    # more bytes on the wire) -- and the rare window with a bucket beyond it takes the variable-size path.
+    sizes_seen = []
     for _ in range(3):
         for p_ in embed.plan_window([v for v in gen.next_values(P)]):
-            big = max(big, max(p_.send_splits))
-    cap_t = torch.tensor([big], dtype=torch.int64, device=dev)
+            sizes_seen.extend(p_.send_splits)
+    st_ = torch.tensor(sizes_seen, dtype=torch.float64)
+    want = max(float(st_.max()), float(st_.mean() + 4.5 * st_.std(unbiased=False)))
+    cap_t = torch.tensor([int(want) + 1], dtype=torch.int64, device=dev)
     allreduce(cap_t, op=dist.ReduceOp.MAX)
-    cap = (int(int(cap_t.item()) * 1.25) + 1023) // 1024 * 1024
+    cap = (int(cap_t.item()) + 255) // 256 * 256
+    bucket_mean = float(st_.mean())
     tr = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or pick_transport("auto", P * world * cap))
     gw = GraphedShardedWindow(embed, P, B * F * L, offsets, lambda out, i: grad, cap, hook_features=F, overlap=args.overlap,
                               transport=tr if args.overlap else None, warmup_ids=[windows[0][i] for i in range(P)])
     state = {"submitted": -1}
+    verify = not args.no_verify and (world == 1 or args.verify_sharded)
+    trained_windows = [0] if verify else None        # GraphedShardedWindow trained its warm-up window once, eagerly
 
     def run_windows(w0, w1):
         for w in range(w0, w1):
@@ -1000,6 +1015,8 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
             else:
                 gw.submit([windows[w][j] for j in range(P)], w % 2)
             gw.run(w % 2)
+            if trained_windows is not None:
+                trained_windows.append(w)
 
     def barrier():
         dist.barrier()
@@ -1058,7 +1075,7 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                    "prefetch_num": P, "prefetch_num_requested": P_req, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})", "host_table_GB_per_gpu": mgr.num_embeddings * D * 4 / 1e9,
                    "sharding": f"row-wise x{world} (row % W); unique rows only; padded equal-split all-to-alls, "
-                               f"capacity {cap} rows per (batch, owner)",
+                               f"capacity {cap} rows per (batch, owner) = {cap / max(bucket_mean, 1.0):.3f} x the mean bucket",
                    "launch": "hipGraph per window" if gw._graphs is not None else
                              "fixed-capacity steps launched one by one (world > 1: CE_SHARDED_GRAPH=1 captures them)",
                    "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
@@ -1069,9 +1086,81 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                   "cache_op_ms_by_phase": {k: v / calls_t for k, v in phases.items() if k != "calls"}},
         "roofline": None, "cpu_baseline": None,
     }
+    if verify:
+        result["verified"] = verify_shard(embed, windows, trained_windows, grad, args, rank, world, dev, P, B, F, L, D, N)
     dist.destroy_process_group()
     if rank == 0:
         emit(result)
+
+
+def verify_shard(embed, windows, trained_windows, grad, args, rank, world, dev, P, B, F, L, D, N):
+    """verify_table for a row-wise shard: rank r holds the rows with (frequency rank) % W == r at local row // W, and
+    every rank's lookups update them -- so every rank gathers the ids (and, once, the upstream gradients) of all
+    ranks for every trained step and checks ITS host shard against the closed form; the counts are summed over the
+    ranks."""
+    from cachedembedding_amd import _lib
+    from oracle.closed_form import SgdLedger
+    t0 = time.time()
+    mgr = embed.cache_weight_mgr
+    torch.cuda.synchronize()
+    embed.flush()
+    torch.cuda.synchronize()
+    n_local = mgr.num_embeddings
+
+    def gather(t):
+        if world == 1:
+            return t.reshape(-1)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        if _host_staged(t):
+            c = [torch.empty_like(t, device="cpu") for _ in range(world)]
+            dist.all_gather(c, t.cpu())
+            outs = [x.to(t.device) for x in c]
+        else:
+            dist.all_gather(outs, t)
+        return torch.cat([o.reshape(-1) for o in outs])
+
+    gflat = grad.transpose(0, 1).reshape(F * B, D).contiguous()
+    if L > 1:
+        gflat = gflat.repeat_interleave(L, dim=0)
+    g_all = gather(gflat).view(-1, D)                      # the lookups of rank 0, rank 1, ... of a step, in that order
+    idx_map = embed.idx_map
+    ledger = SgdLedger(n_local, D, args.lr, None)
+    for w in trained_windows:
+        for i in range(P):
+            ids = gather(windows[w][i].contiguous())
+            rows = ids if idx_map is None else idx_map[ids].long()
+            ledger.record(torch.where(rows % world == rank, rows // world, torch.full_like(rows, -1)), g_all)
+    lo, hi = -1.0 / N, 1.0 / N                             # RowwiseShardedEmbeddingBag's initialisation, seed per rank
+    seed = args.seed + 7919 * rank
+    table_dev = mgr._table.dev_ptr
+
+    def initial_rows(rows):
+        out = torch.empty(rows.numel(), D, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.ce_host_fill_uniform_rows(rows.data_ptr(), rows.numel(), D, lo, hi, seed, out.data_ptr(),
+                                                      _lib.stream_ptr()))
+        return out
+
+    def current_rows(rows):
+        out = torch.empty(rows.numel(), D, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.ce_host_rows_gather(table_dev, n_local, D, rows.data_ptr(), rows.numel(), out.data_ptr(),
+                                                _lib.stream_ptr()))
+        return out
+
+    res = ledger.check(initial_rows, current_rows, hot_rows=256 if world == 1 else 0)
+    tot = torch.tensor([res["bound_violations"], res.get("untouched_mismatch", 0), res["rows"]], dtype=torch.int64, device=dev)
+    allreduce(tot)
+    res["all_ranks"] = {"bound_violations": int(tot[0]), "untouched_mismatch": int(tot[1]), "rows": int(tot[2])}
+    res["pass"] = int(tot[0]) == 0 and int(tot[1]) == 0
+    res["seconds"] = time.time() - t0
+    res["what"] = ("rank 0's shard (counts over all ranks in all_ranks): cache flushed; every local row any rank's trained "
+                   "step looked up vs w0 - lr * (fp64 sum of its lookups' gradient rows over ALL ranks); untouched rows "
+                   "(sample) bit-equal to w0")
+    if rank == 0:
+        print(f"[bench] verified shard of rank 0: {res['rows']} rows / {res['lookups']} lookups / {res['steps']} steps in "
+              f"{res['seconds']:.1f}s; all ranks: {res['all_ranks']}", file=sys.stderr, flush=True)
+        if not res["pass"]:
+            print("[bench] VERIFICATION FAILED: a host shard is not what SGD should have produced", file=sys.stderr, flush=True)
+    return res
 
 
 def cpu_baseline(embed, gen, args, B, F, L, D):

@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void k_dedupe_mark_w(const int64_t* __restrict
 
 template <int IT>
 __global__ __launch_bounds__(256) void k_dedupe_claim_w(const int32_t* __restrict__ rows32, int64_t n,
-                                                        int32_t world, const int32_t* __restrict__ stamp,
-                                                        int32_t* __restrict__ slot_of_row,
+                                                        int32_t world, const int32_t* stamp,
+                                                        int32_t* slot_of_row,      // (may alias stamp: no __restrict__)
                                                         int32_t* __restrict__ bucket_rows,
                                                         unsigned long long* counts, int64_t num_rows,
                                                         int64_t scratch_stride) {
@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256) void k_dedupe_claim_w(const int32_t* __restric
         unsigned long long p = blk_base[own[t]] + rank[t];
         for (int k = 0; k < wv; ++k) p += wave_cnt[k][own[t]];
         bucket_rows[(int64_t)own[t] * n + p] = row[t] / world;
-        slot_of_row[row[t]] = (int32_t)p;
+        // the place is stored as -1 - p: `slot_of_row` may BE the stamp array (one int32 per row instead of two), and a
+        // negative entry can never pass another lookup's claim test `stamp[row] == lookup index`
+        slot_of_row[row[t]] = -1 - (int32_t)p;
       }
     }
     __syncthreads();
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void k_dedupe_finish_w(const int32_t* __restri
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t row = rows32[i];
-    pos_out[i] = row >= 0 ? pre[row % world] + slot_of_row[row] : -1;
+    pos_out[i] = row >= 0 ? pre[row % world] + (-1 - slot_of_row[row]) : -1;
     if (i < n_u) {                       // owner-major compaction of the bucket lists
       int o = 0;
       while (o + 1 < world && pre[o + 1] <= i) ++o;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void k_dedupe_finish_pad(const int32_t* __rest
     const int32_t row = rows32[i];
     int64_t p = -1;
     if (row >= 0) {
-      const int32_t place = slot_of_row[row];
+      const int32_t place = -1 - slot_of_row[row];
       if (place < cap) p = (int64_t)(row % world) * cap + place;
     }
     pos_out[i] = p;
@@ -484,7 +486,8 @@ static int dedupe_bucket_impl(const int64_t* ids, int64_t n, const int32_t* idx_
   CE_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX && num_rows > 0 && num_rows < (int64_t)INT32_MAX, CE_ERR_INVALID,
              "bad sizes");
   CE_REQUIRE(world >= 1 && world <= 64, CE_ERR_UNSUPPORTED, "world size must be in [1, 64]");
-  CE_REQUIRE(stamp && slot_of_row && counts_out, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(stamp && counts_out, CE_ERR_INVALID, "null pointer");
+  if (!slot_of_row) slot_of_row = stamp;      // one scratch array: the claim pass reuses the entry it has just tested
   hipStream_t s = (hipStream_t)stream;
   CE_HIP_CHECK(hipMemsetAsync(counts_out, 0, sizeof(int64_t) * world * n_batches, s));
   if (n == 0 && cap <= 0) return CE_OK;

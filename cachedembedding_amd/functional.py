@@ -142,12 +142,12 @@ class _BagFn(torch.autograd.Function):
             # and a segmented sum over nnz x D floats, most of an unchanged trainer's step) has nothing left to do.
             # One host read (the number of unique rows), as coalesce() has too -- which is why a backward that is being
             # captured into a hipGraph takes the one-row-per-lookup form below instead.
-            # The dedupe scratch (two int32[rows] + int32[2 nnz]; nothing in it needs initialising) comes from the
+            # The dedupe scratch (int32[rows] + int32[2 nnz]; nothing in it needs initialising) comes from the
             # caching allocator per call, so its lifetime is ordered on the stream this backward runs on: two
             # same-sized tables running their backwards on two streams do not share it.
             dev = weight.device
             R = weight.shape[0]
-            ws = (torch.empty(R, dtype=torch.int32, device=dev), torch.empty(R, dtype=torch.int32, device=dev),
+            ws = (torch.empty(R, dtype=torch.int32, device=dev), None,
                   torch.empty(max(2 * nnz, 1 << 16), dtype=torch.int32, device=dev))
             urows = torch.empty(nnz, dtype=torch.int64, device=dev)
             pos = torch.empty(nnz, dtype=torch.int64, device=dev)

@@ -32,7 +32,7 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 from .cache_mgr import CachedParamMgr, EvictionStrategy, HostTable
 from .cached_embedding import CachedEmbeddingBag
-from .functional import _MODES, SrcKeys
+from .functional import _MODES, FORWARD_FROM_KEYS, SrcKeys
 
 
 def get_partition(embedding_dim: int, rank: int, world_size: int) -> Tuple[int, int, bool]:
@@ -254,8 +254,7 @@ class HipShardOps(ShardOps):
         if W > 64:
             raise NotImplementedError("row-wise sharding over more than 64 ranks")
         if self._stamp is None:             # scratch of the dedupe passes; contents carry nothing across calls
-            self._stamp = torch.empty(N, dtype=torch.int32, device=dev)
-            self._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
+            self._stamp = torch.empty(N, dtype=torch.int32, device=dev)      # (also holds the rows' places: one array)
         P = len(ids_list)
         counts = torch.empty(P, W, dtype=torch.int64, device=dev)
         n_max = max(int(ids.numel()) for ids in ids_list)
@@ -324,6 +323,16 @@ class HipShardOps(ShardOps):
         check(lib.ce_bag_forward(ptr(rows), rows.shape[0], self.dim, ptr(perm), perm.numel(), ptr(offsets),
                                  int(offsets.dtype == torch.int64), num_bags, int(include_last), ptr(psw),
                                  _MODES[mode], hook_features, ptr(out), stream_ptr()))
+        return out
+
+    def pool_from_keys(self, table, keys: "SrcKeys", nnz: int):
+        """pooled output of a one-id-per-bag batch straight from its source-row keys over `table` (cache + exchange
+        buffer): a row is loaded once per run of equal rows (ce_bag_forward_src_keys)"""
+        hf, nb = int(keys.hook_features), int(keys.num_bags)
+        shape = (nb // hf, hf, self.dim) if hf else (nb, self.dim)
+        out = torch.empty(shape, dtype=torch.float32, device=table.device)
+        check(lib.ce_bag_forward_src_keys(ptr(table), table.shape[0], self.dim, int(nnz), ptr(keys.keys), ptr(out),
+                                          stream_ptr()))
         return out
 
     def grad_rows(self, grad_out, pos, offsets, psw, mode, include_last, hook_features, n_u, keys=None):
@@ -739,19 +748,21 @@ class GraphedShardedWindow:
             if transport:
                 self.mgr.set_transport(transport)
         # scratch of the dedupe passes: one stamp / place array per batch of the window, so that the P batches are
-        # deduped by ONE launch per pass (P * N * 8 bytes: 11 GB for the Criteo-1TB table at P = 8; set
-        # CE_DEDUPE_PER_BATCH=1 to dedupe batch by batch with one pair of arrays instead)
+        # deduped by ONE launch per pass (P * N * 4 bytes: 5.7 GB for the Criteo-1TB table at P = 8 -- 0.7 GB per batch
+        # of the window, 2 % of a GPU's HBM; CE_DEDUPE_PER_BATCH=1 dedupes batch by batch with one array instead, at
+        # 3 launches per batch)
         N = embed.num_embeddings
         self._window_dedupe = P > 1 and not int(os.environ.get("CE_DEDUPE_PER_BATCH", "0"))
         if self._window_dedupe:
+            # ONE int32 per (batch, row): the claim pass leaves a row's place in its bucket in the stamp entry it has
+            # just checked (as -1 - place: never a lookup index), so there is no second array
             self._stamp = torch.empty(P * N, dtype=torch.int32, device=dev)
-            self._slot_of_row = torch.empty(P * N, dtype=torch.int32, device=dev)
+            self._slot_of_row = None
             self._ids_win = torch.empty(P, n, **i64)
         else:
             if self.ops._stamp is None:
                 self.ops._stamp = torch.empty(N, dtype=torch.int32, device=dev)
-                self.ops._slot_of_row = torch.empty(N, dtype=torch.int32, device=dev)
-            self._stamp, self._slot_of_row = self.ops._stamp, self.ops._slot_of_row
+            self._stamp, self._slot_of_row = self.ops._stamp, None
         self._ws = torch.empty(max(P * (W + 1) * n, 1 << 16), dtype=torch.int32, device=dev)
         if embed.mode != "sum":
             raise NotImplementedError("GraphedShardedWindow: mode='sum' only (the fused fold + update)")
@@ -881,9 +892,12 @@ class GraphedShardedWindow:
         if W > 1:
             rows = ops.owner_gather(self._slots_remote[buf][i])             # [W * cap, D]; padding / own chunk: zeros
             _a2a(self._tail, rows, None, None, ex.group)
-        out = ops.pool(self._table, idx, self.offsets, None, "sum", self.incl, self.hook)
+        keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
+        if self._identity and FORWARD_FROM_KEYS and hasattr(ops, "pool_from_keys"):
+            out = ops.pool_from_keys(self._table, keys, self.n)     # one id per bag: the forward runs from the keys too
+        else:
+            out = ops.pool(self._table, idx, self.offsets, None, "sum", self.incl, self.hook)
         grad = self.dense_fn(out, i)
-        keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook)
         if W > 1:
             self._tail.zero_()
         ops.update_table(self._table, grad, keys, self.n, lr)               # own rows: SGD in place; tail: -lr * sum g

@@ -430,7 +430,9 @@ int ce_bucketize_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int
  * (row / world) in local_rows_out[0 .. sum(counts)), pos_out[j] = position of lookup j's row in that list
  * (-1 for an id outside [0, num_rows)), counts_out[w] = unique rows owned by w (device int64[world]).
  * stamp, slot_of_row: device int32[num_rows] scratch owned by the caller (no initialisation needed, contents
- * are meaningless between calls); scratch: device int32[(world + 1) * n].  world <= 64.
+ * are meaningless between calls); slot_of_row may be NULL: the stamp array then serves both purposes (4 bytes of
+ * scratch per table row instead of 8 -- per batch of a window in the _window form); scratch: device
+ * int32[(world + 1) * n].  world <= 64.
  * No host sync: the bucket sizes stay on the device (the caller all-to-alls them as a fixed-size message). */
 int ce_dedupe_bucket_rows(const int64_t* ids, int64_t n, const int32_t* idx_map, int64_t num_rows,
                           int32_t world, int32_t* stamp, int32_t* slot_of_row, int32_t* scratch,

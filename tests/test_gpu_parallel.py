@@ -113,7 +113,8 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
     torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
 
 
-def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=(5003, 64, 4, 32, 3, 1000)):
+def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=(5003, 64, 4, 32, 3, 1000),
+                     force_graph=False):
     """parallel.GraphedShardedWindow (fixed-capacity exchange, the window's steps replayed as one hipGraph at world 1,
     launched one by one over gloo) against plain torch on the full table: pooled output of every step, table after
     flush.  capacity below the bucket sizes forces every window through the variable-size fallback."""
@@ -162,8 +163,12 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
     ref_w = w_full.clone()
     # window 0 doubles as the warm-up (it trains once eagerly inside the constructor): account for it
     gw = GraphedShardedWindow(emb, P, F * B_loc, offsets, dense_fn, capacity=capacity, hook_features=F,
-                              overlap=overlap, warmup_ids=[i.cuda() for i in all_ids[0]]) if capacity >= 64 else \
+                              overlap=overlap, warmup_ids=[i.cuda() for i in all_ids[0]],
+                              use_graph=True if force_graph else None) if capacity >= 64 else \
         GraphedShardedWindow(emb, P, F * B_loc, offsets, dense_fn, capacity=capacity, hook_features=F, overlap=overlap)
+    if force_graph and rank == 0:
+        print("window steps with RCCL all-to-alls inside:", "captured as hipGraphs" if gw._graphs is not None
+              else "capture refused -> launched one by one", flush=True)
 
     def reference_window(ids_list):
         exp = []
@@ -321,7 +326,9 @@ def test_dedupe_bucket_rows_properties(it, monkeypatch):
         stamp = torch.randint(0, 2**31 - 1, (N,), dtype=torch.int32, device="cuda")   # garbage is fine
         slot = torch.empty(N, dtype=torch.int32, device="cuda")
         scratch = torch.empty((W + 1) * n, dtype=torch.int32, device="cuda")
-        for _rep in (1, 2):      # second call reuses the scratch arrays
+        for _rep in (1, 2, 3):   # second call reuses the scratch arrays; third: ONE scratch array (slot_of_row = NULL)
+            if _rep == 3:
+                slot = None
             rows = torch.full((n,), -7, dtype=torch.int64, device="cuda")
             pos = torch.empty(n, dtype=torch.int64, device="cuda")
             counts = torch.empty(W, dtype=torch.int64, device="cuda")
@@ -367,7 +374,9 @@ def test_dedupe_bucket_rows_padded_window_properties(P):
         pos = torch.full((P, n), -7, dtype=torch.int64, device="cuda")
         counts = torch.full((P, W), -7, dtype=torch.int64, device="cuda")
         ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
-        for _rep in (1, 2):
+        for _rep in (1, 2, 3):   # third: ONE scratch array per batch (slot_of_row = NULL), what the pipelines pass
+            if _rep == 3:
+                slot = None
             ovf.zero_()
             if P == 1:
                 check(lib.ce_dedupe_bucket_rows_padded(ptr(ids), n, ptr(idx_map), N, W, cap, ptr(stamp), ptr(slot),
@@ -484,6 +493,18 @@ def test_rowwise_sharded_over_rccl(overlap):
     world = min(torch.cuda.device_count(), 4)
     _spawn(_rowwise, world, "dataset", True, overlap, backend="nccl")
     _spawn(_rowwise, 2, "lfu", False, overlap, backend="nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+def test_rowwise_graphed_window_captures_rccl_collectives_or_falls_back():
+    """GraphedShardedWindow(use_graph=True) at world 2 over RCCL: a window's steps hold two all_to_all_single calls
+    each; whether this stack can capture them into a hipGraph has never been run here.  Either outcome must train
+    identically to plain torch on the full table: the captured graphs, or -- if the capture is refused -- the clean
+    fallback to launching the same fixed-capacity steps one by one (a warning, no half-captured state)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _spawn(_rowwise_graphed, 2, "dataset", True, 256, True, (5003, 64, 4, 32, 3, 1000), True, backend="nccl")
 
 
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--use_lfu"])])
