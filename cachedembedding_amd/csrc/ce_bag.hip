@@ -51,7 +51,22 @@ struct BagParams {
   int32_t tile_len;         // lookups per workgroup tile of the sorted scatter
   const unsigned long long* presorted;   // optional: segment-grouped keys from ce_bag_presort* (no sort in the kernel)
   int32_t policy;           // bit 0: fwd output stores non-temporal; bit 1: bwd gradient-row loads non-temporal
+  int32_t interleave;       // key-walking kernels: lane group j of workgroup b takes share j * gridDim + b (see share_of)
 };
+
+// Which contiguous share of the key array a lane group walks.  The keys lie segment by segment, i.e. FEATURE by
+// feature, and shares differ a lot in cost: a share of a small table's feature is one long run (gathers only, one
+// row update / one row load), a share of a 45 M-row table's feature is mostly runs of one (an update / a load per
+// key).  Consecutive shares per workgroup put eight alike shares into one workgroup, and with every workgroup resident
+// at once the launch lasts as long as its slowest workgroup.  Interleaved, the groups of a workgroup take shares one
+// eighth of the array apart: every workgroup gets a sample of the whole batch.  Streaming backward at the bench shape,
+// back to back: 61.4 -> 53.5 us (means of four runs; 0.53 -> 0.62 of the HBM peak), 79 -> 75 us beside the cache op.
+// (Keeping the two lane groups of a WAVE on adjacent shares and spreading only the waves: 61 us again -- it is the
+// spreading itself that pays, not less divergence.  The key-driven forward does not gain: its cost per share is its
+// stores, the same for every share.)
+__device__ __forceinline__ int64_t share_of(const BagParams& p, int grp, int ngroups) {
+  return p.interleave ? (int64_t)grp * gridDim.x + blockIdx.x : (int64_t)blockIdx.x * ngroups + grp;
+}
 
 // cache policies of the two big streams (CE_FWD_NT / CE_BWD_NT, default on): see DESIGN.md section 4
 static int bag_policy() {
@@ -866,7 +881,7 @@ __global__ __launch_bounds__(256) void k_bag_bwd_stream(BagParams p, int64_t tot
   const int64_t all_groups = (int64_t)gridDim.x * ngroups;
   const int64_t round = R > 16 ? R : 16;        // shares are whole 16-position blocks (see EXCL)
   const int64_t share = ((total + all_groups - 1) / all_groups + round - 1) / round * round;
-  const int64_t s0 = ((int64_t)blockIdx.x * ngroups + grp) * share;
+  const int64_t s0 = share_of(p, grp, ngroups) * share;
   const int64_t s1 = min(total, s0 + share);
   if (s0 >= s1) return;
   const float alpha = p.alpha;
@@ -971,7 +986,7 @@ __global__ __launch_bounds__(256, 4) void k_bag_fwd_keys(BagParams p, int64_t to
   const int64_t all_groups = (int64_t)gridDim.x * ngroups;
   const int64_t round = R > 16 ? R : 16;
   const int64_t share = ((total + all_groups - 1) / all_groups + round - 1) / round * round;
-  const int64_t s0 = ((int64_t)blockIdx.x * ngroups + grp) * share;
+  const int64_t s0 = share_of(p, grp, ngroups) * share;
   const int64_t s1 = min(total, s0 + share);
   if (s0 >= s1) return;
   const int kc = 4 * G > R ? 4 * G : R;
@@ -1329,6 +1344,8 @@ static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t 
   p.num_rows = (uint32_t)num_rows;
   p.presorted = keys;
   { const char* dbg = getenv("CE_BWD_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
+  static const int il_env = [] { const char* e = getenv("CE_BWD_INTERLEAVE"); return e ? atoi(e) : 1; }();
+  p.interleave = il_env;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
   static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
   static const int excl_env = [] { const char* e = getenv("CE_BWD_EXCL"); return e ? atoi(e) : 1; }();
@@ -1392,6 +1409,8 @@ extern "C" int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, in
   p.dst = out;
   p.num_rows = (uint32_t)num_rows;
   p.presorted = (const unsigned long long*)src_keys;
+  static const int il_env = [] { const char* e = getenv("CE_FWDK_INTERLEAVE"); return e ? atoi(e) : 0; }();
+  p.interleave = il_env;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
   // 8 workgroups per CU (measured at the bench shape, three runs each: 4/CU 2.59-2.82 G lookups/s and 72-74 us per
   // launch beside the cache op, 8/CU 2.79-2.97 G and 64-66 us; the slot-driven forward 2.56-2.76 G and 72-76 us)
