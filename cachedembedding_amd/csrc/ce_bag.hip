@@ -62,7 +62,8 @@ struct BagParams {
 // eighth of the array apart: every workgroup gets a sample of the whole batch.  Streaming backward at the bench shape,
 // back to back: 61.4 -> 53.5 us (means of four runs; 0.53 -> 0.62 of the HBM peak), 79 -> 75 us beside the cache op.
 // (Keeping the two lane groups of a WAVE on adjacent shares and spreading only the waves: 61 us again -- it is the
-// spreading itself that pays, not less divergence.  The key-driven forward does not gain: its cost per share is its
+// spreading itself that pays, not less divergence; a pseudo-random bijection of shares to lane groups: the same
+// 52-57 us as this.  The key-driven forward does not gain: its cost per share is its
 // stores, the same for every share.)
 __device__ __forceinline__ int64_t share_of(const BagParams& p, int grp, int ngroups) {
   return p.interleave ? (int64_t)grp * gridDim.x + blockIdx.x : (int64_t)blockIdx.x * ngroups + grp;
