@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--no_overlap", action="store_true",
                     help="reference semantics: the window's cache op runs on the compute stream (default: the cache op "
                          "of window k+1 runs on a side HIP stream while window k trains, protect_depth=1)")
+    ap.add_argument("--interleaved", action="store_true",
+                    help="no side stream: the cache op of window k+1 is issued on the training stream in two halves "
+                         "around the steps of window k (GraphedWindow(interleaved=True)); its kernels then never run "
+                         "beside the bag kernels, the PCIe admission still overlaps with training")
     ap.add_argument("--cache_cus", type=int, default=0, help="CUs reserved for the side-stream cache op (0 = share all)")
     ap.add_argument("--no_presort", action="store_true", help="sort 1024-lookup tiles inside every backward launch "
                     "instead of grouping the window's slots by row once per window on the cache-op stream "
@@ -122,6 +126,8 @@ def main():
     if args.unchanged_trainer:
         args.no_overlap = args.no_presort = args.no_graph = True
         args.transport = args.transport or "zerocopy"
+    if args.interleaved:
+        args.no_overlap = True          # (one stream; the window logic below still runs one window ahead)
     args.overlap = not args.no_overlap
     if args.plan_ahead == 0:
         args.plan_ahead = 2 if (args.prefetch_num == 1 and args.overlap and not args.graph_cache_op) else 1
@@ -171,7 +177,7 @@ def main():
     del freq
     from cachedembedding_amd.pipeline import pick_transport
     transport = args.transport or ("staged" if args.async_copy else
-                                   (pick_transport("auto", P * B * F * L) if args.overlap else "zerocopy"))
+                                   (pick_transport("auto", P * B * F * L) if (args.overlap or args.interleaved) else "zerocopy"))
     embed.cache_weight_mgr.set_transport(transport)
     transport = embed.cache_weight_mgr.transport_name          # (falls back to zerocopy where the worker one cannot run)
     ref_opt = None
@@ -254,7 +260,7 @@ def main():
                            warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort,
                            transport=None, bag_layout=layout,
                            graph_cache_op=args.graph_cache_op and args.overlap,
-                           plan_ahead=args.plan_ahead if args.overlap else 1)
+                           plan_ahead=args.plan_ahead if args.overlap else 1, interleaved=args.interleaved)
         trained(0, 0, P)          # GraphedWindow ran the window it was given once, eagerly, before capturing
         note("hipGraph of the window's training steps captured" +
              (" (+ the cache op as a graph of its own)" if gw._plan_graphs is not None else ""))
@@ -281,7 +287,7 @@ def main():
             elif use_graph:
                 nb, ahead = gw.nbuf, gw.plan_ahead
                 if i == 0 and not (skip_cache_op and g0 >= W):
-                    if args.overlap:
+                    if args.overlap or args.interleaved:
                         for w2 in range(max(state["submitted"] + 1, w), w + ahead + 1):
                             gw.submit([windows[w2][j] for j in range(P)], w2 % nb)
                             state["submitted"] = w2
@@ -454,6 +460,8 @@ def main():
     # Pass B (only when overlapping): the same launches while the side stream runs the next window's cache op ->
     #         `avg_ms_in_pipeline`; event-bracketed, so it includes the time a kernel waits for CUs held by the
     #         other stream (rocprofv3 of the default command shows 126 / 75 us of pure execution there).
+    if gw is not None:
+        gw.drain()
     ev_first = ((g + P - 1) // P + 1) * P          # fresh windows after the timed blocks
     need_windows(ev_first + 8 * P)
 
@@ -663,7 +671,7 @@ def main():
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})" + (f" + {args.uniform_frac:g} uniform" if args.uniform_frac else ""),
                    "distinct_rows_per_batch_frac": uniq_avg / (B * F * L), "host_table_GB": N * D * 4 / 1e9,
-                   "transport": transport, "overlap": bool(args.overlap),
+                   "transport": transport, "overlap": bool(args.overlap), "interleaved": bool(args.interleaved),
                    "plan_ahead_windows": (gw.plan_ahead if gw is not None else 1) if args.overlap else 0,
                    "launch": "hipGraph per window" if use_graph else "python per step",
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "

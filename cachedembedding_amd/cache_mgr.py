@@ -288,9 +288,25 @@ class CachedParamMgr(torch.nn.Module):
             check(rc)
 
     @torch.no_grad()
-    def prepare_ids_keys(self, ids: torch.Tensor, out: torch.Tensor, keys_out: torch.Tensor, *,
+    def prepare_ids_begin(self, ids: torch.Tensor, out: torch.Tensor, keys_out: Optional[torch.Tensor] = None, **layout):
+        """First half of prepare_ids_keys(ids, out, keys_out, **layout) (or, keys_out=None, of prepare_ids over the
+        [P, n] window): everything up to the staging of the victims; prepare_ids_finish() enqueues the rest on the
+        same stream.  See ce_cache_prepare_ids_begin in include/ce_api.h for why a pipeline would split the call."""
+        return self.prepare_ids_keys(ids, out, keys_out, _begin_only=True, **layout)
+
+    @torch.no_grad()
+    def prepare_ids_finish(self) -> None:
+        if torch.cuda.current_device() == self.device.index:
+            check(lib.ce_cache_prepare_ids_finish(self._handle, stream_ptr()))
+        else:
+            with torch.cuda.device(self.device):
+                check(lib.ce_cache_prepare_ids_finish(self._handle, stream_ptr()))
+        self._strict_check()
+
+    @torch.no_grad()
+    def prepare_ids_keys(self, ids: torch.Tensor, out: torch.Tensor, keys_out: Optional[torch.Tensor], *,
                          offsets: Optional[torch.Tensor] = None, include_last_offset: bool = False,
-                         hook_features: int = 0, identity_bags: bool = False) -> torch.Tensor:
+                         hook_features: int = 0, identity_bags: bool = False, _begin_only: bool = False) -> torch.Tensor:
         """prepare_ids for a prefetch window of P equal batches (ids [P, n] int64) that also leaves the window's keys in
         keys_out ([P, presort_len(n)] int64) -- functional.presort_window's keys, written by the cache op's last kernel
         together with the slots instead of by a launch of its own (ce_cache_prepare_ids_keys).  offsets given: source-row
@@ -300,8 +316,9 @@ class CachedParamMgr(torch.nn.Module):
         P, n = ids.shape
         assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == P * n
         klen = int(lib.ce_bag_presort_len(n))
-        assert keys_out.is_cuda and keys_out.dtype == torch.int64 and keys_out.is_contiguous() and \
-            keys_out.numel() == P * klen
+        assert keys_out is not None or _begin_only
+        assert keys_out is None or (keys_out.is_cuda and keys_out.dtype == torch.int64 and keys_out.is_contiguous()
+                                    and keys_out.numel() == P * klen)
         src, off_ptr, off64, stride, num_bags = 0, 0, 0, 0, n
         if offsets is not None:
             assert offsets.is_cuda and offsets.dtype in (torch.int32, torch.int64) and offsets.is_contiguous()
@@ -316,12 +333,14 @@ class CachedParamMgr(torch.nn.Module):
             off64, stride = int(offsets.dtype == torch.int64), (per if offsets.dim() == 2 else 0)
         args = (self._handle, ptr(ids), P, n, ptr(out), src, off_ptr, off64, stride, num_bags, int(include_last_offset),
                 int(hook_features), ptr(keys_out))
+        fn = lib.ce_cache_prepare_ids_begin if _begin_only else lib.ce_cache_prepare_ids_keys
         if torch.cuda.current_device() == self.device.index:
-            check(lib.ce_cache_prepare_ids_keys(*args, stream_ptr()))
+            check(fn(*args, stream_ptr()))
         else:
             with torch.cuda.device(self.device):
-                check(lib.ce_cache_prepare_ids_keys(*args, stream_ptr()))
-        self._strict_check()
+                check(fn(*args, stream_ptr()))
+        if not _begin_only:
+            self._strict_check()
         return out
 
     def graph_replayed(self, n_calls: int, ids_per_call: int) -> None:

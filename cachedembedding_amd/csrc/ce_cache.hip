@@ -1970,6 +1970,27 @@ struct ce_cache {
   // call's victims: no free-list scan, see free_list_from_victims); the device re-checks the premise (k_emit).
   bool free_zero;
   long long free_reset_seq;    // records up to this call number say nothing about the present
+  // a prepare_ids call issued in two halves (ce_cache_prepare_ids_begin / _finish): what the second half needs
+  struct Pending {
+    bool active = false;
+    int64_t n = 0;
+    int64_t* slots_out = nullptr;
+    hipStream_t s = nullptr;
+    bool worker = false, capturing = false, has_tail = false;
+    long long in_job = 0, seq_arg = 0;
+    int cap_groups = 1, swap_threads = 256, pslot = 0, pmark = 0;
+    const void* prof = nullptr;      // the phase timers the first half recorded into (they may be switched off / on in between)
+    struct {
+      int64_t n_batches, nnz_per_batch;
+      int32_t src_keys;
+      const void* offsets;
+      int32_t offsets_are_i64;
+      int64_t offsets_batch_stride, num_bags;
+      int32_t include_last_offset;
+      int64_t hook_features;
+      uint64_t* keys_out;
+    } tail;
+  } pend;
 };
 
 using namespace ce;
@@ -2350,6 +2371,7 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
                                 ce_stream_t stream) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
   CE_REQUIRE(n >= 0 && n <= h->cfg.cuda_row_num, CE_ERR_INVALID, "preload count out of range");
+  CE_REQUIRE(!h->pend.active, CE_ERR_INVALID, "a cache op begun with ce_cache_prepare_ids_begin has not been finished");
   if (n == 0) return CE_OK;
   if (freq_vals) h->freq_bound_known = false;      // until ce_cache_set_freq_bound states their maximum
   int rc = before_call(h);
@@ -2485,9 +2507,15 @@ struct KeysTail {
   uint64_t* keys_out;
 };
 
+static int prepare_ids_second_half(ce_cache* h);
+
+// split != 0: only the first half is enqueued -- everything up to and including the staging of the victims and the
+// free-slot list, i.e. all that needs nothing from the host table; ce_cache_prepare_ids_finish enqueues the rest (wait
+// for the admitted rows, unpack, maps, slots / keys).  See ce_api.h.
 static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out, ce_stream_t stream,
-                            int allow_pad, const KeysTail* tail = nullptr) {
+                            int allow_pad, const KeysTail* tail = nullptr, int split = 0) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  CE_REQUIRE(!h->pend.active, CE_ERR_INVALID, "a cache op begun with ce_cache_prepare_ids_begin has not been finished");
   CE_REQUIRE(n >= 0 && n <= std::max<int64_t>(h->cfg.max_ids_per_call, 0), CE_ERR_INVALID,
              "n=%lld exceeds max_ids_per_call=%lld", (long long)n, (long long)h->cfg.max_ids_per_call);
   CE_REQUIRE(n == 0 || (ids && slots_out), CE_ERR_INVALID, "null ids/slots");
@@ -2708,6 +2736,45 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
                        h->blk_free, h->free_list, h->ctl);
   }
   CE_PHASE();
+#undef CE_PHASE
+  // ---- second half: from here on the call needs the missed rows
+  ce_cache::Pending& x = h->pend;
+  x.n = n; x.slots_out = slots_out; x.s = s; x.worker = worker; x.capturing = capturing; x.has_tail = tail != nullptr;
+  x.in_job = in_job; x.seq_arg = seq_arg; x.cap_groups = cap_groups; x.swap_threads = swap_threads; x.pslot = pslot;
+  x.pmark = pmark;
+  x.prof = prof;
+  if (tail)
+    x.tail = {tail->n_batches, tail->nnz_per_batch, tail->src_keys, tail->offsets, tail->offsets_are_i64,
+              tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset, tail->hook_features, tail->keys_out};
+  if (split) {
+    CE_REQUIRE(!capturing, CE_ERR_UNSUPPORTED, "a cache op in two halves cannot be captured in a hipGraph");
+    x.active = true;
+    CE_LAUNCH_CHECK();
+    return CE_OK;
+  }
+  return prepare_ids_second_half(h);
+}
+
+static int prepare_ids_second_half(ce_cache* h) {
+  ce_cache::Pending& x = h->pend;
+  x.active = false;
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  const int64_t C = c.cuda_row_num, n = x.n;
+  int64_t* const slots_out = x.slots_out;
+  hipStream_t s = x.s;
+  const ce_stream_t stream = (ce_stream_t)s;
+  const bool worker = x.worker, capturing = x.capturing;
+  const long long in_job = x.in_job, seq_arg = x.seq_arg;
+  const int cap_groups = x.cap_groups, gpb = 256 >> h->g_log2, lfu = c.evict_strategy == CE_EVICT_LFU;
+  const dim3 swap_block(x.swap_threads);
+  ce_call_stats_t* const ring = h->ring_dev;
+  PhaseProf* const prof = (h->prof && (const void*)h->prof == x.prof) ? h->prof : nullptr;
+  const int pslot = x.pslot;
+  int pmark = x.pmark;
+  const decltype(x.tail)* const tail = x.has_tail ? &x.tail : nullptr;
+  int rc = CE_OK;
+#define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   if (worker) {
     // the missed rows arrive in in_stage through the admission worker's hipMemcpyAsync pieces; this stream parks in
     // the command processor until the worker's hipStreamWriteValue64 behind the last piece has executed
@@ -2842,6 +2909,25 @@ extern "C" int ce_cache_prepare_ids_keys(ce_cache_t* h, const int64_t* ids, int6
   return prepare_ids_impl(h, ids, n_batches * nnz_per_batch, slots_out, stream, 0, &t);
 }
 
+extern "C" int ce_cache_prepare_ids_begin(ce_cache_t* h, const int64_t* ids, int64_t n_batches, int64_t nnz_per_batch,
+                                          int64_t* slots_out, int32_t src_keys, const void* offsets,
+                                          int32_t offsets_are_i64, int64_t offsets_batch_stride, int64_t num_bags,
+                                          int32_t include_last_offset, int64_t hook_features, uint64_t* keys_out,
+                                          ce_stream_t stream) {
+  CE_REQUIRE(n_batches > 0 && nnz_per_batch > 0, CE_ERR_INVALID, "bad window shape");
+  if (!keys_out) return prepare_ids_impl(h, ids, n_batches * nnz_per_batch, slots_out, stream, 0, nullptr, 1);
+  KeysTail t{n_batches, nnz_per_batch, src_keys, offsets, offsets_are_i64, offsets_batch_stride, num_bags,
+             include_last_offset, hook_features, keys_out};
+  return prepare_ids_impl(h, ids, n_batches * nnz_per_batch, slots_out, stream, 0, &t, 1);
+}
+
+extern "C" int ce_cache_prepare_ids_finish(ce_cache_t* h, ce_stream_t stream) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  CE_REQUIRE(h->pend.active, CE_ERR_INVALID, "no cache op has been begun");
+  CE_REQUIRE((hipStream_t)stream == h->pend.s, CE_ERR_INVALID, "finish the cache op on the stream it was begun on");
+  return prepare_ids_second_half(h);
+}
+
 extern "C" int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                            ce_stream_t stream) {
   return prepare_ids_impl(h, ids, n, slots_out, stream, 1);
@@ -2936,6 +3022,7 @@ extern "C" int ce_cache_lookup_slots(ce_cache_t* h, const int64_t* ids, int64_t 
 
 extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  CE_REQUIRE(!h->pend.active, CE_ERR_INVALID, "a cache op begun with ce_cache_prepare_ids_begin has not been finished");
   int rc = before_call(h);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -2984,6 +3071,7 @@ extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
   CE_REQUIRE(h && (transport == CE_TRANSPORT_ZEROCOPY || transport == CE_TRANSPORT_STAGED ||
                    transport == CE_TRANSPORT_WORKER), CE_ERR_INVALID, "bad transport");
   if (h->cfg.transport == transport) return CE_OK;
+  CE_REQUIRE(!h->pend.active, CE_ERR_INVALID, "a cache op begun with ce_cache_prepare_ids_begin has not been finished");
   if (h->wb) {
     // leaving (or re-entering) the worker transport: everything queued reaches the table first.  Blocks.
     int rc = h->wb->wait_out(h->wb->out_issued);

@@ -203,7 +203,16 @@ class GraphedWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
                  warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
                  transport: Optional[str] = "auto", bag_layout=None, graph_cache_op: bool = False,
-                 plan_ahead: int = 1):
+                 plan_ahead: int = 1, interleaved: bool = False):
+        # interleaved (instead of overlap): NO side stream.  The cache op of window k+1 is issued on the training stream
+        # in two halves around the steps of window k -- begin(k+1), graph(k), finish(k+1) (ce_cache_prepare_ids_begin /
+        # _finish) -- so its kernels never run BESIDE the bag kernels (side by side they cost each other more than the
+        # cache op's own kernel time: every one of them is bound by the same memory system), while the PCIe admission of
+        # window k+1's rows still overlaps with window k's steps.  Same protection rule as overlap (protect_depth 1).
+        assert not (interleaved and (overlap or graph_cache_op or plan_ahead != 1)), \
+            "interleaved replaces overlap (one stream, plan_ahead 1)"
+        self.interleaved = interleaved
+        self._begun: Optional[int] = None          # buffer whose cache op has been begun and not finished
         # plan_ahead (overlap=True): how many windows the cache op may run ahead of training.  1: the cache op of window
         # k+1 starts when window k-1 has trained (two slot buffers, protect_depth 1).  2: it starts when window k-2 has
         # -- three buffers, protect_depth 2, unique(three consecutive windows) must fit the cache, and the ids handed to
@@ -244,7 +253,7 @@ class GraphedWindow:
         self._events = [None] * nbuf
         self._read_done = [None] * nbuf        # event behind the last training run that read buffer b
         self._step_fn = step_fn
-        if overlap:
+        if overlap or interleaved:
             self.mgr.set_protect_depth(plan_ahead)
             self.mgr.strict = False
             transport = pick_transport(transport, prefetch_num * ids_per_batch)
@@ -318,8 +327,24 @@ class GraphedWindow:
         else:
             step_fn(self._bufs[buf][i], i)
 
-    def _cache_op(self, cat: torch.Tensor, buf: int) -> None:
+    def drain(self) -> None:
+        """interleaved: enqueue the second half of a cache op that was begun and not finished yet (before anything else
+        uses the cache manager)"""
+        self._finish_begun()
+
+    def _finish_begun(self) -> None:
+        if self._begun is not None:
+            self.mgr.prepare_ids_finish()
+            self._begun = None
+
+    def _cache_op(self, cat: torch.Tensor, buf: int, begin_only: bool = False) -> None:
         """cache op of a window into slot buffer `buf`, and its keys when the window is presorted"""
+        if begin_only and self._ranges is None and cat.dtype == torch.int64 and cat.is_contiguous():
+            self.mgr.prepare_ids_begin(cat.view(self.P, self.n), self._bufs[buf],
+                                       self._keys[buf] if self.presort else None,
+                                       **((self._layout or {}) if self.presort else {}))
+            self._begun = buf
+            return
         if self.presort and FUSED_WINDOW_KEYS and self._ranges is None and cat.dtype == torch.int64 and cat.is_contiguous():
             self.mgr.prepare_ids_keys(cat.view(self.P, self.n), self._bufs[buf], self._keys[buf], **(self._layout or {}))
             return
@@ -356,6 +381,12 @@ class GraphedWindow:
             return
         cat = values[0] if len(values) == 1 else torch.cat(list(values))
         assert cat.numel() == self.P * self.n
+        if self.interleaved:
+            with phase("prefetch cache"):
+                self._finish_begun()                 # (a window begun and never trained: first window, or a caller's skip)
+                self._cache_op(cat, buf, begin_only=True)
+            self._events[buf] = None
+            return
         if self.overlap:
             cur = torch.cuda.current_stream(self.mgr.device)
             self._side.wait_stream(cur)
@@ -372,6 +403,8 @@ class GraphedWindow:
     def run_steps(self, buf: int, first: int, last: int) -> None:
         """Batches [first, last) of the window in buffer `buf`, one single-step graph each (a window that a caller
         only trains in part, or across two timed regions)."""
+        if self._begun == buf:
+            self._finish_begun()
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
@@ -380,6 +413,8 @@ class GraphedWindow:
                 self._step_graphs[buf][i].replay()
             else:
                 self._call(self._step_fn, buf, i)
+        if last >= self.P:
+            self._finish_begun()             # interleaved: the next window's second half, behind this window's last step
         if self.plan_ahead > 1:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.mgr.device))
@@ -424,6 +459,8 @@ class GraphedWindow:
     def run(self, buf: int, steps: Optional[int] = None) -> None:
         """Replay the P training steps on the slots in buffer `buf` (waits for its cache op).  steps < P runs
         only the first `steps` batches, eagerly (a trailing partial window)."""
+        if self._begun == buf:                   # (no window trained in between: the two halves back to back)
+            self._finish_begun()
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
@@ -433,6 +470,7 @@ class GraphedWindow:
             self._graphs[buf].replay()
         else:
             self.run_steps(buf, 0, steps)
+        self._finish_begun()                     # interleaved: the NEXT window's second half, behind this window's steps
         if self.plan_ahead > 1:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.mgr.device))

@@ -335,6 +335,22 @@ int ce_cache_prepare_ids_keys(ce_cache_t* h, const int64_t* ids, int64_t n_batch
                               int64_t* slots_out, int32_t src_keys, const void* offsets, int32_t offsets_are_i64,
                               int64_t offsets_batch_stride, int64_t num_bags, int32_t include_last_offset,
                               int64_t hook_features, uint64_t* keys_out, ce_stream_t stream);
+/* ce_cache_prepare_ids_keys (keys_out != NULL) or ce_cache_prepare_ids over a [n_batches, nnz_per_batch] window
+ * (keys_out == NULL) issued in TWO HALVES on one stream, so that a caller can put work of its own between them:
+ *   _begin   unique rows, misses (the admission worker starts fetching them), victim selection, staging of the victims
+ *            (the write-back worker takes them), free-slot list -- everything that needs nothing from the host table;
+ *   _finish  the wait for the admitted rows, their unpacking, the map updates, slots (and keys).
+ * Why: run on a side stream beside the training kernels, the cache op's kernels and the bag kernels slow each other
+ * down by MORE than the cache op's own kernel time (all of them are bound by the same memory system); issued on the
+ * TRAINING stream as begin(window k+1) -> the steps of window k -> finish(window k+1), nothing runs beside anything,
+ * and the one thing that does take wall time without using the GPU -- the PCIe admission -- still overlaps with the
+ * steps in between.  Window k's rows must be protected while begin(k+1) selects victims: protect_depth >= 1.
+ * No other call on the handle between the two; not capturable. */
+int ce_cache_prepare_ids_begin(ce_cache_t* h, const int64_t* ids, int64_t n_batches, int64_t nnz_per_batch,
+                               int64_t* slots_out, int32_t src_keys, const void* offsets, int32_t offsets_are_i64,
+                               int64_t offsets_batch_stride, int64_t num_bags, int32_t include_last_offset,
+                               int64_t hook_features, uint64_t* keys_out, ce_stream_t stream);
+int ce_cache_prepare_ids_finish(ce_cache_t* h, ce_stream_t stream);
 /* The same, for callers whose id lists are PADDED to a fixed capacity (the row-wise exchange's fixed-size buckets):
  * an entry of -1 is padding -- it takes no part in the call and gets slot -1.  Every other id outside the table still
  * fails the call.  Opt-in on purpose: on the plain entry point a -1 sentinel leaking out of a data pipeline must fail

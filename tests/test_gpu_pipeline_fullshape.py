@@ -16,8 +16,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("plan_ahead", [1, 2])
-def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead):
+@pytest.mark.parametrize("plan_ahead,interleaved", [(1, False), (2, False), (1, True)])
+def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead, interleaved):
+    # interleaved: no side stream -- begin(window k+1), the steps of window k, finish(window k+1) on the training stream
     import cachedembedding_amd as ce
     from cachedembedding_amd import _lib, synthetic
     from cachedembedding_amd.pipeline import GraphedWindow
@@ -56,8 +57,9 @@ def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead):
     def step(slots, i, keys=None):
         emb(slots, offsets, hook_features=F, presorted=keys).backward(grad)
 
-    gw = GraphedWindow(emb, P, n, step, overlap=True, warmup_values=[windows[0][i] for i in range(P)], presort=True,
-                       transport="worker", bag_layout=(offsets, True, F), plan_ahead=plan_ahead)
+    gw = GraphedWindow(emb, P, n, step, overlap=not interleaved, warmup_values=[windows[0][i] for i in range(P)],
+                       presort=True, transport="worker", bag_layout=(offsets, True, F), plan_ahead=plan_ahead,
+                       interleaved=interleaved)
     assert mgr.transport_name == "worker" and gw.nbuf == plan_ahead + 1
     ora.prepare_ids(windows[0].view(-1).cpu().numpy())          # GraphedWindow's eager warm-up: one cache op ...
     for i in range(P):
