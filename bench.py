@@ -206,8 +206,8 @@ def main():
     def need_windows(n_steps, first_step=0):
         while len(windows) * P < n_steps + P * args.plan_ahead:   # + the look-ahead windows of the overlapped cache op
             windows.append(gen.next_values(P))          # each [P, F*B*L]
-        for w in range(max(0, first_step // P - 2)):   # windows long done: give the HBM back
-            windows[w] = None
+        for w in range(max(0, first_step // P - 2) if args.no_verify else 0):   # windows long done: give the HBM back
+            windows[w] = None          # (kept when the end-of-run check will read them again)
 
     need_windows(W + K)
     offsets = gen.offsets
@@ -229,10 +229,11 @@ def main():
         if L > 1:
             gflat = gflat.repeat_interleave(L, dim=0)
 
+    trained_log = []
+
     def trained(w, i0, i1):
-        if ledger is not None:
-            for i in range(i0, i1):
-                ledger.record(windows[w][i], gflat)
+        # (inside the timed region: one tuple per call, nothing else -- the ledger entries are made when the run is over)
+        trained_log.append((w, i0, i1))
     # grouping the window's slots costs one workgroup per 16384-lookup segment on the cache-op stream: with only a
     # few segments per batch (B = 2048 shapes) that is ~30 us of latency for a backward of ~18 us -- leave those to
     # the backward's own 1024-lookup tile sort
@@ -693,6 +694,9 @@ def main():
     }
 
     if ledger is not None:
+        for w_, i0_, i1_ in trained_log:
+            for i_ in range(i0_, i1_):
+                ledger.record(windows[w_][i_], gflat)
         result["verified"] = verify_table(ledger, embed, args, N, D, dev, note)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(embed, gen, args, B, F, L, D)
