@@ -316,6 +316,12 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
         if (!CE_MDBG(4)) rows_out[i] = row[u];
         if (!CE_MDBG(2)) inv[u] = inverted[row[u]];
         const int word = row[u] >> 5;
+        // (looking at hot[word] first and skipping the LDS atomic when the bit is set -- what the cold path does with
+        // the global bitmap -- measured in round 4: 67.2 against 65.1 us, no gain.  Also round 4: a RESIDENCY BITMAP
+        // (bit r = row r is resident, kept by the admit / evict kernels) in place of the inverted[] gathers of this
+        // kernel, k_count and k_emit: k_count 13.6 -> 7.8 us, but k_mark 65 -> 69, k_emit 31 -> 37 and the slots +
+        // keys kernel 32 -> 38 -- every lookup needs inverted[row] once anyway (its slot), and this kernel's gather is
+        // what has it in L2 when the later kernels ask; 328 GPU tests green, no net gain, not kept.)
         if (word < hot_words) { if (!CE_MDBG(1)) atomicOr(&hot[word], 1u << (row[u] & 31)); }
         else if (!CE_MDBG(8)) cur[u] = *(volatile uint32_t*)(bitmap + word);
       }
