@@ -507,7 +507,7 @@ def test_rowwise_graphed_window_captures_rccl_collectives_or_falls_back():
         _spawn(_rowwise_graphed, 2, "dataset", True, 256, True, (5003, 64, 4, 32, 3, 1000), True, backend="nccl")
 
 
-@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--use_lfu"])])
+@pytest.mark.parametrize("ranks,extra", [(2, ["--verify_sharded"]), (3, ["--use_lfu"])])
 def test_bench_multi_rank_path_with_ranks_sharing_the_gpu(ranks, extra):
     """`bench.py --gpus N` is launched by the driver as `torch.distributed.run --nproc-per-node N`; no multi-GPU box is
     available to the tests, so the same command runs with N ranks SHARING cuda:0 over gloo (--share_gpu) on a
@@ -528,3 +528,30 @@ def test_bench_multi_rank_path_with_ranks_sharing_the_gpu(ranks, extra):
     out = json.loads(lines[0])
     assert out["n_gpus"] == ranks and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_batch"] == 4096 * ranks
+    if "--verify_sharded" in extra:
+        v = out["verified"]
+        assert v["pass"] and v["all_ranks"]["bound_violations"] == 0 and v["all_ranks"]["untouched_mismatch"] == 0
+        assert v["all_ranks"]["rows"] > 100_000
+
+
+@pytest.mark.parametrize("extra", [[], ["--interleaved"], ["--use_lfu", "--prefetch_num", "1"], ["--force_sharded"]])
+def test_bench_one_gpu_line_carries_roofline_box_and_a_passing_verification(extra):
+    """the driver's command on a scaled-down table: ONE JSON line with `roofline`, `cpu_baseline`-free here, the same-run
+    `box` probe and `verified.pass` -- the closed-form check of the table the run leaves behind -- for the default
+    pipeline, the one-stream form, LFU at prefetch_num 1 (cache op two windows ahead) and the row-wise path at W = 1."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--table_scale", "0.1", "--cache_ratio", "0.03", "--prefetch_num", "4",
+           "--steps", "20", "--warmup", "5", "--no_cpu_baseline", "--min_time", "0.05"] + extra
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 1 and out["unit"] == "lookups/s"
+    v = out["verified"]
+    assert v["pass"] and v["bound_violations"] == 0 and v["untouched_mismatch"] == 0 and v["rows"] > 100_000, v
+    if "--force_sharded" not in extra:
+        assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1.2
+        assert out["box"]["before"]["read_GBps"] > 1000 and out["it_per_s_scope"].startswith("embedding operator only")
