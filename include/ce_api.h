@@ -201,6 +201,9 @@ int ce_bag_backward_dense_presorted(float* grad_weight, int64_t num_rows, int32_
  * (offsets = arange: every Criteo / Avazu batch, recsys/datasets/criteo.py:127-134) without the kernel having to read
  * the offsets to establish it.  The *_presorted_src backward entry points stream over such keys with no per-tile set-up
  * (67 vs 74 us at the bench shape); they trust the keys (grad_out row < num_bags) and ignore rows >= num_rows.
+ * An ignored lookup (index outside [0, num_rows), e.g. slot -1) keeps its grad_out / output row in the low word under
+ * the row 0xffffffff (API 4; all ones before) -- the backward skips it like padding, ce_bag_forward_src_keys writes its
+ * zero row; only the positions beyond nnz_per_batch in the last segment are all ones.
  * Replaces the same upstream call as the forms above (recsys/dlrm_main.py:274-279, loss.backward + optimizer.step). */
 int ce_bag_presort_window_src(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
                               const void* offsets, int32_t offsets_are_i64, int64_t offsets_batch_stride,
