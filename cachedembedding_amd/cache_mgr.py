@@ -498,7 +498,7 @@ class CachedParamMgr(torch.nn.Module):
         cnt = (ctypes.c_int64 * 4)()
         check(lib.ce_cache_swap_stats(self._handle, sec, cnt))
         return dict(out_wait_s=sec[0], out_busy_s=sec[1], in_wait_s=sec[2], in_busy_s=sec[3], in_gather_s=sec[4],
-                    rows=cnt[0], jobs=cnt[1], in_rows=cnt[2], in_jobs=cnt[3])
+                    rows=cnt[0], jobs=cnt[1], in_rows=cnt[2], in_jobs=cnt[3], in_jobs_before_writeback_landed=int(sec[5]))
 
     def raise_on_failed_calls(self):
         """Non-blocking check used by the pipelines that run prepare_ids with strict=False: raises the reference's

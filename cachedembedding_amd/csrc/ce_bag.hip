@@ -1348,10 +1348,14 @@ static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t 
   static const int il_env = [] { const char* e = getenv("CE_BWD_INTERLEAVE"); return e ? atoi(e) : 1; }();
   p.interleave = il_env;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
-  static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 2; }();
+  // 8 workgroups per CU, i.e. 16384 shares of ~26 keys at the bench shape.  Alone on the GPU the share size hardly
+  // matters (2 / 3 / 4 / 6 / 8 per CU: 55.5 / 54 / 58.5 / 53.7 / 55.8 us); beside the cache op's kernels it does --
+  // a workgroup that gets its CU late holds the whole launch back by its share: 77 / 74 / 70.5 / 67 / 68 us
+  // (profiles/r04_*: forward 16/CU + backward 8/CU take the bench line from 2.91 to 3.03-3.07 G over 10 runs each)
+  static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
   static const int excl_env = [] { const char* e = getenv("CE_BWD_EXCL"); return e ? atoi(e) : 1; }();
   const int ngroups = 256 >> p.g_log2;
-  // two workgroups per CU; small inputs: one share of >= 16 keys per lane group
+  // small inputs: one share of >= 16 keys per lane group
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));
   dim3 g(grid), b(256);
   const long long* rg = (const long long*)seg_ranges;
@@ -1413,9 +1417,10 @@ extern "C" int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, in
   static const int il_env = [] { const char* e = getenv("CE_FWDK_INTERLEAVE"); return e ? atoi(e) : 0; }();
   p.interleave = il_env;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
-  // 8 workgroups per CU (measured at the bench shape, three runs each: 4/CU 2.59-2.82 G lookups/s and 72-74 us per
-  // launch beside the cache op, 8/CU 2.79-2.97 G and 64-66 us; the slot-driven forward 2.56-2.76 G and 72-76 us)
-  static const int per_cu = [] { const char* e = getenv("CE_FWDK_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
+  // 16 workgroups per CU: more than fit at once (97 VGPRs: 5), so the dispatcher hands the shares out as CUs free up
+  // (measured at the bench shape beside the cache op: 4/CU 72-74 us per launch, 8/CU 66-70, 16/CU 63-64, 32/CU 62-65;
+  // alone: 8/CU 48, 16/CU 46.7, 5/CU -- exactly resident -- 43 but 66 beside the cache op)
+  static const int per_cu = [] { const char* e = getenv("CE_FWDK_BLOCKS_PER_CU"); return e ? atoi(e) : 16; }();
   static const int r_env = [] { const char* e = getenv("CE_FWDK_R"); return e ? atoi(e) : 16; }();
   const int ngroups = 256 >> p.g_log2;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));

@@ -888,6 +888,48 @@ __device__ __forceinline__ void free_list_from_victims(const unsigned long long*
   }
 }
 
+// Worker transport: "which rows did write-back job j stage, and where" -- so that the NEXT call's admission can take a
+// row that job j evicted out of j's staging buffer (still intact in HBM) instead of waiting until the host has
+// scattered it into the table.  One open-addressing table per job parity; an entry is tag << 32 | row with tag = the
+// low 32 bits of the job number (never 0), its staging position in a parallel array.  A job treats every entry of
+// another tag as free, so the tables are never cleared: job j's entries form gap-free probe runs (j only ever skips
+// entries of its own) until job j + 2 starts overwriting them, by which time job j + 1's admission -- their only
+// reader -- has finished.  At most stage_rows entries per job in >= 4 x stage_rows places.
+struct EvTable {
+  unsigned long long* keys;
+  int32_t* pos;
+  uint32_t mask;
+};
+__device__ __forceinline__ uint32_t evt_hash(int32_t row, uint32_t mask) {
+  return (((uint32_t)row * 2654435761u) >> 7) & mask;
+}
+__device__ __forceinline__ void evt_insert(const EvTable t, uint32_t tag, int32_t row, int32_t pos) {
+  const unsigned long long mine = ((unsigned long long)tag << 32) | (uint32_t)row;
+  uint32_t h = evt_hash(row, t.mask);
+  for (;;) {
+    const unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(cur >> 32) == tag) {          // taken by this job
+      h = (h + 1) & t.mask;
+      continue;
+    }
+    if (atomicCAS(&t.keys[h], cur, mine) == cur) {
+      t.pos[h] = pos;
+      return;
+    }
+  }
+}
+__device__ __forceinline__ int32_t evt_find(const unsigned long long* __restrict__ keys,
+                                            const int32_t* __restrict__ pos, uint32_t mask, uint32_t tag,
+                                            int32_t row) {
+  uint32_t h = evt_hash(row, mask);
+  for (;;) {
+    const unsigned long long cur = keys[h];
+    if ((uint32_t)(cur >> 32) != tag) return -1;
+    if ((uint32_t)cur == (uint32_t)row) return pos[h];
+    h = (h + 1) & mask;
+  }
+}
+
 template <typename VT>
 __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
                                                      int32_t* cached_idx_map, int32_t* inverted,
@@ -895,7 +937,8 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
                                                      long long cap, int rowlen, int g_log2, const Ctl* ctl,
                                                      WbMail* mail, long long job, int stage_grid,
                                                      const unsigned long long* __restrict__ keys, int64_t C,
-                                                     const int32_t* __restrict__ blk_vic, int32_t* free_list) {
+                                                     const int32_t* __restrict__ blk_vic, int32_t* free_list,
+                                                     EvTable evt) {
   if ((int)blockIdx.x >= stage_grid) {       // (only launched with these workgroups in the steady-state form)
     free_list_from_victims(keys, C, blk_vic, free_list, ctl, (int)blockIdx.x - stage_grid);
     return;
@@ -924,6 +967,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
           stage_rows_idx[i + t] = row;
           inverted[row] = -1;
           cached_idx_map[slot[t]] = -1;
+          if (evt.keys) evt_insert(evt, (uint32_t)job, row, (int32_t)(i + t));
         }
         if (gl < rowlen) v[t] = cache[(int64_t)slot[t] * rowlen + gl];
       }
@@ -938,6 +982,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
           stage_rows_idx[i + t] = row;
           inverted[row] = -1;
           cached_idx_map[slot] = -1;
+          if (evt.keys) evt_insert(evt, (uint32_t)job, row, (int32_t)(i + t));
         }
         copy_row(cache + (int64_t)slot * rowlen, stage + (i + t) * rowlen, rowlen, gl, G);
       }
@@ -1129,20 +1174,94 @@ __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows
                             (int)gridDim.x, first);
 }
 
-// worker transport: rows [0, min(n_miss, cap)) arrived contiguously in `in_stage`; move them to their slots
+// Admission kernel of the worker transport when the previous call's write-back has not landed yet: row i comes out
+// of that job's staging buffer if the job evicted it (EvTable above), out of the host table otherwise.
+template <typename VT>
+__global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict__ rows, long long n,
+                                                     const VT* __restrict__ host, VT* dst, int rowlen, int g_log2,
+                                                     const unsigned long long* __restrict__ evt_keys,
+                                                     const int32_t* __restrict__ evt_pos, uint32_t evt_mask,
+                                                     uint32_t tag, const VT* __restrict__ prev_stage) {
+  constexpr int R = kSwapRows;
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
+    if (rowlen <= G) {
+      VT v[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        if (i + t < n) {
+          const int32_t row = rows[i + t];
+          const int32_t p = evt_find(evt_keys, evt_pos, evt_mask, tag, row);
+          const VT* src = p >= 0 ? prev_stage + (int64_t)p * rowlen : host + (int64_t)row * rowlen;
+          if (gl < rowlen) v[t] = src[gl];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if (i + t < n && gl < rowlen) dst[(i + t) * rowlen + gl] = v[t];
+    } else {
+      for (int t = 0; t < R && i + t < n; ++t) {
+        const int32_t row = rows[i + t];
+        const int32_t p = evt_find(evt_keys, evt_pos, evt_mask, tag, row);
+        copy_row(p >= 0 ? prev_stage + (int64_t)p * rowlen : host + (int64_t)row * rowlen, dst + (i + t) * rowlen,
+                 rowlen, gl, G);
+      }
+    }
+  }
+}
+
+// worker transport: rows [0, min(n_miss, cap)) arrived contiguously in `in_stage`; move them to their slots.
+// maps_done != 0 (the early-maps order, see prepare_ids_impl): k_admit_maps and the slot / key kernel have run BEFORE
+// the stream was parked, so this is the call's last kernel: it publishes the call's record, and when the admission
+// worker reports the job lost it takes the rows' map entries back (nothing that never arrived may stay resident --
+// a later flush would write it to the host table).
 template <typename VT>
 __global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restrict__ slots, const long long* n_ptr,
                                                          long long cap, const VT* __restrict__ in_stage, VT* cache,
                                                          int rowlen, int g_log2, Ctl* ctl,
-                                                         const unsigned long long* fail_word, long long job) {
-  if (ctl->status != CE_OK) return;
-  // The admission worker flags a job whose rows did not arrive (a HIP call of its own failed or timed out) in a word
-  // of pinned host memory.  ONE thread fetches it over PCIe and leaves the verdict in the control block for
-  // k_admit_maps, which then marks nothing resident; whatever this kernel copies into the (free) slots meanwhile is
-  // never looked at.
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+                                                         const unsigned long long* fail_word, long long job,
+                                                         int maps_done, const int32_t* __restrict__ rows,
+                                                         int32_t* cached_idx_map, int32_t* inverted,
+                                                         ce_call_stats_t* ring, long long seq_arg) {
+  const bool ok = ctl->status == CE_OK;         // (nothing in this kernel writes ctl->status)
+  bool lost = false;
+  if (maps_done) {
+    // every workgroup asks the pinned word itself (one PCIe read each, all in flight together)
+    __shared__ int lost_s;
+    if (threadIdx.x == 0) lost_s = *(volatile const unsigned long long*)fail_word == (unsigned long long)job;
+    __syncthreads();
+    lost = lost_s != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const long long seq = call_seq(ctl, seq_arg);
+      ce_call_stats_t* const ring_slot = ring + (seq % kRing);
+      if (lost && ok) {
+        // the victims are gone (written back) but their slots stay free: undo the plan's share of the free count
+        ctl->n_free = ctl->n_free + ctl->n_miss;
+        ring_slot->status = CE_ERR_HIP;
+        ring_slot->n_free_after = ctl->n_free;
+      }
+      __threadfence_system();
+      *(volatile long long*)&ring_slot->seq = seq;
+    }
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // The admission worker flags a job whose rows did not arrive (a HIP call of its own failed or timed out) in a
+    // word of pinned host memory.  ONE thread fetches it over PCIe and leaves the verdict in the control block for
+    // k_admit_maps, which then marks nothing resident; whatever this kernel copies into the (free) slots meanwhile
+    // is never looked at.
     ctl->lost = *(volatile const unsigned long long*)fail_word == (unsigned long long)job;
+  }
+  if (!ok) return;
   long long n = *n_ptr;
+  if (lost) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      cached_idx_map[slots[i]] = -1;
+      inverted[rows[i]] = -1;
+    }
+    return;
+  }
   if (n > cap) n = cap;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
@@ -1190,16 +1309,18 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
                                                     int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
                                                     int32_t epoch_imm, Ctl* ctl, ce_call_stats_t* ring,
                                                     long long seq_arg, const unsigned long long* fail_word,
-                                                    long long job) {
-  // ring == NULL (preload): no record to publish, the epoch is the caller's constant
+                                                    long long job, int defer_record = 0) {
+  // ring == NULL (preload): no record to publish, the epoch is the caller's constant.  defer_record (the early-maps
+  // order of the worker transport): this runs BEFORE the rows arrive -- k_unpack_admitted publishes the record and
+  // takes the entries back if they never do
   const long long seq = ring ? call_seq(ctl, seq_arg) : 0;
   const int32_t epoch = ring ? call_epoch(seq) : epoch_imm;
   ce_call_stats_t* const ring_slot = ring ? ring + (seq % kRing) : nullptr;
   // worker transport: the admission worker reports a job it could not complete (failed / timed-out HIP call): the
   // rows never arrived, so nothing may be marked resident.
-  const bool lost = fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
+  const bool lost = !defer_record && fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
   // last kernel of prepare_ids that can change the call's record: publish it (a slot whose seq matches is complete)
-  if (ring_slot && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (ring_slot && !defer_record && blockIdx.x == 0 && threadIdx.x == 0) {
     if (lost && ctl->status == CE_OK) {
       // the victims are gone (written back) but their slots stay free: undo the plan's share of the free count
       ctl->n_free = ctl->n_free + ctl->n_miss;
@@ -1501,11 +1622,13 @@ static const char* const kPhaseNames[kPhases] = {"unique_and_miss", "find_evict_
 struct PhaseProf {
   hipEvent_t ev[kProfDepth][kPhases + 1];
   bool pending[kProfDepth];
+  bool early[kProfDepth];            // the call ran slots + keys BEFORE the admission wait (phases 4 and 5 swapped)
   double ms[kPhases];
   long long calls;
   PhaseProf() : calls(0) {
     for (int i = 0; i < kProfDepth; ++i) {
       pending[i] = false;
+      early[i] = false;
       for (int j = 0; j <= kPhases; ++j) (void)hipEventCreate(&ev[i][j]);
     }
     for (int j = 0; j < kPhases; ++j) ms[j] = 0;
@@ -1519,7 +1642,8 @@ struct PhaseProf {
     if (hipEventSynchronize(ev[i][kPhases]) == hipSuccess) {
       for (int j = 0; j < kPhases; ++j) {
         float t = 0;
-        if (hipEventElapsedTime(&t, ev[i][j], ev[i][j + 1]) == hipSuccess) ms[j] += t;
+        if (hipEventElapsedTime(&t, ev[i][j], ev[i][j + 1]) == hipSuccess)
+          ms[(early[i] && j >= kPhases - 2) ? (2 * kPhases - 3 - j) : j] += t;
       }
       calls += 1;
     }
@@ -1557,6 +1681,18 @@ static inline hipError_t stream_wait_polite(hipStream_t st, double timeout_s = w
   }
 }
 
+static inline hipError_t event_wait_polite(hipEvent_t ev, double timeout_s = worker_timeout_s()) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (spins < 50) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(15));
+    if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      return hipErrorNotReady;      // timed out: the caller reports it
+  }
+}
+
 static const bool g_trace = [] { const char* e = getenv("CE_WORKER_TRACE"); return e && atoi(e) != 0; }();
 #define CE_TRACE(...)                                                                            \
   do {                                                                                           \
@@ -1584,8 +1720,13 @@ static const bool g_trace = [] { const char* e = getenv("CE_WORKER_TRACE"); retu
 //        pinned word the stream polls, once the copies have completed.  k_unpack_admitted then moves the rows to
 //        their slots.
 //
-// Ordering: the gather of call w starts only after the write-back of call w-1 has reached the table (a row evicted
-// by w-1 and missed by w is read back correctly); rows evicted by call w itself are never in its miss list.
+// Ordering: a row evicted by call w-1 and missed by call w must be read back with the payload w-1 staged.  The host
+// gather of call w therefore starts only after the write-back of call w-1 has reached the table; the admission
+// KERNEL waits for the write-back of call w-2 only and, while that of w-1 is still on its way, looks every missed
+// row up in the table of rows w-1 staged (EvTable) and takes a hit out of w-1's staging buffer -- intact until call
+// w+1 stages its own victims, which happens behind call w's admission wait.  (Waiting for w-1 put a 1 ms
+// write-back, the slower PCIe direction beside the admission's reads, on the cache-op stream's cycle: front ->
+// write-back -> admission of the next call.)  Rows evicted by call w itself are never in its miss list.
 // The launch thread blocks only when a worker is two calls behind.  A failing HIP call inside a worker still
 // releases the stream (the error surfaces at the next call / wait) so the GPU is never left parked.
 struct SwapEngine {
@@ -1595,7 +1736,8 @@ struct SwapEngine {
   // ---- out (evictions)
   hipStream_t out_stream = nullptr, out_stream2 = nullptr;      // alternating D2H copy streams
   hipEvent_t out_ev[2] = {nullptr, nullptr};       // staging of the job complete (recorded on the cache-op stream)
-  static constexpr int kOutChunks = 4;
+  static constexpr int kOutChunks = 8;
+  hipEvent_t chunk_ev[kOutChunks + 1] = {nullptr};      // behind every chunk copy of the job being written back
   const float* stage_dev[2] = {nullptr, nullptr};
   const int32_t* idx_dev[2] = {nullptr, nullptr};
   float* rows_host[2] = {nullptr, nullptr};        // pinned landing buffers
@@ -1612,6 +1754,14 @@ struct SwapEngine {
   // (round 2: 8: 0.92 ms admission wait, 2.08 G lookups/s; 16: 0.50 ms, 2.63 G; 32: 0.33 ms, 2.46 G; 64: 0.15 ms, 2.18 G.
   // round 3, with the shorter cache-op chain: 16: 0.61 ms, 2.70 G; 20: 0.55 ms, 2.72 G; 24: 0.53 ms, 2.67 G; 32: 2.5-2.66 G)
   bool admit_by_kernel = false;
+  // relaxed ordering of the kernel admission: the previous call's write-back need not have LANDED, its rows are
+  // taken from its staging buffer (EvTable); only the one before must be in the table
+  bool relax = false;
+  const unsigned long long* evt_keys[2] = {nullptr, nullptr};
+  const int32_t* evt_pos[2] = {nullptr, nullptr};
+  uint32_t evt_mask = 0;
+  long long in_probed = 0;         // admissions that ran while the previous write-back was still on its way
+  int out_delay_us = 0;            // test hook (CE_WORKER_OUT_DELAY_US): every write-back job starts this much late
   const int32_t* miss_list_dev = nullptr;
   const void* table_dev = nullptr;
   int rowlen = 0, g_log2 = 0, vec = 0, admit_blocks = 0, admit_threads = 1024;      // admit_blocks 0 = by job size
@@ -1634,6 +1784,8 @@ struct SwapEngine {
   RowPool* in_pool = nullptr;
   // statistics (what upstream's swap_in_bandwidth / swap_out_bandwidth report)
   double out_wait_s = 0, out_busy_s = 0, in_wait_s = 0, in_busy_s = 0, in_gather_s = 0;
+  double out_wait0_s = 0;
+  double out_copy_wait_s = 0, out_scatter_s = 0;       // parts of out_busy_s (CE_WORKER_PROFILE=1 prints them at exit)
   long long out_rows = 0, out_jobs = 0, in_rows = 0, in_jobs = 0;
 
   void fail(const char* what, hipError_t e) {
@@ -1666,24 +1818,33 @@ struct SwapEngine {
       if (e != hipSuccess) fail("hipEventSynchronize(out)", e);
       const auto t1 = std::chrono::steady_clock::now();
       long long k = mail[b].count;
+      double copy_wait = 0, scatter = 0, wait0 = 0;
+      if (out_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(out_delay_us));
       CE_TRACE("out job %lld: event done (%s), mail job %lld count %lld", job, hipGetErrorString(e), mail[b].job, k);
       if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record moves nothing
       if (k > 0 && !failed()) {
-        // a handful of big copies on two alternating copy streams: chunk c is scattered into the table while chunk
-        // c+1 is on the wire.  The host waits with hipStreamSynchronize only (see run_in: no queue packets).
+        // The packed block leaves in kOutChunks copies, ALL issued at once on the two copy streams in turn, each with
+        // an event behind it; chunk c is scattered into the table while the later ones are on the wire.  (Issuing
+        // chunk c + 1 only when chunk c was being waited for left the copies and the scatters back to back:
+        // 0.6 + 0.55 ms per 54 k-row job instead of overlapped.)  The host polls the events (no queue packets).
         e = hipMemcpyAsync(idx_host[b], idx_dev[b], (size_t)k * 4, hipMemcpyDeviceToHost, out_stream);
-        const int64_t per = std::max<int64_t>(8192, cdiv(k, kOutChunks));
-        auto copy_chunk = [&](int64_t off, int c) {
+        const int64_t per = std::max<int64_t>(4096, cdiv(k, kOutChunks));
+        int nch = 0;
+        for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++nch) {
           const int64_t cnt = std::min<int64_t>(per, k - off);
-          return hipMemcpyAsync(rows_host[b] + off * D, stage_dev[b] + off * D, (size_t)cnt * D * 4,
-                                hipMemcpyDeviceToHost, (c & 1) ? out_stream2 : out_stream);
-        };
-        if (e == hipSuccess) e = copy_chunk(0, 0);
+          hipStream_t cs = (nch & 1) ? out_stream2 : out_stream;
+          e = hipMemcpyAsync(rows_host[b] + off * D, stage_dev[b] + off * D, (size_t)cnt * D * 4, hipMemcpyDeviceToHost, cs);
+          if (e == hipSuccess) e = hipEventRecord(chunk_ev[nch], cs);
+        }
         int c = 0;
         for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++c) {
           const int64_t cnt = std::min<int64_t>(per, k - off);
-          if (off + per < k) e = copy_chunk(off + per, c + 1);                 // next chunk in flight
-          hipError_t e2 = stream_wait_polite((c & 1) ? out_stream2 : out_stream);
+          const auto tc0 = std::chrono::steady_clock::now();
+          // (chunk 0 also needs the row numbers, which went first on out_stream)
+          hipError_t e2 = event_wait_polite(chunk_ev[c]);
+          const auto tc1 = std::chrono::steady_clock::now();
+          copy_wait += std::chrono::duration<double>(tc1 - tc0).count();
+          if (c == 0) wait0 = std::chrono::duration<double>(tc1 - tc0).count();
           if (e == hipSuccess) e = e2;
           if (e != hipSuccess) break;
           float* tb = table;
@@ -1691,9 +1852,20 @@ struct SwapEngine {
           const int32_t* ri = idx_host[b] + off;
           const int64_t d = D;
           out_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) row_copy_stream(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
+            // every row lands on a page of its own: a read prefetch of ANOTHER line of the page of the row 8 ahead
+            // starts its page walk early (the row's own lines are streamed past the cache and must not be pulled
+            // in): 71 -> 48 ns per row on 4 KB pages, 18.5 -> 13 on 2 MB pages (scratch/probe_scatter2.cpp)
+            for (int64_t i = lo; i < hi; ++i) {
+              if (i + 8 < hi) __builtin_prefetch((const void*)((uintptr_t)(tb + (size_t)ri[i + 8] * d) ^ 2048u), 0, 0);
+              row_copy_stream(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
+            }
             row_copy_fence();
           });
+          scatter += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc1).count();
+        }
+        if (e == hipSuccess) {         // both streams idle again before the staging buffer is reused
+          e = stream_wait_polite(out_stream);
+          if (e == hipSuccess) e = stream_wait_polite(out_stream2);
         }
         if (e != hipSuccess) fail(e == hipErrorNotReady ? "write-back copy timed out (CE_WORKER_TIMEOUT_S)" : "D2H copy", e);
       }
@@ -1704,6 +1876,9 @@ struct SwapEngine {
         out_done = job;
         out_wait_s += std::chrono::duration<double>(t1 - t0).count();
         out_busy_s += std::chrono::duration<double>(t2 - t1).count();
+        out_copy_wait_s += copy_wait;
+        out_wait0_s += wait0;
+        out_scatter_s += scatter;
         out_rows += k;
         out_jobs += 1;
       }
@@ -1728,10 +1903,14 @@ struct SwapEngine {
       hipError_t e = hipEventSynchronize(in_ev[job & 1]);
       if (e != hipSuccess) fail("hipEventSynchronize(in)", e);
       CE_TRACE("in job %lld: event done (%s)", job, hipGetErrorString(e));
+      bool probe = false;
       {
-        // rows the earlier calls evicted must be in the table before it is read
+        // rows the earlier calls evicted must be in the table before it is read -- except, with the kernel admission,
+        // those of the call just before: they are still in that job's staging buffer and are taken from there
+        const long long must = (admit_by_kernel && relax) ? need_out - 1 : need_out;
         std::unique_lock<std::mutex> g(m);
-        cv_done.wait(g, [&] { return out_done >= need_out || err != 0; });
+        cv_done.wait(g, [&] { return out_done >= must || err != 0; });
+        probe = out_done < need_out;
       }
       const auto t1 = std::chrono::steady_clock::now();
       long long n = mail[2].count;
@@ -1742,7 +1921,16 @@ struct SwapEngine {
         // this) get 32 workgroups, window-sized jobs 16 (training is the critical path: see the table above).
         // Kaggle 5 % P = 1 (25 k rows): 0.93 -> 1.02 G lookups/s; P = 2: 1.38 -> 1.44 G
         const int blocks = admit_blocks > 0 ? admit_blocks : (n <= 49152 ? 32 : 20);
-        if (vec)
+        const int pb = (int)(need_out & 1);
+        if (probe && vec)
+          hipLaunchKernelGGL((k_admit_probe<f32x4>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,
+                             (const f32x4*)table_dev, (f32x4*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],
+                             evt_mask, (uint32_t)need_out, (const f32x4*)stage_dev[pb]);
+        else if (probe)
+          hipLaunchKernelGGL((k_admit_probe<float>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,
+                             (const float*)table_dev, (float*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],
+                             evt_mask, (uint32_t)need_out, (const float*)stage_dev[pb]);
+        else if (vec)
           hipLaunchKernelGGL((k_admit<f32x4>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
                              (const int32_t*)nullptr, (const long long*)nullptr, n, (const f32x4*)table_dev,
                              (f32x4*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);
@@ -1830,6 +2018,7 @@ struct SwapEngine {
         in_gather_s += std::chrono::duration<double>(tg - t1).count();
         in_rows += n;
         in_jobs += 1;
+        in_probed += probe ? 1 : 0;
       }
       cv_done.notify_all();
     }
@@ -1905,6 +2094,17 @@ struct SwapEngine {
       std::lock_guard<std::mutex> g(m);
       stop = true;
     }
+    if (const char* e = getenv("CE_WORKER_PROFILE"))
+      if (atoi(e) != 0 && in_jobs > 0)
+        fprintf(stderr, "[libce_hip] admission worker: %lld jobs, %lld of them with the previous write-back still on its "
+                "way (rows it evicted taken from its staging buffer)\n", in_jobs, in_probed);
+    if (const char* e = getenv("CE_WORKER_PROFILE"))
+      if (atoi(e) != 0 && out_jobs > 0)
+        fprintf(stderr, "[libce_hip] write-back worker: %lld jobs, %.3f ms busy per job = %.3f waiting for copies + %.3f "
+                "scattering + %.3f other; %.0f rows per job; first chunk's wait %.3f\n", out_jobs, out_busy_s / out_jobs * 1e3,
+                out_copy_wait_s / out_jobs * 1e3, out_scatter_s / out_jobs * 1e3,
+                (out_busy_s - out_copy_wait_s - out_scatter_s) / out_jobs * 1e3, (double)out_rows / out_jobs,
+                out_wait0_s / out_jobs * 1e3);
     cv_job.notify_all();
     if (in_thread.joinable()) in_thread.join();
     if (out_thread.joinable()) out_thread.join();
@@ -1917,6 +2117,8 @@ struct SwapEngine {
     }
     for (int b = 0; b < 2; ++b)
       if (in_ev[b]) (void)hipEventDestroy(in_ev[b]);
+    for (auto& ev : chunk_ev)
+      if (ev) (void)hipEventDestroy(ev);
     if (in_host) (void)hipHostFree(in_host);
     if (miss_host) (void)hipHostFree(miss_host);
     if (sig) (void)hipHostFree(sig);
@@ -1960,6 +2162,9 @@ struct ce_cache {
   int64_t buffer_rows;         // > 0: staged transfers go through at most this many staging rows at a time
   ce::RowPool* pool;           // host threads of the staged transport (created on first use)
   ce::SwapEngine* wb;          // CE_TRANSPORT_WORKER state (created on first use)
+  unsigned long long* evt_keys[2];   // rows staged by the write-back job of either parity (ce::EvTable; worker transport)
+  int32_t* evt_pos[2];
+  uint32_t evt_mask;
   float* stage2;               // second eviction staging buffer + row list, admission staging (workspace)
   int32_t* stage_idx2;
   float* in_stage;
@@ -1985,6 +2190,7 @@ struct ce_cache {
     bool worker = false, capturing = false, has_tail = false;
     long long in_job = 0, seq_arg = 0;
     int cap_groups = 1, swap_threads = 256, pslot = 0, pmark = 0;
+    bool early = false;          // maps + slots / keys were launched before the admission wait (worker transport)
     const void* prof = nullptr;      // the phase timers the first half recorded into (they may be switched off / on in between)
     struct {
       int64_t n_batches, nnz_per_batch;
@@ -2181,6 +2387,10 @@ extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
   (void)hipEventSynchronize(h->ev);
   delete h->wb;          // finishes the queued jobs, joins the workers
+  for (int b = 0; b < 2; ++b) {
+    if (h->evt_keys[b]) (void)hipFree(h->evt_keys[b]);
+    if (h->evt_pos[b]) (void)hipFree(h->evt_pos[b]);
+  }
   delete h->pool;
   delete h->prof;
   (void)hipEventDestroy(h->ev);
@@ -2272,6 +2482,37 @@ static int ensure_writeback(ce_cache* h) {
     w->idx_dev[0] = h->stage_idx;
     w->idx_dev[1] = h->stage_idx2;
     w->in_stage_dev = h->in_stage;
+    {
+      static const int relax_env = [] { const char* e = getenv("CE_WB_RELAX"); return e ? atoi(e) : 1; }();
+      if (relax_env != 0 && !h->evt_keys[0]) {
+        uint32_t places = 4096;
+        while ((int64_t)places < 4 * L.stage_rows && places < (1u << 30)) places <<= 1;
+        bool ok = (int64_t)places >= 4 * L.stage_rows;
+        for (int b = 0; b < 2 && ok; ++b) {
+          ok = hipMalloc((void**)&h->evt_keys[b], (size_t)places * 8) == hipSuccess &&
+               hipMalloc((void**)&h->evt_pos[b], (size_t)places * 4) == hipSuccess &&
+               hipMemset(h->evt_keys[b], 0, (size_t)places * 8) == hipSuccess;
+        }
+        if (ok) {
+          h->evt_mask = places - 1;
+        } else {
+          (void)hipGetLastError();
+          for (int b = 0; b < 2; ++b) {
+            if (h->evt_keys[b]) (void)hipFree(h->evt_keys[b]);
+            if (h->evt_pos[b]) (void)hipFree(h->evt_pos[b]);
+            h->evt_keys[b] = nullptr;
+            h->evt_pos[b] = nullptr;
+          }
+        }
+      }
+      w->relax = h->evt_keys[0] != nullptr;
+      if (const char* e = getenv("CE_WORKER_OUT_DELAY_US")) w->out_delay_us = std::max(0, atoi(e));
+      for (int b = 0; b < 2; ++b) {
+        w->evt_keys[b] = h->evt_keys[b];
+        w->evt_pos[b] = h->evt_pos[b];
+      }
+      w->evt_mask = h->evt_mask;
+    }
     const size_t rows_bytes = (size_t)L.stage_rows * w->D * 4, idx_bytes = (size_t)L.stage_rows * 4;
     // The copy streams must never share a hardware queue with the parked cache-op stream: a hipMemcpyAsync is not
     // queue-free (the runtime brackets the SDMA copy with barrier packets in the stream's queue), so a copy queued
@@ -2326,6 +2567,8 @@ static int ensure_writeback(ce_cache* h) {
       else if (hipHostMalloc((void**)&w->rows_host[b], rows_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
       else if (hipHostMalloc((void**)&w->idx_host[b], idx_bytes, hipHostMallocDefault) != hipSuccess) rc = CE_ERR_NOMEM;
     }
+    for (auto& ev : w->chunk_ev)
+      if (rc == CE_OK && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
     if (rc) break;
     // helper threads per direction: half of what the CPU budget leaves after the launch thread, the two (mostly
     // sleeping) workers and the runtime's own threads -- a cgroup that exceeds its CPU quota is frozen until the next
@@ -2514,6 +2757,7 @@ struct KeysTail {
 };
 
 static int prepare_ids_second_half(ce_cache* h);
+static int launch_maps_and_slots(ce_cache* h);
 
 // split != 0: only the first half is enqueued -- everything up to and including the staging of the victims and the
 // free-slot list, i.e. all that needs nothing from the host table; ce_cache_prepare_ids_finish enqueues the rest (wait
@@ -2700,11 +2944,13 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     const int sgrid = (int)std::min<int64_t>(stage_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
     WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
     const dim3 sg(sgrid + (steady ? n_vblocks : 0));        // + the free-list workgroups of the steady-state form
+    const EvTable evt = (worker && h->wb->relax) ? EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask}
+                                                   : EvTable{nullptr, nullptr, 0u};
     if (h->vec) {
       hipLaunchKernelGGL((k_evict_stage<f32x4>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list);
+                         h->free_list, evt);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                            c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
@@ -2713,7 +2959,7 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
       hipLaunchKernelGGL((k_evict_stage<float>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list);
+                         h->free_list, evt);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
                            c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
@@ -2752,6 +2998,18 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   if (tail)
     x.tail = {tail->n_batches, tail->nnz_per_batch, tail->src_keys, tail->offsets, tail->offsets_are_i64,
               tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset, tail->hook_features, tail->keys_out};
+  // Worker transport, the early-maps order: which slot every missed row gets is known here, and neither the maps nor
+  // the slots / keys of the call's ids need the rows themselves -- so they are launched BEFORE the stream parks and
+  // run while the admission is on the wire (it started behind k_emit); what is left behind the wait is the copy of
+  // the arrived rows into their slots.  60-70 us per window-sized call off the cache-op stream's cycle (front ->
+  // admission -> tail), which on hosts with a slower PCIe path is what bounds the pipeline.
+  static const int early_env = [] { const char* e = getenv("CE_EARLY_MAPS"); return e ? atoi(e) : 1; }();
+  x.early = worker && early_env != 0;
+  if (prof) prof->early[pslot] = x.early;
+  if (x.early) {
+    rc = launch_maps_and_slots(h);
+    if (rc) return rc;
+  }
   if (split) {
     CE_REQUIRE(!capturing, CE_ERR_UNSUPPORTED, "a cache op in two halves cannot be captured in a hipGraph");
     x.active = true;
@@ -2761,29 +3019,70 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   return prepare_ids_second_half(h);
 }
 
-static int prepare_ids_second_half(ce_cache* h) {
+// maps of the admitted rows + the slots (and the window's keys) of the call's ids: behind the row transfer, or -- the
+// worker transport's early-maps order -- before it
+static int launch_maps_and_slots(ce_cache* h) {
   ce_cache::Pending& x = h->pend;
-  x.active = false;
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
   const int64_t C = c.cuda_row_num, n = x.n;
   int64_t* const slots_out = x.slots_out;
   hipStream_t s = x.s;
   const ce_stream_t stream = (ce_stream_t)s;
-  const bool worker = x.worker, capturing = x.capturing;
-  const long long in_job = x.in_job, seq_arg = x.seq_arg;
-  const int cap_groups = x.cap_groups, gpb = 256 >> h->g_log2, lfu = c.evict_strategy == CE_EVICT_LFU;
-  const dim3 swap_block(x.swap_threads);
-  ce_call_stats_t* const ring = h->ring_dev;
+  const int lfu = c.evict_strategy == CE_EVICT_LFU;
   PhaseProf* const prof = (h->prof && (const void*)h->prof == x.prof) ? h->prof : nullptr;
-  const int pslot = x.pslot;
-  int pmark = x.pmark;
   const decltype(x.tail)* const tail = x.has_tail ? &x.tail : nullptr;
   int rc = CE_OK;
-#define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
+  hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
+                     (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
+                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl, h->ring_dev,
+                     x.seq_arg, x.worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, x.in_job,
+                     x.early ? 1 : 0);
+  if (!x.early && prof) (void)hipEventRecord(prof->ev[x.pslot][x.pmark++], s);      // end of "admit_swap"
+  if (n > 0 && lfu) {
+    // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
+    hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, slots_out, n,
+                       c.inverted_cached_idx, c.freq_cnter, (const Ctl*)h->ctl);
+    if (tail) {
+      rc = tail->src_keys
+               ? ce_bag_presort_window_src(slots_out, tail->nnz_per_batch, tail->n_batches, C, tail->offsets,
+                                           tail->offsets_are_i64, tail->offsets_batch_stride, tail->num_bags,
+                                           tail->include_last_offset, tail->hook_features, tail->keys_out, stream)
+               : ce_bag_presort_window(slots_out, tail->nnz_per_batch, tail->n_batches, C, tail->keys_out, stream);
+      if (rc) return rc;
+    }
+  } else if (n > 0 && tail) {
+    // rows -> slots AND the window's keys in one pass (k_slots would write 8 bytes per id for the presort to read back)
+    rc = presort_window_from_rows(slots_out, tail->nnz_per_batch, tail->n_batches, C, c.inverted_cached_idx,
+                                  &h->ctl->status, tail->src_keys, tail->offsets, tail->offsets_are_i64,
+                                  tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset,
+                                  tail->hook_features, tail->keys_out, s);
+    if (rc) return rc;
+  } else if (n > 0) {
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, slots_out, n, c.inverted_cached_idx,
+                       (const Ctl*)h->ctl);
+  }
+  if (prof) (void)hipEventRecord(prof->ev[x.pslot][x.pmark++], s);                   // end of "ids_to_slots"
+  return CE_OK;
+}
+
+static int prepare_ids_second_half(ce_cache* h) {
+  ce_cache::Pending& x = h->pend;
+  x.active = false;
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  const int64_t n = x.n;
+  hipStream_t s = x.s;
+  const bool worker = x.worker, capturing = x.capturing;
+  const long long in_job = x.in_job;
+  const int cap_groups = x.cap_groups, gpb = 256 >> h->g_log2;
+  const dim3 swap_block(x.swap_threads);
+  PhaseProf* const prof = (h->prof && (const void*)h->prof == x.prof) ? h->prof : nullptr;
+  const int pslot = x.pslot;
+  int rc = CE_OK;
   if (worker) {
-    // the missed rows arrive in in_stage through the admission worker's hipMemcpyAsync pieces; this stream parks in
-    // the command processor until the worker's hipStreamWriteValue64 behind the last piece has executed
+    // the missed rows arrive in in_stage through the admission worker; this stream parks in the command processor
+    // until the worker's store to the pinned word it polls
     const long long scap = (long long)L.stage_rows;
     CE_HIP_CHECK(hipStreamWaitValue64(s, h->wb->sig, (uint64_t)in_job, hipStreamWaitValueGte, ~0ull));
     static const int unpack_blocks = [] { const char* e = getenv("CE_UNPACK_BLOCKS"); return e ? atoi(e) : 1024; }();
@@ -2792,7 +3091,8 @@ static int prepare_ids_second_half(ce_cache* h) {
       hipLaunchKernelGGL((k_unpack_admitted<f32x4>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const f32x4*)h->in_stage, (f32x4*)c.cache_weight,
                          h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
-                         in_job);
+                         in_job, x.early ? 1 : 0, (const int32_t*)h->miss_list, c.cached_idx_map,
+                         c.inverted_cached_idx, h->ring_dev, x.seq_arg);
       if (L.list_cap > L.stage_rows)      // more misses than the staging holds (rare): the rest is read zero-copy
         hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
                            (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
@@ -2801,7 +3101,8 @@ static int prepare_ids_second_half(ce_cache* h) {
       hipLaunchKernelGGL((k_unpack_admitted<float>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const float*)h->in_stage, (float*)c.cache_weight,
                          h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
-                         in_job);
+                         in_job, x.early ? 1 : 0, (const int32_t*)h->miss_list, c.cached_idx_map,
+                         c.inverted_cached_idx, h->ring_dev, x.seq_arg);
       if (L.list_cap > L.stage_rows)
         hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
                            (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
@@ -2863,36 +3164,12 @@ static int prepare_ids_second_half(ce_cache* h) {
       }
     }
   }
-  hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
-                     (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl, ring,
-                     seq_arg, worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, in_job);
-  CE_PHASE();
-  if (n > 0 && lfu) {
-    // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
-    hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, slots_out, n,
-                       c.inverted_cached_idx, c.freq_cnter, (const Ctl*)h->ctl);
-    if (tail) {
-      rc = tail->src_keys
-               ? ce_bag_presort_window_src(slots_out, tail->nnz_per_batch, tail->n_batches, C, tail->offsets,
-                                           tail->offsets_are_i64, tail->offsets_batch_stride, tail->num_bags,
-                                           tail->include_last_offset, tail->hook_features, tail->keys_out, stream)
-               : ce_bag_presort_window(slots_out, tail->nnz_per_batch, tail->n_batches, C, tail->keys_out, stream);
-      if (rc) return rc;
-    }
-  } else if (n > 0 && tail) {
-    // rows -> slots AND the window's keys in one pass (k_slots would write 8 bytes per id for the presort to read back)
-    rc = presort_window_from_rows(slots_out, tail->nnz_per_batch, tail->n_batches, C, c.inverted_cached_idx,
-                                  &h->ctl->status, tail->src_keys, tail->offsets, tail->offsets_are_i64,
-                                  tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset,
-                                  tail->hook_features, tail->keys_out, s);
+  if (x.early) {
+    if (prof) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);                  // end of "admit_swap"
+  } else {
+    rc = launch_maps_and_slots(h);
     if (rc) return rc;
-  } else if (n > 0) {
-    hipLaunchKernelGGL(k_slots, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, slots_out, n, c.inverted_cached_idx,
-                       (const Ctl*)h->ctl);
   }
-  CE_PHASE();
-#undef CE_PHASE
   if (prof) prof->pending[pslot] = true;
   CE_LAUNCH_CHECK();
   if (!capturing) CE_HIP_CHECK(hipEventRecord(h->ev, s));
@@ -3145,6 +3422,7 @@ extern "C" int ce_cache_swap_stats(ce_cache_t* h, double* seconds6, int64_t* cou
     seconds4[0] = h->wb->out_wait_s; seconds4[1] = h->wb->out_busy_s;
     seconds4[2] = h->wb->in_wait_s;  seconds4[3] = h->wb->in_busy_s;
     seconds6[4] = h->wb->in_gather_s;
+    seconds6[5] = (double)h->wb->in_probed;
     counts4[0] = h->wb->out_rows; counts4[1] = h->wb->out_jobs;
     counts4[2] = h->wb->in_rows;  counts4[3] = h->wb->in_jobs;
   }

@@ -3,9 +3,13 @@
 // multi-threaded initialisation (CachedEmbeddingBag weight init uniform_(-1/N, 1/N), A.7 --
 // the reference fills 91 GB with one thread).
 #include <stdarg.h>
+#include <stdlib.h>
+#include <sys/mman.h>
 
 #include <algorithm>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "ce_common.h"
@@ -54,15 +58,11 @@ using namespace ce;
 extern "C" int ce_version(void) { return CE_API_VERSION; }
 extern "C" const char* ce_last_error(void) { return g_err; }
 
-extern "C" int ce_host_alloc(size_t bytes, int threads, void** host_ptr, void** dev_ptr) {
-  CE_REQUIRE(host_ptr && dev_ptr && bytes > 0, CE_ERR_INVALID, "bad arguments");
-  void* p = nullptr;
-  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable);
-  if (e != hipSuccess) {
-    set_error("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-    (void)hipGetLastError();
-    return CE_ERR_NOMEM;
-  }
+// Blocks that came from mmap + MADV_HUGEPAGE + hipHostRegister (ce_host_free has to undo exactly that)
+static std::mutex g_huge_m;
+static std::unordered_map<void*, size_t> g_huge;
+
+static void touch_pages(void* p, size_t bytes, int threads) {
   // touch every page from several threads so the zero-fill is not a single-thread walk
   parallel_for((int64_t)(bytes / 4096) + 1, threads, [=](int64_t lo, int64_t hi) {
     volatile char* c = (volatile char*)p;
@@ -71,6 +71,59 @@ extern "C" int ce_host_alloc(size_t bytes, int threads, void** host_ptr, void** 
       if (off < bytes) c[off] = 0;
     }
   });
+}
+
+// The swap workers' helper threads move single 512-byte rows between the table and pinned staging, every row on a
+// page of its own: on 4 KB pages each costs a TLB miss -- scratch/probe_scatter2.cpp on the bench box's EPYC 9575F,
+// 48 k rows, 6 threads: 71 ns per row and thread (0.57 ms per write-back job), 18.5 ns (0.15 ms) on 2 MB pages.
+// hipHostMalloc gives 4 KB pages where transparent huge pages are in `madvise` mode, so a large block is mapped here,
+// 2 MB-aligned, advised MADV_HUGEPAGE, first-touched and then registered.  CE_HOST_THP=0 keeps hipHostMalloc.
+static void* alloc_huge(size_t bytes, int threads, void** dev_ptr) {
+  constexpr size_t kHuge = (size_t)2 << 20;
+  const size_t len = (bytes + kHuge - 1) / kHuge * kHuge;
+  char* raw = (char*)mmap(nullptr, len + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (raw == (char*)MAP_FAILED) return nullptr;
+  char* p = (char*)(((uintptr_t)raw + kHuge - 1) / kHuge * kHuge);
+  if (p > raw) (void)munmap(raw, (size_t)(p - raw));
+  if (p + len < raw + len + kHuge) (void)munmap(p + len, (size_t)(raw + len + kHuge - (p + len)));
+  (void)madvise(p, len, MADV_HUGEPAGE);
+  touch_pages(p, len, threads);
+  if (hipHostRegister(p, len, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)munmap(p, len);
+    return nullptr;
+  }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    d = p;
+  }
+  *dev_ptr = d;
+  std::lock_guard<std::mutex> g(g_huge_m);
+  g_huge[p] = len;
+  return p;
+}
+
+extern "C" int ce_host_alloc(size_t bytes, int threads, void** host_ptr, void** dev_ptr) {
+  CE_REQUIRE(host_ptr && dev_ptr && bytes > 0, CE_ERR_INVALID, "bad arguments");
+  static const int thp_env = [] { const char* e = getenv("CE_HOST_THP"); return e ? atoi(e) : 1; }();
+  if (thp_env != 0 && bytes >= ((size_t)64 << 20)) {
+    void* d = nullptr;
+    if (void* p = alloc_huge(bytes, threads, &d)) {
+      *host_ptr = p;
+      *dev_ptr = d;
+      return CE_OK;
+    }
+    // (no address space / registration refused: the plain pinned allocation below)
+  }
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable);
+  if (e != hipSuccess) {
+    set_error("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return CE_ERR_NOMEM;
+  }
+  touch_pages(p, bytes, threads);
   void* d = nullptr;
   if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
     (void)hipGetLastError();
@@ -83,6 +136,20 @@ extern "C" int ce_host_alloc(size_t bytes, int threads, void** host_ptr, void** 
 
 extern "C" int ce_host_free(void* host_ptr) {
   if (!host_ptr) return CE_OK;
+  size_t len = 0;
+  {
+    std::lock_guard<std::mutex> g(g_huge_m);
+    auto it = g_huge.find(host_ptr);
+    if (it != g_huge.end()) {
+      len = it->second;
+      g_huge.erase(it);
+    }
+  }
+  if (len) {
+    CE_HIP_CHECK(hipHostUnregister(host_ptr));
+    (void)munmap(host_ptr, len);
+    return CE_OK;
+  }
   CE_HIP_CHECK(hipHostFree(host_ptr));
   return CE_OK;
 }

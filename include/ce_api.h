@@ -54,11 +54,17 @@ extern "C" {
                                     host table by a worker thread inside the library; missed rows are brought into
                                     an HBM staging block under the control of a second worker thread -- it waits for
                                     the miss list and for earlier write-backs to land, then either launches a
-                                    16-workgroup kernel on a private stream that reads them out of the mapped table
-                                    (default), or gathers them into pinned staging and copies that with
+                                    small kernel on a private stream that reads them out of the mapped table
+                                    (default; it does not wait for the write-back of the call just before: a row that
+                                    call evicted is taken out of its staging block, still in HBM), or gathers them
+                                    into pinned staging and copies that with
                                     hipMemcpyAsync (CE_WORKER_ADMIT=sdma, and tables without a device mapping) --
-                                    and the cache-op stream waits for them in a hipStreamWaitValue64 while it selects
-                                    and stages the victims.  prepare_ids stays
+                                    and the cache-op stream waits for them in a hipStreamWaitValue64 after it has
+                                    selected and staged the victims, updated the maps and written the call's slots
+                                    (and keys); the arrived rows are then copied into their slots.  An admission the
+                                    worker reports lost (a HIP call of its own failed / timed out) gives the call
+                                    CE_ERR_HIP and takes the rows' map entries back; the slots / keys the call wrote
+                                    are then meaningless and every later call fails.  prepare_ids stays
                                     one asynchronous call, but returns before the host table has the evicted rows
                                     (ce_cache_writeback_wait / ce_cache_flush make it current).  Not capture-safe.
                                     The library does not trust the environment for this: the first call on a stream
@@ -89,7 +95,9 @@ int ce_stream_destroy(ce_stream_t stream);
  * Host table (the `weight` of CachedParamMgr, A.1; `pin_weight=True` at
  * benchmark/benchmark_fbgemm_uvm.py:98-105).  Pinned + device-mapped host memory.
  * ce_host_alloc pins `bytes` (first-touched by `threads` workers so a 91 GB table is
- * spread over the NUMA nodes); ce_host_register pins memory the caller already owns
+ * spread over the NUMA nodes; blocks of 64 MB and more are mapped 2 MB-aligned with
+ * MADV_HUGEPAGE and then registered -- the swap workers touch one row per page -- unless
+ * CE_HOST_THP=0 or the registration is refused); ce_host_register pins memory the caller already owns
  * (e.g. a `_weight` tensor).  Both return in *dev_ptr the address device code must use.
  */
 int ce_host_alloc(size_t bytes, int threads, void** host_ptr, void** dev_ptr);
@@ -423,7 +431,9 @@ int ce_cache_writeback_wait(ce_cache_t* h);
 /* Worker-side accounting of the row swap (upstream's swap_out_bandwidth / swap_in_bandwidth, printed by
  * print_comm_stats, recsys/dlrm_main.py:294): seconds6 = {out: waiting for staging, out: copying + scattering,
  * in: waiting for the miss list and earlier write-backs, in: gathering + copying, in: of which gathering +
- * enqueueing the copies, reserved}, counts4 = {rows out, jobs out, rows in, jobs in}. */
+ * enqueueing the copies, (a count, not seconds) admission jobs that ran while the previous call's write-back was
+ * still on its way -- the rows that call evicted were taken from its staging buffer in HBM}, counts4 = {rows out,
+ * jobs out, rows in, jobs in}. */
 int ce_cache_swap_stats(ce_cache_t* h, double* seconds6, int64_t* counts4);
 /* upstream buffer_size / LimitBuffIndexCopyer: rows > 0 bounds the pinned + device staging of the STAGED
  * transport to `rows` rows; larger swaps walk it in chunks.  0 (default) = stage a whole swap at once. */

@@ -59,15 +59,20 @@ def test_golden_streams_worker(name, strategy, admit, monkeypatch):
     assert mgr.writeback_stats()["jobs"] == calls
 
 
-@pytest.mark.parametrize("admit", ["kernel", "sdma"])
+@pytest.mark.parametrize("admit", ["kernel", "kernel_slow_writeback", "sdma"])
 @pytest.mark.parametrize("strategy", ["dataset", "lfu"])
 @pytest.mark.parametrize("depth", [0, 1])
 @pytest.mark.parametrize("N,C,D,per_call", [(6000, 700, 128, 300), (20000, 1500, 32, 500), (3001, 257, 20, 100)])
 def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call, admit, monkeypatch):
     """Every call asks for half of the rows the previous call evicted (plus fresh ones): their only up-to-date copy is
     the previous call's staging buffer while the worker is still copying it out.  Cache payloads are compared after
-    every call, the host table at the end and at two intermediate writeback_wait() points."""
-    monkeypatch.setenv("CE_WORKER_ADMIT", admit)
+    every call, the host table at the end and at two intermediate writeback_wait() points.
+    kernel_slow_writeback: every write-back job starts 2 ms late (test hook), so the kernel admission of the next call
+    runs before it has landed and must take those rows out of the staging buffer (it only waits for the job before)."""
+    slow = admit == "kernel_slow_writeback"
+    monkeypatch.setenv("CE_WORKER_ADMIT", "kernel" if slow else admit)
+    if slow:
+        monkeypatch.setenv("CE_WORKER_OUT_DELAY_US", "2000")
     ce = _ce()
     from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
     rng = np.random.default_rng(N * 7 + C + depth)
@@ -108,6 +113,8 @@ def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call,
     np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
     st = mgr.writeback_stats()
     assert st["rows"] == sum(ora.num_write_back_history)
+    if slow:
+        assert st["in_jobs_before_writeback_landed"] >= 10, st
 
 
 def test_transport_switches_keep_the_table_consistent():
