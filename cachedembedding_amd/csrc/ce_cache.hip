@@ -1538,7 +1538,14 @@ namespace ce {
 class RowPool {
  public:
   explicit RowPool(int n) {
-    for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+    // the helpers move rows between the host table and pinned staging: keep them on the GPU's NUMA node
+    cpu_set_t set;
+    const bool near = near_gpu_cpus(&set);
+    for (int i = 0; i < n; ++i)
+      workers_.emplace_back([this, i, near, set] {
+        if (near) (void)sched_setaffinity(0, sizeof set, &set);
+        run(i);
+      });
   }
   ~RowPool() {
     {
@@ -1802,6 +1809,7 @@ struct SwapEngine {
 
   void run_out() {
     (void)hipSetDevice(device);
+    bind_thread_near_gpu();
     tight_timer_slack();
     for (;;) {
       long long job;
@@ -1888,6 +1896,7 @@ struct SwapEngine {
 
   void run_in() {
     (void)hipSetDevice(device);
+    bind_thread_near_gpu();
     tight_timer_slack();
     for (;;) {
       long long job, need_out;

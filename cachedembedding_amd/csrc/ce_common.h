@@ -1,6 +1,7 @@
 // Shared helpers for the HIP sources of libce_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -58,6 +59,14 @@ int presort_window_from_rows(int64_t* slots_io, int64_t nnz_per_batch, int64_t n
                              const int32_t* inverted, const int* status, int32_t src_keys, const void* offsets,
                              int32_t offsets_are_i64, int64_t offsets_batch_stride, int64_t num_bags,
                              int32_t include_last_offset, int64_t hook_features, uint64_t* keys_out, hipStream_t stream);
+
+// ce_host.hip: pins the CALLING thread to the CPUs of the current GPU's NUMA node (sysfs local_cpulist of its PCI
+// function, intersected with the CPUs the process may use); no-op when that cannot be read or CE_NUMA_BIND=0.  For
+// the library's own threads only -- the swap workers, their helpers and the first touch of ce_host_alloc -- so that
+// the host table and the staging buffers sit behind the GPU's own root complex.
+void bind_thread_near_gpu();
+// the same CPU set for threads that have not selected the device themselves (taken by their creator); false = none
+bool near_gpu_cpus(cpu_set_t* out);
 
 // lanes cooperating on one embedding row: 16 B per lane, power of two, at most one wave
 static inline int group_lanes_for_dim(int dim) {

@@ -2,6 +2,8 @@
 // SURVEY.md Appendix A.1 / pin_weight at benchmark/benchmark_fbgemm_uvm.py:98-105) and its
 // multi-threaded initialisation (CachedEmbeddingBag weight init uniform_(-1/N, 1/N), A.7 --
 // the reference fills 91 GB with one thread).
+#include <ctype.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <sys/mman.h>
@@ -30,6 +32,51 @@ static inline uint64_t splitmix64(uint64_t x) {
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
+}
+
+// CPUs next to the current GPU (its PCI function's local_cpulist) that this process may run on
+static bool gpu_local_cpus(cpu_set_t* out) {
+  int dev = 0;
+  char bdf[64] = {0};
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  char line[1024] = {0};
+  const bool got = fgets(line, sizeof line, f) != nullptr;
+  fclose(f);
+  if (!got) return false;
+  cpu_set_t allowed;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+  CPU_ZERO(out);
+  int n = 0;
+  for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int k = sscanf(tok, "%d-%d", &a, &b);
+    if (k < 1) continue;
+    if (k == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (c >= 0 && CPU_ISSET(c, &allowed)) {
+        CPU_SET(c, out);
+        ++n;
+      }
+  }
+  return n > 0;
+}
+
+bool near_gpu_cpus(cpu_set_t* out) {
+  static const int on = [] { const char* e = getenv("CE_NUMA_BIND"); return e ? atoi(e) : 1; }();
+  return on != 0 && gpu_local_cpus(out);
+}
+
+void bind_thread_near_gpu() {
+  cpu_set_t set;
+  if (near_gpu_cpus(&set)) (void)sched_setaffinity(0, sizeof set, &set);
 }
 
 template <typename F>
@@ -63,14 +110,29 @@ static std::mutex g_huge_m;
 static std::unordered_map<void*, size_t> g_huge;
 
 static void touch_pages(void* p, size_t bytes, int threads) {
-  // touch every page from several threads so the zero-fill is not a single-thread walk
-  parallel_for((int64_t)(bytes / 4096) + 1, threads, [=](int64_t lo, int64_t hi) {
-    volatile char* c = (volatile char*)p;
-    for (int64_t i = lo; i < hi; ++i) {
-      const size_t off = (size_t)i * 4096;
-      if (off < bytes) c[off] = 0;
-    }
-  });
+  // touch every page from several threads so the zero-fill is not a single-thread walk; threads of their own (never
+  // the caller's), pinned next to the GPU: first touch decides which NUMA node a page lives on, and the swap reads
+  // and writes single rows of this block over the GPU's PCIe link
+  int dev = 0;
+  const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+  const int64_t pages = (int64_t)(bytes / 4096) + 1;
+  const int t = (int)std::max<int64_t>(1, std::min<int64_t>(threads, pages / 4096 + 1));
+  const int64_t per = (pages + t - 1) / t;
+  std::vector<std::thread> pool;
+  for (int i = 0; i < t; ++i) {
+    const int64_t lo = i * per, hi = std::min<int64_t>(pages, lo + per);
+    if (lo >= hi) break;
+    pool.emplace_back([=] {
+      if (have_dev) (void)hipSetDevice(dev);
+      bind_thread_near_gpu();
+      volatile char* c = (volatile char*)p;
+      for (int64_t j = lo; j < hi; ++j) {
+        const size_t off = (size_t)j * 4096;
+        if (off < bytes) c[off] = 0;
+      }
+    });
+  }
+  for (auto& th : pool) th.join();
 }
 
 // The swap workers' helper threads move single 512-byte rows between the table and pinned staging, every row on a
