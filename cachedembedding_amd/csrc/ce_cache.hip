@@ -3007,13 +3007,16 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   if (tail)
     x.tail = {tail->n_batches, tail->nnz_per_batch, tail->src_keys, tail->offsets, tail->offsets_are_i64,
               tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset, tail->hook_features, tail->keys_out};
-  // Worker transport, the early-maps order: which slot every missed row gets is known here, and neither the maps nor
-  // the slots / keys of the call's ids need the rows themselves -- so they are launched BEFORE the stream parks and
-  // run while the admission is on the wire (it started behind k_emit); what is left behind the wait is the copy of
-  // the arrived rows into their slots.  60-70 us per window-sized call off the cache-op stream's cycle (front ->
-  // admission -> tail), which on hosts with a slower PCIe path is what bounds the pipeline.
-  static const int early_env = [] { const char* e = getenv("CE_EARLY_MAPS"); return e ? atoi(e) : 1; }();
-  x.early = worker && early_env != 0;
+  // Worker transport, the early-maps order (CE_EARLY_MAPS=1; off by default): which slot every missed row gets is
+  // known here, and neither the maps nor the slots / keys of the call's ids need the rows themselves -- so they can be
+  // launched BEFORE the stream parks and run while the admission is on the wire (it started behind k_emit); what is
+  // left behind the wait is the copy of the arrived rows into their slots.  Measured: the slot / key kernel is slower
+  // beside the admission kernel than alone behind it (window-sized calls 0.10 -> 0.15 ms, prefetch_num 1 0.03 ->
+  // 0.08 ms), which eats what the shorter tail gives: the bench line is unchanged within its noise (2.40 against
+  // 2.43 G, four interleaved runs each) and Kaggle 5 % at prefetch_num 1, where the chain IS the step, loses 12 %
+  // (1.08 against 1.22 G).  Kept for hosts whose admission is much slower than this one's.
+  const char* const early_env = getenv("CE_EARLY_MAPS");
+  x.early = worker && early_env && atoi(early_env) != 0;
   if (prof) prof->early[pslot] = x.early;
   if (x.early) {
     rc = launch_maps_and_slots(h);

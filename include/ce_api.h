@@ -60,11 +60,11 @@ extern "C" {
                                     into pinned staging and copies that with
                                     hipMemcpyAsync (CE_WORKER_ADMIT=sdma, and tables without a device mapping) --
                                     and the cache-op stream waits for them in a hipStreamWaitValue64 after it has
-                                    selected and staged the victims, updated the maps and written the call's slots
-                                    (and keys); the arrived rows are then copied into their slots.  An admission the
-                                    worker reports lost (a HIP call of its own failed / timed out) gives the call
-                                    CE_ERR_HIP and takes the rows' map entries back; the slots / keys the call wrote
-                                    are then meaningless and every later call fails.  prepare_ids stays
+                                    selected and staged the victims; the arrived rows are then copied into their
+                                    slots, the maps updated and the call's slots (and keys) written (CE_EARLY_MAPS=1:
+                                    maps, slots and keys before the wait).  An admission the worker reports lost (a
+                                    HIP call of its own failed / timed out) gives the call CE_ERR_HIP with nothing
+                                    marked resident; every later call fails.  prepare_ids stays
                                     one asynchronous call, but returns before the host table has the evicted rows
                                     (ce_cache_writeback_wait / ce_cache_flush make it current).  Not capture-safe.
                                     The library does not trust the environment for this: the first call on a stream

@@ -32,11 +32,14 @@ def _state_equal(mgr, ora, lfu):
     np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
 
 
-@pytest.mark.parametrize("admit", ["kernel", "sdma"])
+@pytest.mark.parametrize("admit", ["kernel", "kernel_early_maps", "sdma"])
 @pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"),
                                            ("cache_lfu_freq", "lfu"), ("cache_lfu_nofreq", "lfu")])
 def test_golden_streams_worker(name, strategy, admit, monkeypatch):
     ce = _ce()
+    if admit == "kernel_early_maps":                  # maps + slots launched before the admission wait (read per call)
+        monkeypatch.setenv("CE_EARLY_MAPS", "1")
+        admit = "kernel"
     monkeypatch.setenv("CE_WORKER_ADMIT", admit)      # read when the manager's swap engine is created
     z = np.load(GOLD / f"{name}.npz")
     N, C, D, n_ids, calls, warm = (int(v) for v in z["meta"])
@@ -73,6 +76,7 @@ def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call,
     monkeypatch.setenv("CE_WORKER_ADMIT", "kernel" if slow else admit)
     if slow:
         monkeypatch.setenv("CE_WORKER_OUT_DELAY_US", "2000")
+        monkeypatch.setenv("CE_EARLY_MAPS", "1" if depth else "0")      # (and the early-maps order in half of the cases)
     ce = _ce()
     from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
     rng = np.random.default_rng(N * 7 + C + depth)
