@@ -1862,7 +1862,7 @@ struct SwapEngine {
           out_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
             // every row lands on a page of its own: a read prefetch of ANOTHER line of the page of the row 8 ahead
             // starts its page walk early (the row's own lines are streamed past the cache and must not be pulled
-            // in): 71 -> 48 ns per row on 4 KB pages, 18.5 -> 13 on 2 MB pages (scratch/probe_scatter2.cpp)
+            // in): 71 -> 48 ns per row on 4 KB pages, 18.5 -> 13 on 2 MB pages (profiles/probes/probe_scatter2.cpp)
             for (int64_t i = lo; i < hi; ++i) {
               if (i + 8 < hi) __builtin_prefetch((const void*)((uintptr_t)(tb + (size_t)ri[i + 8] * d) ^ 2048u), 0, 0);
               row_copy_stream(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
@@ -1919,7 +1919,7 @@ struct SwapEngine {
         const long long must = (admit_by_kernel && relax) ? need_out - 1 : need_out;
         std::unique_lock<std::mutex> g(m);
         cv_done.wait(g, [&] { return out_done >= must || err != 0; });
-        probe = out_done < need_out;
+        probe = admit_by_kernel && relax && out_done < need_out;
       }
       const auto t1 = std::chrono::steady_clock::now();
       long long n = mail[2].count;

@@ -55,7 +55,8 @@ static bool gpu_local_cpus(cpu_set_t* out) {
   if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
   CPU_ZERO(out);
   int n = 0;
-  for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+  char* save = nullptr;      // (several library threads come through here at once: no strtok)
+  for (char* tok = strtok_r(line, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
     int a = 0, b = 0;
     const int k = sscanf(tok, "%d-%d", &a, &b);
     if (k < 1) continue;
@@ -136,7 +137,7 @@ static void touch_pages(void* p, size_t bytes, int threads) {
 }
 
 // The swap workers' helper threads move single 512-byte rows between the table and pinned staging, every row on a
-// page of its own: on 4 KB pages each costs a TLB miss -- scratch/probe_scatter2.cpp on the bench box's EPYC 9575F,
+// page of its own: on 4 KB pages each costs a TLB miss -- profiles/probes/probe_scatter2.cpp on the bench box's EPYC 9575F,
 // 48 k rows, 6 threads: 71 ns per row and thread (0.57 ms per write-back job), 18.5 ns (0.15 ms) on 2 MB pages.
 // hipHostMalloc gives 4 KB pages where transparent huge pages are in `madvise` mode, so a large block is mapped here,
 // 2 MB-aligned, advised MADV_HUGEPAGE, first-touched and then registered.  CE_HOST_THP=0 keeps hipHostMalloc.

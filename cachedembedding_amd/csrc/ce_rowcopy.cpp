@@ -1,7 +1,7 @@
 // Host-side row copy for the swap workers of libce_hip (plain C++: x86 intrinsics stay out of the HIP passes).
 //
 // A worker helper moves 512-byte rows between the host table (random row addresses) and contiguous pinned staging.
-// Measured on the bench box's EPYC 9575F (scratch/probe_scatter.cpp: 54 k rows, 6 threads): into the TABLE a plain
+// Measured on the bench box's EPYC 9575F (profiles/probes/probe_scatter.cpp: 54 k rows, 6 threads): into the TABLE a plain
 // memcpy pays a read-for-ownership miss per destination line (0.81 ms) and 16-byte non-temporal stores are no better
 // (0.84 ms); 64-byte (AVX-512) / 32-byte (AVX2) non-temporal stores write whole lines without reading them (0.61 ms).
 // Into the STAGING buffer (sequential) memcpy and 64-byte non-temporal stores tie (0.42 ms), 16-byte ones lose (0.54).
