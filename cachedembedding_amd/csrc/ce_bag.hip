@@ -1348,11 +1348,12 @@ static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t 
   static const int il_env = [] { const char* e = getenv("CE_BWD_INTERLEAVE"); return e ? atoi(e) : 1; }();
   p.interleave = il_env;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
-  // 8 workgroups per CU, i.e. 16384 shares of ~26 keys at the bench shape.  Alone on the GPU the share size hardly
-  // matters (2 / 3 / 4 / 6 / 8 per CU: 55.5 / 54 / 58.5 / 53.7 / 55.8 us); beside the cache op's kernels it does --
-  // a workgroup that gets its CU late holds the whole launch back by its share: 77 / 74 / 70.5 / 67 / 68 us
-  // (profiles/r04_*: forward 16/CU + backward 8/CU take the bench line from 2.91 to 3.03-3.07 G over 10 runs each)
-  static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
+  // 6 workgroups per CU, i.e. 12288 shares of ~35 keys at the bench shape.  Alone on the GPU the share size matters
+  // little (2 / 3 / 4 / 5 / 6 / 8 / 12 per CU: 55.5 / 54 / 58.5 / 56 / 53.7 / 55.8 / 58.6 us); beside the cache op's
+  // kernels it does -- a workgroup that gets its CU late holds the whole launch back by its share: 77 / 74 / 70.5 /
+  // 67.5 / 67 / 68 / 70.5 us (profiles/r04_late/grid_sweep_*.txt: forward 16/CU + backward 6 or 8/CU take the bench
+  // line from 2.91 to 3.02-3.03 G over 10 runs each; 6 is the one that is also fastest alone)
+  static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 6; }();
   static const int excl_env = [] { const char* e = getenv("CE_BWD_EXCL"); return e ? atoi(e) : 1; }();
   const int ngroups = 256 >> p.g_log2;
   // small inputs: one share of >= 16 keys per lane group
