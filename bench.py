@@ -68,6 +68,11 @@ def parse():
                     help="no side stream: the cache op of window k+1 is issued on the training stream in two halves "
                          "around the steps of window k (GraphedWindow(interleaved=True)); its kernels then never run "
                          "beside the bag kernels, the PCIe admission still overlaps with training")
+    ap.add_argument("--arrangement", default="auto", choices=["auto", "overlap", "interleaved"],
+                    help="where the next window's cache op runs: beside this window's steps on a side stream (overlap), "
+                         "in two halves around them on the training stream (interleaved; = --interleaved), or whichever "
+                         "of the two measures faster in an untimed trial after the warm-up (auto, the default: which one "
+                         "wins depends on the hour the shared host has -- DESIGN.md section 4)")
     ap.add_argument("--cache_cus", type=int, default=0, help="CUs reserved for the side-stream cache op (0 = share all)")
     ap.add_argument("--no_presort", action="store_true", help="sort 1024-lookup tiles inside every backward launch "
                     "instead of grouping the window's slots by row once per window on the cache-op stream "
@@ -380,6 +385,38 @@ def main():
     barrier()
     warm_s = time.perf_counter() - tw
     note(f"warmup done ({W} steps, {1e3 * warm_s / max(W, 1):.3f} ms/step incl. pipeline fill)")
+    # ---- arrangement trial (untimed, counted as warm-up steps): both arrangements of the cache op train real windows,
+    # two blocks each in turn; the faster one is kept for everything that follows
+    arrangement = {"mode": gw.arrangement if gw is not None else ("overlap" if args.overlap else "sequential"),
+                   "chosen_by": "flag"}
+    g_trial = 0
+    if (gw is not None and gw.switchable and args.arrangement == "auto" and not args.interleaved and world == 1
+            and not skip_cache_op):
+        # windows per trial block: a block is bracketed by synchronisation, so it pays one pipeline fill and drain
+        # (~1.5 ms: a cache op that overlaps with nothing) -- 6-window blocks measured that, not the arrangement
+        T = max(8, -(-256 // P))
+        trial = {"overlap": [], "interleaved": []}
+        g = W
+        for mode in ("overlap", "interleaved", "overlap", "interleaved"):
+            need_windows(g + T * P, g)
+            gw.set_arrangement(mode)
+            barrier()
+            t0 = time.perf_counter()
+            run_range(g, g + T * P)
+            barrier()
+            trial[mode].append(1e3 * (time.perf_counter() - t0) / T)
+            g += T * P
+        best = min(trial, key=lambda m: min(trial[m]))
+        gw.set_arrangement(best)
+        g_trial = g - W
+        arrangement = {"mode": best, "chosen_by": f"trial after the warm-up: {T}-window blocks, two per arrangement in "
+                                                  "turn, the smaller minimum wins; untimed, counted in warmup_steps_run",
+                       "trial_ms_per_window": {m: [round(v, 4) for v in trial[m]] for m in trial}}
+        note(f"arrangement trial: {arrangement['trial_ms_per_window']} -> {best}")
+        W = g
+    elif gw is not None and gw.switchable and args.arrangement == "interleaved":
+        gw.set_arrangement("interleaved")
+        arrangement["mode"] = "interleaved"
     # ---- timed region.  K steps at the default sizes are 4-50 ms: a region that short measures pipeline fill and
     # drain (one cache op of ~1 ms cannot overlap with anything when both ends are synchronised), not the pipeline.
     # So: (1) one K-step block bracketed by barrier + synchronize on its own -- reported as block_ms.single, and used
@@ -580,6 +617,10 @@ def main():
                              else "mean of per-launch hipEvent brackets around eager launches")
     bwd_roof["event_samples_dropped_as_host_stalls"] = dropped[0]
     fwd_roof["avg_ms_in_pipeline"], bwd_roof["avg_ms_in_pipeline"] = fwd_pipe, bwd_pipe
+    if args.overlap:
+        # (pass B is an eager side-stream window: it says what the launches cost BESIDE the cache op's kernels, i.e. in
+        # the overlap arrangement, whichever arrangement the timed region ran in)
+        bwd_roof["avg_ms_in_pipeline_arrangement"] = fwd_roof["avg_ms_in_pipeline_arrangement"] = "overlap"
     for r in (fwd_roof, bwd_roof):
         r["frac"] = r["achieved"] / r["peak"]
         r["traffic"] = None
@@ -672,7 +713,8 @@ def main():
                    "cuda_row_num": C, "prefetch_num": P, "evict": "LFU" if args.use_lfu else "DATASET",
                    "id_dist": f"{args.dist}(s={args.skew})" + (f" + {args.uniform_frac:g} uniform" if args.uniform_frac else ""),
                    "distinct_rows_per_batch_frac": uniq_avg / (B * F * L), "host_table_GB": N * D * 4 / 1e9,
-                   "transport": transport, "overlap": bool(args.overlap), "interleaved": bool(args.interleaved),
+                   "transport": transport, "overlap": arrangement["mode"] == "overlap",
+                   "interleaved": arrangement["mode"] == "interleaved", "arrangement": arrangement,
                    "plan_ahead_windows": (gw.plan_ahead if gw is not None else 1) if args.overlap else 0,
                    "launch": "hipGraph per window" if use_graph else "python per step",
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "

@@ -212,6 +212,9 @@ class GraphedWindow:
         assert not (interleaved and (overlap or graph_cache_op or plan_ahead != 1)), \
             "interleaved replaces overlap (one stream, plan_ahead 1)"
         self.interleaved = interleaved
+        # both arrangements on one object: built with overlap=True (the side stream exists), set_arrangement() then
+        # moves the NEXT window's cache op between the side stream and the two halves on the training stream
+        self.switchable = overlap and plan_ahead == 1 and not graph_cache_op
         self._begun: Optional[int] = None          # buffer whose cache op has been begun and not finished
         # plan_ahead (overlap=True): how many windows the cache op may run ahead of training.  1: the cache op of window
         # k+1 starts when window k-1 has trained (two slot buffers, protect_depth 1).  2: it starts when window k-2 has
@@ -332,6 +335,25 @@ class GraphedWindow:
         uses the cache manager)"""
         self._finish_begun()
 
+    @property
+    def arrangement(self) -> str:
+        return "interleaved" if self.interleaved else ("overlap" if self.overlap else "sequential")
+
+    def set_arrangement(self, mode: str) -> None:
+        """'overlap' (the next window's cache op on the side stream, beside this window's steps) or 'interleaved' (its
+        two halves on the training stream, around this window's steps) for the cache ops submitted FROM NOW ON.  Which
+        one is faster depends on what the host's side of the row swap does to the kernels that run beside it (DESIGN.md
+        section 4): the bench measures both after its warm-up and keeps the faster.  Only between windows: a cache op
+        that was begun must have been finished (run() does that)."""
+        assert mode in ("overlap", "interleaved")
+        if mode == self.arrangement:
+            return
+        if not self.switchable:
+            raise ValueError("this window was not built with overlap=True, plan_ahead=1 and no cache-op graph")
+        self._finish_begun()
+        self.interleaved = mode == "interleaved"
+        self.overlap = not self.interleaved
+
     def _finish_begun(self) -> None:
         if self._begun is not None:
             self.mgr.prepare_ids_finish()
@@ -384,6 +406,12 @@ class GraphedWindow:
         if self.interleaved:
             with phase("prefetch cache"):
                 self._finish_begun()                 # (a window begun and never trained: first window, or a caller's skip)
+                if self._side is not None:
+                    # (switchable: a cache op still running on the side stream comes first -- its event stays for run())
+                    cur = torch.cuda.current_stream(self.mgr.device)
+                    for ev in self._events:
+                        if ev is not None:
+                            cur.wait_event(ev)
                 self._cache_op(cat, buf, begin_only=True)
             self._events[buf] = None
             return

@@ -140,7 +140,7 @@ def test_tablewise_parallel(world):
 
 
 @pytest.mark.parametrize("presort", [False, True, "src"])
-@pytest.mark.parametrize("mode", ["sequential", "overlap", "graph", "graph_interleaved"])
+@pytest.mark.parametrize("mode", ["sequential", "overlap", "graph", "graph_interleaved", "graph_switching"])
 def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, presort):
     """_train's window block in its three forms gives the same training trajectory as a plain full-table
     EmbeddingBag with SGD (each window's unique rows fit the cache even when two windows are protected)."""
@@ -166,16 +166,24 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
         out = emb(slots, off, hook_features=F, presorted=keys)
         out.backward(grad)
 
-    if mode in ("graph", "graph_interleaved"):
+    if mode in ("graph", "graph_interleaved", "graph_switching"):
         il = mode == "graph_interleaved"        # the cache op in two halves around the previous window's steps, one stream
+        # graph_switching: one object, the arrangement changed between windows (what bench.py's trial does)
+        plan = ["overlap", "interleaved", "interleaved", "overlap", "interleaved", "overlap", "overlap"]
         gw = GraphedWindow(emb, P, F * B, step, overlap=not il, warmup_values=[v.cuda() for v in windows[0]],
                            presort=presort, transport="worker", bag_layout=layout, interleaved=il)
         # the capture warm-up trained on window 0 twice over (eager pass + nothing else): replay that on the ref
         for v in windows[0]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
+        if mode == "graph_switching":
+            assert gw.switchable
+            gw.set_arrangement(plan[0])
         gw.submit([v.cuda() for v in windows[0]], 0)
         for w in range(nwin):
             if w + 1 < nwin:
+                if mode == "graph_switching":
+                    gw.set_arrangement(plan[w + 1])
+                    assert gw.arrangement == plan[w + 1]
                 gw.submit([v.cuda() for v in windows[w + 1]], (w + 1) % 2)
             gw.run(w % 2)
     else:
