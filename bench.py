@@ -406,11 +406,14 @@ def main():
             barrier()
             trial[mode].append(1e3 * (time.perf_counter() - t0) / T)
             g += T * P
-        best = min(trial, key=lambda m: min(trial[m]))
+        # the SLOWER of an arrangement's two blocks decides: the side-stream arrangement's blocks differ by up to 30 %
+        # (the one-stream arrangement's by < 1 %) and the timed region gets the mix, not the better block -- choosing by
+        # the minimum picked the side stream on one good block and then measured 2.67 G where the other gives 2.9
+        best = min(trial, key=lambda m: max(trial[m]))
         gw.set_arrangement(best)
         g_trial = g - W
         arrangement = {"mode": best, "chosen_by": f"trial after the warm-up: {T}-window blocks, two per arrangement in "
-                                                  "turn, the smaller minimum wins; untimed, counted in warmup_steps_run",
+                                                  "turn, the arrangement whose slower block is faster wins; untimed, counted in warmup_steps_run",
                        "trial_ms_per_window": {m: [round(v, 4) for v in trial[m]] for m in trial}}
         note(f"arrangement trial: {arrangement['trial_ms_per_window']} -> {best}")
         W = g
