@@ -514,7 +514,10 @@ class CachedParamMgr(torch.nn.Module):
                     "CUDA (with an overlapped window: unique(window k U window k+1)). Please increase cuda_row_num "
                     "or decrease the training batch size.")
             if st.value == _lib.CE_ERR_RANGE:
-                raise IndexError(f"cache op #{sq.value}: an id is outside [0, {self.num_embeddings})")
+                raise IndexError(f"cache op #{sq.value}: an id is outside [0, {self.num_embeddings}) -- every slot of "
+                                 "that call is -1.  (Since API 4 an id of -1 is a bad id on prepare_ids / "
+                                 "ce_cache_prepare_ids too; padded id lists go through prepare_ids(..., padded=True) / "
+                                 "ce_cache_prepare_ids_padded.)")
             raise _lib.CeError(st.value, f"cache op #{sq.value} failed")
 
     def acknowledge_failures(self) -> int:

@@ -1,17 +1,24 @@
 // EmbeddingBag gather-reduce forward (K12) and gradient scatter backward (K13/K14) for
 // gfx950.  Replaces F.embedding_bag + autograd + SGD.step on the cache parameter
 // (reference call sites: recsys/models/dlrm.py:99-110, benchmark/benchmark_cache.py:62-65,
-// recsys/dlrm_main.py:274-279).  Bandwidth-bound gather: no MFMA, no LDS tiles -- the
-// bag descriptors of a 64-bag tile live in one VGPR per lane and are broadcast with
-// ds_bpermute (__shfl), each row is moved by a lane group with 16-byte accesses.
-//
-// Mapping: a wave owns tiles of 64 consecutive bags.  A group of G lanes (G*16 B >= one
-// row, G = 32 for D = 128) handles one bag at a time, so a wave works on 64/G bags per
-// step.  When every bag of the tile holds exactly one id (all Criteo / Avazu batches:
-// recsys/datasets/criteo.py:129-130) the tile takes the single-id path: 64 ids are
-// fetched with one coalesced load and U independent row loads per lane are put in flight
-// before the first store.  Output stores are non-temporal (never re-read here); row loads
-// use the default policy so hot rows stay in L2 / Infinity Cache.
+// recsys/dlrm_main.py:274-279).  Bandwidth-bound gather / scatter: no MFMA.  A row is always moved by a
+// lane group of G lanes (G * 16 B >= one row, G = 32 for D = 128) with 16-byte accesses.  What is in this file:
+//   * k_bag_fwd -- the general forward (any offsets, mean, per-sample weights): a wave owns tiles of 64 consecutive
+//     bags, descriptors in one VGPR per lane broadcast with ds_bpermute; single-id tiles (all Criteo / Avazu batches:
+//     recsys/datasets/criteo.py:129-130) fetch 64 ids with one coalesced load and keep U row loads per lane in flight;
+//     tiles with multi-id bags stage their contiguous index range in LDS.
+//   * k_bag_presort_seg -- once per prefetch window: every 16384-lookup segment GROUPED by row with one LDS counting
+//     pass (8192 bucket counters, a returning LDS atomic per lookup, a scan, a scatter); optionally resolves the
+//     grad_out row of every lookup (SRC: source-row keys), the slot of every row (ROWS: the cache op's last kernel)
+//     and owner-exclusive runs (EXCL: the whole segment's keys staged in 128 KB of LDS).
+//   * k_bag_fwd_keys / k_bag_bwd_stream -- what the window pipelines and bench.py run: both walk the window's keys in
+//     contiguous shares, keys staged through a group-private LDS slice, 16 rows in flight per lane group; the forward
+//     loads a cache row once per run of equal rows, the backward folds a run and issues ONE transposed atomic row
+//     update per run.  Shares are handed out at run time when the caller provides a claim counter (claim_share).
+//   * k_bag_bwd_tile -- the backward for mean / per-sample weights / unsorted input (sorts 1024-lookup tiles in
+//     registers + LDS itself, or walks presorted segments), k_bag_bwd_rows (COO values), k_rows_axpy (row-wise exchange).
+// Output stores are non-temporal (never re-read here); row loads use the default policy so hot rows stay in
+// L2 / Infinity Cache.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -1029,7 +1036,8 @@ __global__ __launch_bounds__(256, 4) void k_bag_fwd_keys(BagParams p, int64_t to
 #pragma unroll
           for (int c = 0; c < NCH; ++c) prev[c] = v[t][c];       // a new run: its row stays in `prev` until the next head
         }
-        const int64_t orow = (int64_t)(uint32_t)k;
+        // (owner-exclusive keys -- presort_window(ids=...) -- carry kExclFlag in bit 31 of the low word: not part of the row)
+        const int64_t orow = (int64_t)((uint32_t)k & ~kExclFlag);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int ch = gl + c * G;

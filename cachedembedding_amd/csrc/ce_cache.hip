@@ -2013,6 +2013,16 @@ struct SwapEngine {
       CE_TRACE("in job %lld: rows gathered, copies enqueued", job);
       e = stream_wait_polite(in_stream);
       if (e != hipSuccess) fail(e == hipErrorNotReady ? "admission timed out (CE_WORKER_TIMEOUT_S)" : "waiting for the H2D copies", e);
+      if (probe && n >= stage_rows) {
+        // More misses than the staging holds: the rows past it are read ZERO-COPY out of the host table by the k_admit
+        // behind the parked wait (prepare_ids_second_half), and that kernel knows nothing of the previous call's
+        // staging buffer -- a row the previous call evicted through its staged part and this call misses in its tail
+        // would be read before (or while) its write-back lands.  The relaxed order therefore ends here for such a
+        // call: the stream stays parked until that write-back is in the table (mail[2].count is clamped
+        // to stage_rows, so "== stage_rows" means "possibly more").
+        std::unique_lock<std::mutex> g(m);
+        cv_done.wait(g, [&] { return out_done >= need_out || err != 0; });
+      }
       // a job that did not bring its rows in is flagged BEFORE the stream is released: k_unpack_admitted /
       // k_admit_maps then admit nothing and the call's record says CE_ERR_HIP
       if (n > 0 && failed()) __atomic_store_n(sig + 1, (unsigned long long)job, __ATOMIC_RELEASE);

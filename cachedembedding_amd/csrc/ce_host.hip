@@ -150,6 +150,9 @@ static void* alloc_huge(size_t bytes, int threads, void** dev_ptr) {
   if (p > raw) (void)munmap(raw, (size_t)(p - raw));
   if (p + len < raw + len + kHuge) (void)munmap(p + len, (size_t)(raw + len + kHuge - (p + len)));
   (void)madvise(p, len, MADV_HUGEPAGE);
+  // not inherited by fork() (DataLoader workers): a child would have to copy the page tables of the whole block, and a
+  // parent write after the fork would COW-move the page away from the physical page the GPU mapping points at
+  (void)madvise(p, len, MADV_DONTFORK);
   touch_pages(p, len, threads);
   if (hipHostRegister(p, len, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
@@ -203,13 +206,16 @@ extern "C" int ce_host_free(void* host_ptr) {
   {
     std::lock_guard<std::mutex> g(g_huge_m);
     auto it = g_huge.find(host_ptr);
-    if (it != g_huge.end()) {
-      len = it->second;
-      g_huge.erase(it);
-    }
+    if (it != g_huge.end()) len = it->second;
   }
   if (len) {
+    // the entry goes only once the registration is undone: a failed unregister leaves the block known as mmap'd
+    // memory, so a retry does not fall through to hipHostFree
     CE_HIP_CHECK(hipHostUnregister(host_ptr));
+    {
+      std::lock_guard<std::mutex> g(g_huge_m);
+      g_huge.erase(host_ptr);
+    }
     (void)munmap(host_ptr, len);
     return CE_OK;
   }

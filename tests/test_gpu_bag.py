@@ -215,7 +215,8 @@ def test_full_size_batch_properties():
     assert torch.equal(out.sum(dim=(0, 1)).isfinite().all().cpu(), torch.tensor(True))
 
 
-@pytest.mark.parametrize("presort", [False, True, "src", "src_identity", "src_excl", "src_excl_shared"])
+@pytest.mark.parametrize("presort", [False, True, "src", "src_identity", "src_excl", "src_excl_shared",
+                                     "src_excl_identity"])
 def test_full_size_step_vs_torch_cpu(presort):
     """BASELINE config [2] step at its real shape -- cache of C = 1,779,442 rows x 128, B = 16384, F = 26, long-tail
     slots -- against the calls the reference makes on the CPU (F.embedding_bag, then SGD on the summed gradient):
@@ -233,22 +234,26 @@ def test_full_size_step_vs_torch_cpu(presort):
     off = torch.arange(B * F + 1, dtype=torch.int32)
     go = torch.randn(B, F, D, generator=g) * 0.01
     wc = w.cuda().requires_grad_(True)
-    if presort in ("src_excl", "src_excl_shared"):
+    if presort in ("src_excl", "src_excl_shared", "src_excl_identity"):
         # owner-exclusive rows (k_bag_presort_seg<true, true> -> k_bag_bwd_stream<EXCL>): ids == slots here.
         # "src_excl": every feature draws from its own slice of the table, so the segments' id ranges are disjoint and
         # the plain-store path is live; "src_excl_shared": all features share the rows (ranges overlap) -> the kernel
         # must notice and keep the atomics
-        if presort == "src_excl":
+        if presort != "src_excl_shared":
             per = C // F
             idx = (idx % per) + torch.arange(F).repeat_interleave(B) * per
         keys = presort_window(idx.cuda().view(1, -1), C, offsets=off.cuda(), include_last_offset=True,
-                              hook_features=F, ids=idx.cuda().view(1, -1))[0]
+                              hook_features=F, ids=idx.cuda().view(1, -1),
+                              identity_bags=presort == "src_excl_identity")[0]
+        # "src_excl_identity" (ADVICE r4): flagged keys AND the forward from the keys -- the flag (bit 31 of the low
+        # word) is not part of the output row
+        assert keys.identity == (presort == "src_excl_identity")
         assert keys.ranges is not None and keys.ranges.shape == (F, 2)
         flagged = int(((keys.keys & 0x80000000) != 0).sum())
         assert flagged > 1000, "the presort marked no owner-exclusive runs"
         lo, hi = keys.ranges[:, 0].cpu(), keys.ranges[:, 1].cpu()
         disjoint = bool((hi[:-1] < lo[1:]).all())
-        assert disjoint == (presort == "src_excl")
+        assert disjoint == (presort != "src_excl_shared")
     elif presort in ("src", "src_identity"):
         keys = presort_window(idx.cuda().view(1, -1), C, offsets=off.cuda(), include_last_offset=True,
                               hook_features=F, identity_bags=presort == "src_identity")[0]

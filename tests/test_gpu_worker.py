@@ -174,6 +174,42 @@ def test_more_victims_than_the_staging_buffer_holds():
     np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
 
 
+def test_overflow_tail_readmits_rows_of_a_slow_previous_writeback(monkeypatch):
+    """a call that misses more rows than the staging buffer holds reads the rows past it zero-copy
+    out of the host table.  With the relaxed write-back order the previous call's write-back may still be on its way
+    then -- so rows that call evicted THROUGH ITS STAGED PART and that land in this call's overflow tail must not be
+    read before it has arrived.  Call 2's miss list is [300k, 550k) + [600k, 650k): positions >= 262144 are rows
+    [612144, 650k), which call 1 evicted among its first 262144 (staged) victims; every write-back starts 30 ms late."""
+    monkeypatch.setenv("CE_WORKER_ADMIT", "kernel")
+    monkeypatch.setenv("CE_WORKER_OUT_DELAY_US", "30000")
+    ce = _ce()
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    rng = np.random.default_rng(12)
+    N, C, D = 900_000, 300_000, 4
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 1.0)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C)
+    mgr.reorder(None, 1.0)
+    mgr.set_transport("worker")
+    calls = [np.arange(600_000, 900_000), np.arange(0, 300_000),
+             np.concatenate([np.arange(300_000, 550_000), np.arange(600_000, 650_000)])]
+    for c, ids in enumerate(calls):
+        eslots = ora.prepare_ids(ids)
+        slots = mgr.prepare_ids(torch.from_numpy(ids).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+        if c == 2:
+            tail = ora.traces[-1].miss_rows[262144:]
+            assert len(tail) and np.isin(tail, calls[0][:262144]).all()       # the case this test is about
+        np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
+        ora.cuda_cached_weight += np.float32(c + 1.0)
+        with torch.no_grad():
+            mgr.cuda_cached_weight += c + 1.0
+    mgr.flush()
+    ora.flush()
+    np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+
+
 def test_overlapped_window_raises_on_overflow():
     """strict=False pipelines must not train on -1 slots silently: the failed call is reported one window late"""
     ce = _ce()
