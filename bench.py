@@ -262,11 +262,16 @@ def main():
     gw = None
     if use_graph:
         from cachedembedding_amd.pipeline import GraphedWindow
+        plan_ahead = args.plan_ahead if args.overlap else 1
+        can_switch = args.overlap and plan_ahead == 1 and not args.graph_cache_op
+        # the arrangement is the LIBRARY's choice (GraphedWindow(arrangement="auto"), its default): bench.py only says
+        # which one it wants to see (--arrangement overlap / interleaved) and reports what the library chose
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,
                            warmup_values=[windows[0][i] for i in range(P)], cache_cus=args.cache_cus, presort=presort,
                            transport=None, bag_layout=layout,
                            graph_cache_op=args.graph_cache_op and args.overlap,
-                           plan_ahead=args.plan_ahead if args.overlap else 1, interleaved=args.interleaved)
+                           plan_ahead=plan_ahead, interleaved=args.interleaved,
+                           arrangement=args.arrangement if can_switch else None)
         trained(0, 0, P)          # GraphedWindow ran the window it was given once, eagerly, before capturing
         note("hipGraph of the window's training steps captured" +
              (" (+ the cache op as a graph of its own)" if gw._plan_graphs is not None else ""))
@@ -385,41 +390,27 @@ def main():
     barrier()
     warm_s = time.perf_counter() - tw
     note(f"warmup done ({W} steps, {1e3 * warm_s / max(W, 1):.3f} ms/step incl. pipeline fill)")
-    # ---- arrangement trial (untimed, counted as warm-up steps): both arrangements of the cache op train real windows,
-    # two blocks each in turn; the faster one is kept for everything that follows
+    # ---- the library's arrangement trial (pipeline.ArrangementTrial, inside GraphedWindow): it runs while whole windows
+    # train; the windows below are untimed and counted as warm-up steps -- the timed region starts after its verdict
     arrangement = {"mode": gw.arrangement if gw is not None else ("overlap" if args.overlap else "sequential"),
                    "chosen_by": "flag"}
     g_trial = 0
-    if (gw is not None and gw.switchable and args.arrangement == "auto" and not args.interleaved and world == 1
-            and not skip_cache_op):
-        # windows per trial block: a block is bracketed by synchronisation, so it pays one pipeline fill and drain
-        # (~1.5 ms: a cache op that overlaps with nothing) -- 6-window blocks measured that, not the arrangement
-        T = max(8, -(-256 // P))
-        trial = {"overlap": [], "interleaved": []}
+    if gw is not None and gw.trial is not None and world == 1 and not skip_cache_op:
         g = W
-        for mode in ("overlap", "interleaved", "overlap", "interleaved"):
-            need_windows(g + T * P, g)
-            gw.set_arrangement(mode)
-            barrier()
-            t0 = time.perf_counter()
-            run_range(g, g + T * P)
-            barrier()
-            trial[mode].append(1e3 * (time.perf_counter() - t0) / T)
-            g += T * P
-        # the SLOWER of an arrangement's two blocks decides: the side-stream arrangement's blocks differ by up to 30 %
-        # (the one-stream arrangement's by < 1 %) and the timed region gets the mix, not the better block -- choosing by
-        # the minimum picked the side stream on one good block and then measured 2.67 G where the other gives 2.9
-        best = min(trial, key=lambda m: max(trial[m]))
-        gw.set_arrangement(best)
+        while gw.trial.decided is None and g - W < 4096 * P:
+            need_windows(g + 8 * P, g)
+            run_range(g, g + 8 * P)
+            g += 8 * P
+            if gw.trial.blocks_enqueued:          # every block of the trial has been trained: wait for its events
+                barrier()
+                gw.settle_arrangement(wait=True)
+        barrier()
         g_trial = g - W
-        arrangement = {"mode": best, "chosen_by": f"trial after the warm-up: {T}-window blocks, two per arrangement in "
-                                                  "turn, the arrangement whose slower block is faster wins; untimed, counted in warmup_steps_run",
-                       "trial_ms_per_window": {m: [round(v, 4) for v in trial[m]] for m in trial}}
-        note(f"arrangement trial: {arrangement['trial_ms_per_window']} -> {best}")
+        arrangement = gw.trial.report()
+        arrangement["mode"] = gw.arrangement
+        arrangement["trial_windows"] = g_trial // P
+        note(f"arrangement trial (library): {arrangement['trial_ms_per_window']} -> {gw.arrangement}")
         W = g
-    elif gw is not None and gw.switchable and args.arrangement == "interleaved":
-        gw.set_arrangement("interleaved")
-        arrangement["mode"] = "interleaved"
     # ---- timed region.  K steps at the default sizes are 4-50 ms: a region that short measures pipeline fill and
     # drain (one cache op of ~1 ms cannot overlap with anything when both ends are synchronised), not the pipeline.
     # So: (1) one K-step block bracketed by barrier + synchronize on its own -- reported as block_ms.single, and used
@@ -753,7 +744,8 @@ def verify_table(ledger, embed, args, N, D, dev, note):
     """The table the run leaves behind against the closed form of SGD (oracle/closed_form.py): flush the cache, then
     for EVERY row any trained step looked up -- warm-up, both timed brackets, the profiling block and the per-kernel
     passes included -- host_table[row] vs w0[row] - lr * sum of its lookups' gradient rows (fp64), per element within
-    1e-5 * |ref| + 2e-6 + 3e-7 * sqrt(lookups of the row); rows no step looked up must still hold w0 bit for bit
+    the bound of that module (a row with ONE lookup bit for bit, <= 4 lookups 1e-5 relative to max(|ref|, sum |lr g|) with
+    no absolute floor, more 1e-5 |ref| + 3e-4 lr grad_rms sqrt(lookups)); rows no step looked up must still hold w0 bit for bit
     (sample).  w0 is regenerated from the seed (ce_host_fill_uniform is counter-based), the rows are read back through
     the table's device mapping."""
     from cachedembedding_amd import _lib

@@ -62,9 +62,132 @@ EXCLUSIVE_ROWS = bool(int(__import__("os").environ.get("CE_EXCLUSIVE_ROWS", "0")
 FUSED_WINDOW_KEYS = bool(int(__import__("os").environ.get("CE_FUSED_WINDOW_KEYS", "1")))
 
 
+ARRANGEMENTS = ("overlap", "interleaved")
+
+
+class ArrangementTrial:
+    """Which arrangement of the next window's cache op trains faster HERE, NOW -- measured by the library while it
+    trains, with hipEvents on the training stream and no host wait (recsys/dlrm_main.py:243-282 is the loop it sits in).
+
+    'overlap': the cache op of window k+1 runs on a side stream beside the steps of window k (north_star's design
+    point).  'interleaved': its two halves run on the training stream around those steps, so no kernel runs beside
+    another and only the PCIe admission overlaps.  Side by side the bag kernels and the cache-op chain slow each other
+    by about as much as the overlap hides; which way the balance tips depends on what the host's side of the row swap
+    does that hour (1.16 against 1.24 ms per window one morning, 2.03 against 1.30 on another box).
+    So the window objects measure: blocks of `block_windows` windows, `rounds` per arrangement in turn, starting with
+    the steady one ('interleaved': its blocks differ by < 1 %); the first `settle` windows of a block (the hand-over
+    between arrangements, pipeline fill) are not timed; the arrangement whose SLOWER block is the faster one is kept
+    (the side-stream arrangement's blocks differ by up to 30 %: choosing by the better block picked it on one lucky
+    block).  Every window of the trial trains for real.  `retrial_every` windows later the trial runs again."""
+
+    def __init__(self, steps_per_window: int, block_windows: int = 0, rounds: int = 2, settle: int = 2,
+                 retrial_every: int = 16384):
+        self.block_windows = int(block_windows) if block_windows else max(8, -(-256 // max(1, steps_per_window)))
+        self.settle = min(int(settle), self.block_windows - 2)
+        self.rounds, self.retrial_every = int(rounds), int(retrial_every)
+        self.decided: Optional[str] = None
+        self.trials = 0
+        self.history: List[dict] = []
+        self._start()
+
+    def _start(self) -> None:
+        self._order = ["interleaved", "overlap"] * self.rounds
+        self._blk = 0
+        self._marks: List[torch.cuda.Event] = []
+        self._blocks: List[tuple] = []            # (mode, first timed event, last event, windows between them)
+        self._since = 0
+
+    @property
+    def mode(self) -> str:
+        """arrangement for the cache ops submitted from now on"""
+        if self._blk < len(self._order):
+            return self._order[self._blk]
+        return self.decided or "interleaved"
+
+    @property
+    def running(self) -> bool:
+        return self._blk < len(self._order) or (self.decided is None and bool(self._blocks))
+
+    @property
+    def blocks_enqueued(self) -> bool:
+        """every block of the running trial has been trained (its verdict only waits for their events)"""
+        return self._blk >= len(self._order)
+
+    def reset_block(self) -> None:
+        """a window was trained in part / out of order: the current block starts over"""
+        self._marks = []
+
+    def window_done(self, stream) -> str:
+        """call when a whole window has been enqueued on `stream`; returns the arrangement to use from now on"""
+        if self._blk < len(self._order):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self._marks.append(ev)
+            if len(self._marks) == self.block_windows + 1:
+                m = self._marks
+                self._blocks.append((self._order[self._blk], m[self.settle], m[-1], self.block_windows - self.settle))
+                # the block's last event doubles as the next block's first mark (that block settles anyway)
+                self._marks = [m[-1]]
+                self._blk += 1
+        elif self.decided is None:
+            self.poll()
+        else:
+            self._since += 1
+            if self.retrial_every and self._since >= self.retrial_every:
+                self.decided_before = self.decided
+                self.decided = None
+                self._start()
+        return self.mode
+
+    def poll(self, wait: bool = False) -> Optional[str]:
+        """decide once every block's events have completed (wait=True: synchronise on them)"""
+        if self.decided is not None or self._blk < len(self._order):
+            return self.decided
+        if wait:
+            self._blocks[-1][2].synchronize()
+        if not all(b[2].query() for b in self._blocks):
+            return None
+        ms = {m: [] for m in ARRANGEMENTS}
+        for mode, e0, e1, n in self._blocks:
+            ms[mode].append(e0.elapsed_time(e1) / n)
+        self.decided = min(ms, key=lambda m: max(ms[m]))
+        self.trials += 1
+        self.history.append({"chosen": self.decided, "ms_per_window": {m: [round(v, 4) for v in ms[m]] for m in ms}})
+        self._blocks = []
+        return self.decided
+
+    def report(self) -> dict:
+        last = self.history[-1] if self.history else {}
+        return {"mode": self.decided, "chosen_by": (
+            f"the library (pipeline.ArrangementTrial): {self.block_windows}-window blocks, {self.rounds} per arrangement in "
+            f"turn while training, the first {self.settle} windows of a block untimed, hipEvents on the training stream; the "
+            "arrangement whose slower block is faster is kept"), "trial_ms_per_window": last.get("ms_per_window"),
+            "trials": self.trials}
+
+
+def _resolve_arrangement(arrangement: Optional[str], switchable: bool) -> Optional[str]:
+    """None -> the library default for a window object that can do both (CE_ARRANGEMENT, 'auto' unless set)"""
+    if arrangement is None:
+        arrangement = DEFAULT_ARRANGEMENT if switchable else None
+    if arrangement is not None and arrangement not in ("auto",) + ARRANGEMENTS:
+        raise ValueError(f"arrangement={arrangement!r}: 'auto', 'overlap' or 'interleaved'")
+    if arrangement is not None and not switchable:
+        raise ValueError("arrangement= needs a window built with overlap=True (plan_ahead 1, no cache-op graph)")
+    return arrangement
+
+
+DEFAULT_ARRANGEMENT = __import__("os").environ.get("CE_ARRANGEMENT", "auto")
+
+
 class PrefetchWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int = 1, overlap: bool = False, cache_cus: int = 0,
-                 presort: bool = False, transport: Optional[str] = "auto", bag_layout=None):
+                 presort: bool = False, transport: Optional[str] = "auto", bag_layout=None,
+                 arrangement: Optional[str] = None, arrangement_trial: Optional[dict] = None):
+        # arrangement (overlap=True only): where the submitted window's cache op runs -- 'overlap' on the side stream
+        # beside the current window's steps, 'interleaved' in two halves on the CURRENT stream (submit() enqueues the
+        # first, collect() the second: the caller's training steps lie in between), 'auto' (the default): both are
+        # measured while training and the faster one is kept (ArrangementTrial; arrangement_trial = its keyword
+        # arguments).  The slots, the keys and the cache state are the same either way.
         # bag_layout = (offsets, include_last_offset, hook_features) of the batches (presort=True, mode='sum' without
         # per-sample weights): the window's keys become source-row keys (functional.SrcKeys), which the backward
         # streams over without a per-tile bag search
@@ -95,23 +218,45 @@ class PrefetchWindow:
             if transport and transport != "auto":
                 self.mgr.set_transport(transport)
         self._auto = overlap and transport == "auto"
+        self.trial: Optional[ArrangementTrial] = None
+        self._mode = "overlap" if overlap else "sequential"
+        arrangement = _resolve_arrangement(arrangement, overlap) if (overlap or arrangement is not None) else None
+        if arrangement == "auto":
+            self.trial = ArrangementTrial(prefetch_num, **(arrangement_trial or {}))
+            self._mode = self.trial.mode
+        elif arrangement is not None:
+            self._mode = arrangement
+
+    @property
+    def arrangement(self) -> str:
+        return self._mode
+
+    def set_arrangement(self, mode: str) -> None:
+        """'overlap' / 'interleaved' for the windows submitted from now on (between collect() and submit())"""
+        assert mode in ARRANGEMENTS and self.overlap and self._pending is None
+        self._mode = mode
 
     @torch.no_grad()
-    def _cache_op(self, values: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    def _cache_op(self, values: Sequence[torch.Tensor], begin_only: bool = False) -> Optional[List[torch.Tensor]]:
+        """begin_only: enqueue the first half only (ce_cache_prepare_ids_begin) when the window has the shape that call
+        takes -- equal int64 batches, fused keys or none -- and return None if it does not (the caller then takes the
+        side stream for this window)"""
         counts = [int(v.numel()) for v in values]
         cat = values[0] if len(values) == 1 else torch.cat(list(values))
         if self._auto:
             self._auto = False
             self.mgr.set_transport(pick_transport("auto", int(cat.numel())))
         lay = self._layout or {}
-        fused = (self.presort and FUSED_WINDOW_KEYS and len(set(counts)) == 1 and counts[0] > 0
-                 and not (lay and EXCLUSIVE_ROWS) and cat.dim() == 1 and cat.dtype == torch.int64)
+        equal = len(set(counts)) == 1 and counts[0] > 0 and cat.dim() == 1 and cat.dtype == torch.int64
+        fused = self.presort and FUSED_WINDOW_KEYS and equal and not (lay and EXCLUSIVE_ROWS)
+        if begin_only and not (equal and (fused or not self.presort)):
+            return None
         with phase("prefetch cache"):                      # the reference's range name (recsys/dlrm_main.py:258)
-            if fused:       # slots and the window's keys out of one call
+            if fused or begin_only:       # slots and the window's keys out of one call
                 P_, n_ = len(counts), counts[0]
                 slots = torch.empty(P_ * n_, dtype=torch.int64, device=cat.device)
-                kbuf = torch.empty(P_, presort_len(n_), dtype=torch.int64, device=cat.device)
-                self.mgr.prepare_ids_keys(cat.view(P_, n_), slots, kbuf, **lay)
+                kbuf = torch.empty(P_, presort_len(n_), dtype=torch.int64, device=cat.device) if fused else None
+                self.mgr.prepare_ids_keys(cat.view(P_, n_), slots, kbuf, **(lay if fused else {}), _begin_only=begin_only)
             else:
                 slots = self.mgr.prepare_ids(cat)
         # split by per-batch id counts (torch.chunk in the reference is only right for equal sizes, B#13)
@@ -146,9 +291,15 @@ class PrefetchWindow:
         return slots
 
     def submit(self, values: Sequence[torch.Tensor]) -> None:
-        """Start the cache op for the NEXT window on the side stream (overlap=True)."""
+        """Start the cache op for the NEXT window: on the side stream (arrangement 'overlap'), or its first half on the
+        current stream ('interleaved'; collect() enqueues the second half behind whatever the caller trains meanwhile)."""
         assert self.overlap and self._pending is None
         cur = torch.cuda.current_stream(self.mgr.device)
+        if self._mode == "interleaved":
+            slots = self._cache_op(values, begin_only=True)
+            if slots is not None:
+                self._pending = (None, slots, self._keys_tmp)
+                return
         self._side.wait_stream(cur)          # ids were produced on the current stream
         with torch.cuda.stream(self._side):
             slots = self._cache_op(values)
@@ -168,14 +319,19 @@ class PrefetchWindow:
         # back slots of -1; raise like the reference as soon as its record has arrived (no host wait)
         self.mgr.raise_on_failed_calls()
         cur = torch.cuda.current_stream(self.mgr.device)
-        cur.wait_event(ev)
-        for s in slots:
-            s.record_stream(cur)
-        for k in keys or []:
-            (k.keys if isinstance(k, SrcKeys) else k).record_stream(cur)
-            if isinstance(k, SrcKeys) and k.ranges is not None:
-                k.ranges.record_stream(cur)
+        if ev is None:                       # interleaved: the second half, on the stream the first one went to
+            self.mgr.prepare_ids_finish()
+        else:
+            cur.wait_event(ev)
+            for s in slots:
+                s.record_stream(cur)
+            for k in keys or []:
+                (k.keys if isinstance(k, SrcKeys) else k).record_stream(cur)
+                if isinstance(k, SrcKeys) and k.ranges is not None:
+                    k.ranges.record_stream(cur)
         self.keys = keys
+        if self.trial is not None:           # a window boundary on the training stream: the trial's clock
+            self._mode = self.trial.window_done(cur)
         return slots
 
 
@@ -203,7 +359,11 @@ class GraphedWindow:
     def __init__(self, embed: CachedEmbeddingBag, prefetch_num: int, ids_per_batch: int, step_fn, overlap: bool = True,
                  warmup_values: Optional[Sequence[torch.Tensor]] = None, cache_cus: int = 0, presort: bool = False,
                  transport: Optional[str] = "auto", bag_layout=None, graph_cache_op: bool = False,
-                 plan_ahead: int = 1, interleaved: bool = False):
+                 plan_ahead: int = 1, interleaved: bool = False, arrangement: Optional[str] = None,
+                 arrangement_trial: Optional[dict] = None):
+        # arrangement: 'overlap' | 'interleaved' | 'auto' for a window built with overlap=True, plan_ahead 1 and no
+        # cache-op graph (it can do both: set_arrangement).  'auto' -- the DEFAULT for such a window -- measures both while
+        # training and keeps the faster (ArrangementTrial; `arrangement_trial` = its keyword arguments; `self.trial`).
         # interleaved (instead of overlap): NO side stream.  The cache op of window k+1 is issued on the training stream
         # in two halves around the steps of window k -- begin(k+1), graph(k), finish(k+1) (ce_cache_prepare_ids_begin /
         # _finish) -- so its kernels never run BESIDE the bag kernels (side by side they cost each other more than the
@@ -215,6 +375,9 @@ class GraphedWindow:
         # both arrangements on one object: built with overlap=True (the side stream exists), set_arrangement() then
         # moves the NEXT window's cache op between the side stream and the two halves on the training stream
         self.switchable = overlap and plan_ahead == 1 and not graph_cache_op
+        arrangement = _resolve_arrangement(arrangement, self.switchable and not interleaved) \
+            if (arrangement is not None or (self.switchable and not interleaved)) else None
+        self.trial: Optional[ArrangementTrial] = None
         self._begun: Optional[int] = None          # buffer whose cache op has been begun and not finished
         # plan_ahead (overlap=True): how many windows the cache op may run ahead of training.  1: the cache op of window
         # k+1 starts when window k-1 has trained (two slot buffers, protect_depth 1).  2: it starts when window k-2 has
@@ -305,6 +468,31 @@ class GraphedWindow:
                 for t in self._ids:
                     t.view(-1).copy_(wcat.reshape(-1))
             self._capture_plans()
+        if arrangement == "auto":
+            self.trial = ArrangementTrial(self.P, **(arrangement_trial or {}))
+            self.set_arrangement(self.trial.mode)
+        elif arrangement is not None:
+            self.set_arrangement(arrangement)
+
+    def _trial_tick(self, whole_window: bool) -> None:
+        if self.trial is None:
+            return
+        if not whole_window:
+            self.trial.reset_block()
+            return
+        mode = self.trial.window_done(torch.cuda.current_stream(self.mgr.device))
+        if mode != self.arrangement:
+            self.set_arrangement(mode)
+
+    def settle_arrangement(self, wait: bool = True) -> Optional[str]:
+        """the trial's verdict so far (None while blocks are still being trained; wait=True synchronises on the last
+        block's events once all have been enqueued) -- for a caller that wants its own measurement to start after it"""
+        if self.trial is None:
+            return self.arrangement
+        mode = self.trial.poll(wait=wait)
+        if mode is not None and mode != self.arrangement and not self.trial.running:
+            self.set_arrangement(mode)
+        return mode
 
     def _capture_plans(self) -> None:
         # the cache op + presort that fill buffer b as a graph of their own, replayed on the side stream
@@ -447,6 +635,7 @@ class GraphedWindow:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.mgr.device))
             self._read_done[buf] = ev
+        self._trial_tick(False)
 
     @torch.no_grad()
     def run_and_submit(self, buf: int, next_values: Sequence[torch.Tensor]) -> None:
@@ -494,7 +683,8 @@ class GraphedWindow:
             self._events[buf] = None
         if not self.mgr.strict:
             self.mgr.raise_on_failed_calls()     # non-blocking; see PrefetchWindow.collect
-        if steps is None or steps >= self.P:
+        whole = steps is None or steps >= self.P
+        if whole:
             self._graphs[buf].replay()
         else:
             self.run_steps(buf, 0, steps)
@@ -503,3 +693,5 @@ class GraphedWindow:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.mgr.device))
             self._read_done[buf] = ev
+        if whole:
+            self._trial_tick(True)

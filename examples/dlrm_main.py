@@ -71,6 +71,11 @@ def parse_args(argv=None):
     p.add_argument("--use_overlap", action="store_true")
     p.add_argument("--overlap_cache_op", action="store_true",
                    help="run the cache op of window k+1 on a side stream while window k trains (not in the reference)")
+    p.add_argument("--arrangement", default="auto", choices=["auto", "overlap", "interleaved"],
+                   help="with --overlap_cache_op: where the next window's cache op runs -- on a side stream beside this "
+                        "window's steps (overlap), in two halves on the training stream around them (interleaved), or "
+                        "whichever of the two the library measures faster while training (auto, the library's default: "
+                        "pipeline.ArrangementTrial)")
     # additions of this build
     p.add_argument("--fused_sgd", action="store_true", help="apply the embedding SGD inside backward")
     p.add_argument("--fold_hook", action="store_true", help="write [B,F,D] from the gather kernel")
@@ -218,7 +223,9 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
         F = model.sparse_modules.sparse_feature_num
         offsets = torch.arange(F * args.batch_size + 1, dtype=torch.int32, device=device)     # one id per bag (KJT lengths = 1)
         layout = (offsets, True, F)
-    win = PrefetchWindow(embed, P, overlap=args.overlap_cache_op, presort=layout is not None, bag_layout=layout)
+    win = PrefetchWindow(embed, P, overlap=args.overlap_cache_op, presort=layout is not None, bag_layout=layout,
+                         arrangement=args.arrangement if args.overlap_cache_op else None)
+    train.window = win
     elapsed, done, loss = 0.0, 0, None
     steady = {"t0": None, "done0": 0}
     model.train()
@@ -346,7 +353,15 @@ def main(argv=None):
                     "it_per_s": train.steady_it_per_s, "it_per_s_scope": "whole model: data iterator + cache op + "
                     "embedding forward + dense forward + loss + backward + optimizer step",
                     "lookups_per_s": train.steady_it_per_s * args.batch_size * len(sizes),
-                    "ms_per_iteration": 1e3 / train.steady_it_per_s, "it_per_s_whole_run_host_clock": done / max(elapsed, 1e-9),
+                    "ms_per_iteration": 1e3 / train.steady_it_per_s,
+                    "arrangement": (train.window.trial.report() | {"mode": train.window.arrangement}
+                                    if train.window.trial is not None else {"mode": train.window.arrangement}),
+                    # the reference's own "average throughput" print (recsys/dlrm_main.py:297): iterations over the
+                    # HOST time of the whole epoch, i.e. including the first `warmup_iterations` iterations (library
+                    # initialisation, GEMM algorithm search, pipeline fill -- seconds, for a run of a few hundred
+                    # iterations) and without a GPU synchronisation at the end.  Not comparable with it_per_s, which
+                    # is bracketed by synchronisation and starts after the warm-up; kept because the reference prints it.
+                    "it_per_s_reference_print_host_clock_incl_warmup": done / max(elapsed, 1e-9),
                     "loss_first_quarter": head, "loss_last_quarter": tail}, indent=1))
     if world > 1:
         dist.destroy_process_group()

@@ -30,9 +30,36 @@ from typing import Callable, List, Optional
 
 import torch
 
-# per-element bound of tests/test_gpu_bag.py::test_full_size_step_vs_torch_cpu:
-#   |got - ref64| <= REL * |ref64| + ATOL + SQRT * sqrt(n)        n = lookups summed into the row
-REL, ATOL, SQRT = 1e-5, 2e-6, 3e-7
+# Per-element bound (round 5: BASELINE.json north_star's "within 1e-5 rel fp32", with no absolute floor).
+#   n = trained lookups summed into the row, ref64 = the closed form in fp64, S = sum_j |lr * g_j| (per element)
+#   n == 1   the row saw ONE fp32 update: it must equal fp32(w0 + fp32(-lr * g)) -- or the fused form
+#            fp32(w0 - lr * g), one rounding; both occur (an atomic add of the scaled gradient / an FMA onto the loaded
+#            row) -- BIT FOR BIT.  Reported as single_lookup_rows / single_lookup_mismatch; a mismatch is a violation.
+#   n <= 4   |got - ref64| <= REL * max(|ref64|, S): relative to the larger of the result and of what was added up
+#            (a cold row at |w| ~ 1e-3 is held to ~1e-8, where the round-4 bound allowed 2e-6)
+#   n  > 4   |got - ref64| <= REL * |ref64| + SQRT_REL * lr * grad_rms * sqrt(n): fp32 accumulation in ANY order
+#            differs by a random walk of roundings whose step follows the size of the summands, so the term is scaled
+#            by the workload's gradient (3e-7 * sqrt(n) at the bench's lr = 1, grad_rms = 1e-3: the round-4 constant)
+REL, SQRT_REL, COLD_MAX = 1e-5, 3e-4, 4
+
+
+def elementwise_bound(ref64: torch.Tensor, n: torch.Tensor, abs_sum: torch.Tensor, lr: float, grad_rms: float) -> torch.Tensor:
+    """ref64 [k, D] fp64, n [k] lookups per row, abs_sum [k, D] fp64 = sum_j |lr * g_j| (only read where n <= COLD_MAX)
+    -> the per-element bound [k, D] described above (the n == 1 rows get the n <= 4 bound here; their bit-for-bit
+    check is separate: single_lookup_ok)."""
+    nn = n.double().unsqueeze(1)
+    cold = torch.maximum(ref64.abs(), abs_sum).mul(REL)
+    hot = ref64.abs().mul(REL).add(nn.sqrt() * (SQRT_REL * abs(lr) * grad_rms))
+    return torch.where(nn <= COLD_MAX, cold, hot)
+
+
+def single_lookup_ok(got32: torch.Tensor, w0_32: torch.Tensor, g32: torch.Tensor, lr: float) -> torch.Tensor:
+    """[k] bool: got == fp32(w0 + fp32(-lr * g)) or got == fp32(w0 - lr * g) in every element, compared as bits"""
+    two = w0_32 + g32 * (-lr)                                                  # fp32 multiply, then fp32 add
+    lr32 = float(torch.tensor(-lr, dtype=torch.float32))                      # the scalar as the fp32 arithmetic sees it
+    one = (w0_32.double() + g32.double() * lr32).float()                      # fused: exact in fp64, ONE rounding to fp32
+    gb = got32.view(torch.int32)
+    return ((gb == two.view(torch.int32)) | (gb == one.view(torch.int32))).all(dim=1)
 
 
 class SgdLedger:
@@ -126,11 +153,12 @@ class SgdLedger:
         gs = torch.stack([g.float().pow(2).mean() for g in {id(g): g for _, g in self.entries}.values()]).mean().sqrt()
         grad_rms = float(gs)
         free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 8 << 30
-        chunk = max(1, min(T, int(0.35 * free) // (48 * D)))
+        chunk = max(1, min(T, int(0.35 * free) // (72 * D)))
         if max_chunk_rows:
             chunk = min(chunk, int(max_chunk_rows))
         res = dict(rows=T, lookups=int(n_lookups.sum()), steps=len(self.entries), bound_violations=0, max_err=0.0,
-                   max_err_over_bound=0.0, rows_violating=0, chunks=0)
+                   max_err_over_bound=0.0, rows_violating=0, chunks=0, single_lookup_rows=0, single_lookup_mismatch=0,
+                   cold_rows=0, max_rel_err_cold=0.0)
         worst = None
         t_marked = now()
         K = min(int(hot_rows), T)
@@ -153,12 +181,52 @@ class SgdLedger:
             if K > 0:
                 inch = (hot >= c0) & (hot < c1)
                 hot_e64[inch] = exp[hot[inch] - c0]
-            got = current_rows(rows).double()
+            # cold rows (n <= COLD_MAX): what was added up, sum_j |lr g_j|, and -- rows with ONE lookup -- that gradient row
+            nl = n_lookups[c0:c1]
+            is_cold = nl <= COLD_MAX
+            cold_of = torch.full((c1 - c0 + 1,), -1, dtype=torch.int64, device=dev)
+            n_cold = int(is_cold.sum())
+            cold_of[:c1 - c0][is_cold] = torch.arange(n_cold, device=dev)
+            s_cold = torch.zeros(n_cold, D, dtype=torch.float64, device=dev)
+            one_of = torch.full((c1 - c0 + 1,), -1, dtype=torch.int64, device=dev)
+            is_one = nl == 1
+            n_one = int(is_one.sum())
+            one_of[:c1 - c0][is_one] = torch.arange(n_one, device=dev)
+            g_one = torch.zeros(n_one, D, dtype=torch.float32, device=dev)
+            for ids, g in self.entries:
+                ci = ci_of(ids)
+                inch = (ci >= c0) & (ci < c1)
+                ck = cold_of[torch.where(inch, ci - c0, torch.full_like(ci, c1 - c0))]
+                sel = ck >= 0
+                if bool(sel.any()):
+                    gs_ = g[sel].float()
+                    s_cold.index_add_(0, ck[sel], gs_.double().abs_(), alpha=abs(lr))
+                    ok1 = one_of[ci[sel] - c0]
+                    s1 = ok1 >= 0
+                    g_one[ok1[s1]] = gs_[s1]
+            got32 = current_rows(rows)
+            if n_one:
+                ok = single_lookup_ok(got32[is_one], w0[is_one], g_one, lr)
+                res["single_lookup_rows"] += n_one
+                res["single_lookup_mismatch"] += int((~ok).sum())
+            got = got32.double()
             err = (got - exp).abs_()
-            del got
-            bound = exp.abs().mul_(REL).add_(ATOL).add_(n_lookups[c0:c1].double().sqrt_().mul_(SQRT).unsqueeze(1))
-            ratio = err / bound
+            del got, got32
+            # (elementwise_bound without a [rows, D] tensor of mostly zeros: the n > 4 form everywhere, then the cold rows)
+            bound = exp.abs().mul_(REL).add_(nl.double().sqrt_().mul_(SQRT_REL * abs(lr) * grad_rms).unsqueeze(1))
+            if n_cold:
+                bound[is_cold] = torch.maximum(exp[is_cold].abs(), s_cold).mul_(REL)
+            ratio = torch.where(bound > 0, err / bound.clamp(min=1e-300), (err > 0).double() * float("inf"))
+            if n_cold:
+                scale = torch.maximum(exp[is_cold].abs(), s_cold)
+                rel = torch.where(scale > 0, err[is_cold] / scale.clamp(min=1e-300), (err[is_cold] > 0).double() * float("inf"))
+                res["cold_rows"] += n_cold
+                res["max_rel_err_cold"] = max(res["max_rel_err_cold"], float(rel.max()))
             bad = ratio > 1.0
+            if n_one:                                     # a single-lookup row that is not bit-exact violates, whatever its size
+                row_bad = torch.zeros(c1 - c0, dtype=torch.bool, device=dev)
+                row_bad[is_one.nonzero(as_tuple=False).view(-1)[~ok]] = True
+                bad = bad | (row_bad.unsqueeze(1) & (err > 0))
             res["bound_violations"] += int(bad.sum())
             res["rows_violating"] += int(bad.any(dim=1).sum())
             res["max_err"] = max(res["max_err"], float(err.max()))
@@ -169,9 +237,10 @@ class SgdLedger:
                 worst = dict(row=int(rows[k]), lookups=int(n_lookups[c0 + k]), err=float(err[k].max()),
                              ref_abs_max=float(exp[k].abs().max()))
             res["chunks"] += 1
-            del err, bound, ratio, bad, exp, w0
+            del err, bound, ratio, bad, exp, w0, s_cold, g_one
         res["worst"] = worst
-        res["bound"] = f"|table - ref64| <= {REL:g}*|ref64| + {ATOL:g} + {SQRT:g}*sqrt(lookups of the row), per element"
+        res["bound"] = (f"per element: rows with 1 lookup == fp32(w0 - lr*g) bit for bit; <= {COLD_MAX} lookups: |table - ref64| <= "
+                        f"{REL:g}*max(|ref64|, sum|lr*g|); more: <= {REL:g}*|ref64| + {SQRT_REL:g}*lr*grad_rms*sqrt(lookups)")
         res["grad_rms"] = grad_rms
         t_main = now()
         # ---- the reference's own fp32 arithmetic on the rows that sum the most gradients, held to the same bound
@@ -189,7 +258,9 @@ class SgdLedger:
                 step = torch.zeros(K, D, dtype=torch.float32, device=dev).index_add_(0, hk[sel], g[sel].float())
                 w32.add_(step, alpha=-lr)
             e64 = hot_e64
-            bound = e64.abs() * REL + ATOL + n_lookups[hot].double().sqrt().mul(SQRT).unsqueeze(1)
+            # (hot rows sum thousands of gradients; should one have <= COLD_MAX lookups -- a toy run -- it gets the
+            # n > 4 form too: abs_sum is not kept per hot row)
+            bound = e64.abs() * REL + n_lookups[hot].double().sqrt().mul(SQRT_REL * abs(lr) * grad_rms).unsqueeze(1)
             got = current_rows(rows).double()
             scale = e64.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
             res["hot_rows_checked"] = K

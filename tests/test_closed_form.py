@@ -79,3 +79,39 @@ def test_padding_ids_are_no_lookups():
     w[7] -= 1
     res = led.check(lambda r: w0[r], lambda r: w[r], hot_rows=4, untouched_sample=512)
     assert res["rows"] == 2 and res["lookups"] == 3 and res["bound_violations"] == 0 and res["untouched_mismatch"] == 0
+
+
+def test_single_lookup_rows_are_checked_bit_for_bit():
+    """a row that was looked up exactly once saw ONE fp32 update: one ulp off is a violation (VERDICT r4 #4)"""
+    N, D, lr = 6000, 8, 0.5
+    w0, w, led, batches = _train(N, D, steps=3, n=300, lr=lr, seed=21)
+    res = led.check(lambda r: w0[r], lambda r: w[r], hot_rows=0, untouched_sample=0)
+    assert res["single_lookup_rows"] > 500 and res["single_lookup_mismatch"] == 0 and res["bound_violations"] == 0
+    assert res["cold_rows"] >= res["single_lookup_rows"] and res["max_rel_err_cold"] < 1e-6
+    counts = torch.bincount(torch.cat([b[0] for b in batches]), minlength=N)
+    row = int((counts == 1).nonzero()[0])
+    off = w.clone()
+    off[row, 5] = float(np.nextafter(np.float32(off[row, 5]), np.float32(10)))       # one ulp
+    res = led.check(lambda r: w0[r], lambda r: off[r], hot_rows=0, untouched_sample=0)
+    assert res["single_lookup_mismatch"] == 1 and res["rows_violating"] == 1 and res["bound_violations"] >= 1
+
+
+def test_cold_rows_are_held_to_1e_5_relative_without_an_absolute_floor():
+    """a row with 2-4 lookups at |w| ~ 1e-3: an error of 1e-4 relative (1e-7 absolute -- far inside the round-4 floor
+    of 2e-6) is rejected, an error of 1e-6 relative is accepted"""
+    N, D, lr = 6000, 8, 0.5
+    g = torch.Generator().manual_seed(4)
+    w0 = (torch.rand(N, D, generator=g) - 0.5) * 2e-3
+    ids = torch.randint(0, N, (900,), generator=g)
+    grad = torch.randn(900, D, generator=g) * 1e-3
+    w = w0.clone().index_add_(0, ids, grad, alpha=-lr)
+    led = SgdLedger(N, D, lr)
+    led.record(ids, grad)
+    counts = torch.bincount(ids, minlength=N)
+    row = int((counts == 2).nonzero()[0])
+    assert led.check(lambda r: w0[r], lambda r: w[r], hot_rows=0, untouched_sample=0)["bound_violations"] == 0
+    for rel, violates in ((1e-6, False), (1e-4, True)):
+        off = w.clone()
+        off[row, 2] = float(np.float32(off[row, 2]) * np.float32(1.0 + rel))
+        res = led.check(lambda r: w0[r], lambda r: off[r], hot_rows=0, untouched_sample=0)
+        assert (res["rows_violating"] == 1) == violates, (rel, res)

@@ -140,14 +140,18 @@ def test_tablewise_parallel(world):
 
 
 @pytest.mark.parametrize("presort", [False, True, "src"])
-@pytest.mark.parametrize("mode", ["sequential", "overlap", "graph", "graph_interleaved", "graph_switching"])
+@pytest.mark.parametrize("mode", ["sequential", "overlap", "overlap_interleaved", "overlap_auto", "graph",
+                                  "graph_interleaved", "graph_switching", "graph_auto"])
 def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, presort):
     """_train's window block in its three forms gives the same training trajectory as a plain full-table
     EmbeddingBag with SGD (each window's unique rows fit the cache even when two windows are protected)."""
     import cachedembedding_amd as ce
     from cachedembedding_amd.pipeline import GraphedWindow, PrefetchWindow
     torch.manual_seed(0)
-    N, D, F, B, P, lr, nwin = 20000, 64, 4, 64, 4, 0.5, 6
+    N, D, F, B, P, lr, nwin = 20000, 64, 4, 64, 4, 0.5, (10 if mode.endswith("_auto") else 6)
+    # *_auto: the library's own trial (pipeline.ArrangementTrial) switches the arrangement while these windows train --
+    # blocks of 2 windows, one per arrangement, then its verdict
+    trial_args = dict(block_windows=2, rounds=1, settle=0)
     w0 = torch.randn(N, D)
     emb = ce.CachedEmbeddingBag(N, D, sparse=True, _weight=w0.clone(), mode="sum", include_last_offset=True,
                                 cuda_row_num=4 * F * B * P, warmup_ratio=0.5, strict=False)
@@ -166,12 +170,15 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
         out = emb(slots, off, hook_features=F, presorted=keys)
         out.backward(grad)
 
-    if mode in ("graph", "graph_interleaved", "graph_switching"):
+    if mode in ("graph", "graph_interleaved", "graph_switching", "graph_auto"):
         il = mode == "graph_interleaved"        # the cache op in two halves around the previous window's steps, one stream
-        # graph_switching: one object, the arrangement changed between windows (what bench.py's trial does)
+        # graph_switching: one object, the arrangement changed between windows by the caller; graph_auto: by the library
         plan = ["overlap", "interleaved", "interleaved", "overlap", "interleaved", "overlap", "overlap"]
         gw = GraphedWindow(emb, P, F * B, step, overlap=not il, warmup_values=[v.cuda() for v in windows[0]],
-                           presort=presort, transport="worker", bag_layout=layout, interleaved=il)
+                           presort=presort, transport="worker", bag_layout=layout, interleaved=il,
+                           arrangement=None if il else ("auto" if mode == "graph_auto" else "overlap"),
+                           arrangement_trial=trial_args if mode == "graph_auto" else None)
+        assert gw.arrangement == ("overlap" if mode in ("graph", "graph_switching") else "interleaved")
         # the capture warm-up trained on window 0 twice over (eager pass + nothing else): replay that on the ref
         for v in windows[0]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)
@@ -186,13 +193,25 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
                     assert gw.arrangement == plan[w + 1]
                 gw.submit([v.cuda() for v in windows[w + 1]], (w + 1) % 2)
             gw.run(w % 2)
+        if mode == "graph_auto":
+            assert gw.settle_arrangement(wait=True) in ("overlap", "interleaved") and gw.trial.trials == 1
+            rep = gw.trial.report()
+            assert set(rep["trial_ms_per_window"]) == {"overlap", "interleaved"}
+            other = "overlap" if rep["mode"] == "interleaved" else "interleaved"
+            assert max(rep["trial_ms_per_window"][rep["mode"]]) <= max(rep["trial_ms_per_window"][other])
+            assert gw.arrangement == rep["mode"]
     else:
-        win = PrefetchWindow(emb, P, overlap=(mode == "overlap"), presort=presort, transport="worker",
-                             bag_layout=layout)
-        if mode == "overlap":
+        ov = mode.startswith("overlap")
+        win = PrefetchWindow(emb, P, overlap=ov, presort=presort, transport="worker", bag_layout=layout,
+                             arrangement={"overlap": "overlap", "overlap_interleaved": "interleaved",
+                                          "overlap_auto": "auto"}.get(mode),
+                             arrangement_trial=trial_args if mode == "overlap_auto" else None)
+        if ov:
             win.submit([v.cuda() for v in windows[0]])
+        modes_seen = []
         for w in range(nwin):
-            if mode == "overlap":
+            if ov:
+                modes_seen.append("interleaved" if win._pending[0] is None else "overlap")
                 slots = win.collect()
                 if w + 1 < nwin:
                     win.submit([v.cuda() for v in windows[w + 1]])
@@ -200,6 +219,12 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
                 slots = win.prepare([v.cuda() for v in windows[w]])
             for i in range(P):
                 step(slots[i], i, win.keys[i] if presort else None)
+        if mode == "overlap_interleaved":
+            assert set(modes_seen) == {"interleaved"}
+        if mode == "overlap_auto":           # both arrangements trained real windows, then the trial settled
+            assert {"interleaved", "overlap"} <= set(modes_seen)
+            torch.cuda.synchronize()
+            assert win.trial.poll() in ("overlap", "interleaved")
     for w in range(nwin):
         for v in windows[w]:
             ref.index_add_(0, v, grad.cpu().transpose(0, 1).reshape(-1, D), alpha=-lr)

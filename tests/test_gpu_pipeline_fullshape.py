@@ -6,7 +6,8 @@ Two independent checks per run:
   * the cache's index state after the last window -- cached_idx_map, the hit / miss / write-back histories of every
     call -- against oracle/cache_oracle.py replaying the same calls with the same protect_depth;
   * the host table after flush() against the closed form of SGD (oracle/closed_form.py): every row any trained step
-    looked up within 1e-5 |ref| + 2e-6 + 3e-7 sqrt(lookups), untouched rows bit-equal to their initial value, the
+    looked up within the per-element bound of that module (rows with one lookup bit for bit, rows with <= 4 lookups
+    1e-5 relative with no absolute floor, hotter rows 1e-5 |ref| + 3e-4 lr grad_rms sqrt(lookups)), untouched rows bit-equal to their initial value, the
     hottest rows also against torch's fp32 step-by-step arithmetic.
 """
 import numpy as np
@@ -16,9 +17,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("plan_ahead,interleaved", [(1, False), (2, False), (1, True)])
+@pytest.mark.parametrize("plan_ahead,interleaved", [(1, False), (2, False), (1, True), (1, "auto")])
 def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead, interleaved):
     # interleaved: no side stream -- begin(window k+1), the steps of window k, finish(window k+1) on the training stream
+    # "auto": the library's default -- GraphedWindow(arrangement="auto") measures both arrangements on 3-window blocks
+    # while these windows train and keeps the one whose slower block is faster (it must never keep an
+    # arrangement whose slower block is more than 5 % behind the other's)
+    auto = interleaved == "auto"
+    interleaved = False if auto else interleaved
     import cachedembedding_amd as ce
     from cachedembedding_amd import _lib, synthetic
     from cachedembedding_amd.pipeline import GraphedWindow
@@ -27,7 +33,7 @@ def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead, in
 
     dev = torch.device("cuda")
     sizes = synthetic.scale_tables(synthetic.TABLES["criteo_1tb"], 0.115)
-    N, D, B, F, P, lr, seed, nwin = sum(sizes), 128, 16384, 26, 8, 1.0, 77, 7
+    N, D, B, F, P, lr, seed, nwin = sum(sizes), 128, 16384, 26, 8, 1.0, 77, (14 if auto else 7)
     assert N >= 20_000_000
     n = B * F
     gen = synthetic.SyntheticKJT(sizes, B, 1, "power_law", 0.25, seed=seed, device=dev)
@@ -59,7 +65,8 @@ def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead, in
 
     gw = GraphedWindow(emb, P, n, step, overlap=not interleaved, warmup_values=[windows[0][i] for i in range(P)],
                        presort=True, transport="worker", bag_layout=(offsets, True, F), plan_ahead=plan_ahead,
-                       interleaved=interleaved)
+                       interleaved=interleaved, arrangement="auto" if auto else (None if (interleaved or plan_ahead > 1) else "overlap"),
+                       arrangement_trial=dict(block_windows=3, rounds=2, settle=1) if auto else None)
     assert mgr.transport_name == "worker" and gw.nbuf == plan_ahead + 1
     ora.prepare_ids(windows[0].view(-1).cpu().numpy())          # GraphedWindow's eager warm-up: one cache op ...
     for i in range(P):
@@ -86,6 +93,14 @@ def test_graphed_window_worker_transport_at_the_benchmarked_shape(plan_ahead, in
     torch.cuda.synchronize()
     assert mgr.sync_stats().status == 0
     mgr.raise_on_failed_calls()                                 # no call of the run overflowed
+    if auto:
+        assert gw.settle_arrangement(wait=True) is not None
+        rep = gw.trial.report()
+        ms = rep["trial_ms_per_window"]
+        other = "overlap" if rep["mode"] == "interleaved" else "interleaved"
+        assert len(ms["overlap"]) == 2 and len(ms["interleaved"]) == 2, rep
+        assert max(ms[rep["mode"]]) <= 1.05 * max(ms[other]), rep
+        assert gw.arrangement == rep["mode"]
     # ---- index state vs the oracle
     assert mgr.num_hits_history == ora.num_hits_history and mgr.num_miss_history == ora.num_miss_history
     assert mgr.num_write_back_history == ora.num_write_back_history
