@@ -1128,7 +1128,14 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                    "launch": "hipGraph per window" if gw._graphs is not None else
                              "fixed-capacity steps launched one by one (world > 1: CE_SHARDED_GRAPH=1 captures them)",
                    "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
-                   "windows_on_the_variable_size_path": gw.fallback_windows},
+                   "windows_on_the_variable_size_path": gw.fallback_windows,
+                   "exchange_split": ({"on": True, "rows_per_peer_and_step": dict(zip(("early", "late", "deferred", "urgent"), gw.split_caps)),
+                                       "measured_on_the_warmup_window": gw.split_stats,
+                                       "what": "rows nobody looked up in the step before leave their owner while that "
+                                               "step computes (early), the others behind its update (late); gradients of "
+                                               "rows nobody needs in the step after return behind that step's forward "
+                                               "(deferred), the others at once (urgent): DESIGN.md section 5"}
+                                      if gw._split else {"on": False})},
         "cache": {"rank0_unique_hit_rate": hits / max(1, hits + miss), "rank0_rows_in": tot["cpu_to_cuda_numel"] // D,
                   "rank0_rows_out": tot["cuda_to_cpu_numel"] // D, "prefill_cache_ops": prefill, "setup_s": setup_s,
                   "host_enqueue_s": enqueue_s,

@@ -162,6 +162,13 @@ SIGNATURES = {
                                                     c_void_p, c_void_p]),
     "ce_exchange_local_index": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                         c_void_p, c_void_p]),
+    "ce_split_classify": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                  c_void_p]),
+    "ce_split_places": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "ce_exchange_local_index_split": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                              c_int64, c_int64, c_int64, c_void_p, c_int32, c_int64, c_int64, c_int64,
+                                              c_void_p, c_void_p, c_void_p]),
     "ce_bag_forward_max": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_int32,
                                    c_int64, c_void_p, c_void_p, c_void_p]),
     "ce_bag_backward_max": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,

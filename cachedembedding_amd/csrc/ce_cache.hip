@@ -360,6 +360,101 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
   }
 }
 
+// k_mark with the repeats of a chunk of ids folded in LDS first (round 5).  A Criteo window is 3.4 M ids of which
+// ~90 % repeat inside their own batch (whole features draw from tables of 3 ... 100 rows; the large tables' heads), and
+// k_mark above pays three random accesses per ID: idx_map, inverted, the bitmap word -- 10 M of them, which is what its
+// 66 us are (the memory system's random-access rate: profiles/r03_mark_ablations.txt).  Here a workgroup takes chunks
+// of kMarkChunk consecutive ids, enters them into an open-addressing table in LDS (key = id, looked at before the
+// compare-and-swap, so the lanes that hold a hot id read one broadcast word instead of serialising on an atomic) and
+// only the lane that ENTERED an id does the global work for it -- one idx_map gather, one inverted gather (the miss
+// statistic, and what has the entry in L2 when k_count / k_emit / the slot kernel ask), one look at the bitmap word and
+// the atomic if the bit is clear -- and leaves the row (bit 31: not resident) beside the key.  After a barrier every id
+// of the chunk reads its row out of the table.  ~0.4 M distinct (chunk, id) pairs per window instead of 3.4 M ids; no
+// LDS window for the hot bitmap words and no ballot merge are needed: a hot row costs one access per chunk.
+constexpr int kMarkChunk = 8192;
+constexpr int kMarkTab = 16384;            // entries: load factor <= 0.5 whatever the ids
+__global__ __launch_bounds__(1024) void k_mark_dedupe(const int64_t* __restrict__ ids, int64_t n,
+                                                     const int32_t* __restrict__ idx_map,
+                                                     const int32_t* __restrict__ inverted, int64_t N, uint32_t* bitmap,
+                                                     Ctl* ctl, int64_t* rows_out, int allow_pad) {
+  constexpr int U = kMarkChunk / 1024;
+  __shared__ uint32_t tkey[kMarkTab];      // id + 1 (0 = free)
+  __shared__ uint32_t tval[kMarkTab];      // row | (not resident) << 31
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t nchunks = (n + kMarkChunk - 1) / kMarkChunk;
+  int cold = 0;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (int e = tid; e < kMarkTab; e += 1024) tkey[e] = 0;
+    __syncthreads();
+    const int64_t base = chunk * kMarkChunk;
+    uint32_t key[U];
+    int hh[U];
+    bool own[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 1024 + tid;
+      key[u] = 0;
+      own[u] = false;
+      hh[u] = 0;
+      if (i < n) {
+        const int64_t id = ids[i];
+        if ((unsigned long long)id >= (unsigned long long)N) {
+          if (!(allow_pad && id == -1)) ctl->status = CE_ERR_RANGE;     // (see k_mark)
+          rows_out[i] = -1;
+        } else {
+          key[u] = (uint32_t)id + 1u;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!key[u]) continue;
+      uint32_t h = (key[u] * 2654435761u) >> (32 - 14);
+      for (;;) {
+        uint32_t cur = *(volatile uint32_t*)&tkey[h];
+        if (cur == 0) cur = atomicCAS(&tkey[h], 0u, key[u]);
+        if (cur == 0) { own[u] = true; break; }
+        if (cur == key[u]) break;
+        h = (h + 1) & (kMarkTab - 1);
+      }
+      hh[u] = (int)h;
+    }
+    // ---- the lanes that entered an id: the global accesses, all U in flight per step
+    int32_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (own[u]) row[u] = idx_map ? idx_map[key[u] - 1u] : (int32_t)(key[u] - 1u);
+    int32_t inv[U];
+    uint32_t cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (own[u]) {
+        inv[u] = inverted[row[u]];
+        cur[u] = *(volatile uint32_t*)(bitmap + (row[u] >> 5));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (own[u]) {
+        const uint32_t bit = 1u << (row[u] & 31);
+        if (!(cur[u] & bit)) atomicOr(bitmap + (row[u] >> 5), bit);
+        tval[hh[u]] = (uint32_t)row[u] | (inv[u] < 0 ? 0x80000000u : 0u);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!key[u]) continue;
+      const uint32_t v = tval[hh[u]];
+      rows_out[base + u * 1024 + tid] = (int64_t)(v & 0x7fffffffu);
+      cold += (int)(v >> 31);
+    }
+    __syncthreads();
+  }
+  cold = wave_sum(cold);
+  if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
+}
+
 // unique / missing rows per 32768-row chunk of the bitmap (one uint4 = 128 rows per thread), and their sums per 64
 // chunks (two device atomics per workgroup on ~85 addresses: k_emit adds those up instead of 5431 chunk counts)
 __global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4,
@@ -1165,24 +1260,23 @@ __device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, con
   }
 }
 
-template <typename VT>
+template <typename VT, int R = kSwapRows>
 __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                                const long long* n_ptr, long long n_imm,
                                                const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
                                                const Ctl* ctl, long long first) {
-  admit_rows<VT, kSwapRows>(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x,
-                            (int)gridDim.x, first);
+  admit_rows<VT, R>(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x,
+                    (int)gridDim.x, first);
 }
 
 // Admission kernel of the worker transport when the previous call's write-back has not landed yet: row i comes out
 // of that job's staging buffer if the job evicted it (EvTable above), out of the host table otherwise.
-template <typename VT>
+template <typename VT, int R = kSwapRows>
 __global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict__ rows, long long n,
                                                      const VT* __restrict__ host, VT* dst, int rowlen, int g_log2,
                                                      const unsigned long long* __restrict__ evt_keys,
                                                      const int32_t* __restrict__ evt_pos, uint32_t evt_mask,
                                                      uint32_t tag, const VT* __restrict__ prev_stage) {
-  constexpr int R = kSwapRows;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
@@ -1931,7 +2025,25 @@ struct SwapEngine {
         // Kaggle 5 % P = 1 (25 k rows): 0.93 -> 1.02 G lookups/s; P = 2: 1.38 -> 1.44 G
         const int blocks = admit_blocks > 0 ? admit_blocks : (n <= 49152 ? 32 : 20);
         const int pb = (int)(need_out & 1);
-        if (probe && vec)
+        // rows in flight per lane group (CE_ADMIT_ROWS; 16 unless set): the grid's rows in flight are what occupies the
+        // L2's miss queues for a PCIe round trip each -- see DESIGN.md section 4 (round 5) for the sweep
+        static const int admit_rows_env = [] { const char* e = getenv("CE_ADMIT_ROWS"); return e ? atoi(e) : 0; }();
+#define CE_ADMIT_R(RR)                                                                                                   \
+  do {                                                                                                                   \
+    if (probe)                                                                                                           \
+      hipLaunchKernelGGL((k_admit_probe<f32x4, RR>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,  \
+                         (const f32x4*)table_dev, (f32x4*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],       \
+                         evt_mask, (uint32_t)need_out, (const f32x4*)stage_dev[pb]);                                     \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_admit<f32x4, RR>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,           \
+                         (const int32_t*)nullptr, (const long long*)nullptr, n, (const f32x4*)table_dev,                 \
+                         (f32x4*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);                                \
+  } while (0)
+        if (vec && admit_rows_env == 2) CE_ADMIT_R(2);
+        else if (vec && admit_rows_env == 4) CE_ADMIT_R(4);
+        else if (vec && admit_rows_env == 8) CE_ADMIT_R(8);
+        else if (vec && admit_rows_env == 32) CE_ADMIT_R(32);
+        else if (probe && vec)
           hipLaunchKernelGGL((k_admit_probe<f32x4>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,
                              (const f32x4*)table_dev, (f32x4*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],
                              evt_mask, (uint32_t)need_out, (const f32x4*)stage_dev[pb]);
@@ -1947,6 +2059,7 @@ struct SwapEngine {
           hipLaunchKernelGGL((k_admit<float>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
                              (const int32_t*)nullptr, (const long long*)nullptr, n, (const float*)table_dev,
                              (float*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);
+#undef CE_ADMIT_R
         e = hipGetLastError();
         if (e != hipSuccess) fail("admission kernel launch", e);
       } else if (n > 0 && !failed()) {
@@ -2890,7 +3003,14 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     const int mark_threads = mark_threads_env > 0 ? std::min(mark_threads_env, 1024) : (ranked ? 512 : 256);
     const bool mark_merge = mark_merge_env >= 0 ? mark_merge_env != 0 : !ranked;
     const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
-    if (n > 0) {
+    // calls of a window's size: the repeats of every 8192-id chunk folded in LDS first (CE_MARK_DEDUPE=0: the per-id kernel)
+    static const int mark_dedupe = [] { const char* e = getenv("CE_MARK_DEDUPE"); return e ? atoi(e) : 1; }();
+    static const int mark_dd_blocks = [] { const char* e = getenv("CE_MARK_DEDUPE_BLOCKS"); return e ? atoi(e) : 512; }();
+    if (n >= 65536 && mark_dedupe && !mark_dbg) {
+      const int grid = (int)std::min<int64_t>(cdiv(n, kMarkChunk), mark_dd_blocks);
+      hipLaunchKernelGGL(k_mark_dedupe, dim3(grid), dim3(1024), 0, s, ids, n, c.idx_map, c.inverted_cached_idx, N,
+                         h->bitmap, h->ctl, slots_out, allow_pad);
+    } else if (n > 0) {
       const int u = (n >= 65536 && mark_u != 1) ? (mark_u == 2 ? 2 : 4) : 1;
       const dim3 mg(std::min(grid_for(n, mark_threads * u), mark_blocks)), mb(mark_threads);
 #define CE_MARK(M, U_)                                                                                          \
@@ -2907,9 +3027,15 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
                      h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, ring,
                      worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
                      worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr, steady ? 1 : 0);
-  if (worker) {
-    // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) while this
-    // stream selects and stages the victims; it first lets every earlier write-back land
+  // the admission worker starts gathering the missed rows (host table -> in_stage) while this stream selects and
+  // stages the victims; it first lets every earlier write-back land.  In the two-half form (split: nothing runs beside
+  // this stream's kernels except that admission) it can be started BEHIND the first half instead (CE_ADMIT_LATE=1): the
+  // admission kernel's PCIe reads slow the selection / staging kernels beside it by more than their own time (k_hist
+  // 7 -> 35 us, k_victims 8 -> 90 us, k_evict_stage 26 -> 65 us in a rocprofv3 timeline), and the steps of the window
+  // that train between the two halves leave it 0.8 ms anyway.
+  static const int admit_late_env = [] { const char* e = getenv("CE_ADMIT_LATE"); return e ? atoi(e) : 0; }();
+  const bool admit_late = worker && split && admit_late_env != 0;
+  if (worker && !admit_late) {
     CE_HIP_CHECK(hipEventRecord(h->wb->in_ev[in_job & 1], s));
     h->wb->push_in(out_job - 1);
   }
@@ -3008,6 +3134,10 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   }
   CE_PHASE();
 #undef CE_PHASE
+  if (admit_late) {
+    CE_HIP_CHECK(hipEventRecord(h->wb->in_ev[in_job & 1], s));
+    h->wb->push_in(out_job - 1);
+  }
   // ---- second half: from here on the call needs the missed rows
   ce_cache::Pending& x = h->pend;
   x.n = n; x.slots_out = slots_out; x.s = s; x.worker = worker; x.capturing = capturing; x.has_tail = tail != nullptr;

@@ -409,6 +409,197 @@ __global__ __launch_bounds__(256) void k_exchange_local_index(const int64_t* __r
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Early / late split of the row-wise exchange (round 5).  A row of step t must carry the update
+// of step t-1 only if SOME rank looked it up in step t-1; every other row can leave its owner while step t-1 still
+// computes.  The owner sees every rank's requests of the whole window when it plans, so it classifies them:
+//   bit 0 LATE    the row is requested, by any peer, in the batch before  -> travels after that step's update
+//   bit 1 URGENT  the row is requested, by any peer, in the batch after   -> its returned gradient must be applied
+//                                                                             before that step's rows leave
+// One uint64 per local row holds "requested in batch b" in bit b (bit 63: in the last batch of the window before);
+// three passes over the window's requests: set, read, clear -- the scratch is all zero again afterwards.
+constexpr int kSplitPrevBit = 63;
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_split_set(const int64_t* __restrict__ serve, int world, int P, int64_t cap,
+                                                   int64_t n_rows, const int64_t* __restrict__ prev, int64_t n_prev,
+                                                   unsigned long long* mask) {
+  const int64_t total = (int64_t)world * P * cap;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + n_prev; e += stride) {
+    int64_t row;
+    int bit;
+    if (e < total) {
+      row = serve[e];
+      bit = (int)((e / cap) % P);
+    } else {
+      row = prev[e - total];
+      bit = kSplitPrevBit;
+    }
+    if (row < 0 || row >= n_rows) continue;
+    const unsigned long long b = 1ull << bit;
+    if (!(__hip_atomic_load(&mask[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(&mask[row], b);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_split_read(const int64_t* __restrict__ serve, int world, int P, int64_t cap,
+                                                    int64_t n_rows, int have_prev, const unsigned long long* __restrict__ mask,
+                                                    uint8_t* __restrict__ flags) {
+  const int64_t total = (int64_t)world * P * cap;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t row = serve[e];
+    uint8_t f = 0;
+    if (row >= 0 && row < n_rows) {
+      const int b = (int)((e / cap) % P);
+      const unsigned long long m = mask[row];
+      // no window before this one (have_prev == 0): nothing is in flight that batch 0 could depend on -> all EARLY
+      const bool late = b == 0 ? (have_prev && ((m >> kSplitPrevBit) & 1)) : ((m >> (b - 1)) & 1);
+      // the window after this one is not planned yet: the last batch returns everything at once
+      const bool urgent = b == P - 1 ? true : ((m >> (b + 1)) & 1);
+      f = (uint8_t)((late ? 1 : 0) | (urgent ? 2 : 0));
+    }
+    flags[e] = f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_split_clear(const int64_t* __restrict__ serve, int64_t total, int64_t n_rows,
+                                                     const int64_t* __restrict__ prev, int64_t n_prev,
+                                                     unsigned long long* mask) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total + n_prev; e += stride) {
+    const int64_t row = e < total ? serve[e] : prev[e - total];
+    if (row >= 0 && row < n_rows) mask[row] = 0ull;
+  }
+}
+
+// Places inside the split exchange buffers: one workgroup per (batch, peer) chunk of `cap` requests.  ids / flags are
+// batch-major [P][W][cap].  Forward buffer: EARLY rows of peer w at [w * cap_e, ...), LATE rows at W * cap_e + [w * cap_l,
+// ...), each in request order; an early row beyond cap_e spills behind the chunk's late rows (sending a row later is
+// always correct).  Backward buffer the same with DEFERRED (not urgent) first.  caps[b] = {cap_e, cap_l, cap_d, cap_u}
+// of batch b.  counts[b][w] = {early, late, deferred, urgent} as classified (before any spill).
+__global__ __launch_bounds__(1024) void k_split_places(const int64_t* __restrict__ ids, const uint8_t* __restrict__ flags,
+                                                       int world, int64_t cap, int skip_peer,
+                                                       const int32_t* __restrict__ caps, int32_t* __restrict__ place_fwd,
+                                                       int32_t* __restrict__ place_bwd, int32_t* counts, int32_t* overflow) {
+  __shared__ int run[2];          // late / urgent rows of the chunk seen so far
+  __shared__ int tot[2];          // ... in the whole chunk
+  __shared__ int red[16][3];
+  __shared__ unsigned long long wsum[16];
+  const int b = (int)(blockIdx.x / world), w = (int)(blockIdx.x % world);
+  const int64_t base = (int64_t)blockIdx.x * cap;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ce = caps[4 * b + 0], cl = caps[4 * b + 1], cd = caps[4 * b + 2], cu = caps[4 * b + 3];
+  const bool skip = w == skip_peer;
+  // pass 1: the chunk's class totals (the spill positions need the number of late / urgent rows of the WHOLE chunk)
+  int nl = 0, nu = 0, nv = 0;
+  for (int64_t j = tid; j < cap; j += 1024) {
+    if (ids[base + j] < 0) continue;
+    const uint8_t f = flags[base + j];
+    nv += 1;
+    nl += f & 1;
+    nu += (f >> 1) & 1;
+  }
+  nl = wave_sum_i(nl); nu = wave_sum_i(nu); nv = wave_sum_i(nv);
+  if (lane == 0) { red[wv][0] = nl; red[wv][1] = nu; red[wv][2] = nv; }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0, c = 0, v = 0;
+    for (int k = 0; k < 16; ++k) { a += red[k][0]; c += red[k][1]; v += red[k][2]; }
+    tot[0] = a; tot[1] = c;
+    run[0] = run[1] = 0;
+    if (counts) {
+      int32_t* o = counts + 4 * (int64_t)blockIdx.x;
+      o[0] = v - a; o[1] = a; o[2] = v - c; o[3] = c;
+    }
+    if (!skip) {
+      const int spill_l = max(0, (v - a) - ce), spill_u = max(0, (v - c) - cd);
+      if (a + spill_l > cl || c + spill_u > cu) atomicOr(overflow, 1);
+    }
+  }
+  __syncthreads();
+  const int n_late = tot[0], n_urg = tot[1];
+  // pass 2: ranks in request order, tile by tile
+  int done_v = 0;                  // valid rows of the tiles before this one (uniform)
+  for (int64_t j0 = 0; j0 < cap; j0 += 1024) {
+    const int64_t j = j0 + tid;
+    const bool valid = j < cap && ids[base + j] >= 0;
+    const uint8_t f = valid ? flags[base + j] : 0;
+    const int isl = valid ? (f & 1) : 0, isu = valid ? ((f >> 1) & 1) : 0, isv = valid ? 1 : 0;
+    // three inclusive wave scans packed into one: late (10 bits would do, 21 each to be safe)
+    unsigned long long pk = (unsigned long long)isl | ((unsigned long long)isu << 21) | ((unsigned long long)isv << 42);
+    unsigned long long inc = pk;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    unsigned long long pre = inc - pk, all = 0;
+    for (int k = 0; k < 16; ++k) { if (k < wv) pre += wsum[k]; all += wsum[k]; }
+    const int r_l = (int)(pre & 0x1fffff) + run[0], r_u = (int)((pre >> 21) & 0x1fffff) + run[1];
+    const int r_v = (int)(pre >> 42) + done_v;
+    if (j < cap) {
+      int pf = -1, pb = -1;
+      if (valid && !skip) {
+        const int r_e = r_v - r_l, r_d = r_v - r_u;        // rank among the early / deferred rows
+        if (isl) pf = r_l < cl ? world * ce + w * cl + r_l : -1;
+        else if (r_e < ce) pf = w * ce + r_e;
+        else { const int q = n_late + (r_e - ce); pf = q < cl ? world * ce + w * cl + q : -1; }
+        if (isu) pb = r_u < cu ? world * cd + w * cu + r_u : -1;
+        else if (r_d < cd) pb = w * cd + r_d;
+        else { const int q = n_urg + (r_d - cd); pb = q < cu ? world * cd + w * cu + q : -1; }
+      }
+      place_fwd[base + j] = pf;
+      place_bwd[base + j] = pb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      run[0] += (int)(all & 0x1fffff);
+      run[1] += (int)((all >> 21) & 0x1fffff);
+    }
+    done_v += (int)(all >> 42);
+    __syncthreads();
+  }
+}
+
+// Requester side: lookup -> row of "cache + exchange buffers" for the pooling (forward buffers) and for the fused
+// fold + SGD (backward buffers).  A place in this rank's own chunk [local_lo, local_hi) is the cache slot its own
+// owner-side cache op resolved; any other place p goes through place_fwd / place_bwd (k_split_places).  The EARLY and
+// the DEFERRED region exist twice (a step's early rows arrive while the step before still reads its own; a step's
+// deferred gradients leave while the next step already folds): batch b uses copy b & 1.
+// fwd: tail_base + [E0 | E1 | L], bwd: tail_base + bwd_base + [D0 | D1 | U]; n_e = W * max cap_e etc. are region sizes.
+__global__ __launch_bounds__(256) void k_exchange_local_index_split(
+    const int64_t* __restrict__ pos, int64_t n_per_batch, int64_t total, const int64_t* __restrict__ slots,
+    const int32_t* __restrict__ place_fwd, const int32_t* __restrict__ place_bwd, int64_t chunk_stride, int64_t lo,
+    int64_t hi, int64_t tail_base, int64_t bwd_base, const int32_t* __restrict__ caps, int world, int64_t n_e,
+    int64_t n_l, int64_t n_d, int64_t* __restrict__ idx_fwd, int64_t* __restrict__ idx_bwd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t p = pos[i];
+    const int64_t b = i / n_per_batch;
+    int64_t f = -1, g = -1;
+    if (p >= lo && p < hi) {
+      f = g = slots[b * chunk_stride + p];
+    } else if (p >= 0) {
+      const int pf = place_fwd[b * chunk_stride + p], pb = place_bwd[b * chunk_stride + p];
+      const int64_t we = (int64_t)world * caps[4 * b + 0], wd = (int64_t)world * caps[4 * b + 2];
+      if (pf >= 0) f = tail_base + (pf < we ? (b & 1) * n_e + pf : 2 * n_e + (pf - we));
+      if (pb >= 0) g = tail_base + bwd_base + (pb < wd ? (b & 1) * n_d + pb : 2 * n_d + (pb - wd));
+    }
+    idx_fwd[i] = f;
+    idx_bwd[i] = g;
+  }
+  (void)n_l;
+}
+
 struct SortWs {
   int32_t *keys[2], *vals[2], *bag_of, *hist, *total;
   size_t bytes;
@@ -562,6 +753,55 @@ extern "C" int ce_exchange_local_index(const int64_t* pos, int64_t n_per_batch, 
              "the local range must lie inside one batch's slots");
   hipLaunchKernelGGL(k_exchange_local_index, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pos,
                      n_per_batch, total, slots, slots_batch_stride, local_lo, local_hi, tail_base, index_out);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_split_classify(const int64_t* serve, int32_t world, int32_t n_batches, int64_t capacity,
+                                 int64_t n_local_rows, const int64_t* prev, int64_t n_prev, uint64_t* mask,
+                                 uint8_t* flags_out, ce_stream_t stream) {
+  const int64_t total = (int64_t)world * n_batches * capacity;
+  if (total <= 0) return CE_OK;
+  CE_REQUIRE(serve && mask && flags_out && n_local_rows > 0, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(world >= 1 && n_batches >= 1 && n_batches < kSplitPrevBit, CE_ERR_UNSUPPORTED,
+             "a window of at most %d batches", kSplitPrevBit - 1);
+  CE_REQUIRE(n_prev >= 0 && (prev || n_prev == 0), CE_ERR_INVALID, "bad prev");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(grid_for(total + n_prev, 256)), b(256);
+  hipLaunchKernelGGL(k_split_set, g, b, 0, s, serve, (int)world, (int)n_batches, capacity, n_local_rows, prev, n_prev,
+                     (unsigned long long*)mask);
+  hipLaunchKernelGGL(k_split_read, g, b, 0, s, serve, (int)world, (int)n_batches, capacity, n_local_rows,
+                     n_prev > 0 ? 1 : 0, (const unsigned long long*)mask, flags_out);
+  hipLaunchKernelGGL(k_split_clear, g, b, 0, s, serve, total, n_local_rows, prev, n_prev, (unsigned long long*)mask);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_split_places(const int64_t* ids, const uint8_t* flags, int32_t n_batches, int32_t world,
+                               int64_t capacity, int32_t skip_peer, const int32_t* caps, int32_t* place_fwd,
+                               int32_t* place_bwd, int32_t* counts_out, int32_t* overflow_flag, ce_stream_t stream) {
+  if ((int64_t)n_batches * world * capacity <= 0) return CE_OK;
+  CE_REQUIRE(ids && flags && caps && place_fwd && place_bwd && overflow_flag, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(capacity < (1 << 21), CE_ERR_UNSUPPORTED, "capacity beyond 2^21 rows per bucket");
+  hipLaunchKernelGGL(k_split_places, dim3((unsigned)(n_batches * world)), dim3(1024), 0, (hipStream_t)stream, ids, flags,
+                     (int)world, capacity, (int)skip_peer, caps, place_fwd, place_bwd, counts_out, overflow_flag);
+  CE_LAUNCH_CHECK();
+  return CE_OK;
+}
+
+extern "C" int ce_exchange_local_index_split(const int64_t* pos, int64_t n_per_batch, int64_t n_batches,
+                                             const int64_t* slots, const int32_t* place_fwd, const int32_t* place_bwd,
+                                             int64_t chunk_stride, int64_t local_lo, int64_t local_hi, int64_t tail_base,
+                                             int64_t bwd_base, const int32_t* caps, int32_t world, int64_t n_early,
+                                             int64_t n_late, int64_t n_deferred, int64_t* index_fwd, int64_t* index_bwd,
+                                             ce_stream_t stream) {
+  const int64_t total = n_per_batch * n_batches;
+  if (total <= 0) return CE_OK;
+  CE_REQUIRE(pos && slots && place_fwd && place_bwd && caps && index_fwd && index_bwd, CE_ERR_INVALID, "null pointer");
+  CE_REQUIRE(local_lo >= 0 && local_hi <= chunk_stride && tail_base >= 0 && bwd_base >= 0, CE_ERR_INVALID, "bad ranges");
+  hipLaunchKernelGGL(k_exchange_local_index_split, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                     n_per_batch, total, slots, place_fwd, place_bwd, chunk_stride, local_lo, local_hi, tail_base,
+                     bwd_base, caps, (int)world, n_early, n_late, n_deferred, index_fwd, index_bwd);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }

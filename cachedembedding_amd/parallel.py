@@ -713,7 +713,11 @@ class GraphedShardedWindow:
     def __init__(self, embed: "RowwiseShardedEmbeddingBag", prefetch_num: int, ids_per_batch: int, offsets: torch.Tensor,
                  dense_fn, capacity: int, hook_features: int = 0, overlap: bool = True,
                  use_graph: Optional[bool] = None,
-                 transport: Optional[str] = None, warmup_ids: Optional[Sequence[torch.Tensor]] = None):
+                 transport: Optional[str] = None, warmup_ids: Optional[Sequence[torch.Tensor]] = None,
+                 split: Optional[bool] = None, split_caps: Optional[Sequence[int]] = None):
+        # split (W > 1; default on, CE_SHARDED_SPLIT=0 switches it off): the EARLY / LATE split of both row exchanges of
+        # a step (class docstring).  split_caps = (cap_early, cap_late, cap_deferred, cap_urgent) rows per peer and
+        # step; None: measured on the warm-up window (mean + 4.5 sigma of every class, agreed over the ranks).
         from .functional import is_identity_layout, presort_len
         self.embed, self.ex, self.ops = embed, embed.exchange, embed.ops
         self.mgr = embed.cache_weight_mgr
@@ -768,24 +772,39 @@ class GraphedShardedWindow:
             raise NotImplementedError("GraphedShardedWindow: mode='sum' only (the fused fold + update)")
         self.rank = self.ops.rank
         self._C = self.mgr.cuda_row_num
-        self._tail = self.mgr.reserve_tail(W * cap)                                 # rows received, behind the cache
-        self._table = self.mgr.cache_with_tail[:self._C + W * cap]
-        self._idx = [torch.full((P, n), -1, **i64) for _ in range(2)]               # lookup -> row of _table
-        self._slots_remote = [torch.full((P, W * cap), -1, **i64) for _ in range(2)] if W > 1 else None
-        self._recv = torch.empty(W * cap, embed.embedding_dim, dtype=torch.float32, device=dev) if W > 1 else None
+        if split is None:
+            split = os.environ.get("CE_SHARDED_SPLIT", "1") != "0"
+        self._split = bool(split) and W > 1
+        self._force_late = self._split and os.environ.get("CE_SPLIT_FORCE", "") == "late"
         self._graphs = None
         self.fallback_windows = 0
+        self.split_stats = None
+        if self._split:
+            self._setup_split(split_caps, warmup_ids, klen, i64)
+        else:
+            self._tail = self.mgr.reserve_tail(W * cap)                             # rows received, behind the cache
+            self._table = self.mgr.cache_with_tail[:self._C + W * cap]
+        self._idx = [torch.full((P, n), -1, **i64) for _ in range(2)]               # lookup -> row of _table
+        self._slots_remote = [torch.full((P, W * cap), -1, **i64) for _ in range(2)] if W > 1 else None
+        self._recv = torch.empty(W * cap, embed.embedding_dim, dtype=torch.float32, device=dev) \
+            if (W > 1 and not self._split) else None
         if warmup_ids is not None:
             self._plan(list(warmup_ids), 0)
             self._plan_owner(0)
-            for t in (self._slots, self._pos, self._keys, self._idx) + ((self._slots_remote,) if W > 1 else ()):
+            twins = (self._slots, self._pos, self._keys, self._idx) + ((self._slots_remote,) if W > 1 else ())
+            if self._split:
+                twins += (self._idx_b, self._keys_b, self._lists_f, self._lists_b)
+            for t in twins:
                 t[1].copy_(t[0])
             torch.cuda.synchronize(dev)
             if int(self._ovf[0].item()) != 0:
                 raise ValueError(f"capacity {cap} is smaller than a bucket of the warm-up window "
                                  f"(largest: {int(self._counts[0].max().item())} rows)")
-            for i in range(P):                       # eager once (lazy initialisation must not happen in a capture)
-                self._step(0, i)
+            if self._split:                          # eager once (lazy initialisation must not happen in a capture)
+                self._window_split(0)
+            else:
+                for i in range(P):
+                    self._step(0, i)
             torch.cuda.synchronize(dev)
             # use_graph None: at W = 1 (no collective in the steps, the host is the bottleneck: 1.73 -> 2.05 G) yes; at
             # W > 1 only when asked for (CE_SHARDED_GRAPH=1): a step then holds two all-to-alls of tens of microseconds
@@ -829,7 +848,21 @@ class GraphedShardedWindow:
                                                        cap, ptr(self._stamp), ptr(self._slot_of_row), ptr(self._ws),
                                                        self._req[buf][b].data_ptr(), self._pos[buf][b].data_ptr(),
                                                        self._counts[buf][b].data_ptr(), ptr(self._ovf[buf]), sp))
-        if W > 1:       # the ranks must agree on which path a window takes: its collectives differ
+        if not self._split:
+            self._agree_on_overflow(buf)
+        if W > 1:
+            # peer-major for the exchange; local rows fit 32 bits (N / W < 2^31): half the bytes of the id exchange
+            req_wpc = self._req[buf].permute(1, 0, 2).to(torch.int32)
+            got = torch.empty_like(req_wpc)
+            _a2a(got, req_wpc, None, None, self.ex.group)
+            self._serve[buf].copy_(got)
+        else:
+            self._serve[buf].copy_(self._req[buf].permute(1, 0, 2))
+
+    def _agree_on_overflow(self, buf: int) -> None:
+        """the ranks must agree on which path a window takes (its collectives differ): MAX over the ranks' flags, then
+        the one read-back of the window, asynchronously"""
+        if self.W > 1:
             if dist.get_backend(self.ex.group) == "gloo":
                 f = self._ovf[buf].cpu()
                 dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.ex.group)
@@ -837,11 +870,6 @@ class GraphedShardedWindow:
             else:
                 dist.all_reduce(self._ovf[buf], op=dist.ReduceOp.MAX, group=self.ex.group)
         self._ovf_host[buf].copy_(self._ovf[buf], non_blocking=True)
-        req_wpc = self._req[buf].permute(1, 0, 2).contiguous()                       # peer-major for the exchange
-        if W > 1:
-            _a2a(self._serve[buf], req_wpc, None, None, self.ex.group)
-        else:
-            self._serve[buf].copy_(req_wpc)
 
     @torch.no_grad()
     def _plan_owner(self, buf: int) -> None:
@@ -849,14 +877,225 @@ class GraphedShardedWindow:
         slots = self.mgr.prepare_ids(self._serve[buf].view(-1), padded=True)         # -1 = padding: slot -1
         self._slots[buf].view(P, W, cap).copy_(slots.view(W, P, cap).permute(1, 0, 2))
         r = self.rank
+        from .functional import presort_window
+        if self._split:
+            self._plan_split(buf)
+            return
         check(lib.ce_exchange_local_index(ptr(self._pos[buf]), self.n, P, ptr(self._slots[buf]), W * cap, r * cap,
                                           (r + 1) * cap, self._C, ptr(self._idx[buf]), stream_ptr()))
         if W > 1:                      # what the owner side still serves: everything but this rank's own requests
             self._slots_remote[buf].copy_(self._slots[buf])
             self._slots_remote[buf].view(P, W, cap)[:, r].fill_(-1)
-        from .functional import presort_window
         presort_window(self._idx[buf], self._C + W * cap, keys_out=self._keys[buf], offsets=self.offsets,
                        include_last_offset=self.incl, hook_features=self.hook, identity_bags=self._identity)
+
+    # ---- the early / late split (W > 1)
+    def _setup_split(self, split_caps, warmup_ids, klen: int, i64: dict) -> None:
+        W, P, cap, n, dev = self.W, self.P, self.cap, self.n, self.mgr.device
+        D = self.embed.embedding_dim
+        n_local = int(self.mgr.num_embeddings)
+        self._mask = torch.zeros(n_local, dtype=torch.int64, device=dev)            # ce_split_classify's scratch
+        self._flags_o = [torch.zeros(W, P, cap, dtype=torch.uint8, device=dev) for _ in range(2)]    # what I serve
+        self._flags_r = [torch.zeros(P, W, cap, dtype=torch.uint8, device=dev) for _ in range(2)]    # what I request
+        if self._force_late:
+            split_caps = (128, cap, 128, cap)
+        if split_caps is None and warmup_ids is not None:
+            split_caps = self._measure_split_caps(list(warmup_ids))
+        if split_caps is None:         # nothing to measure on: every class may take a whole bucket
+            split_caps = (cap, cap, cap, cap)
+        ce_, cl, cd, cu = (int(v) for v in split_caps)
+        assert min(ce_, cl, cd, cu) >= 1 and max(ce_, cl, cd, cu) <= cap
+        self.split_caps = (ce_, cl, cd, cu)
+        caps = torch.tensor([[ce_, cl, cd, cu]] * P, dtype=torch.int32)
+        caps[P - 1, 2], caps[P - 1, 3] = 1, cap       # the last batch returns everything at once (next window unknown)
+        self._caps_host = caps.tolist()
+        self._caps = caps.to(dev)
+        ne, nl, nd, nu = W * ce_, W * cl, W * max(cd, 1), W * cap
+        self._n = (ne, nl, nd, nu)
+        self._bwd_base = 2 * ne + nl
+        T = 2 * ne + nl + 2 * nd + nu
+        self._tail = self.mgr.reserve_tail(T)
+        self._table = self.mgr.cache_with_tail[:self._C + T]
+        t = self._tail
+        self._E = [t[0:ne], t[ne:2 * ne]]
+        self._L = t[2 * ne:2 * ne + nl]
+        b0 = self._bwd_base
+        self._Dg = [t[b0:b0 + nd], t[b0 + nd:b0 + 2 * nd]]
+        self._U = t[b0 + 2 * nd:b0 + 2 * nd + nu]
+        i32 = dict(dtype=torch.int32, device=dev)
+        self._pf_req = [torch.full((P, W * cap), -1, **i32) for _ in range(2)]
+        self._pb_req = [torch.full((P, W * cap), -1, **i32) for _ in range(2)]
+        self._pf_srv = [torch.full((P, W * cap), -1, **i32) for _ in range(2)]
+        self._pb_srv = [torch.full((P, W * cap), -1, **i32) for _ in range(2)]
+        # owner-side gather / update lists of every batch: [P, ne + nl (+1 dummy)] and [P, nd + nu (+1)]
+        self._lists_f = [torch.full((P, ne + nl + 1), -1, **i64) for _ in range(2)]
+        self._lists_b = [torch.full((P, nd + nu + 1), -1, **i64) for _ in range(2)]
+        self._idx_b = [torch.full((P, n), -1, **i64) for _ in range(2)]
+        self._keys_b = [torch.full((P, klen), -1, **i64) for _ in range(2)]
+        self._recv_u = torch.empty(nu, D, dtype=torch.float32, device=dev)
+        self._recv_d = torch.empty(nd, D, dtype=torch.float32, device=dev)
+        self._comm = torch.cuda.Stream(device=dev)
+
+    def _classify(self, buf: int) -> None:
+        W, P, cap = self.W, self.P, self.cap
+        check(lib.ce_split_classify(ptr(self._serve[buf]), W, P, cap, self._mask.numel(), None, 0, ptr(self._mask),
+                                    ptr(self._flags_o[buf]), stream_ptr()))
+        if self._force_late:           # test mode: every row late and urgent (the synchronous exchange, in split form)
+            self._flags_o[buf].fill_(3)
+
+    @torch.no_grad()
+    def _measure_split_caps(self, ids_list) -> Tuple[int, int, int, int]:
+        """capacities of the four classes from one window: dedupe + id exchange + classification, then every
+        (batch, peer) chunk's class counts; mean + 4.5 sigma (or the largest seen), rounded to 128 rows, such that an
+        early / deferred surplus always finds room behind the late / urgent rows; MAX over the ranks"""
+        W, P, cap, dev = self.W, self.P, self.cap, self.mgr.device
+        self._plan(ids_list, 0)
+        self._classify(0)
+        caps = torch.tensor([[cap] * 4] * P, dtype=torch.int32, device=dev)
+        counts = torch.zeros(P, W, 4, dtype=torch.int32, device=dev)
+        ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+        pf = torch.empty(P, W * cap, dtype=torch.int32, device=dev)
+        pb = torch.empty_like(pf)
+        check(lib.ce_split_places(ptr(self._serve[0].permute(1, 0, 2).contiguous()),
+                                  ptr(self._flags_o[0].permute(1, 0, 2).contiguous()), P, W, cap, -1, ptr(caps), ptr(pf),
+                                  ptr(pb), ptr(counts), ptr(ovf), stream_ptr()))
+        c = counts.double().cpu()                                                # [P, W, 4]: early, late, deferred, urgent
+        fwd = c[1:] if P > 1 else c                  # batch 0 is all early (nothing precedes the window)
+        bwd = c[:-1] if P > 1 else c                 # the last batch is all urgent
+        def need(x):
+            x = x.reshape(-1)
+            return max(float(x.max()), float(x.mean() + 4.5 * x.std(unbiased=False)))
+        r128 = lambda v: min(cap, (int(v) + 1 + 127) // 128 * 128)
+        cl, cu = r128(need(fwd[..., 1])), r128(need(bwd[..., 3]))
+        ce_ = max(r128(need(fwd[..., 0])), min(cap, cap - cl + 128))
+        cd = max(r128(need(bwd[..., 2])), min(cap, cap - cu + 128))
+        out = torch.tensor([ce_, cl, cd, cu], dtype=torch.int64)
+        self.split_stats = {"early_frac": float(fwd[..., 0].sum() / max(1.0, float(fwd[..., :2].sum()))),
+                            "deferred_frac": float(bwd[..., 2].sum() / max(1.0, float(bwd[..., 2:].sum()))),
+                            "mean_bucket": float(c[..., :2].sum(dim=-1).mean())}
+        if dist.get_backend(self.ex.group) == "gloo":
+            dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.ex.group)
+        else:
+            o = out.to(dev)
+            dist.all_reduce(o, op=dist.ReduceOp.MAX, group=self.ex.group)
+            out = o.cpu()
+        return tuple(int(v) for v in out)
+
+    @torch.no_grad()
+    def _plan_split(self, buf: int) -> None:
+        """owner: classify what every peer asks for, tell the peers, lay out the gather / update lists of every
+        step; requester: the same places from the flags the owners sent, then the two lookup indices and their keys"""
+        from .functional import presort_window
+        W, P, cap, n, r = self.W, self.P, self.cap, self.n, self.rank
+        ne, nl, nd, nu = self._n
+        sp = stream_ptr()
+        self._classify(buf)
+        got = torch.empty_like(self._flags_o[buf])
+        _a2a(got, self._flags_o[buf], None, None, self.ex.group)                     # [owner, P, cap]
+        self._flags_r[buf].copy_(got.permute(1, 0, 2))
+        serve_pwc = self._serve[buf].permute(1, 0, 2).contiguous()
+        flags_o_pwc = self._flags_o[buf].permute(1, 0, 2).contiguous()
+        check(lib.ce_split_places(ptr(serve_pwc), ptr(flags_o_pwc), P, W, cap, r, ptr(self._caps), ptr(self._pf_srv[buf]),
+                                  ptr(self._pb_srv[buf]), None, ptr(self._ovf[buf]), sp))
+        check(lib.ce_split_places(ptr(self._req[buf]), ptr(self._flags_r[buf]), P, W, cap, r, ptr(self._caps),
+                                  ptr(self._pf_req[buf]), ptr(self._pb_req[buf]), None, ptr(self._ovf[buf]), sp))
+        self._agree_on_overflow(buf)
+        # owner lists: the slot of every served row at its place in the step's messages (early | late, deferred | urgent)
+        slots = self._slots[buf]                                                     # [P, W * cap]
+        caps = self._caps.long()
+        for pl, lists, first, n_first, col in ((self._pf_srv[buf], self._lists_f[buf], ne, ne, 0),
+                                               (self._pb_srv[buf], self._lists_b[buf], nd, nd, 2)):
+            lists.fill_(-1)
+            wfirst = (W * caps[:, col]).unsqueeze(1)                                 # rows of the first region, per batch
+            p64 = pl.long()
+            dest = torch.where(p64 < wfirst, p64, n_first + p64 - wfirst)
+            dest = torch.where(p64 >= 0, dest, torch.full_like(dest, lists.shape[1] - 1))     # the dummy column
+            lists.scatter_(1, dest, slots)
+            lists[:, -1] = -1
+        check(lib.ce_exchange_local_index_split(ptr(self._pos[buf]), n, P, ptr(slots), ptr(self._pf_req[buf]),
+                                                ptr(self._pb_req[buf]), W * cap, r * cap, (r + 1) * cap, self._C,
+                                                self._bwd_base, ptr(self._caps), W, ne, nl, nd, ptr(self._idx[buf]),
+                                                ptr(self._idx_b[buf]), sp))
+        rows = self._table.shape[0]
+        for idx, keys in ((self._idx[buf], self._keys[buf]), (self._idx_b[buf], self._keys_b[buf])):
+            presort_window(idx, rows, keys_out=keys, offsets=self.offsets, include_last_offset=self.incl,
+                           hook_features=self.hook, identity_bags=self._identity)
+
+    def _send_rows(self, buf: int, i: int, late: bool) -> None:
+        """owner gather of batch i's early / late rows and their all-to-all into the peers' forward buffers"""
+        ne, nl, _, _ = self._n
+        ce_, cl = self._caps_host[i][0], self._caps_host[i][1]
+        if late:
+            sl, dst = self._lists_f[buf][i, ne:ne + self.W * cl], self._L[:self.W * cl]
+        else:
+            sl, dst = self._lists_f[buf][i, :self.W * ce_], self._E[i & 1][:self.W * ce_]
+        rows = self.ops.owner_gather(sl)
+        _a2a(dst, rows, None, None, self.ex.group)
+
+    def _return_grads(self, buf: int, i: int, urgent: bool) -> None:
+        """all-to-all of batch i's urgent / deferred row deltas back to their owners, which add them to the cache"""
+        _, _, nd, _ = self._n
+        cd, cu = self._caps_host[i][2], self._caps_host[i][3]
+        if urgent:
+            src, rcv, sl = self._U[:self.W * cu], self._recv_u[:self.W * cu], self._lists_b[buf][i, nd:nd + self.W * cu]
+        else:
+            src, rcv, sl = self._Dg[i & 1][:self.W * cd], self._recv_d[:self.W * cd], self._lists_b[buf][i, :self.W * cd]
+        _a2a(rcv, src, None, None, self.ex.group)
+        self.ops.owner_update(sl, rcv, -1.0)                                         # cache row += received delta
+
+    def _window_split(self, buf: int) -> None:
+        """The P steps of a window with both row exchanges split (W > 1).  Communication stream, per step i:
+            U(i-1) urgent deltas of the step before -> L(i) late rows of this step -> D(i-1) deferred deltas -> E(i+1)
+            early rows of the NEXT step
+        Compute stream: wait for E(i) and L(i), pool, the caller's dense part, zero the delta buffers, fold + SGD.
+        Only U(i-1) and L(i) sit between two steps' kernels; D(i-1) and E(i+1) travel while step i computes."""
+        ex, ops, W, P = self.ex, self.ops, self.W, self.P
+        lr = self.embed._lr[0]
+        if lr is None:
+            raise RuntimeError("row-wise sharded embedding needs set_fused_sgd(lr)")
+        dev = self.mgr.device
+        cur, comm = torch.cuda.current_stream(dev), self._comm
+        comm.wait_stream(cur)                  # everything before this window, its last gradients included
+        with torch.cuda.stream(comm):
+            self._send_rows(buf, 0, late=False)
+            ev_e = torch.cuda.Event()
+            ev_e.record(comm)
+        ev_fold = None
+        for i in range(P):
+            ev_e_next = None
+            with torch.cuda.stream(comm):
+                if i > 0:
+                    comm.wait_event(ev_fold)
+                    self._return_grads(buf, i - 1, urgent=True)
+                self._send_rows(buf, i, late=True)
+                ev_l = torch.cuda.Event()
+                ev_l.record(comm)
+                if i > 0 and self._caps_host[i - 1][2] > 0:
+                    self._return_grads(buf, i - 1, urgent=False)
+                if i + 1 < P:
+                    self._send_rows(buf, i + 1, late=False)
+                    ev_e_next = torch.cuda.Event()
+                    ev_e_next.record(comm)
+            cur.wait_event(ev_e)
+            cur.wait_event(ev_l)
+            keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
+            if self._identity and FORWARD_FROM_KEYS and hasattr(ops, "pool_from_keys"):
+                out = ops.pool_from_keys(self._table, keys, self.n)
+            else:
+                out = ops.pool(self._table, self._idx[buf][i], self.offsets, None, "sum", self.incl, self.hook)
+            grad = self.dense_fn(out, i)
+            cd, cu = self._caps_host[i][2], self._caps_host[i][3]
+            self._Dg[i & 1][:W * cd].zero_()
+            self._U[:W * cu].zero_()
+            keys_b = SrcKeys(self._keys_b[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
+            ops.update_table(self._table, grad, keys_b, self.n, lr)       # own rows: SGD in place; buffers: -lr * sum g
+            ev_fold = torch.cuda.Event()
+            ev_fold.record(cur)
+            ev_e = ev_e_next
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_fold)
+            self._return_grads(buf, P - 1, urgent=True)                   # (the last batch has no deferred rows)
+        cur.wait_stream(comm)
 
     def submit(self, ids_list: Sequence[torch.Tensor], buf: int) -> None:
         """Plan of a window into buffer `buf` (0/1); call it before run() of the previous window so they overlap."""
@@ -922,8 +1161,11 @@ class GraphedShardedWindow:
             for b in range(2):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, **mode):
-                    for i in range(self.P):
-                        self._step(b, i)
+                    if self._split:
+                        self._window_split(b)
+                    else:
+                        for i in range(self.P):
+                            self._step(b, i)
                 graphs.append(g)
             self._graphs = graphs
         except Exception as e:                      # e.g. a collective backend that cannot be captured
@@ -959,6 +1201,8 @@ class GraphedShardedWindow:
             return
         if self._graphs is not None:
             self._graphs[buf].replay()
+        elif self._split:
+            self._window_split(buf)
         else:
             for i in range(self.P):
                 self._step(buf, i)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CE_API_VERSION 4
+#define CE_API_VERSION 5
 
 /* status codes */
 #define CE_OK 0
@@ -501,6 +501,50 @@ int ce_dedupe_bucket_rows_padded_window(const int64_t* ids, int64_t n, int64_t n
 int ce_exchange_local_index(const int64_t* pos, int64_t n_per_batch, int64_t n_batches, const int64_t* slots,
                             int64_t slots_batch_stride, int64_t local_lo, int64_t local_hi, int64_t tail_base,
                             int64_t* index_out, ce_stream_t stream);
+
+/* Early / late split of the row-wise exchange (API 5).  The reference exchanges the KJT
+ * synchronously before every forward (recsys/datasets/utils.py:20-54) and the pooled embeddings after it; row-wise
+ * sharding (baselines/dlrm_main.py:715-716 is the only place the reference can select it) exchanges ROWS, and a row of
+ * step t depends on step t-1 only if some rank looked it up in step t-1.  The owner of a shard sees every rank's
+ * requests of a whole prefetch window when it plans the window, so it can tell the two kinds apart:
+ *   serve: device int64 [world][n_batches][capacity] -- the local rows peer w asks for in batch b (-1 = padding), as
+ *          the id all-to-all of the window delivered them;
+ *   prev / n_prev: the rows ANY peer asked for in the LAST batch of the window trained before this one (-1 entries
+ *          are ignored), or NULL / 0 when no window precedes (then batch 0 depends on nothing in flight);
+ *   mask:  scratch, device uint64 [n_local_rows], all zero on entry and all zero again on return;
+ *   flags_out: device uint8, same shape as serve: bit 0 = LATE (requested by any peer in the batch before: the row
+ *          must leave after that step's update has been applied), bit 1 = URGENT (requested by any peer in the batch
+ *          after: the gradient returned for it must be applied before that step's late rows leave).  The last batch
+ *          of the window is all URGENT (the next window is not planned yet).  Three launches, no host wait. */
+int ce_split_classify(const int64_t* serve, int32_t world, int32_t n_batches, int64_t capacity, int64_t n_local_rows,
+                      const int64_t* prev, int64_t n_prev, uint64_t* mask, uint8_t* flags_out, ce_stream_t stream);
+
+/* Places of a window's requests inside the split exchange buffers (API 5), identical on both sides of the exchange:
+ * the requester calls it on its requests and the flags the owners sent back, the owner on what it serves and its own
+ * flags -- both batch-major, device int64 / uint8 [n_batches][world][capacity].  caps: device int32 [n_batches][4] =
+ * {cap_early, cap_late, cap_deferred, cap_urgent} of every batch (the fixed message sizes of that step, rows per peer).
+ * place_fwd (device int32, same shape): an EARLY row of peer w gets w * cap_early + its rank among the chunk's early
+ * rows, a LATE row world * cap_early + w * cap_late + its rank among the late ones; an early row that does not fit
+ * cap_early is placed behind the chunk's late rows (a row may always be sent later).  place_bwd the same with
+ * DEFERRED (= not urgent) first.  Entries of peer `skip_peer` (a rank's requests to itself never travel: -1 = none),
+ * padding and rows that fit nowhere get -1; the latter also set *overflow_flag (device int32, OR-ed): the caller
+ * re-plans that window on the variable-size path.  counts_out (optional): device int32 [n_batches][world][4] = rows
+ * classified {early, late, deferred, urgent} per chunk, for choosing the capacities. */
+int ce_split_places(const int64_t* ids, const uint8_t* flags, int32_t n_batches, int32_t world, int64_t capacity,
+                    int32_t skip_peer, const int32_t* caps, int32_t* place_fwd, int32_t* place_bwd,
+                    int32_t* counts_out, int32_t* overflow_flag, ce_stream_t stream);
+
+/* ce_exchange_local_index for the split exchange (API 5): TWO indices per lookup, one into "cache + forward buffers"
+ * for the pooling, one into "cache + backward buffers" for the fused fold + SGD.  Behind the cache (tail_base rows
+ * from its first row, one allocation: ce_cache_set_cache_weight) lie [E0 | E1 | L] -- n_early, n_early, n_late rows:
+ * the early region exists twice because a step's early rows arrive while the step before still pools from its own,
+ * batch b uses copy b & 1 -- and, bwd_base rows further, [D0 | D1 | U] (n_deferred, n_deferred, then the urgent rows).
+ * Places in [local_lo, local_hi) (this rank's own chunk) become the cache slot in both indices. */
+int ce_exchange_local_index_split(const int64_t* pos, int64_t n_per_batch, int64_t n_batches, const int64_t* slots,
+                                  const int32_t* place_fwd, const int32_t* place_bwd, int64_t chunk_stride,
+                                  int64_t local_lo, int64_t local_hi, int64_t tail_base, int64_t bwd_base,
+                                  const int32_t* caps, int32_t world, int64_t n_early, int64_t n_late,
+                                  int64_t n_deferred, int64_t* index_fwd, int64_t* index_bwd, ce_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * The F.embedding_bag arguments the reference forwards (recsys/models/dlrm.py:99-110 -> upstream A.7) and none of its

@@ -150,7 +150,25 @@ class SgdLedger:
             sums[:, 1:] -= cum.index_select(1, ends[:-1] - 1)
             return uniq, sums.t()
 
-        gs = torch.stack([g.float().pow(2).mean() for g in {id(g): g for _, g in self.entries}.values()]).mean().sqrt()
+        gtensors = {id(g): g for _, g in self.entries}
+        cold_cache = {}
+
+        def cold_lookups():
+            """the lookups of rows with <= COLD_MAX lookups, gathered ONCE over all entries and grouped by the gradient
+            tensor they read: {id(g): (touched-row index [k], position in g [k])} -- a run of thousands of steps has a
+            few million of them, and a pass per entry was most of this check's time"""
+            if not cold_cache:
+                n_ext = torch.cat([n_lookups, torch.full((1,), 1 << 40, dtype=n_lookups.dtype, device=dev)])
+                parts = {}
+                for ids, g in self.entries:
+                    ci = ci_of(ids)
+                    pos = (n_ext[ci] <= COLD_MAX).nonzero(as_tuple=False).view(-1)
+                    parts.setdefault(id(g), []).append((ci[pos], pos))
+                for k_, lst in parts.items():
+                    cold_cache[k_] = (torch.cat([a for a, _ in lst]), torch.cat([b for _, b in lst]))
+            return cold_cache
+
+        gs = torch.stack([g.float().pow(2).mean() for g in gtensors.values()]).mean().sqrt()
         grad_rms = float(gs)
         free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 8 << 30
         chunk = max(1, min(T, int(0.35 * free) // (72 * D)))
@@ -193,15 +211,15 @@ class SgdLedger:
             n_one = int(is_one.sum())
             one_of[:c1 - c0][is_one] = torch.arange(n_one, device=dev)
             g_one = torch.zeros(n_one, D, dtype=torch.float32, device=dev)
-            for ids, g in self.entries:
-                ci = ci_of(ids)
-                inch = (ci >= c0) & (ci < c1)
-                ck = cold_of[torch.where(inch, ci - c0, torch.full_like(ci, c1 - c0))]
-                sel = ck >= 0
-                if bool(sel.any()):
-                    gs_ = g[sel].float()
-                    s_cold.index_add_(0, ck[sel], gs_.double().abs_(), alpha=abs(lr))
-                    ok1 = one_of[ci[sel] - c0]
+            for g, (ci_c, pos_c) in cold_lookups().items():             # per distinct gradient tensor: ONE pass
+                inch = (ci_c >= c0) & (ci_c < c1)
+                ck = cold_of[torch.where(inch, ci_c - c0, torch.full_like(ci_c, c1 - c0))]
+                for a in range(0, int(ck.numel()), 1 << 22):            # (bounded temporaries: 4 M lookups x D at a time)
+                    ck_a, pos_a = ck[a:a + (1 << 22)], pos_c[a:a + (1 << 22)]
+                    sel = ck_a >= 0
+                    gs_ = gtensors[g][pos_a[sel]].float()
+                    s_cold.index_add_(0, ck_a[sel], gs_.double().abs_(), alpha=abs(lr))
+                    ok1 = one_of[ci_c[a:a + (1 << 22)][sel] - c0]
                     s1 = ok1 >= 0
                     g_one[ok1[s1]] = gs_[s1]
             got32 = current_rows(rows)

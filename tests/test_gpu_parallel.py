@@ -114,7 +114,10 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
 
 
 def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=(5003, 64, 4, 32, 3, 1000),
-                     force_graph=False):
+                     force_graph=False, stream="random", expect_split=None):
+    # stream: how consecutive batches relate -- "random" draws; "same": every batch of a window looks up the SAME rows
+    # (every row late and urgent: what the split must not overtake); "disjoint": consecutive batches share no row (all
+    # early / deferred: everything may travel ahead)
     """parallel.GraphedShardedWindow (fixed-capacity exchange, the window's steps replayed as one hipGraph at world 1,
     launched one by one over gloo) against plain torch on the full table: pooled output of every step, table after
     flush.  capacity below the bucket sizes forces every window through the variable-size fallback."""
@@ -143,6 +146,15 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
     if N > 100000:       # bench-shaped: skewed ids, ~10 % distinct rows per batch
         all_ids = [[(torch.rand(F * B_loc, generator=g) ** 5 * N).long().clamp_(0, N - 1) for _ in range(P)]
                    for _ in range(nwin + 1)]
+    elif stream == "same":
+        gs = torch.Generator().manual_seed(7)              # (the same rows on EVERY rank, too)
+        all_ids = [[torch.randint(0, N, (F * B_loc,), generator=gs)] * P for _ in range(nwin + 1)]
+    elif stream == "disjoint":
+        # batch b of a window draws from the rows congruent to b modulo P + 1 (and the first batch of the next window
+        # from another class than the last batch of this one): on every rank, so no row is touched in two consecutive steps
+        k = P + 1
+        all_ids = [[torch.randint(0, N // k, (F * B_loc,), generator=g) * k + (b + w_) % k for b in range(P)]
+                   for w_ in range(nwin + 1)]
     else:
         all_ids = [[torch.randint(0, N, (F * B_loc,), generator=g) for _ in range(P)] for _ in range(nwin + 1)]
     go = torch.randn(P, B_loc, F, D, generator=g)               # one static upstream gradient per batch of a window
@@ -210,6 +222,16 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
             # summed by the end of this window (a hot row collects thousands of fp32 atomic updates per window)
             c = cnt[id2row[all_ids[w][i]]].view(F, B_loc, 1).transpose(0, 1)
             assert bool(((outs[i].cpu().double() - exp[i]).abs() <= bound(exp[i], c)).all())
+    if expect_split is not None:
+        assert gw._split == (expect_split and world > 1)
+    if gw._split and stream in ("same", "disjoint") and capacity >= 64:
+        # the classification of the last planned window, as the owner made it (bit 0 late, bit 1 urgent)
+        fl = gw._flags_o[nwin % 2].cpu()
+        valid = gw._serve[nwin % 2].cpu() >= 0
+        if stream == "same":
+            assert bool((fl[:, 1:][valid[:, 1:]] & 1).bool().all()) and bool((fl[valid] & 2).bool().all())
+        else:
+            assert not bool((fl[valid] & 1).bool().any()) and not bool((fl[:, :-1][valid[:, :-1]] & 2).bool().any())
     if capacity < 64:
         assert gw.fallback_windows == nwin
     else:
@@ -233,6 +255,22 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
 @pytest.mark.parametrize("capacity,overlap", [(256, True), (256, False), (8, True)])
 def test_rowwise_graphed_fixed_capacity_window(world, strategy, with_freq, capacity, overlap):
     _spawn(_rowwise_graphed, world, strategy, with_freq, capacity, overlap)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["split", "all_late", "off", "stream_same", "stream_disjoint"])
+def test_rowwise_graphed_window_early_late_split(world, mode, monkeypatch):
+    """The early / late split of the row exchanges: rows nobody touched in the step before travel while
+    that step computes, the gradients of rows nobody needs in the step after return behind it.  Same per-step pooled
+    outputs and the same table as plain torch on the full table with the split as classified ("split"), with every row
+    forced late + urgent ("all_late": the synchronous exchange in split form), switched off ("off": round 4's step),
+    and on id streams that make every row late ("stream_same") or every row early ("stream_disjoint")."""
+    if mode == "all_late":
+        monkeypatch.setenv("CE_SPLIT_FORCE", "late")
+    if mode == "off":
+        monkeypatch.setenv("CE_SHARDED_SPLIT", "0")
+    stream = {"stream_same": "same", "stream_disjoint": "disjoint"}.get(mode, "random")
+    _spawn(_rowwise_graphed, world, "dataset", True, 512, True, (5003, 64, 4, 32, 4, 1000), False, stream, mode != "off")
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -555,3 +593,95 @@ def test_bench_one_gpu_line_carries_roofline_box_and_a_passing_verification(extr
     if "--force_sharded" not in extra:
         assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1.2
         assert out["box"]["before"]["read_GBps"] > 1000 and out["it_per_s_scope"].startswith("embedding operator only")
+
+
+@pytest.mark.parametrize("W,P,cap,n_rows,fill", [(2, 4, 64, 500, 0.8), (3, 8, 1100, 9000, 0.9), (8, 8, 2500, 40000, 0.95),
+                                                 (4, 1, 300, 1000, 0.5), (2, 5, 1024, 300, 1.0)])
+def test_split_classify_and_places_against_a_plain_restatement(W, P, cap, n_rows, fill):
+    """ce_split_classify / ce_split_places (the early / late split of the row-wise exchange) against loops in numpy:
+    a row is LATE when any peer asks for it in the batch before, URGENT when any peer asks for it in the batch after
+    (the last batch: always); places = rank inside the chunk's class, early rows that do not fit spill behind the late
+    ones; the scratch mask is all zero again afterwards."""
+    import numpy as np
+    from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(W * 1000 + P * 10 + cap)
+    serve = np.full((W, P, cap), -1, dtype=np.int64)
+    for w in range(W):
+        for b in range(P):
+            k = int(cap * fill * rng.uniform(0.7, 1.0))
+            serve[w, b, :k] = rng.choice(n_rows, size=min(k, n_rows), replace=False)[:k] if k <= n_rows else \
+                rng.integers(0, n_rows, size=k)
+    dev = "cuda"
+    sv = torch.from_numpy(serve).to(dev)
+    mask = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+    flags = torch.full((W, P, cap), 77, dtype=torch.uint8, device=dev)
+    check(lib.ce_split_classify(ptr(sv), W, P, cap, n_rows, None, 0, ptr(mask), ptr(flags), stream_ptr()))
+    assert int(mask.abs().sum()) == 0
+    got = flags.cpu().numpy()
+    sets = [set(serve[:, b, :][serve[:, b, :] >= 0].tolist()) for b in range(P)]
+    exp = np.zeros_like(got)
+    for w in range(W):
+        for b in range(P):
+            for j in range(cap):
+                r = serve[w, b, j]
+                if r < 0:
+                    continue
+                late = b > 0 and r in sets[b - 1]
+                urgent = b == P - 1 or r in sets[b + 1]
+                exp[w, b, j] = (1 if late else 0) | (2 if urgent else 0)
+    assert np.array_equal(got, exp)
+    # ---- places, batch-major, with capacities small enough to make some early / deferred rows spill
+    ids = np.ascontiguousarray(serve.transpose(1, 0, 2))
+    fl = np.ascontiguousarray(exp.transpose(1, 0, 2))
+    valid = ids >= 0
+    n_l = (valid & ((fl & 1) > 0)).sum(-1)
+    n_e = valid.sum(-1) - n_l
+    n_u = (valid & ((fl & 2) > 0)).sum(-1)
+    n_d = valid.sum(-1) - n_u
+    ce_ = max(1, int(n_e.max() * 0.8))
+    cl = int(n_l.max() + max(0, n_e.max() - ce_)) + 1
+    cd = max(1, int(n_d[:-1].max() * 0.8)) if P > 1 else 1
+    caps = np.array([[ce_, cl, cd, cap]] * P, dtype=np.int32)
+    skip = 1 % W
+    pf = torch.empty(P, W * cap, dtype=torch.int32, device=dev)
+    pb = torch.empty_like(pf)
+    counts = torch.zeros(P, W, 4, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.ce_split_places(ptr(torch.from_numpy(ids).to(dev)), ptr(torch.from_numpy(fl).to(dev)), P, W, cap, skip,
+                              ptr(torch.from_numpy(caps).to(dev)), ptr(pf), ptr(pb), ptr(counts), ptr(ovf), stream_ptr()))
+    assert int(ovf) == 0
+    c = counts.cpu().numpy()
+    assert np.array_equal(c[..., 0], n_e) and np.array_equal(c[..., 1], n_l)
+    assert np.array_equal(c[..., 2], n_d) and np.array_equal(c[..., 3], n_u)
+    pf, pb = pf.cpu().numpy().reshape(P, W, cap), pb.cpu().numpy().reshape(P, W, cap)
+    for b in range(P):
+        for w in range(W):
+            re = rl = rd = ru = 0
+            for j in range(cap):
+                if ids[b, w, j] < 0 or w == skip:
+                    assert pf[b, w, j] == -1 and pb[b, w, j] == -1
+                    continue
+                if fl[b, w, j] & 1:
+                    want = W * ce_ + w * cl + rl
+                    rl += 1
+                else:
+                    want = w * ce_ + re if re < ce_ else W * ce_ + w * cl + n_l[b, w] + (re - ce_)
+                    re += 1
+                assert pf[b, w, j] == want, (b, w, j)
+                cdb, cub = caps[b, 2], caps[b, 3]
+                if fl[b, w, j] & 2:
+                    want = W * cdb + w * cub + ru
+                    ru += 1
+                else:
+                    want = w * cdb + rd if rd < cdb else W * cdb + w * cub + n_u[b, w] + (rd - cdb)
+                    rd += 1
+                assert pb[b, w, j] == want, (b, w, j)
+    # a late region that is too small is reported, not silently truncated
+    caps2 = caps.copy()
+    caps2[:, 1] = max(1, int(n_l.max()) - 1)
+    ovf.zero_()
+    if n_l.max() > 1:
+        check(lib.ce_split_places(ptr(torch.from_numpy(ids).to(dev)), ptr(torch.from_numpy(fl).to(dev)), P, W, cap, -1,
+                                  ptr(torch.from_numpy(caps2).to(dev)), ptr(pf := torch.empty(P, W * cap, dtype=torch.int32, device=dev)),
+                                  ptr(torch.empty(P, W * cap, dtype=torch.int32, device=dev)), None, ptr(ovf), stream_ptr()))
+        assert int(ovf) == 1
