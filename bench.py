@@ -39,6 +39,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# What the link does with both directions of a window's swap at once, measured by profiles/probes/probe_pcie_duplex.hip
+# (profiles/r05_probe_pcie_duplex.txt): filled in from that file, None until it has been collected
+PCIE_DUPLEX_PROBE = None
 
 
 def parse():
@@ -112,6 +115,9 @@ def parse():
                          "build's additions (fused SGD, folded hook, window keys, overlapped cache op, hipGraph, "
                          "worker transport).  What a maintainer gets before opting into anything.")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_reference_semantics", action="store_true",
+                    help="skip the extra block that runs the same steps with the reference's window semantics (one "
+                         "synchronous cache op per window, no protect_depth) next to the headline")
     ap.add_argument("--verify_sharded", action="store_true",
                     help="row-wise sharded runs at N > 1: the same end-of-run check per shard (every rank gathers all "
                          "ranks' ids of every trained step: steps x N x 3.4 MB of HBM per rank).  On by default for "
@@ -485,6 +491,50 @@ def main():
     hits, miss = sum(mgr.num_hits_history), sum(mgr.num_miss_history)
     tot = mgr.totals()
 
+    # ---- the same steps with the REFERENCE's window semantics (recsys/dlrm_main.py:243-262: the window's cache op runs
+    # when the window before has trained, on the training stream, nothing protected beyond the call's own ids), next to
+    # the headline: the pipelined arrangements above keep the rows of the window in training out of the next cache
+    # op's victim selection (`protect_depth` 1, an addition of this build -- the evict sets are exact against the oracle
+    # WITH that rule), this block does not need it.  Same kernels, same hipGraph of the steps, worker transport.
+    ref_semantics = None
+    if (gw is not None and (args.overlap or args.interleaved) and world == 1 and not skip_cache_op
+            and not args.no_reference_semantics and gw._plan_graphs is None):
+        from cachedembedding_amd.pipeline import GraphedWindow
+        gw.drain()
+        barrier()
+        mgr.set_protect_depth(0)
+        gs = ((g + P - 1) // P) * P
+        n_ref = max(8, -(-192 // P))                       # windows in the block
+        need_windows(gs + (n_ref + 2) * P, gs)
+        w_ref = gs // P
+        gw_seq = GraphedWindow(embed, P, B * F * L, train_step, overlap=False,
+                               warmup_values=[windows[w_ref][i] for i in range(P)], presort=presort, transport=None,
+                               bag_layout=layout)
+        trained(w_ref, 0, P)                                # (its constructor trains the window it is given once)
+        for w_ in (w_ref + 1, w_ref + 2):                   # settle
+            gw_seq.submit([windows[w_][j] for j in range(P)], w_ % 2)
+            gw_seq.run(w_ % 2)
+            trained(w_, 0, P)
+        barrier()
+        t_r = time.perf_counter()
+        for w_ in range(w_ref + 3, w_ref + 3 + n_ref - 3):
+            gw_seq.submit([windows[w_][j] for j in range(P)], w_ % 2)
+            gw_seq.run(w_ % 2)
+            trained(w_, 0, P)
+        barrier()
+        dt_r = time.perf_counter() - t_r
+        steps_r = (n_ref - 3) * P
+        ref_semantics = {"lookups_per_s": steps_r * B * F * L / dt_r, "ms_per_step": 1e3 * dt_r / steps_r, "steps": steps_r,
+                         "what": "reference window semantics (no `protect_depth`): one synchronous cache op per window on "
+                                 "the training stream, then the window's steps (the same hipGraph) -- recsys/dlrm_main.py:"
+                                 "243-262 with this build's kernels; the headline keeps the next window's cache op in "
+                                 "flight while this window trains and protects this window's rows from it"}
+        g = (w_ref + n_ref + 1) * P
+        del gw_seq
+        mgr.set_protect_depth(gw.plan_ahead)
+        note(f"reference window semantics: {ref_semantics['lookups_per_s'] / 1e9:.3f} G lookups/s "
+             f"({ref_semantics['ms_per_step']:.4f} ms/step over {steps_r} steps)")
+
     # ---- per-kernel launch duration with HIP events on the launch stream (separate passes over the same data).
     # Pass A: cache op on the compute stream, i.e. each kernel has the GPU to itself -> `avg_ms`, the number the
     #         roofline uses; `rocprofv3 --kernel-trace --stats -- python bench.py --no_overlap --no_graph` reports
@@ -680,6 +730,19 @@ def main():
     if swap_roof["avg_ms"] <= 0:          # no phase timers ran (cache op replayed from a hipGraph): no rate to quote
         swap_roof["achieved"] = None
     swap_roof["frac"] = None if swap_roof["achieved"] is None else swap_roof["achieved"] / swap_roof["peak"]
+    if transport == "worker" and wbs["in_jobs"]:
+        # two denominators, both stated: the admission worker's busy time (launch of the admission kernel
+        # to its completion: what the PCIe reads take) and the admit_swap phase on the cache-op stream (what the stream
+        # waited; in the interleaved arrangement that bracket spans the window's training steps, so it is long by design)
+        swap_roof["frac_by_worker_busy"] = swap_roof["frac"]
+        swap_roof["frac_by_phase"] = (swap_bytes / max(swap_ms, 1e-9) / 1e6) / swap_roof["peak"] if swap_ms > 0 else None
+        swap_roof["frac_basis"] = "frac = frac_by_worker_busy"
+        swap_roof["avg_ms_bracketed_in"] = f"the admit_swap phase of the {arrangement['mode']} arrangement"
+        out_bytes = wbs["rows"] * row_b / max(1, wbs["jobs"])
+        swap_roof["both_directions_GBps_by_worker_busy"] = (swap_bytes + out_bytes) / max(
+            in_busy_ms, 1e3 * wbs["out_busy_s"] / max(1, wbs["jobs"]), 1e-9) / 1e6
+        pd = PCIE_DUPLEX_PROBE
+        swap_roof["peak_duplex"] = pd
     # `roofline` = the kernel with the largest share of a step's GPU time (a step = 1 fwd + 1 bwd + 1/P swap)
     for r, per_step in ((fwd_roof, 1.0), (bwd_roof, 1.0), (swap_roof, 1.0 / P)):
         r["ms_per_step_share"] = r["avg_ms"] * per_step
@@ -728,6 +791,22 @@ def main():
                     {k: dominant[k] for k in dominant if k not in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
         "roofline_other": other,
     }
+    if ref_semantics is not None:
+        result["reference_window_semantics"] = ref_semantics
+    # what a window is made of (VERDICT r4 #2c): its length in the timed region, the back-to-back durations of its 2 P
+    # bag kernels, the cache-op chain's phases as timed in the pipeline (without the admission wait, which spans the
+    # window's steps in the interleaved arrangement), and what is neither: launch gaps, the graph's launch, the parked
+    # stream's release, k_unpack_admitted / k_admit_maps behind it.  The launch thread is not what the GPU waits for:
+    # host_enqueue_cpu_s is its CPU time for the whole region.
+    chain_ms = sum(v for k_, v in cache_phases.items() if k_ != "admit_swap")
+    win_ms = 1e3 * elapsed / K * P
+    result["window"] = {"ms": win_ms, "bag_kernels_ms": P * (fwd_avg + bwd_avg), "cache_op_chain_ms": chain_ms,
+                        "window_gap_ms": win_ms - P * (fwd_avg + bwd_avg) - chain_ms,
+                        "arrangement": arrangement["mode"], "host_enqueue_wall_s": enqueue_s,
+                        "host_enqueue_cpu_s": enqueue_cpu_s, "region_s": region,
+                        "what": "window_gap_ms = window - P x (forward + backward, back to back) - cache-op phases "
+                                "without admit_swap; in the overlap arrangement the chain runs beside the steps, so the "
+                                "gap can be negative there"}
 
     if ledger is not None:
         for w_, i0_, i1_ in trained_log:

@@ -295,6 +295,16 @@ class CachedParamMgr(torch.nn.Module):
         return self.prepare_ids_keys(ids, out, keys_out, _begin_only=True, **layout)
 
     @torch.no_grad()
+    def prepare_ids_begin_padded(self, ids: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """First half of prepare_ids(ids, out=out, padded=True) (flat int64 ids, -1 = padding); prepare_ids_finish()
+        enqueues the rest on the same stream."""
+        assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
+        assert out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == ids.numel()
+        with torch.cuda.device(self.device):
+            check(lib.ce_cache_prepare_ids_begin_padded(self._handle, ptr(ids), ids.numel(), ptr(out), stream_ptr()))
+        return out
+
+    @torch.no_grad()
     def prepare_ids_finish(self) -> None:
         if torch.cuda.current_device() == self.device.index:
             check(lib.ce_cache_prepare_ids_finish(self._handle, stream_ptr()))

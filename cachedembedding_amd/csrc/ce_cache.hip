@@ -270,7 +270,7 @@ __device__ __forceinline__ uint32_t miss_mask_stamp(const int32_t* __restrict__ 
 #ifdef CE_ABLATIONS
 #define CE_MDBG(x) (dbg & (x))
 #else
-#define CE_MDBG(x) 0
+#define CE_MDBG(x) (0 && (x))
 #endif
 template <bool MERGE, int U>
 __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
@@ -371,28 +371,32 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
 // the atomic if the bit is clear -- and leaves the row (bit 31: not resident) beside the key.  After a barrier every id
 // of the chunk reads its row out of the table.  ~0.4 M distinct (chunk, id) pairs per window instead of 3.4 M ids; no
 // LDS window for the hot bitmap words and no ballot merge are needed: a hot row costs one access per chunk.
-constexpr int kMarkChunk = 8192;
-constexpr int kMarkTab = 16384;            // entries: load factor <= 0.5 whatever the ids
-__global__ __launch_bounds__(1024) void k_mark_dedupe(const int64_t* __restrict__ ids, int64_t n,
-                                                     const int32_t* __restrict__ idx_map,
-                                                     const int32_t* __restrict__ inverted, int64_t N, uint32_t* bitmap,
-                                                     Ctl* ctl, int64_t* rows_out, int allow_pad) {
-  constexpr int U = kMarkChunk / 1024;
-  __shared__ uint32_t tkey[kMarkTab];      // id + 1 (0 = free)
-  __shared__ uint32_t tval[kMarkTab];      // row | (not resident) << 31
+// CHUNK ids per workgroup pass, THREADS threads, table of 2 * CHUNK entries (load factor <= 0.5 whatever the ids):
+// 8192 / 1024 -> 128 KB of LDS (one workgroup per CU), 4096 / 512 -> 64 KB, 2048 / 256 -> 32 KB.
+template <int CHUNK, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_mark_dedupe(const int64_t* __restrict__ ids, int64_t n,
+                                                        const int32_t* __restrict__ idx_map,
+                                                        const int32_t* __restrict__ inverted, int64_t N, uint32_t* bitmap,
+                                                        Ctl* ctl, int64_t* rows_out, int allow_pad, int dbg) {
+  constexpr int U = CHUNK / THREADS;
+  constexpr int TAB = 2 * CHUNK;
+  constexpr int TAB_LOG2 = CHUNK == 8192 ? 14 : (CHUNK == 4096 ? 13 : 12);
+  static_assert(CHUNK == 8192 || CHUNK == 4096 || CHUNK == 2048, "table size");
+  __shared__ uint32_t tkey[TAB];           // id + 1 (0 = free)
+  __shared__ uint32_t tval[TAB];           // row | (not resident) << 31
   const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t nchunks = (n + kMarkChunk - 1) / kMarkChunk;
+  const int64_t nchunks = (n + CHUNK - 1) / CHUNK;
   int cold = 0;
   for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    for (int e = tid; e < kMarkTab; e += 1024) tkey[e] = 0;
+    for (int e = tid; e < TAB; e += THREADS) tkey[e] = 0;
     __syncthreads();
-    const int64_t base = chunk * kMarkChunk;
+    const int64_t base = chunk * CHUNK;
     uint32_t key[U];
     int hh[U];
     bool own[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = base + u * 1024 + tid;
+      const int64_t i = base + u * THREADS + tid;
       key[u] = 0;
       own[u] = false;
       hh[u] = 0;
@@ -409,28 +413,34 @@ __global__ __launch_bounds__(1024) void k_mark_dedupe(const int64_t* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!key[u]) continue;
-      uint32_t h = (key[u] * 2654435761u) >> (32 - 14);
+      if (CE_MDBG(8)) { own[u] = true; continue; }               // ablation: no table, every id does its own global work
+      uint32_t h = (key[u] * 2654435761u) >> (32 - TAB_LOG2);
       for (;;) {
-        uint32_t cur = *(volatile uint32_t*)&tkey[h];
+        // (an LDS read proper -- ds_read_b32; a volatile access through a plain pointer compiles to a FLAT load here)
+        uint32_t cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == 0) cur = atomicCAS(&tkey[h], 0u, key[u]);
         if (cur == 0) { own[u] = true; break; }
         if (cur == key[u]) break;
-        h = (h + 1) & (kMarkTab - 1);
+        h = (h + 1) & (TAB - 1);
       }
       hh[u] = (int)h;
     }
     // ---- the lanes that entered an id: the global accesses, all U in flight per step
     int32_t row[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (own[u]) row[u] = idx_map ? idx_map[key[u] - 1u] : (int32_t)(key[u] - 1u);
+    for (int u = 0; u < U; ++u) {
+      row[u] = 0;
+      if (own[u]) row[u] = (idx_map && !CE_MDBG(1)) ? idx_map[key[u] - 1u] : (int32_t)(key[u] - 1u);
+    }
     int32_t inv[U];
     uint32_t cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      inv[u] = 0;
+      cur[u] = ~0u;
       if (own[u]) {
-        inv[u] = inverted[row[u]];
-        cur[u] = *(volatile uint32_t*)(bitmap + (row[u] >> 5));
+        if (!CE_MDBG(2)) inv[u] = inverted[row[u]];
+        if (!CE_MDBG(4)) cur[u] = __hip_atomic_load(bitmap + (row[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
 #pragma unroll
@@ -438,16 +448,23 @@ __global__ __launch_bounds__(1024) void k_mark_dedupe(const int64_t* __restrict_
       if (own[u]) {
         const uint32_t bit = 1u << (row[u] & 31);
         if (!(cur[u] & bit)) atomicOr(bitmap + (row[u] >> 5), bit);
-        tval[hh[u]] = (uint32_t)row[u] | (inv[u] < 0 ? 0x80000000u : 0u);
+        if (CE_MDBG(8)) {
+          rows_out[base + u * THREADS + tid] = (int64_t)row[u];
+          cold += inv[u] < 0;
+        } else {
+          tval[hh[u]] = (uint32_t)row[u] | (inv[u] < 0 ? 0x80000000u : 0u);
+        }
       }
     }
     __syncthreads();
+    if (!CE_MDBG(8)) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!key[u]) continue;
-      const uint32_t v = tval[hh[u]];
-      rows_out[base + u * 1024 + tid] = (int64_t)(v & 0x7fffffffu);
-      cold += (int)(v >> 31);
+      for (int u = 0; u < U; ++u) {
+        if (!key[u]) continue;
+        const uint32_t v = tval[hh[u]];
+        rows_out[base + u * THREADS + tid] = (int64_t)(v & 0x7fffffffu);
+        cold += (int)(v >> 31);
+      }
     }
     __syncthreads();
   }
@@ -3004,12 +3021,16 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     const bool mark_merge = mark_merge_env >= 0 ? mark_merge_env != 0 : !ranked;
     const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
     // calls of a window's size: the repeats of every 8192-id chunk folded in LDS first (CE_MARK_DEDUPE=0: the per-id kernel)
-    static const int mark_dedupe = [] { const char* e = getenv("CE_MARK_DEDUPE"); return e ? atoi(e) : 1; }();
-    static const int mark_dd_blocks = [] { const char* e = getenv("CE_MARK_DEDUPE_BLOCKS"); return e ? atoi(e) : 512; }();
-    if (n >= 65536 && mark_dedupe && !mark_dbg) {
-      const int grid = (int)std::min<int64_t>(cdiv(n, kMarkChunk), mark_dd_blocks);
-      hipLaunchKernelGGL(k_mark_dedupe, dim3(grid), dim3(1024), 0, s, ids, n, c.idx_map, c.inverted_cached_idx, N,
-                         h->bitmap, h->ctl, slots_out, allow_pad);
+    static const int mark_dedupe = [] { const char* e = getenv("CE_MARK_DEDUPE"); return e ? atoi(e) : 0; }();
+    static const int mark_dd_blocks = [] { const char* e = getenv("CE_MARK_DEDUPE_BLOCKS"); return e ? atoi(e) : 4096; }();
+    if (n >= 65536 && mark_dedupe) {
+#define CE_MARK_DD(CH, TH)                                                                                          \
+  hipLaunchKernelGGL((k_mark_dedupe<CH, TH>), dim3((unsigned)std::min<int64_t>(cdiv(n, CH), mark_dd_blocks)), dim3(TH), \
+                     0, s, ids, n, c.idx_map, c.inverted_cached_idx, N, h->bitmap, h->ctl, slots_out, allow_pad, mark_dbg)
+      if (mark_dedupe == 1) CE_MARK_DD(8192, 1024);
+      else if (mark_dedupe == 2) CE_MARK_DD(4096, 512);
+      else CE_MARK_DD(2048, 256);
+#undef CE_MARK_DD
     } else if (n > 0) {
       const int u = (n >= 65536 && mark_u != 1) ? (mark_u == 2 ? 2 : 4) : 1;
       const dim3 mg(std::min(grid_for(n, mark_threads * u), mark_blocks)), mb(mark_threads);
@@ -3366,6 +3387,11 @@ extern "C" int ce_cache_prepare_ids_finish(ce_cache_t* h, ce_stream_t stream) {
 extern "C" int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                            ce_stream_t stream) {
   return prepare_ids_impl(h, ids, n, slots_out, stream, 1);
+}
+
+extern "C" int ce_cache_prepare_ids_begin_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                                 ce_stream_t stream) {
+  return prepare_ids_impl(h, ids, n, slots_out, stream, 1, nullptr, 1);
 }
 
 extern "C" int ce_cache_graph_replayed(ce_cache_t* h, int64_t n_calls, int64_t ids_per_call, ce_stream_t stream) {

@@ -714,7 +714,14 @@ class GraphedShardedWindow:
                  dense_fn, capacity: int, hook_features: int = 0, overlap: bool = True,
                  use_graph: Optional[bool] = None,
                  transport: Optional[str] = None, warmup_ids: Optional[Sequence[torch.Tensor]] = None,
-                 split: Optional[bool] = None, split_caps: Optional[Sequence[int]] = None):
+                 split: Optional[bool] = None, split_caps: Optional[Sequence[int]] = None,
+                 arrangement: Optional[str] = None, arrangement_trial: Optional[dict] = None):
+        # arrangement (overlap=True): where the NEXT window's plan runs -- "overlap": on the two side streams beside this
+        # window's steps; "interleaved": on the training stream, the owner-side cache op in two halves around this
+        # window's steps (ce_cache_prepare_ids_begin_padded / _finish), so that no kernel of the plan runs beside a bag
+        # kernel and only the PCIe admission overlaps -- what pipeline.GraphedWindow's one-stream arrangement is to the
+        # unsharded module; "auto" (W = 1 only: the verdict is local): pipeline.ArrangementTrial measures both while
+        # training.  None: "auto" at W = 1, "overlap" otherwise (no multi-GPU measurement exists to choose by).
         # split (W > 1; default on, CE_SHARDED_SPLIT=0 switches it off): the EARLY / LATE split of both row exchanges of
         # a step (class docstring).  split_caps = (cap_early, cap_late, cap_deferred, cap_urgent) rows per peer and
         # step; None: measured on the warm-up window (mean + 4.5 sigma of every class, agreed over the ranks).
@@ -742,6 +749,8 @@ class GraphedShardedWindow:
         self._counts = [torch.zeros(P, W, **i64) for _ in range(2)]
         self._ovf = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
         self._ovf_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._ovf_event = [None, None]               # behind the flag's copy to the host
+        self._ovf_pending = [False, False]
         self._events = [None, None]
         self._ids = [None, None]
         self._side = torch.cuda.Stream(device=dev) if overlap else None        # dedupe + id exchange
@@ -751,6 +760,20 @@ class GraphedShardedWindow:
             self.mgr.strict = False
             if transport:
                 self.mgr.set_transport(transport)
+        from .pipeline import ARRANGEMENTS, ArrangementTrial, DEFAULT_ARRANGEMENT
+        if arrangement is None:
+            arrangement = (DEFAULT_ARRANGEMENT if W == 1 else "overlap") if overlap else None
+        if arrangement is not None:
+            if arrangement not in ("auto",) + ARRANGEMENTS:
+                raise ValueError(f"arrangement={arrangement!r}: 'auto', 'overlap' or 'interleaved'")
+            if not overlap:
+                raise ValueError("arrangement= needs overlap=True (the next window planned while this one trains)")
+            if arrangement == "auto" and W > 1:
+                raise ValueError("arrangement='auto' needs the ranks to agree on a verdict: W = 1 only for now")
+        self.trial = ArrangementTrial(P, **(arrangement_trial or {})) if arrangement == "auto" else None
+        self._mode = self.trial.mode if self.trial is not None else (arrangement or "sequential")
+        self._begun: Optional[int] = None            # interleaved: buffer whose owner-side cache op is begun, not finished
+        self._begun_slots = None
         # scratch of the dedupe passes: one stamp / place array per batch of the window, so that the P batches are
         # deduped by ONE launch per pass (P * N * 4 bytes: 5.7 GB for the Criteo-1TB table at P = 8 -- 0.7 GB per batch
         # of the window, 2 % of a GPU's HBM; CE_DEDUPE_PER_BATCH=1 dedupes batch by batch with one array instead, at
@@ -852,7 +875,7 @@ class GraphedShardedWindow:
             self._agree_on_overflow(buf)
         if W > 1:
             # peer-major for the exchange; local rows fit 32 bits (N / W < 2^31): half the bytes of the id exchange
-            req_wpc = self._req[buf].permute(1, 0, 2).to(torch.int32)
+            req_wpc = self._req[buf].permute(1, 0, 2).to(torch.int32, memory_format=torch.contiguous_format)
             got = torch.empty_like(req_wpc)
             _a2a(got, req_wpc, None, None, self.ex.group)
             self._serve[buf].copy_(got)
@@ -870,11 +893,47 @@ class GraphedShardedWindow:
             else:
                 dist.all_reduce(self._ovf[buf], op=dist.ReduceOp.MAX, group=self.ex.group)
         self._ovf_host[buf].copy_(self._ovf[buf], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ovf_event[buf] = ev
 
     @torch.no_grad()
     def _plan_owner(self, buf: int) -> None:
-        W, P, cap = self.W, self.P, self.cap
         slots = self.mgr.prepare_ids(self._serve[buf].view(-1), padded=True)         # -1 = padding: slot -1
+        self._plan_owner_rest(buf, slots)
+
+    @torch.no_grad()
+    def _plan_owner_begin(self, buf: int) -> None:
+        """interleaved: the first half of the owner-side cache op (everything that needs nothing from the host table)"""
+        self._begun_slots = torch.empty(self._serve[buf].numel(), dtype=torch.int64, device=self.mgr.device)
+        self.mgr.prepare_ids_begin_padded(self._serve[buf].view(-1), self._begun_slots)
+        self._begun = buf
+
+    @torch.no_grad()
+    def _finish_begun(self) -> None:
+        if self._begun is None:
+            return
+        buf, slots = self._begun, self._begun_slots
+        self._begun, self._begun_slots = None, None
+        self.mgr.prepare_ids_finish()
+        self._plan_owner_rest(buf, slots)
+
+    @property
+    def arrangement(self) -> str:
+        return self._mode
+
+    def set_arrangement(self, mode: str) -> None:
+        """'overlap' / 'interleaved' for the windows submitted from now on (between windows)"""
+        assert mode in ("overlap", "interleaved") and self.overlap
+        self._finish_begun()
+        self._mode = mode
+
+    def drain(self) -> None:
+        self._finish_begun()
+
+    @torch.no_grad()
+    def _plan_owner_rest(self, buf: int, slots: torch.Tensor) -> None:
+        W, P, cap = self.W, self.P, self.cap
         self._slots[buf].view(P, W, cap).copy_(slots.view(W, P, cap).permute(1, 0, 2))
         r = self.rank
         from .functional import presort_window
@@ -1109,6 +1168,17 @@ class GraphedShardedWindow:
             self._events[buf] = ev
             return
         cur = torch.cuda.current_stream(dev)
+        if self._mode == "interleaved":
+            # one stream: dedupe + id exchange + the first half of the owner-side cache op now, i.e. BEFORE the steps of
+            # the window in training; run() enqueues the second half and the rest of the plan behind those steps
+            self._finish_begun()
+            for e_ in self._events:                    # (a plan still running on the side streams comes first)
+                if e_ is not None:
+                    cur.wait_event(e_)
+            self._plan(ids_list, buf)
+            self._plan_owner_begin(buf)
+            self._events[buf] = None
+            return
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             self._plan(ids_list, buf)
@@ -1177,11 +1247,17 @@ class GraphedShardedWindow:
     def run(self, buf: int) -> None:
         """Train the P batches of the window in buffer `buf` (waits for its plan)."""
         dev = self.mgr.device
+        if self._begun == buf:             # (no window trained in between: the two halves back to back)
+            self._finish_begun()
         ev = self._events[buf]
         if ev is not None:
             ev.synchronize()               # the plan was enqueued a whole window ago: the flag is there
             torch.cuda.current_stream(dev).wait_event(ev)
             self._events[buf] = None
+        elif self._mode == "interleaved" or self._ovf_pending[buf]:
+            # interleaved: the plan ran on this stream; its overflow flag was copied to the host behind it
+            if self._ovf_event[buf] is not None:
+                self._ovf_event[buf].synchronize()
         if not self.mgr.strict:
             self.mgr.raise_on_failed_calls()
         if int(self._ovf_host[buf][0]) != 0:
@@ -1206,6 +1282,11 @@ class GraphedShardedWindow:
         else:
             for i in range(self.P):
                 self._step(buf, i)
+        self._finish_begun()                 # interleaved: the NEXT window's second half, behind this window's steps
+        if self.trial is not None:
+            mode = self.trial.window_done(torch.cuda.current_stream(dev))
+            if mode != self._mode:
+                self.set_arrangement(mode)
 
 
 class ParallelCachedEmbeddingBag(CachedEmbeddingBag):

@@ -165,6 +165,28 @@ class ArrangementTrial:
             "trials": self.trials}
 
 
+def cat_window(values: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The window's ids as one tensor (recsys/dlrm_main.py:259 `torch.cat(sparse_values)`) -- without the copy when the
+    batches already ARE consecutive pieces of one contiguous int64 tensor (a loader that hands out a window at a time, the
+    bench's generator): then the view over all of them is returned."""
+    if len(values) == 1:
+        return values[0]
+    first = values[0]
+    if first.dtype == torch.int64 and first.dim() == 1 and first.is_contiguous():
+        n, st, end = first.numel(), first.untyped_storage(), first.data_ptr()
+        ok = True
+        for v in values:
+            if not (v.dtype == torch.int64 and v.dim() == 1 and v.is_contiguous() and v.data_ptr() == end
+                    and v.untyped_storage().data_ptr() == st.data_ptr()):
+                ok = False
+                break
+            end += 8 * v.numel()
+        if ok:
+            total = sum(int(v.numel()) for v in values)
+            return torch.empty(0, dtype=torch.int64, device=first.device).set_(st, first.storage_offset(), (total,))
+    return torch.cat(list(values))
+
+
 def _resolve_arrangement(arrangement: Optional[str], switchable: bool) -> Optional[str]:
     """None -> the library default for a window object that can do both (CE_ARRANGEMENT, 'auto' unless set)"""
     if arrangement is None:
@@ -242,7 +264,7 @@ class PrefetchWindow:
         takes -- equal int64 batches, fused keys or none -- and return None if it does not (the caller then takes the
         side stream for this window)"""
         counts = [int(v.numel()) for v in values]
-        cat = values[0] if len(values) == 1 else torch.cat(list(values))
+        cat = cat_window(values)
         if self._auto:
             self._auto = False
             self.mgr.set_transport(pick_transport("auto", int(cat.numel())))
@@ -580,7 +602,7 @@ class GraphedWindow:
             with torch.cuda.stream(self._side), phase("prefetch cache"):
                 if self._read_done[buf] is not None:
                     self._side.wait_event(self._read_done[buf])
-                cat = values[0] if len(values) == 1 else torch.cat(list(values))
+                cat = cat_window(values)
                 assert cat.numel() == self.P * self.n
                 self._cache_op(cat, buf)
                 ev = torch.cuda.Event()
@@ -589,7 +611,7 @@ class GraphedWindow:
                 v.record_stream(self._side)
             self._events[buf] = ev
             return
-        cat = values[0] if len(values) == 1 else torch.cat(list(values))
+        cat = cat_window(values)
         assert cat.numel() == self.P * self.n
         if self.interleaved:
             with phase("prefetch cache"):

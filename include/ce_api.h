@@ -368,6 +368,11 @@ int ce_cache_prepare_ids_finish(ce_cache_t* h, ce_stream_t stream);
  * loudly, not train on zero rows. */
 int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                 ce_stream_t stream);
+/* First half of ce_cache_prepare_ids_padded (API 5): as ce_cache_prepare_ids_begin, for a padded id list and without
+ * keys; ce_cache_prepare_ids_finish enqueues the second half.  The owner-side cache op of the row-wise exchange in its
+ * one-stream arrangement (parallel.GraphedShardedWindow(arrangement="interleaved")). */
+int ce_cache_prepare_ids_begin_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
+                                      ce_stream_t stream);
 
 /* Blocks until the most recent prepare_ids/preload/flush has finished on the device and
  * returns that call's statistics; returns its status (CE_ERR_CAPACITY ...). */
