@@ -1153,6 +1153,17 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
     Ww = W // P
     run_windows(0, Ww)
     barrier()
+    if gw.trial is not None:                 # W = 1: the library's arrangement trial settles before anything is timed
+        while gw.trial.decided is None and Ww < 8192:
+            need_windows((Ww + 9) * P, Ww * P)
+            run_windows(Ww, Ww + 8)
+            Ww += 8
+            if gw.trial.blocks_enqueued:
+                barrier()
+                gw.trial.poll(wait=True)
+        barrier()
+        if gw.trial.decided is not None and gw.trial.decided != gw.arrangement:
+            gw.set_arrangement(gw.trial.decided)
     Kw = max(1, K // P)                      # whole windows per block
     need_windows((Ww + Kw) * P, Ww * P)
     mgr.set_profiling(True)                  # phase timers in the separately bracketed block only (their events cost
@@ -1208,6 +1219,7 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                              "fixed-capacity steps launched one by one (world > 1: CE_SHARDED_GRAPH=1 captures them)",
                    "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
                    "windows_on_the_variable_size_path": gw.fallback_windows,
+                   "arrangement": (gw.trial.report() | {"mode": gw.arrangement}) if gw.trial is not None else {"mode": gw.arrangement},
                    "exchange_split": ({"on": True, "rows_per_peer_and_step": dict(zip(("early", "late", "deferred", "urgent"), gw.split_caps)),
                                        "measured_on_the_warmup_window": gw.split_stats,
                                        "what": "rows nobody looked up in the step before leave their owner while that "

@@ -29,6 +29,7 @@
 // pinned staging + hipMemcpyAsync with host worker threads doing the table gather/scatter.
 #include <sched.h>
 #include <stdlib.h>
+#include <string.h>
 #include <sys/prctl.h>
 
 #include <algorithm>
@@ -2681,6 +2682,29 @@ static int ensure_writeback(ce_cache* h) {
         hipStreamCreateWithPriority(&w->in_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
       rc = CE_ERR_HIP;
       break;
+    }
+    {
+      // Where the admission kernel's workgroups sit (CE_ADMIT_CU_MASK; experiment, off unless set).  Its reads of the
+      // mapped host table hold miss-queue entries of the L2 they pass through for a PCIe round trip each, and every XCD
+      // has an L2 of its own: on an unmasked stream the 20 workgroups land on all eight XCDs and an HBM-bound kernel
+      // beside them runs at 0.69 of its speed (profiles/r05_probe_pcie_duplex.txt).  "8th": every 8th CU (32 CUs),
+      // "low32": CUs 0..31, "4th" / "low64": 64 CUs.  A CU-masked stream has a hardware queue of its own (the mask is a
+      // queue property), which is what the priority above is for; the first-use self-test covers it like the others.
+      const char* cm = getenv("CE_ADMIT_CU_MASK");
+      if (cm && *cm && strcmp(cm, "0") != 0) {
+        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!strcmp(cm, "8th")) { for (int i = 0; i < kNumCU; i += 8) m[i / 32] |= 1u << (i % 32); }
+        else if (!strcmp(cm, "4th")) { for (int i = 0; i < kNumCU; i += 4) m[i / 32] |= 1u << (i % 32); }
+        else if (!strcmp(cm, "low64")) { m[0] = m[1] = 0xffffffffu; }
+        else { m[0] = 0xffffffffu; }
+        hipStream_t ms = nullptr;
+        if (hipExtStreamCreateWithCUMask(&ms, 8, m) == hipSuccess) {
+          (void)hipStreamDestroy(w->in_stream);
+          w->in_stream = ms;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
     }
     void* p = nullptr;
     void* pd = nullptr;

@@ -1264,6 +1264,7 @@ class GraphedShardedWindow:
             # a bucket did not fit `capacity`: this window goes through the variable-size exchange (its rows are
             # resident already -- the padded plan admitted every row that did fit; plan_window admits the rest)
             self.fallback_windows += 1
+            self._finish_begun()             # (interleaved: the next window's cache op is begun: finish it first)
             if self._side2 is not None:      # the next window's plan is in flight: the cache manager is not re-entrant
                 self._side2.synchronize()
             plans = self.embed.plan_window(self._ids[buf])

@@ -155,6 +155,53 @@ int main(int argc, char** argv) {
   timeit("opposite engines: write-back kernel 16 x 1024 scattering rows into the host table, alone", R_, [&] { wb_kernel(16); }, 0, job);
   timeit("BOTH, opposite engines: SDMA H2D contiguous + write-back kernel 16 x 1024", R_, [&] { h2d_sdma(); wb_kernel(16); }, job, job);
   timeit("BOTH, two SDMA copies: D2H 8 chunks + H2D contiguous", R_, [&] { d2h(8); h2d_sdma(); }, job, job);
+  // ---- where the admission kernel's workgroups sit.  Its reads hold miss-queue entries of the L2 they pass through for a
+  // PCIe round trip each; every XCD has its own L2, and a 20-workgroup grid on an unmasked stream lands on all eight.
+  // hipExtStreamCreateWithCUMask: bit i of the mask = CU i; which XCD a bit belongs to is what the two patterns probe
+  // (every 8th bit = one XCD if the driver deals the bits round-robin to the XCCs; the low 32 bits = one XCD if not).
+  auto masked_stream = [&](int pattern) {
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pattern == 0) for (int i = 0; i < 256; i += 8) m[i / 32] |= 1u << (i % 32);        // every 8th CU: 32 CUs
+    else if (pattern == 1) m[0] = 0xffffffffu;                                             // CUs 0..31
+    else if (pattern == 2) for (int i = 0; i < 256; i += 4) m[i / 32] |= 1u << (i % 32);   // every 4th: 64 CUs
+    else { m[0] = 0xffffffffu; m[1] = 0xffffffffu; }                                       // CUs 0..63
+    hipStream_t st;
+    CK(hipExtStreamCreateWithCUMask(&st, 8, m));
+    return st;
+  };
+  const char* pat_name[4] = {"every 8th CU (32)", "CUs 0..31", "every 4th CU (64)", "CUs 0..63"};
+  hipStream_t s_saved = s_in;
+  for (int pat = 0; pat < 4; ++pat) {
+    s_in = masked_stream(pat);
+    char buf[160];
+    snprintf(buf, sizeof buf, "admission 20 x 1024 x 16 on a stream masked to %s, alone", pat_name[pat]);
+    timeit(buf, R_, [&] { admit(20, 16); }, job, 0);
+    const double b0 = timeit("   HBM-bound neighbour alone (8 x copy of 1 GiB)", 5, [&] { stream_kernel(8); }, 0, 0);
+    snprintf(buf, sizeof buf, "   neighbour beside admission kernels on the stream masked to %s", pat_name[pat]);
+    const double d1 = timeit(buf, 5, [&] { for (int k = 0; k < 6; ++k) admit(20, 16); stream_kernel(8); }, 0, 0);
+    printf("       -> x%.3f\n", d1 / b0);
+    snprintf(buf, sizeof buf, "   neighbour beside 32 x 1024 x 16 admission kernels, masked to %s", pat_name[pat]);
+    const double d2 = timeit(buf, 5, [&] { for (int k = 0; k < 6; ++k) admit(32, 16); stream_kernel(8); }, 0, 0);
+    printf("       -> x%.3f\n", d2 / b0);
+    CK(hipStreamDestroy(s_in));
+  }
+  s_in = s_saved;
+  // both directions as KERNELS (no SDMA, no host scatter): write-back kernel + admission kernel, unmasked and masked
+  timeit("BOTH as kernels: write-back 16 x 1024 + admission 20 x 1024 x 16, unmasked streams", R_, [&] { wb_kernel(16); admit(20, 16); }, job, job);
+  {
+    hipStream_t keep_in = s_in, keep_out = s_out[0];
+    s_in = masked_stream(0);
+    s_out[0] = masked_stream(0);
+    timeit("BOTH as kernels, both streams masked to every 8th CU", R_, [&] { wb_kernel(16); admit(20, 16); }, job, job);
+    const double b0 = timeit("   HBM-bound neighbour alone (8 x copy of 1 GiB)", 5, [&] { stream_kernel(8); }, 0, 0);
+    const double d1 = timeit("   neighbour beside both kernels (masked), back to back for its duration", 5,
+                             [&] { for (int k = 0; k < 5; ++k) { wb_kernel(16); admit(20, 16); } stream_kernel(8); }, 0, 0);
+    printf("       -> x%.3f\n", d1 / b0);
+    CK(hipStreamDestroy(s_in));
+    CK(hipStreamDestroy(s_out[0]));
+    s_in = keep_in;
+    s_out[0] = keep_out;
+  }
   // what the admission does to an HBM-bound neighbour (1 GiB copy, 8 launches), by rows in flight
   const double base = timeit("HBM-bound neighbour alone (8 x copy of 1 GiB)", 5, [&] { stream_kernel(8); }, 0, 0);
   for (int R : {16, 4, 2}) {
