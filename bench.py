@@ -41,7 +41,13 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # What the link does with both directions of a window's swap at once, measured by profiles/probes/probe_pcie_duplex.hip
 # (profiles/r05_probe_pcie_duplex.txt): filled in from that file, None until it has been collected
-PCIE_DUPLEX_PROBE = None
+PCIE_DUPLEX_PROBE = {
+    "source": "profiles/r05_probe_pcie_duplex.txt (+ _box2.txt: another allocation), 28 MB each way, GB/s both directions together",
+    "this_transport_sdma_out_plus_kernel_in": [27.8, 56.6], "admission_kernel_alone_one_way": [49.8, 53.9],
+    "sdma_out_alone_one_way": [16.6, 56.1], "sdma_in_plus_kernel_out": [71.0, 80.6], "both_as_kernels": [70.5],
+    "both_as_sdma_copies": [32.6, 86.6],
+    "note": "two allocations, two very different hosts for the SDMA direction; the transport's engine assignment is the one "
+            "whose kernel half needs no host gather and whose copy half does not slow the kernels beside it (x1.02)"}
 
 
 def parse():
@@ -741,8 +747,7 @@ def main():
         out_bytes = wbs["rows"] * row_b / max(1, wbs["jobs"])
         swap_roof["both_directions_GBps_by_worker_busy"] = (swap_bytes + out_bytes) / max(
             in_busy_ms, 1e3 * wbs["out_busy_s"] / max(1, wbs["jobs"]), 1e-9) / 1e6
-        pd = PCIE_DUPLEX_PROBE
-        swap_roof["peak_duplex"] = pd
+        swap_roof["peak_duplex"] = PCIE_DUPLEX_PROBE
     # `roofline` = the kernel with the largest share of a step's GPU time (a step = 1 fwd + 1 bwd + 1/P swap)
     for r, per_step in ((fwd_roof, 1.0), (bwd_roof, 1.0), (swap_roof, 1.0 / P)):
         r["ms_per_step_share"] = r["avg_ms"] * per_step

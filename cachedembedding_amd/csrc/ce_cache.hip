@@ -1051,13 +1051,32 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
                                                      WbMail* mail, long long job, int stage_grid,
                                                      const unsigned long long* __restrict__ keys, int64_t C,
                                                      const int32_t* __restrict__ blk_vic, int32_t* free_list,
-                                                     EvTable evt) {
+                                                     EvTable evt, VT* host_overflow) {
   if ((int)blockIdx.x >= stage_grid) {       // (only launched with these workgroups in the steady-state form)
     free_list_from_victims(keys, C, blk_vic, free_list, ctl, (int)blockIdx.x - stage_grid);
     return;
   }
-  long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  const long long k_all = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  long long k = k_all;
   if (k > cap) k = cap;
+  if (host_overflow && k_all > cap) {
+    // More victims than the staging holds (a cache larger than 262144 slots turning over in one call: never at the
+    // bench sizes): the rest goes to the host table directly, a row per lane group at a time -- a loop in this grid
+    // instead of a kernel of its own that every call launched to find nothing to do (round 5: -1 launch per call).
+    const int G0 = 1 << g_log2;
+    const int gl0 = threadIdx.x & (G0 - 1);
+    const int64_t gs0 = ((int64_t)stage_grid * blockDim.x) >> g_log2;
+    for (int64_t i = cap + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2); i < k_all; i += gs0) {
+      const int32_t slot = victims[i];
+      const int32_t row = cached_idx_map[slot];
+      copy_row(cache + (int64_t)slot * rowlen, host_overflow + (int64_t)row * rowlen, rowlen, gl0, G0);
+      __builtin_amdgcn_wave_barrier();
+      if (gl0 == 0) {
+        inverted[row] = -1;
+        cached_idx_map[slot] = -1;
+      }
+    }
+  }
   if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // read by the worker after this kernel's event
     mail->count = k;
     mail->job = job;
@@ -1336,7 +1355,8 @@ __global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restri
                                                          const unsigned long long* fail_word, long long job,
                                                          int maps_done, const int32_t* __restrict__ rows,
                                                          int32_t* cached_idx_map, int32_t* inverted,
-                                                         ce_call_stats_t* ring, long long seq_arg) {
+                                                         ce_call_stats_t* ring, long long seq_arg,
+                                                         const VT* __restrict__ host_overflow) {
   const bool ok = ctl->status == CE_OK;         // (nothing in this kernel writes ctl->status)
   bool lost = false;
   if (maps_done) {
@@ -1374,10 +1394,17 @@ __global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restri
     }
     return;
   }
-  if (n > cap) n = cap;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  if (host_overflow && n > cap) {
+    // more misses than the staging holds (rare): the rest is read zero-copy out of the host table -- here, behind the
+    // parked wait (the worker keeps the stream parked until the previous write-back has landed for such a call), in
+    // this grid instead of a launch of its own
+    for (int64_t i = cap + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2); i < n; i += gstride)
+      copy_row(host_overflow + (int64_t)rows[i] * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
+  }
+  if (n > cap) n = cap;
   constexpr int R = kStageRowsInFlight;
   for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
     if (rowlen <= G) {
@@ -2683,29 +2710,6 @@ static int ensure_writeback(ce_cache* h) {
       rc = CE_ERR_HIP;
       break;
     }
-    {
-      // Where the admission kernel's workgroups sit (CE_ADMIT_CU_MASK; experiment, off unless set).  Its reads of the
-      // mapped host table hold miss-queue entries of the L2 they pass through for a PCIe round trip each, and every XCD
-      // has an L2 of its own: on an unmasked stream the 20 workgroups land on all eight XCDs and an HBM-bound kernel
-      // beside them runs at 0.69 of its speed (profiles/r05_probe_pcie_duplex.txt).  "8th": every 8th CU (32 CUs),
-      // "low32": CUs 0..31, "4th" / "low64": 64 CUs.  A CU-masked stream has a hardware queue of its own (the mask is a
-      // queue property), which is what the priority above is for; the first-use self-test covers it like the others.
-      const char* cm = getenv("CE_ADMIT_CU_MASK");
-      if (cm && *cm && strcmp(cm, "0") != 0) {
-        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (!strcmp(cm, "8th")) { for (int i = 0; i < kNumCU; i += 8) m[i / 32] |= 1u << (i % 32); }
-        else if (!strcmp(cm, "4th")) { for (int i = 0; i < kNumCU; i += 4) m[i / 32] |= 1u << (i % 32); }
-        else if (!strcmp(cm, "low64")) { m[0] = m[1] = 0xffffffffu; }
-        else { m[0] = 0xffffffffu; }
-        hipStream_t ms = nullptr;
-        if (hipExtStreamCreateWithCUMask(&ms, 8, m) == hipSuccess) {
-          (void)hipStreamDestroy(w->in_stream);
-          w->in_stream = ms;
-        } else {
-          (void)hipGetLastError();
-        }
-      }
-    }
     void* p = nullptr;
     void* pd = nullptr;
     if (hipHostMalloc(&p, sizeof(WbMail) * 3, hipHostMallocMapped) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
@@ -3140,20 +3144,12 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
       hipLaunchKernelGGL((k_evict_stage<f32x4>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list, evt);
-      if (L.list_cap > L.stage_rows)
-        hipLaunchKernelGGL((k_evict<f32x4>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
-                           c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)c.host_weight_dev, scap,
-                           h->rowlen, h->g_log2, h->ctl);
+                         h->free_list, evt, L.list_cap > L.stage_rows ? (f32x4*)c.host_weight_dev : (f32x4*)nullptr);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list, evt);
-      if (L.list_cap > L.stage_rows)
-        hipLaunchKernelGGL((k_evict<float>), dim3(cap_groups), swap_block, 0, s, h->victims, c.cached_idx_map,
-                           c.inverted_cached_idx, (const float*)c.cache_weight, (float*)c.host_weight_dev, scap,
-                           h->rowlen, h->g_log2, h->ctl);
+                         h->free_list, evt, L.list_cap > L.stage_rows ? (float*)c.host_weight_dev : (float*)nullptr);
     }
     if (worker) {
       // the write-back worker takes it from here: D2H of the packed block + scatter into the table
@@ -3289,21 +3285,15 @@ static int prepare_ids_second_half(ce_cache* h) {
                          (const long long*)&h->ctl->n_miss, scap, (const f32x4*)h->in_stage, (f32x4*)c.cache_weight,
                          h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
                          in_job, x.early ? 1 : 0, (const int32_t*)h->miss_list, c.cached_idx_map,
-                         c.inverted_cached_idx, h->ring_dev, x.seq_arg);
-      if (L.list_cap > L.stage_rows)      // more misses than the staging holds (rare): the rest is read zero-copy
-        hipLaunchKernelGGL((k_admit<f32x4>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
-                           (const long long*)&h->ctl->n_miss, 0ll, (const f32x4*)c.host_weight_dev,
-                           (f32x4*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl, scap);
+                         c.inverted_cached_idx, h->ring_dev, x.seq_arg,
+                         L.list_cap > L.stage_rows ? (const f32x4*)c.host_weight_dev : (const f32x4*)nullptr);
     } else {
       hipLaunchKernelGGL((k_unpack_admitted<float>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const float*)h->in_stage, (float*)c.cache_weight,
                          h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
                          in_job, x.early ? 1 : 0, (const int32_t*)h->miss_list, c.cached_idx_map,
-                         c.inverted_cached_idx, h->ring_dev, x.seq_arg);
-      if (L.list_cap > L.stage_rows)
-        hipLaunchKernelGGL((k_admit<float>), dim3(cap_groups), swap_block, 0, s, h->miss_list, h->free_list,
-                           (const long long*)&h->ctl->n_miss, 0ll, (const float*)c.host_weight_dev,
-                           (float*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl, scap);
+                         c.inverted_cached_idx, h->ring_dev, x.seq_arg,
+                         L.list_cap > L.stage_rows ? (const float*)c.host_weight_dev : (const float*)nullptr);
     }
   } else if (c.transport == CE_TRANSPORT_ZEROCOPY) {
     // write-back of the staged victims + admission of the missed rows, one launch, both PCIe directions busy

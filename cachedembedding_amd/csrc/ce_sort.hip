@@ -575,12 +575,14 @@ __global__ __launch_bounds__(1024) void k_split_places(const int64_t* __restrict
 // owner-side cache op resolved; any other place p goes through place_fwd / place_bwd (k_split_places).  The EARLY and
 // the DEFERRED region exist twice (a step's early rows arrive while the step before still reads its own; a step's
 // deferred gradients leave while the next step already folds): batch b uses copy b & 1.
-// fwd: tail_base + [E0 | E1 | L], bwd: tail_base + bwd_base + [D0 | D1 | U]; n_e = W * max cap_e etc. are region sizes.
+// fwd: tail_base + [E0 | E1 | L], bwd: tail_base + bwd_base + [D0 | U | D1] (the urgent region in the middle: the two
+// regions a step's fold writes -- its deferred copy and U -- are then ONE contiguous range to zero, whichever copy it is);
+// n_e = W * cap_e etc. are region sizes.
 __global__ __launch_bounds__(256) void k_exchange_local_index_split(
     const int64_t* __restrict__ pos, int64_t n_per_batch, int64_t total, const int64_t* __restrict__ slots,
     const int32_t* __restrict__ place_fwd, const int32_t* __restrict__ place_bwd, int64_t chunk_stride, int64_t lo,
     int64_t hi, int64_t tail_base, int64_t bwd_base, const int32_t* __restrict__ caps, int world, int64_t n_e,
-    int64_t n_l, int64_t n_d, int64_t* __restrict__ idx_fwd, int64_t* __restrict__ idx_bwd) {
+    int64_t n_u, int64_t n_d, int64_t* __restrict__ idx_fwd, int64_t* __restrict__ idx_bwd) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t p = pos[i];
@@ -592,12 +594,11 @@ __global__ __launch_bounds__(256) void k_exchange_local_index_split(
       const int pf = place_fwd[b * chunk_stride + p], pb = place_bwd[b * chunk_stride + p];
       const int64_t we = (int64_t)world * caps[4 * b + 0], wd = (int64_t)world * caps[4 * b + 2];
       if (pf >= 0) f = tail_base + (pf < we ? (b & 1) * n_e + pf : 2 * n_e + (pf - we));
-      if (pb >= 0) g = tail_base + bwd_base + (pb < wd ? (b & 1) * n_d + pb : 2 * n_d + (pb - wd));
+      if (pb >= 0) g = tail_base + bwd_base + (pb < wd ? (b & 1) * (n_d + n_u) + pb : n_d + (pb - wd));
     }
     idx_fwd[i] = f;
     idx_bwd[i] = g;
   }
-  (void)n_l;
 }
 
 struct SortWs {
@@ -793,7 +794,7 @@ extern "C" int ce_exchange_local_index_split(const int64_t* pos, int64_t n_per_b
                                              const int64_t* slots, const int32_t* place_fwd, const int32_t* place_bwd,
                                              int64_t chunk_stride, int64_t local_lo, int64_t local_hi, int64_t tail_base,
                                              int64_t bwd_base, const int32_t* caps, int32_t world, int64_t n_early,
-                                             int64_t n_late, int64_t n_deferred, int64_t* index_fwd, int64_t* index_bwd,
+                                             int64_t n_urgent, int64_t n_deferred, int64_t* index_fwd, int64_t* index_bwd,
                                              ce_stream_t stream) {
   const int64_t total = n_per_batch * n_batches;
   if (total <= 0) return CE_OK;
@@ -801,7 +802,7 @@ extern "C" int ce_exchange_local_index_split(const int64_t* pos, int64_t n_per_b
   CE_REQUIRE(local_lo >= 0 && local_hi <= chunk_stride && tail_base >= 0 && bwd_base >= 0, CE_ERR_INVALID, "bad ranges");
   hipLaunchKernelGGL(k_exchange_local_index_split, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, pos,
                      n_per_batch, total, slots, place_fwd, place_bwd, chunk_stride, local_lo, local_hi, tail_base,
-                     bwd_base, caps, (int)world, n_early, n_late, n_deferred, index_fwd, index_bwd);
+                     bwd_base, caps, (int)world, n_early, n_urgent, n_deferred, index_fwd, index_bwd);
   CE_LAUNCH_CHECK();
   return CE_OK;
 }

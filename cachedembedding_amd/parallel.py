@@ -979,8 +979,10 @@ class GraphedShardedWindow:
         self._E = [t[0:ne], t[ne:2 * ne]]
         self._L = t[2 * ne:2 * ne + nl]
         b0 = self._bwd_base
-        self._Dg = [t[b0:b0 + nd], t[b0 + nd:b0 + 2 * nd]]
-        self._U = t[b0 + 2 * nd:b0 + 2 * nd + nu]
+        # [D0 | U | D1]: a step's fold writes its deferred copy and U -- one contiguous range to zero either way
+        self._Dg = [t[b0:b0 + nd], t[b0 + nd + nu:b0 + 2 * nd + nu]]
+        self._U = t[b0 + nd:b0 + nd + nu]
+        self._bwd_zero = [t[b0:b0 + nd + nu], t[b0 + nd:b0 + 2 * nd + nu]]
         i32 = dict(dtype=torch.int32, device=dev)
         self._pf_req = [torch.full((P, W * cap), -1, **i32) for _ in range(2)]
         self._pb_req = [torch.full((P, W * cap), -1, **i32) for _ in range(2)]
@@ -1015,9 +1017,10 @@ class GraphedShardedWindow:
         ovf = torch.zeros(1, dtype=torch.int32, device=dev)
         pf = torch.empty(P, W * cap, dtype=torch.int32, device=dev)
         pb = torch.empty_like(pf)
-        check(lib.ce_split_places(ptr(self._serve[0].permute(1, 0, 2).contiguous()),
-                                  ptr(self._flags_o[0].permute(1, 0, 2).contiguous()), P, W, cap, -1, ptr(caps), ptr(pf),
-                                  ptr(pb), ptr(counts), ptr(ovf), stream_ptr()))
+        serve_pwc = self._serve[0].permute(1, 0, 2).contiguous()        # (named: a temporary inside the call would be
+        flags_pwc = self._flags_o[0].permute(1, 0, 2).contiguous()       # freed, and its block reused, before the launch)
+        check(lib.ce_split_places(ptr(serve_pwc), ptr(flags_pwc), P, W, cap, -1, ptr(caps), ptr(pf), ptr(pb), ptr(counts),
+                                  ptr(ovf), stream_ptr()))
         c = counts.double().cpu()                                                # [P, W, 4]: early, late, deferred, urgent
         fwd = c[1:] if P > 1 else c                  # batch 0 is all early (nothing precedes the window)
         bwd = c[:-1] if P > 1 else c                 # the last batch is all urgent
@@ -1073,7 +1076,7 @@ class GraphedShardedWindow:
             lists[:, -1] = -1
         check(lib.ce_exchange_local_index_split(ptr(self._pos[buf]), n, P, ptr(slots), ptr(self._pf_req[buf]),
                                                 ptr(self._pb_req[buf]), W * cap, r * cap, (r + 1) * cap, self._C,
-                                                self._bwd_base, ptr(self._caps), W, ne, nl, nd, ptr(self._idx[buf]),
+                                                self._bwd_base, ptr(self._caps), W, ne, nu, nd, ptr(self._idx[buf]),
                                                 ptr(self._idx_b[buf]), sp))
         rows = self._table.shape[0]
         for idx, keys in ((self._idx[buf], self._keys[buf]), (self._idx_b[buf], self._keys_b[buf])):
@@ -1143,9 +1146,7 @@ class GraphedShardedWindow:
             else:
                 out = ops.pool(self._table, self._idx[buf][i], self.offsets, None, "sum", self.incl, self.hook)
             grad = self.dense_fn(out, i)
-            cd, cu = self._caps_host[i][2], self._caps_host[i][3]
-            self._Dg[i & 1][:W * cd].zero_()
-            self._U[:W * cu].zero_()
+            self._bwd_zero[i & 1].zero_()
             keys_b = SrcKeys(self._keys_b[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
             ops.update_table(self._table, grad, keys_b, self.n, lr)       # own rows: SGD in place; buffers: -lr * sum g
             ev_fold = torch.cuda.Event()

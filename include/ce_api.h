@@ -543,12 +543,13 @@ int ce_split_places(const int64_t* ids, const uint8_t* flags, int32_t n_batches,
  * for the pooling, one into "cache + backward buffers" for the fused fold + SGD.  Behind the cache (tail_base rows
  * from its first row, one allocation: ce_cache_set_cache_weight) lie [E0 | E1 | L] -- n_early, n_early, n_late rows:
  * the early region exists twice because a step's early rows arrive while the step before still pools from its own,
- * batch b uses copy b & 1 -- and, bwd_base rows further, [D0 | D1 | U] (n_deferred, n_deferred, then the urgent rows).
+ * batch b uses copy b & 1 -- and, bwd_base rows further, [D0 | U | D1] (n_deferred, n_urgent, n_deferred rows: with U
+ * between the two deferred copies a step's fold writes ONE contiguous range, which is what is zeroed before it).
  * Places in [local_lo, local_hi) (this rank's own chunk) become the cache slot in both indices. */
 int ce_exchange_local_index_split(const int64_t* pos, int64_t n_per_batch, int64_t n_batches, const int64_t* slots,
                                   const int32_t* place_fwd, const int32_t* place_bwd, int64_t chunk_stride,
                                   int64_t local_lo, int64_t local_hi, int64_t tail_base, int64_t bwd_base,
-                                  const int32_t* caps, int32_t world, int64_t n_early, int64_t n_late,
+                                  const int32_t* caps, int32_t world, int64_t n_early, int64_t n_urgent,
                                   int64_t n_deferred, int64_t* index_fwd, int64_t* index_bwd, ce_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-# Regenerates every artefact under profiles/ (r04_*) on an MI355X box (run from the repo root; writes to gpurun_out/).
+# Regenerates every artefact under profiles/ (r05_*) on an MI355X box (run from the repo root; writes to gpurun_out/).
 # NOTE on rocprofv3: with the profiler attached the HIP runtime executes hipMemcpyAsync as a blit KERNEL
 # (__amd_rocclr_copyBuffer) instead of an SDMA transfer (profiles/r02_probe_sdma.txt), so a profiled run of the
 # default (worker-transport) pipeline shows copy kernels that an unprofiled run does not have, and runs slower.
@@ -15,23 +15,24 @@ python bench.py --no_cpu_baseline --use_lfu > gpurun_out/bench_lfu.json 2>/dev/n
 python bench.py --no_cpu_baseline --async_copy 2>/dev/null | tail -1 > gpurun_out/bench_staged.json
 python bench.py --no_cpu_baseline --unchanged_trainer 2>/dev/null | tail -1 > gpurun_out/bench_unchanged_trainer.json
 python bench.py --force_sharded --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_sharded_w1.json
-python bench.py --no_cpu_baseline --interleaved 2>/dev/null | tail -1 > gpurun_out/bench_interleaved.json
+python bench.py --no_cpu_baseline --arrangement interleaved 2>/dev/null | tail -1 > gpurun_out/bench_interleaved.json
+python bench.py --no_cpu_baseline --arrangement overlap 2>/dev/null | tail -1 > gpurun_out/bench_overlap.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 64 --warmup 16 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/bench_torchrun1.json
 python profiles/probe_sdma.py > gpurun_out/probe_sdma.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_seq -o r04 -- python $R/bench.py --no_cpu_baseline --no_verify --no_overlap --no_graph --transport zerocopy > $R/gpurun_out/prof_seq.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ov -o r04 -- python $R/bench.py --no_cpu_baseline --no_verify > $R/gpurun_out/prof_ov.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sh -o r04 -- python $R/bench.py --no_cpu_baseline --no_verify --force_sharded --transport zerocopy > $R/gpurun_out/prof_sh.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_seq -o r05 -- python $R/bench.py --no_cpu_baseline --no_verify --no_overlap --no_graph --transport zerocopy > $R/gpurun_out/prof_seq.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ov -o r05 -- python $R/bench.py --no_cpu_baseline --no_verify > $R/gpurun_out/prof_ov.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sh -o r05 -- python $R/bench.py --no_cpu_baseline --no_verify --force_sharded --transport zerocopy > $R/gpurun_out/prof_sh.log 2>&1
 mkdir -p $R/gpurun_out/pmc
 for m in calib bench; do for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc/${m}_$c -o p -- python $R/profiles/pmc_probe.py $m > $R/gpurun_out/pmc/${m}_$c.log 2>&1
 done; done
 cd $R
-python profiles/rocpd_summary.py gpurun_out/prof_seq/r04_results.db 40 > gpurun_out/stats_seq.txt
-python profiles/rocpd_summary.py gpurun_out/prof_ov/r04_results.db 40 > gpurun_out/stats_ov.txt
-python profiles/rocpd_summary.py gpurun_out/prof_sh/r04_results.db 45 > gpurun_out/stats_sharded_w1.txt
-python profiles/rocpd_timeline.py gpurun_out/prof_seq/r04_results.db -4 > gpurun_out/timeline_seq.txt
-python profiles/rocpd_timeline.py gpurun_out/prof_ov/r04_results.db -4 > gpurun_out/timeline_ov.txt
+python profiles/rocpd_summary.py gpurun_out/prof_seq/r05_results.db 40 > gpurun_out/stats_seq.txt
+python profiles/rocpd_summary.py gpurun_out/prof_ov/r05_results.db 40 > gpurun_out/stats_ov.txt
+python profiles/rocpd_summary.py gpurun_out/prof_sh/r05_results.db 45 > gpurun_out/stats_sharded_w1.txt
+python profiles/rocpd_timeline.py gpurun_out/prof_seq/r05_results.db -4 > gpurun_out/timeline_seq.txt
+python profiles/rocpd_timeline.py gpurun_out/prof_ov/r05_results.db steady > gpurun_out/timeline_ov.txt
 python profiles/pmc_summary.py gpurun_out/pmc --json gpurun_out/traffic.json > gpurun_out/pmc_hbm_traffic.txt 2>&1
 rm -rf gpurun_out/prof_ov gpurun_out/prof_seq gpurun_out/prof_sh
 find gpurun_out/pmc -name "*kernel_trace.csv" -size +20M -delete

@@ -1,7 +1,7 @@
 # Copies what profiles/collect.sh left in gpurun_out/ to the tracked names of this round (run from the repo root).
-R=${1:-r04}
+R=${1:-r05}
 cp gpurun_out/final_pytest.txt profiles/${R}_pytest_gpu.txt
-for n in default driver_args zerocopy seq lfu staged unchanged_trainer sharded_w1 torchrun1 interleaved avazu_p1_graph_cache_op; do
+for n in default driver_args zerocopy seq lfu staged unchanged_trainer sharded_w1 torchrun1 interleaved overlap avazu_p1_graph_cache_op; do
   cp gpurun_out/bench_$n.json profiles/${R}_bench_$n.json
 done
 cp gpurun_out/stats_seq.txt profiles/${R}_kernel_stats_criteo1tb_seq.txt

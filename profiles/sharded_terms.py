@@ -165,7 +165,7 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         idx_f = torch.empty(P, n, dtype=torch.int64, device=dev)
         idx_b = torch.empty_like(idx_f)
         check(lib.ce_exchange_local_index_split(ptr(plans[0][1]), n, P, ptr(slots_pwc), ptr(pf_r), ptr(pb_r), W * cap, 0, cap,
-                                                C_local, 2 * ne + nl, ptr(caps_d), W, ne, nl, nd, ptr(idx_f), ptr(idx_b),
+                                                C_local, 2 * ne + nl, ptr(caps_d), W, ne, nu, nd, ptr(idx_f), ptr(idx_b),
                                                 stream_ptr()))
         keys_f = presort_window(idx_f, C_local + T, offsets=offsets, include_last_offset=True, hook_features=F, identity_bags=True)
         keys_b = presort_window(idx_b, C_local + T, offsets=offsets, include_last_offset=True, hook_features=F, identity_bags=True)
@@ -193,7 +193,7 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         st["pooling from keys (critical)"] = timed(lambda r: check(lib.ce_bag_forward_src_keys(
             ptr(tab), tab.shape[0], D, n, ptr(keys_f[steps[r % len(steps)]].keys), ptr(out), sp)), REPS * P)
         b0 = 2 * ne + nl
-        st["zero-fill of the delta buffers (critical)"] = timed(lambda r: (tail[b0:b0 + nd].zero_(), tail[b0 + 2 * nd:b0 + 2 * nd + W * cu].zero_()), REPS * P)
+        st["zero-fill of the delta buffers (critical)"] = timed(lambda r: tail[b0 + (r & 1) * nd:b0 + (r & 1) * nd + nd + nu].zero_(), REPS * P)
         st["fused fold + SGD (critical)"] = timed(lambda r: check(lib.ce_bag_backward_sgd_presorted_src(
             ptr(tab), tab.shape[0], D, n, ptr(grad), 1.0, ptr(keys_b[steps[r % len(steps)]].keys), sp)), REPS * P)
         st["urgent axpy (critical)"] = timed(lambda r: check(lib.ce_rows_axpy(

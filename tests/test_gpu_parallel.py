@@ -647,8 +647,9 @@ def test_split_classify_and_places_against_a_plain_restatement(W, P, cap, n_rows
     pb = torch.empty_like(pf)
     counts = torch.zeros(P, W, 4, dtype=torch.int32, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(lib.ce_split_places(ptr(torch.from_numpy(ids).to(dev)), ptr(torch.from_numpy(fl).to(dev)), P, W, cap, skip,
-                              ptr(torch.from_numpy(caps).to(dev)), ptr(pf), ptr(pb), ptr(counts), ptr(ovf), stream_ptr()))
+    ids_d, fl_d, caps_d = torch.from_numpy(ids).to(dev), torch.from_numpy(fl).to(dev), torch.from_numpy(caps).to(dev)
+    check(lib.ce_split_places(ptr(ids_d), ptr(fl_d), P, W, cap, skip, ptr(caps_d), ptr(pf), ptr(pb), ptr(counts), ptr(ovf),
+                              stream_ptr()))
     assert int(ovf) == 0
     c = counts.cpu().numpy()
     assert np.array_equal(c[..., 0], n_e) and np.array_equal(c[..., 1], n_l)
@@ -681,7 +682,9 @@ def test_split_classify_and_places_against_a_plain_restatement(W, P, cap, n_rows
     caps2[:, 1] = max(1, int(n_l.max()) - 1)
     ovf.zero_()
     if n_l.max() > 1:
-        check(lib.ce_split_places(ptr(torch.from_numpy(ids).to(dev)), ptr(torch.from_numpy(fl).to(dev)), P, W, cap, -1,
-                                  ptr(torch.from_numpy(caps2).to(dev)), ptr(pf := torch.empty(P, W * cap, dtype=torch.int32, device=dev)),
-                                  ptr(torch.empty(P, W * cap, dtype=torch.int32, device=dev)), None, ptr(ovf), stream_ptr()))
+        caps2_d = torch.from_numpy(caps2).to(dev)
+        pf2 = torch.empty(P, W * cap, dtype=torch.int32, device=dev)
+        pb2 = torch.empty_like(pf2)
+        check(lib.ce_split_places(ptr(ids_d), ptr(fl_d), P, W, cap, -1, ptr(caps2_d), ptr(pf2), ptr(pb2), None, ptr(ovf),
+                                  stream_ptr()))
         assert int(ovf) == 1
