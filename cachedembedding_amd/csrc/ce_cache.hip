@@ -1769,31 +1769,41 @@ struct PhaseProf {
   hipEvent_t ev[kProfDepth][kPhases + 1];
   bool pending[kProfDepth];
   bool early[kProfDepth];            // the call ran slots + keys BEFORE the admission wait (phases 4 and 5 swapped)
+  // a call in two halves whose selection / staging part was deferred to the second half: the second phase starts at
+  // `resume` (recorded when the second half begins), not at the mark behind k_emit -- the training steps between the
+  // two halves are no phase of the cache op
+  hipEvent_t resume[kProfDepth];
+  bool resumed[kProfDepth];
   double ms[kPhases];
   long long calls;
   PhaseProf() : calls(0) {
     for (int i = 0; i < kProfDepth; ++i) {
       pending[i] = false;
       early[i] = false;
+      resumed[i] = false;
+      (void)hipEventCreate(&resume[i]);
       for (int j = 0; j <= kPhases; ++j) (void)hipEventCreate(&ev[i][j]);
     }
     for (int j = 0; j < kPhases; ++j) ms[j] = 0;
   }
   ~PhaseProf() {
-    for (int i = 0; i < kProfDepth; ++i)
+    for (int i = 0; i < kProfDepth; ++i) {
+      (void)hipEventDestroy(resume[i]);
       for (int j = 0; j <= kPhases; ++j) (void)hipEventDestroy(ev[i][j]);
+    }
   }
   void collect(int i) {              // blocks until call slot i has finished
     if (!pending[i]) return;
     if (hipEventSynchronize(ev[i][kPhases]) == hipSuccess) {
       for (int j = 0; j < kPhases; ++j) {
         float t = 0;
-        if (hipEventElapsedTime(&t, ev[i][j], ev[i][j + 1]) == hipSuccess)
+        if (hipEventElapsedTime(&t, (j == 1 && resumed[i]) ? resume[i] : ev[i][j], ev[i][j + 1]) == hipSuccess)
           ms[(early[i] && j >= kPhases - 2) ? (2 * kPhases - 3 - j) : j] += t;
       }
       calls += 1;
     }
     pending[i] = false;
+    resumed[i] = false;
   }
 };
 
@@ -2368,6 +2378,12 @@ struct ce_cache {
     long long in_job = 0, seq_arg = 0;
     int cap_groups = 1, swap_threads = 256, pslot = 0, pmark = 0;
     bool early = false;          // maps + slots / keys were launched before the admission wait (worker transport)
+    bool sel_pending = false;    // the selection / staging part has not been launched yet (select_and_stage)
+    hipStream_t sel_s = nullptr;
+    int64_t sel_n = 0;
+    bool sel_steady = false;
+    long long sel_out_job = 0;
+    int sel_wbuf = 0, sel_n_vblocks = 0;
     const void* prof = nullptr;      // the phase timers the first half recorded into (they may be switched off / on in between)
     struct {
       int64_t n_batches, nnz_per_batch;
@@ -2922,6 +2938,127 @@ static int worker_selftest(ce_cache* h, hipStream_t s) {
 }
 
 // the window's keys, written by the call's last kernel (ce_cache_prepare_ids_keys)
+// Second part of a cache op's front: victim selection, staging of the victims (and the write-back job), free-slot list.
+// Runs inline behind k_emit, or -- a call in two halves on the worker transport (SelArgs::deferred) -- at the start of
+// the SECOND half: the admission kernel the worker launches behind k_emit reads the host table over PCIe for ~0.7 ms,
+// and these kernels run 2-3x slower beside it (find_evict_ids 0.042 -> 0.072 ms, evict_stage 0.030 -> 0.065 ms in the
+// bench's phase timers); behind the window's training steps the admission has long finished and they run alone, while
+// the admission itself starts as early as before.
+struct SelArgs {
+  hipStream_t s;
+  int64_t n;
+  bool worker, capturing, steady;
+  long long out_job, seq_arg;
+  int wbuf, n_vblocks, pslot;
+  const void* prof_id;
+};
+
+static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  const int64_t N = c.num_embeddings, C = c.cuda_row_num, n = a.n;
+  hipStream_t s = a.s;
+  const bool worker = a.worker, capturing = a.capturing, steady = a.steady;
+  const long long out_job = a.out_job, seq_arg = a.seq_arg;
+  const int wbuf = a.wbuf, n_vblocks = a.n_vblocks, pslot = a.pslot;
+  const int lfu = c.evict_strategy == CE_EVICT_LFU;
+  const int gpb = 256 >> h->g_log2;
+  ce_call_stats_t* const ring = h->ring_dev;
+  PhaseProf* const prof = (h->prof && (const void*)h->prof == a.prof_id) ? h->prof : nullptr;
+  int pmark = *pmark_io;
+  int rc = CE_OK;
+#define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
+  // ---- victim selection (all kernels return at once when k == 0)
+  const int cgrid = grid_for(C, 256 * 4);
+  // DATASET keys are < N: the digits above the highest digit of N-1 are zero for every eligible slot, so the
+  // radix select starts there (3 passes of 11 bits at N = 178 M).  The top pass is taken by k_keys itself.
+  int top_pass = kLevels - 1;
+  if (!lfu) {
+    top_pass = 0;
+    while (top_pass < kLevels - 1 && ((uint64_t)(N - 1) >> (kDigitBits * (top_pass + 1))) != 0) ++top_pass;
+  } else {
+    // LFU keys are freq << slot_bits | slot.  No counter can exceed the largest value ever preloaded plus the ids
+    // seen so far (a call adds at most its own length to a counter), so the digits above that bound are zero in
+    // every eligible key.  (k_keys clamps a counter that a caller pushed beyond it -- freq_cnter is the caller's
+    // tensor -- so a key never has bits above the top digit.)
+    // (a captured call is replayed an unknown number of times: its pass count allows for kGraphFreqHeadroom more
+    // ids; ce_cache_graph_replayed keeps the bound and asks for a new capture once it is used up)
+    uint64_t bound = h->freq_bound + (uint64_t)n;
+    if (capturing) {
+      bound = h->freq_bound + kGraphFreqHeadroom;
+      h->graph_freq_limit = bound;
+    } else {
+      h->freq_bound = bound;
+    }
+    const int bits = 64 - __builtin_clzll(bound | 1ull) + h->slot_bits;
+    top_pass = h->freq_bound_known ? std::min(kLevels - 1, std::max(0, (bits + kDigitBits - 1) / kDigitBits - 1))
+                                   : kLevels - 1;
+  }
+  hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
+                     seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
+  const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
+  // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
+  // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs; one launch per pass with the LAST
+  // workgroup picking the digit: the agent-scope fences it needs write back the L2 of every XCD, 0.22 -> 0.72 ms
+  // beside the training kernels.  What works: every workgroup of pass p recomputes the digits of the passes above
+  // level above it from that level's histogram in its prologue -- select_level -- so there is no pick kernel at all)
+  for (int pass = top_pass - 1; pass >= 0; --pass)
+    hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
+  hipLaunchKernelGGL(k_victims, dim3((unsigned)n_vblocks), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
+                     (const uint32_t*)h->hist, top_pass, ring, seq_arg, steady ? h->blk_free : (int32_t*)nullptr);
+  CE_PHASE();
+  float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
+  int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
+  if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
+    // ---- victims -> HBM staging (fast); rows beyond the staging capacity (rare) are written back directly
+    // by k_evict; map clear, free-slot list, admit stay on the caller's stream
+    const long long scap = (long long)L.stage_rows;
+    static const int stage_blocks = [] { const char* e = getenv("CE_STAGE_BLOCKS"); return e ? atoi(e) : 512; }();
+    const int sgrid = (int)std::min<int64_t>(stage_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
+    const dim3 sg(sgrid + (steady ? n_vblocks : 0));        // + the free-list workgroups of the steady-state form
+    const EvTable evt = (worker && h->wb->relax) ? EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask}
+                                                   : EvTable{nullptr, nullptr, 0u};
+    if (h->vec) {
+      hipLaunchKernelGGL((k_evict_stage<f32x4>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
+                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
+                         h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
+                         h->free_list, evt, L.list_cap > L.stage_rows ? (f32x4*)c.host_weight_dev : (f32x4*)nullptr);
+    } else {
+      hipLaunchKernelGGL((k_evict_stage<float>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
+                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
+                         h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
+                         h->free_list, evt, L.list_cap > L.stage_rows ? (float*)c.host_weight_dev : (float*)nullptr);
+    }
+    if (worker) {
+      // the write-back worker takes it from here: D2H of the packed block + scatter into the table
+      CE_HIP_CHECK(hipEventRecord(h->wb->out_ev[wbuf], s));
+      h->wb->push_out();
+    }
+  } else {
+    rc = staged_swap(h, s);
+    if (rc) return rc;
+  }
+  CE_PHASE();
+  // (one workgroup walks 4096 slots per round: beyond a few rounds the pair of wide kernels is faster --
+  // C = 94 k, Avazu at 1 %: 18.3 us against 13.6 us for the pair)
+  if (steady) {
+    // (the list was written by k_evict_stage's free-list workgroups)
+  } else if (C <= 16384) {
+    hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, h->free_list, h->ctl);
+  } else {
+    hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
+                       h->blk_free, h->ctl);
+    hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
+                       h->blk_free, h->free_list, h->ctl);
+  }
+  CE_PHASE();
+#undef CE_PHASE
+  *pmark_io = pmark;
+  (void)rc;
+  return CE_OK;
+}
+
 struct KeysTail {
   int64_t n_batches, nnz_per_batch;
   int32_t src_keys;
@@ -2966,8 +3103,6 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   if (!capturing) h->seq += 1;
   const long long seq_arg = capturing ? 0ll : (long long)h->seq;     // 0: the device's own count
   ce_call_stats_t* const ring = h->ring_dev;
-  const int lfu = c.evict_strategy == CE_EVICT_LFU;
-  const int gpb = 256 >> h->g_log2;
   // swap kernels: small grid (default 2 workgroups per CU's worth of slots is left to training kernels)
   // protect_depth > 0 means the call overlaps with training kernels on another stream: stay small (32
   // workgroups measured best: 1.43 -> 1.82 G lookups/s); alone on the GPU a wider grid finishes sooner
@@ -3076,115 +3211,30 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
                      h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, ring,
                      worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
                      worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr, steady ? 1 : 0);
-  // the admission worker starts gathering the missed rows (host table -> in_stage) while this stream selects and
-  // stages the victims; it first lets every earlier write-back land.  In the two-half form (split: nothing runs beside
-  // this stream's kernels except that admission) it can be started BEHIND the first half instead (CE_ADMIT_LATE=1): the
-  // admission kernel's PCIe reads slow the selection / staging kernels beside it by more than their own time (k_hist
-  // 7 -> 35 us, k_victims 8 -> 90 us, k_evict_stage 26 -> 65 us in a rocprofv3 timeline), and the steps of the window
-  // that train between the two halves leave it 0.8 ms anyway.
-  static const int admit_late_env = [] { const char* e = getenv("CE_ADMIT_LATE"); return e ? atoi(e) : 0; }();
-  const bool admit_late = worker && split && admit_late_env != 0;
-  if (worker && !admit_late) {
+  // the admission worker starts gathering the missed rows (host table -> in_stage) right behind k_emit; it first lets
+  // every earlier write-back land
+  if (worker) {
     CE_HIP_CHECK(hipEventRecord(h->wb->in_ev[in_job & 1], s));
     h->wb->push_in(out_job - 1);
   }
   CE_PHASE();
-  // ---- victim selection (all kernels return at once when k == 0)
-  const int cgrid = grid_for(C, 256 * 4);
-  // DATASET keys are < N: the digits above the highest digit of N-1 are zero for every eligible slot, so the
-  // radix select starts there (3 passes of 11 bits at N = 178 M).  The top pass is taken by k_keys itself.
-  int top_pass = kLevels - 1;
-  if (!lfu) {
-    top_pass = 0;
-    while (top_pass < kLevels - 1 && ((uint64_t)(N - 1) >> (kDigitBits * (top_pass + 1))) != 0) ++top_pass;
-  } else {
-    // LFU keys are freq << slot_bits | slot.  No counter can exceed the largest value ever preloaded plus the ids
-    // seen so far (a call adds at most its own length to a counter), so the digits above that bound are zero in
-    // every eligible key.  (k_keys clamps a counter that a caller pushed beyond it -- freq_cnter is the caller's
-    // tensor -- so a key never has bits above the top digit.)
-    // (a captured call is replayed an unknown number of times: its pass count allows for kGraphFreqHeadroom more
-    // ids; ce_cache_graph_replayed keeps the bound and asks for a new capture once it is used up)
-    uint64_t bound = h->freq_bound + (uint64_t)n;
-    if (capturing) {
-      bound = h->freq_bound + kGraphFreqHeadroom;
-      h->graph_freq_limit = bound;
-    } else {
-      h->freq_bound = bound;
-    }
-    const int bits = 64 - __builtin_clzll(bound | 1ull) + h->slot_bits;
-    top_pass = h->freq_bound_known ? std::min(kLevels - 1, std::max(0, (bits + kDigitBits - 1) / kDigitBits - 1))
-                                   : kLevels - 1;
-  }
-  hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
-                     seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
-  const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
-  // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
-  // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs; one launch per pass with the LAST
-  // workgroup picking the digit: the agent-scope fences it needs write back the L2 of every XCD, 0.22 -> 0.72 ms
-  // beside the training kernels.  What works: every workgroup of pass p recomputes the digits of the passes above
-  // level above it from that level's histogram in its prologue -- select_level -- so there is no pick kernel at all)
-  for (int pass = top_pass - 1; pass >= 0; --pass)
-    hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
-  hipLaunchKernelGGL(k_victims, dim3((unsigned)n_vblocks), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
-                     (const uint32_t*)h->hist, top_pass, ring, seq_arg, steady ? h->blk_free : (int32_t*)nullptr);
-  CE_PHASE();
-  float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
-  int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
-  if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
-    // ---- victims -> HBM staging (fast); rows beyond the staging capacity (rare) are written back directly
-    // by k_evict; map clear, free-slot list, admit stay on the caller's stream
-    const long long scap = (long long)L.stage_rows;
-    static const int stage_blocks = [] { const char* e = getenv("CE_STAGE_BLOCKS"); return e ? atoi(e) : 512; }();
-    const int sgrid = (int)std::min<int64_t>(stage_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
-    WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
-    const dim3 sg(sgrid + (steady ? n_vblocks : 0));        // + the free-list workgroups of the steady-state form
-    const EvTable evt = (worker && h->wb->relax) ? EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask}
-                                                   : EvTable{nullptr, nullptr, 0u};
-    if (h->vec) {
-      hipLaunchKernelGGL((k_evict_stage<f32x4>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
-                         h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list, evt, L.list_cap > L.stage_rows ? (f32x4*)c.host_weight_dev : (f32x4*)nullptr);
-    } else {
-      hipLaunchKernelGGL((k_evict_stage<float>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
-                         c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
-                         h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list, evt, L.list_cap > L.stage_rows ? (float*)c.host_weight_dev : (float*)nullptr);
-    }
-    if (worker) {
-      // the write-back worker takes it from here: D2H of the packed block + scatter into the table
-      CE_HIP_CHECK(hipEventRecord(h->wb->out_ev[wbuf], s));
-      h->wb->push_out();
-    }
-  } else {
-    rc = staged_swap(h, s);
+  SelArgs sel{s, n, worker, capturing, steady, out_job, seq_arg, wbuf, n_vblocks, pslot, (const void*)prof};
+  // a call in two halves on the worker transport: the selection / staging part moves into the second half
+  static const int split_after_emit_env = [] { const char* e = getenv("CE_SPLIT_AFTER_EMIT"); return e ? atoi(e) : 1; }();
+  const bool defer_sel = split && worker && split_after_emit_env != 0;
+  if (!defer_sel) {
+    rc = select_and_stage(h, sel, &pmark);
     if (rc) return rc;
   }
-  CE_PHASE();
-  // (one workgroup walks 4096 slots per round: beyond a few rounds the pair of wide kernels is faster --
-  // C = 94 k, Avazu at 1 %: 18.3 us against 13.6 us for the pair)
-  if (steady) {
-    // (the list was written by k_evict_stage's free-list workgroups)
-  } else if (C <= 16384) {
-    hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, h->free_list, h->ctl);
-  } else {
-    hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
-                       h->blk_free, h->ctl);
-    hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
-                       h->blk_free, h->free_list, h->ctl);
-  }
-  CE_PHASE();
 #undef CE_PHASE
-  if (admit_late) {
-    CE_HIP_CHECK(hipEventRecord(h->wb->in_ev[in_job & 1], s));
-    h->wb->push_in(out_job - 1);
-  }
   // ---- second half: from here on the call needs the missed rows
   ce_cache::Pending& x = h->pend;
   x.n = n; x.slots_out = slots_out; x.s = s; x.worker = worker; x.capturing = capturing; x.has_tail = tail != nullptr;
   x.in_job = in_job; x.seq_arg = seq_arg; x.cap_groups = cap_groups; x.swap_threads = swap_threads; x.pslot = pslot;
   x.pmark = pmark;
   x.prof = prof;
+  x.sel_pending = defer_sel;
+  x.sel_s = s; x.sel_n = n; x.sel_steady = steady; x.sel_out_job = out_job; x.sel_wbuf = wbuf; x.sel_n_vblocks = n_vblocks;
   if (tail)
     x.tail = {tail->n_batches, tail->nnz_per_batch, tail->src_keys, tail->offsets, tail->offsets_are_i64,
               tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset, tail->hook_features, tail->keys_out};
@@ -3199,7 +3249,7 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   const char* const early_env = getenv("CE_EARLY_MAPS");
   x.early = worker && early_env && atoi(early_env) != 0;
   if (prof) prof->early[pslot] = x.early;
-  if (x.early) {
+  if (x.early && !defer_sel) {
     rc = launch_maps_and_slots(h);
     if (rc) return rc;
   }
@@ -3262,6 +3312,21 @@ static int launch_maps_and_slots(ce_cache* h) {
 static int prepare_ids_second_half(ce_cache* h) {
   ce_cache::Pending& x = h->pend;
   x.active = false;
+  if (x.sel_pending) {
+    x.sel_pending = false;
+    SelArgs sel{x.sel_s, x.sel_n, x.worker, x.capturing, x.sel_steady, x.sel_out_job, x.seq_arg, x.sel_wbuf, x.sel_n_vblocks,
+                x.pslot, x.prof};
+    if (h->prof && (const void*)h->prof == x.prof) {
+      (void)hipEventRecord(h->prof->resume[x.pslot], x.sel_s);
+      h->prof->resumed[x.pslot] = true;
+    }
+    int rc0 = select_and_stage(h, sel, &x.pmark);
+    if (rc0) return rc0;
+    if (x.early) {
+      rc0 = launch_maps_and_slots(h);
+      if (rc0) return rc0;
+    }
+  }
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
   const int64_t n = x.n;

@@ -76,6 +76,9 @@ def parse_args(argv=None):
                         "window's steps (overlap), in two halves on the training stream around them (interleaved), or "
                         "whichever of the two the library measures faster while training (auto, the library's default: "
                         "pipeline.ArrangementTrial)")
+    p.add_argument("--arrangement_block_windows", type=int, default=8,
+                   help="--arrangement auto: windows per block of the library's trial (3 blocks per arrangement; a window "
+                        "of a whole model takes tens of milliseconds, so short blocks measure well)")
     # additions of this build
     p.add_argument("--fused_sgd", action="store_true", help="apply the embedding SGD inside backward")
     p.add_argument("--fold_hook", action="store_true", help="write [B,F,D] from the gather kernel")
@@ -224,7 +227,9 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
         offsets = torch.arange(F * args.batch_size + 1, dtype=torch.int32, device=device)     # one id per bag (KJT lengths = 1)
         layout = (offsets, True, F)
     win = PrefetchWindow(embed, P, overlap=args.overlap_cache_op, presort=layout is not None, bag_layout=layout,
-                         arrangement=args.arrangement if args.overlap_cache_op else None)
+                         arrangement=args.arrangement if args.overlap_cache_op else None,
+                         arrangement_trial=dict(block_windows=args.arrangement_block_windows, settle=2)
+                         if (args.overlap_cache_op and args.arrangement == "auto") else None)
     train.window = win
     elapsed, done, loss = 0.0, 0, None
     steady = {"t0": None, "done0": 0}

@@ -348,14 +348,20 @@ int ce_cache_prepare_ids_keys(ce_cache_t* h, const int64_t* ids, int64_t n_batch
                               int64_t hook_features, uint64_t* keys_out, ce_stream_t stream);
 /* ce_cache_prepare_ids_keys (keys_out != NULL) or ce_cache_prepare_ids over a [n_batches, nnz_per_batch] window
  * (keys_out == NULL) issued in TWO HALVES on one stream, so that a caller can put work of its own between them:
- *   _begin   unique rows, misses (the admission worker starts fetching them), victim selection, staging of the victims
- *            (the write-back worker takes them), free-slot list -- everything that needs nothing from the host table;
- *   _finish  the wait for the admitted rows, their unpacking, the map updates, slots (and keys).
+ *   _begin   unique rows, misses (the admission worker starts fetching them); with the zero-copy / staged transports
+ *            also victim selection, staging of the victims and the free-slot list -- everything that needs nothing from
+ *            the host table;
+ *   _finish  (worker transport, API 5: victim selection, staging of the victims -- the write-back worker takes them --,
+ *            free-slot list: beside the admission kernel's PCIe reads these kernels ran 2-3 x slower than alone, behind
+ *            the caller's steps they run alone and the admission starts as early as before; CE_SPLIT_AFTER_EMIT=0
+ *            restores the API-4 split point), then the wait for the admitted rows, their unpacking, the map updates,
+ *            slots (and keys).
  * Why: run on a side stream beside the training kernels, the cache op's kernels and the bag kernels slow each other
  * down by MORE than the cache op's own kernel time (all of them are bound by the same memory system); issued on the
  * TRAINING stream as begin(window k+1) -> the steps of window k -> finish(window k+1), nothing runs beside anything,
  * and the one thing that does take wall time without using the GPU -- the PCIe admission -- still overlaps with the
- * steps in between.  Window k's rows must be protected while begin(k+1) selects victims: protect_depth >= 1.
+ * steps in between.  Window k's rows must be protected while the cache op of window k+1 selects victims:
+ * protect_depth >= 1.
  * No other call on the handle between the two; not capturable. */
 int ce_cache_prepare_ids_begin(ce_cache_t* h, const int64_t* ids, int64_t n_batches, int64_t nnz_per_batch,
                                int64_t* slots_out, int32_t src_keys, const void* offsets, int32_t offsets_are_i64,
