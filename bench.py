@@ -767,7 +767,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / K, "it_per_s": K / elapsed,
         "it_per_s_scope": "embedding operator only (cache op + EmbeddingBag forward + backward/SGD), no dense part: "
                           "the whole-model it/s of examples/dlrm_main.py at this configuration is in profiles/ "
-                          "(r04_dlrm_main_criteo1tb.json)",
+                          "(r05_dlrm_main_criteo1tb_*.json)",
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "box": box,
         "config": {"workload": f"{args.workload} table_scale={args.table_scale}", "num_embeddings": N,

@@ -14,7 +14,7 @@
 //   * k_bag_fwd_keys / k_bag_bwd_stream -- what the window pipelines and bench.py run: both walk the window's keys in
 //     contiguous shares, keys staged through a group-private LDS slice, 16 rows in flight per lane group; the forward
 //     loads a cache row once per run of equal rows, the backward folds a run and issues ONE transposed atomic row
-//     update per run.  Shares are handed out at run time when the caller provides a claim counter (claim_share).
+//     update per run.  Shares are static but many (16 / 6 workgroups per CU: the dispatcher hands them out as CUs free up).
 //   * k_bag_bwd_tile -- the backward for mean / per-sample weights / unsorted input (sorts 1024-lookup tiles in
 //     registers + LDS itself, or walks presorted segments), k_bag_bwd_rows (COO values), k_rows_axpy (row-wise exchange).
 // Output stores are non-temporal (never re-read here); row loads use the default policy so hot rows stay in

@@ -43,3 +43,4 @@ python bench.py --no_cpu_baseline --workload avazu --cache_ratio 0.01 --use_lfu 
 cp gpurun_out/traffic.json profiles/traffic.json
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -3 gpurun_out/bench_default.err
 python bench.py --steps 20 --warmup 5 --no_cpu_baseline > gpurun_out/bench_driver_args.json 2>/dev/null
+bash profiles/dlrm_main_run.sh > gpurun_out/dlrm_main_run.log 2>&1
