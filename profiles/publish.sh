@@ -13,3 +13,6 @@ cp gpurun_out/pmc_hbm_traffic.txt profiles/${R}_pmc_hbm_traffic.txt
 cp gpurun_out/traffic.json profiles/traffic.json
 cp gpurun_out/config_matrix.md profiles/${R}_config_matrix.md
 cp gpurun_out/probe_sdma.txt profiles/${R}_probe_sdma.txt
+for n in auto overlap interleaved unchanged; do
+  [ -f gpurun_out/dlrm_main_$n.json ] && cp gpurun_out/dlrm_main_$n.json profiles/${R}_dlrm_main_criteo1tb_$n.json
+done

@@ -161,9 +161,10 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
     big = N > 100000
     if big:
         # bench shape: held to the per-element bound of tests/test_gpu_bag.py::test_full_size_step_vs_torch_cpu
-        # (1e-5 |ref| + 2e-6 + 3e-7 sqrt(lookups of the row), reference accumulated in fp64, gradients of its scale)
+        # (oracle/closed_form.py's: cold rows 1e-5 relative with no floor, hot rows + 3e-4 lr grad_rms sqrt(lookups); reference in fp64)
         go *= 0.01
         ref64 = w_full.double()
+        abs64 = torch.zeros(N, D, dtype=torch.float64)           # sum |lr g| per row and element (the cold rows' scale)
         cnt = torch.zeros(N, dtype=torch.float64)
     go_d = go.cuda()
     outs = torch.zeros(P, B_loc, F, D, device="cuda")
@@ -195,11 +196,15 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
                 ref_w.index_add_(0, id2row[pids], pgo.transpose(0, 1).reshape(-1, D), alpha=-lr)
                 if big:
                     ref64.index_add_(0, id2row[pids], pgo.transpose(0, 1).reshape(-1, D).double(), alpha=-lr)
+                    abs64.index_add_(0, id2row[pids], pgo.transpose(0, 1).reshape(-1, D).double().abs(), alpha=lr)
                     cnt.add_(torch.bincount(id2row[pids], minlength=N))
         return exp
 
-    def bound(ref, rows_cnt):
-        return 1e-5 * ref.abs() + 2e-6 + 3e-7 * rows_cnt.sqrt()
+    def bound(ref, rows_cnt, abs_sum):
+        # oracle/closed_form.py's bound (round 5): <= 4 lookups 1e-5 of max(|ref|, sum |lr g|), no absolute floor;
+        # more: 1e-5 |ref| + 3e-4 lr grad_rms sqrt(lookups)
+        from oracle.closed_form import elementwise_bound
+        return elementwise_bound(ref.reshape(-1, D), rows_cnt.reshape(-1), abs_sum.reshape(-1, D), lr, 0.01).view(ref.shape)
 
     if capacity >= 64:
         reference_window(all_ids[0])                 # the eager warm-up pass of the constructor
@@ -220,8 +225,10 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
                 continue
             # a pooled row IS the table row at that step (one id per bag): the row's bound, with the lookups it has
             # summed by the end of this window (a hot row collects thousands of fp32 atomic updates per window)
-            c = cnt[id2row[all_ids[w][i]]].view(F, B_loc, 1).transpose(0, 1)
-            assert bool(((outs[i].cpu().double() - exp[i]).abs() <= bound(exp[i], c)).all())
+            rws = id2row[all_ids[w][i]]
+            c = cnt[rws].view(F, B_loc).transpose(0, 1)
+            a = abs64[rws].view(F, B_loc, D).transpose(0, 1)
+            assert bool(((outs[i].cpu().double() - exp[i]).abs() <= bound(exp[i], c, a)).all())
     if expect_split is not None:
         assert gw._split == (expect_split and world > 1)
     if gw._split and stream in ("same", "disjoint") and capacity >= 64:
@@ -243,10 +250,11 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
     if not big:
         torch.testing.assert_close(emb.weight, ref_w[rank::world], rtol=1e-4, atol=1e-5)
     else:
-        mine, c = ref64[rank::world], cnt[rank::world].unsqueeze(1)
+        mine, c, a = ref64[rank::world], cnt[rank::world], abs64[rank::world]
         err = (emb.weight.double() - mine).abs()
-        assert bool((err <= bound(mine, c)).all()), float((err / bound(mine, c)).max())
-        assert bool(((ref_w[rank::world].double() - mine).abs() <= bound(mine, c)).all())      # torch fp32: same bound
+        bd = bound(mine, c, a)
+        assert bool((err <= bd).all()), float((err / bd.clamp(min=1e-300)).max())
+        assert bool(((ref_w[rank::world].double() - mine).abs() <= bd).all())      # torch fp32: same bound
         assert float(cnt.max()) > 1e5, "the case must have rows that sum very many gradients"
 
 
