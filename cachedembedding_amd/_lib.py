@@ -87,6 +87,7 @@ SIGNATURES = {
     "ce_host_fill_uniform_rows": (c_int, [c_void_p, c_int64, c_int32, c_float, c_float, c_uint64, c_void_p, c_void_p]),
     "ce_host_rows_gather": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "ce_box_probe": (c_int, [c_void_p, c_size_t, c_int32, POINTER(c_double), POINTER(c_double), c_void_p]),
+    "ce_probe_rows": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_int32, POINTER(c_double), POINTER(c_double), c_void_p]),
     "ce_bag_forward": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,
                                c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "ce_bag_backward_dense": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64,

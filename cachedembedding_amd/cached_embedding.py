@@ -93,7 +93,9 @@ class CachedEmbeddingBag(nn.Module):
 
     def forward(self, input: torch.Tensor, offsets: Optional[torch.Tensor] = None,
                 per_sample_weights: Optional[torch.Tensor] = None, shape_hook: Optional[Callable] = None,
-                *, hook_features: int = 0, presorted: Optional[torch.Tensor] = None) -> torch.Tensor:
+                *, hook_features: int = 0, presorted: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        # out (addition): the pooled output is written into this tensor (functional.embedding_bag(out=...))
         masked = False
         if self.cache_op:
             with torch.no_grad():
@@ -112,7 +114,7 @@ class CachedEmbeddingBag(nn.Module):
         out = embedding_bag(input, self.cache_weight_mgr.cuda_cached_weight, offsets, self.max_norm,
                             self.norm_type, self.scale_grad_by_freq, self.mode, self.sparse, per_sample_weights,
                             self.include_last_offset, None, hook_features=hook_features,
-                            fused_sgd=self.fused_sgd, presorted=presorted, masked_indices=masked)
+                            fused_sgd=self.fused_sgd, presorted=presorted, masked_indices=masked, out=out)
         if shape_hook is not None:
             out = shape_hook(out)
         return out

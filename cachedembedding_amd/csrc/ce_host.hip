@@ -417,6 +417,62 @@ extern "C" int ce_box_probe(void* scratch, size_t bytes, int32_t reps, double* r
   return CE_OK;
 }
 
+// rows of a [rows, dim] buffer visited the way the hook-folded forward stores them / the streaming backward reads them:
+// consecutive lane groups take rows `fold` apart (i = f * (rows / fold) + b  ->  row b * fold + f)
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_probe_rows(f32x4* buf, int64_t rows, int rowlen, int g_log2, int64_t fold) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t per = rows / fold;
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < per * fold; i += gstride) {
+    const int64_t f = i / per, b = i - f * per;
+    f32x4* row = buf + (b * fold + f) * rowlen;
+    for (int c = gl; c < rowlen; c += G) {
+      if (WRITE) __builtin_nontemporal_store(acc, row + c);
+      else acc += __builtin_nontemporal_load(row + c);
+    }
+  }
+  if (!WRITE && acc.x == 12345.678f) buf[0] = acc;
+}
+
+extern "C" int ce_probe_rows(float* buf, int64_t rows, int32_t dim, int64_t fold, int32_t reps, double* write_us,
+                             double* read_us, ce_stream_t stream) {
+  CE_REQUIRE(buf && rows > 0 && dim > 0 && dim % 4 == 0 && fold > 0 && rows % fold == 0 && reps > 0 && write_us && read_us,
+             CE_ERR_INVALID, "bad arguments (dim must be a multiple of 4, fold must divide rows)");
+  CE_REQUIRE((((uintptr_t)buf) & 15) == 0, CE_ERR_INVALID, "buffer must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int rowlen = dim / 4;
+  int g = 1, gl2 = 0;
+  while (g < rowlen && g < 64) { g <<= 1; ++gl2; }
+  hipEvent_t e0, e1, e2;
+  CE_HIP_CHECK(hipEventCreate(&e0));
+  CE_HIP_CHECK(hipEventCreate(&e1));
+  CE_HIP_CHECK(hipEventCreate(&e2));
+  const dim3 grid(kNumCU * 8), block(256);
+  hipLaunchKernelGGL((k_probe_rows<true>), grid, block, 0, s, (f32x4*)buf, rows, rowlen, gl2, fold);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_probe_rows<true>), grid, block, 0, s, (f32x4*)buf, rows, rowlen, gl2, fold);
+  (void)hipEventRecord(e1, s);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_probe_rows<false>), grid, block, 0, s, (f32x4*)buf, rows, rowlen, gl2, fold);
+  (void)hipEventRecord(e2, s);
+  hipError_t e = hipEventSynchronize(e2);
+  float ms_w = 0, ms_r = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms_w, e0, e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms_r, e1, e2);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  if (e != hipSuccess) {
+    set_error("row probe failed: %s", hipGetErrorString(e));
+    return CE_ERR_HIP;
+  }
+  *write_us = (double)ms_w * 1e3 / reps;
+  *read_us = (double)ms_r * 1e3 / reps;
+  return CE_OK;
+}
+
 extern "C" int ce_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words, ce_stream_t* out) {
   CE_REQUIRE(out && words >= 0 && (words == 0 || cu_mask), CE_ERR_INVALID, "bad arguments");
   hipStream_t s = nullptr;

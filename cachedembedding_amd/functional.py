@@ -66,7 +66,7 @@ class SrcKeys(NamedTuple):
 class _BagFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, indices, offsets, psw, mode, include_last, hook_features, sparse, fused, presorted,
-                bwd_scale=None, masked=False):
+                bwd_scale=None, masked=False, out_box=None):
         _lib.require_gpu()
         assert weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
         if psw is not None and ctx.needs_input_grad[3] and fused is not None and fused.lr is not None:
@@ -76,11 +76,16 @@ class _BagFn(torch.autograd.Function):
             raise NotImplementedError("gradient w.r.t. per_sample_weights with the fused SGD update")
         num_bags = offsets.numel() - 1 if include_last else offsets.numel()
         dim = weight.shape[1]
-        if hook_features:
-            out = torch.empty(num_bags // hook_features, hook_features, dim, device=weight.device,
-                              dtype=torch.float32)
+        shape = (num_bags // hook_features, hook_features, dim) if hook_features else (num_bags, dim)
+        if out_box is not None:
+            # the caller's buffer (embedding_bag(out=...)): a static output for graph-captured steps, or one chosen by
+            # pick_fast_buffer.  It comes in a box because it is no input of the autograd function.
+            out = out_box[0]
+            if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or \
+                    out.device != weight.device:
+                raise ValueError(f"out= must be a contiguous fp32 tensor of shape {shape} on {weight.device}")
         else:
-            out = torch.empty(num_bags, dim, device=weight.device, dtype=torch.float32)
+            out = torch.empty(shape, device=weight.device, dtype=torch.float32)
         if FORWARD_FROM_KEYS and isinstance(presorted, SrcKeys) and presorted.identity and psw is None \
                 and mode == _lib.CE_MODE_SUM and num_bags == indices.numel():
             # one id per bag: out[bag] = W[slot], and the window's keys hold (slot, output row) grouped by slot
@@ -193,7 +198,7 @@ class _BagFn(torch.autograd.Function):
             check(lib.ce_bag_backward_psw(ptr(weight), weight.shape[0], dim, ptr(indices), nnz, ptr(offsets), off64,
                                           num_bags, int(include_last), hook_features, ptr(grad_out), ptr(gpsw),
                                           stream_ptr()))
-        return gw, None, None, gpsw, None, None, None, None, None, None, None, None
+        return gw, None, None, gpsw, None, None, None, None, None, None, None, None, None
 
 
 # forward from the window's source-row keys when they were built for the one-id-per-bag layout (CE_FWD_KEYS=0: always
@@ -274,7 +279,10 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                   mode: str = "mean", sparse: bool = False, per_sample_weights: Optional[torch.Tensor] = None,
                   include_last_offset: bool = False, padding_idx: Optional[int] = None, *,
                   hook_features: int = 0, fused_sgd: Optional[FusedSGD] = None,
-                  presorted: Union[torch.Tensor, SrcKeys, None] = None, masked_indices: bool = False) -> torch.Tensor:
+                  presorted: Union[torch.Tensor, SrcKeys, None] = None, masked_indices: bool = False,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    # out: write the pooled output into this tensor (contiguous fp32, the shape the call would allocate) and return it --
+    # a static output buffer for steps replayed from a hipGraph, possibly one chosen by pick_fast_buffer
     # masked_indices: the caller already replaced ignored lookups (padding) by -1 -- the kernels skip them; the
     # sparse=True backward then parks their (zero) gradient rows at index 0 so the COO tensor stays valid
     if mode not in _MODES and mode != "max":
@@ -304,6 +312,8 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
             if padding_idx < 0:
                 padding_idx += weight.shape[0]
             indices = torch.where(indices == padding_idx, torch.full_like(indices, -1), indices)
+        if out is not None:
+            raise NotImplementedError("out= with mode='max'")
         return _BagMaxFn.apply(weight, indices, offsets, bool(include_last_offset), int(hook_features), fused_sgd)
     if per_sample_weights is not None and per_sample_weights.numel() != indices.numel():
         raise ValueError("per_sample_weights must have the same number of elements as input")
@@ -377,7 +387,41 @@ def embedding_bag(indices: torch.Tensor, weight: torch.Tensor, offsets: Optional
                                   "the per-bag count of non-padding entries)")
     return _BagFn.apply(weight, indices, offsets, per_sample_weights, _MODES[mode], bool(include_last_offset),
                         int(hook_features), bool(sparse), fused_sgd, presorted, bwd_scale,
-                        padding_idx is not None or bool(masked_indices))
+                        padding_idx is not None or bool(masked_indices), None if out is None else [out])
+
+
+def probe_rows(buf: torch.Tensor, fold: int, reps: int = 6):
+    """(us per pass of row stores, us per pass of row loads) over buf [rows, dim] visited `fold` rows apart
+    (ce_probe_rows); buf's contents are overwritten"""
+    import ctypes
+    assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+    flat = buf.view(-1, buf.shape[-1])
+    w, r = ctypes.c_double(), ctypes.c_double()
+    check(lib.ce_probe_rows(ptr(flat), flat.shape[0], flat.shape[1], int(fold), int(reps), ctypes.byref(w), ctypes.byref(r),
+                            stream_ptr()))
+    return w.value, r.value
+
+
+def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "write"):
+    """A contiguous fp32 tensor of `shape` ([..., D]) that is FAST for the hook-folded access pattern: rows visited
+    `fold` rows apart, every row on another page -- what the forward's stores into a [B, F, D] output (fold = F) and the
+    streaming backward's loads of the upstream gradient do.  How fast depends on how the allocation happens to be
+    mapped, not on its address: the same forward launch takes 38 or 45 us on two buffers of one process
+    (profiles/r05_alloc_lottery.txt), which is also why the same bench line differed by 15 % in its forward between
+    processes.  So: allocate `candidates` buffers, time the pattern on each (ce_probe_rows, a few passes), keep the
+    fastest, give the others back.  use = "write" (an output buffer) or "read" (a gradient buffer).
+    Returns (tensor, {"us": [...], "picked": i}).  For static buffers of graph-captured steps; torch decides where
+    everything else lives."""
+    assert use in ("write", "read")
+    bufs = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(max(1, int(candidates)))]
+    us = []
+    for b in bufs:
+        w, r = probe_rows(b, fold)
+        us.append(w if use == "write" else r)
+    best = min(range(len(bufs)), key=lambda i: us[i])
+    keep = bufs[best]
+    del bufs
+    return keep, {"us": [round(u, 2) for u in us], "picked": best}
 
 
 def is_identity_layout(offsets: torch.Tensor, include_last_offset: bool) -> bool:

@@ -123,6 +123,15 @@ int ce_host_rows_gather(const float* table_dev, int64_t num_rows, int32_t dim, c
  * the two rates so that a reader can tell a slow box from slow code (allocations of the same GPU model differ by
  * several per cent). */
 int ce_box_probe(void* scratch, size_t bytes, int32_t reps, double* read_GBps, double* fill_GBps, ce_stream_t stream);
+/* How fast is THIS buffer when its rows are visited `fold` rows apart (API 5)?  The hook-folded forward stores -- and
+ * the streaming backward reads -- 512-byte rows of a [B, F, D] tensor in an order that touches a different page with
+ * every row (row b * F + f for consecutive b): how long that takes depends on how the allocation is mapped (the same
+ * launch measures 38 or 45 us on two buffers of one process: profiles/r05_alloc_lottery.txt), not on its address or on
+ * the table.  `reps` passes of row stores, then of row loads, over buf = device fp32 [rows, dim] (contents are
+ * overwritten), hipEvent-bracketed on `stream`; blocks until done.  cachedembedding_amd.functional.pick_fast_buffer
+ * allocates a few candidates and keeps the fastest. */
+int ce_probe_rows(float* buf, int64_t rows, int32_t dim, int64_t fold, int32_t reps, double* write_us, double* read_us,
+                  ce_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K12: F.embedding_bag(slots, cuda_cached_weight, offsets, mode, per_sample_weights,

@@ -866,3 +866,35 @@ def test_max_norm_renormalises_the_named_rows_like_torch(D, norm_type):
     torch.testing.assert_close(wc.cpu(), wr, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
     assert torch.equal(wc.cpu()[R // 2:], w[R // 2:])
+
+
+@pytest.mark.parametrize("hook", [True, False])
+def test_out_argument_and_the_buffer_picker(hook):
+    """embedding_bag(out=...) writes the pooled output into the caller's tensor (a static buffer for graph-captured
+    steps) with the same values and the same backward; functional.pick_fast_buffer hands out a tensor of the asked
+    shape together with what it measured on every candidate (ce_probe_rows)."""
+    ce = _ce()
+    from cachedembedding_amd.functional import pick_fast_buffer, probe_rows
+    B, F, D, C = 512, 6, 128, 4000
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(C, D, generator=g)
+    idx = torch.randint(0, C, (B * F,), generator=g).cuda()
+    off = torch.arange(B * F + 1, dtype=torch.int32).cuda()
+    shape = (B, F, D) if hook else (B * F, D)
+    buf, rep = pick_fast_buffer(shape, torch.device("cuda"), F, candidates=3, use="write")
+    assert tuple(buf.shape) == shape and buf.is_contiguous() and len(rep["us"]) == 3 and 0 <= rep["picked"] < 3
+    assert rep["us"][rep["picked"]] == min(rep["us"]) and min(rep["us"]) > 0
+    wr, rd = probe_rows(torch.empty(shape, device="cuda"), F)
+    assert wr > 0 and rd > 0
+    kw = dict(mode="sum", include_last_offset=True, hook_features=F if hook else 0)
+    w1 = w.cuda().requires_grad_(True)
+    ref = ce.embedding_bag(idx, w1, off, **kw)
+    w2 = w.cuda().requires_grad_(True)
+    got = ce.embedding_bag(idx, w2, off, out=buf, **kw)
+    assert got.data_ptr() == buf.data_ptr() and torch.equal(got, ref)
+    go = torch.randn(shape, generator=g).cuda()
+    ref.backward(go)
+    got.backward(go)
+    assert torch.equal(w1.grad, w2.grad)
+    with pytest.raises(ValueError):
+        ce.embedding_bag(idx, w2, off, out=torch.empty(3, 3, device="cuda"), **kw)
