@@ -413,11 +413,16 @@ def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "
     Returns (tensor, {"us": [...], "picked": i}).  For static buffers of graph-captured steps; torch decides where
     everything else lives."""
     assert use in ("write", "read")
-    bufs = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(max(1, int(candidates)))]
-    us = []
-    for b in bufs:
+    bufs, us = [], []
+    for _ in range(max(1, int(candidates))):
+        b = torch.empty(shape, dtype=torch.float32, device=device)       # (all candidates stay alive while the search runs:
+        bufs.append(b)                                                  # every one is another allocation)
         w, r = probe_rows(b, fold)
         us.append(w if use == "write" else r)
+        if len(us) >= 4:
+            med = sorted(us)[len(us) // 2]
+            if us[-1] < 0.94 * med:          # the fast kind is ~8 % faster than the common kind in this probe: found one
+                break
     best = min(range(len(bufs)), key=lambda i: us[i])
     keep = bufs[best]
     del bufs

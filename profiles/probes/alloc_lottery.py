@@ -17,6 +17,7 @@ from cachedembedding_amd.functional import presort_window  # noqa: E402
 B, F, D, C = 16384, 26, 128, 1_779_442
 dev = torch.device("cuda", 0)
 n = B * F
+early = [torch.empty(n * D, device=dev) for _ in range(3)]        # allocated before anything else lives on the device
 gen = synthetic.SyntheticKJT(synthetic.TABLES["criteo_1tb"], B, 1, "power_law", 0.25, seed=1024, device=dev)
 freq = gen.id_freq_map(16)
 rank = torch.empty_like(freq)
@@ -43,8 +44,13 @@ def timed(fn, reps=24):
 
 tables = [torch.randn(C, D, device=dev) for _ in range(3)]
 arena = torch.empty(6 * n * D + (64 << 20), dtype=torch.float32, device=dev)
-offs_elems = [0, n * D + 1024, 2 * n * D + 16 * 1024, 3 * n * D + (1 << 19) + 4096, 4 * n * D + (3 << 20), 5 * n * D + (7 << 20) + 256 * 1024]
-outs = [arena[o:o + n * D] for o in offs_elems] + [torch.empty(n * D, device=dev) for _ in range(3)]
+assert arena.data_ptr() % (2 << 20) == 0
+# slices of one allocation at offsets (in floats) whose BYTE offset is: 0, 4 KB, 1 KB, 0xe400, 0xde400, 0xede400 past a 2 MB line
+offs_elems = [0, n * D + 1024, 2 * n * D + 256, 3 * n * D + 0xe400 // 4, 4 * n * D + 0xde400 // 4, 5 * n * D + 0xede400 // 4]
+outs = [arena[o:o + n * D] for o in offs_elems] + [torch.empty(n * D, device=dev) for _ in range(3)] + early
+from cachedembedding_amd.functional import probe_rows  # noqa: E402
+print("# ce_probe_rows (write us, read us) per output buffer [6 arena slices, 3 late allocations, 3 EARLY allocations]:")
+print("  " + "  ".join("%.1f/%.1f" % probe_rows(o.view(n, D), F) for o in outs))
 print("# forward from keys: us per launch (24 back to back), by table copy x output buffer")
 for ti, t in enumerate(tables):
     row = []
@@ -53,7 +59,7 @@ for ti, t in enumerate(tables):
         row.append(us)
     print(f"table {ti} @{t.data_ptr() % (1 << 30):#011x}: " + "  ".join(f"{u:5.1f}" for u in row))
 print("# output buffers @ (mod 1 GiB): " + " ".join(f"{o.data_ptr() % (1 << 30):#x}" for o in outs))
-grads = [torch.randn(n * D, device=dev) * 1e-3 for _ in range(4)] + [arena[o:o + n * D] for o in offs_elems[:3]]
+grads = [torch.randn(n * D, device=dev) * 1e-3 for _ in range(4)] + [arena[o:o + n * D] for o in offs_elems[:3]] + early
 print("# streaming backward + SGD: us per launch, by table copy x gradient buffer")
 for ti, t in enumerate(tables[:2]):
     row = []
