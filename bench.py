@@ -121,6 +121,8 @@ def parse():
                          "build's additions (fused SGD, folded hook, window keys, overlapped cache op, hipGraph, "
                          "worker transport).  What a maintainer gets before opting into anything.")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--probe_lottery", action="store_true",
+                    help="choose the static buffers by the probe pattern instead of the step's own kernels")
     ap.add_argument("--no_buffer_lottery", action="store_true",
                     help="let torch place the forward's output and the upstream gradient (default: the library tries "
                          "--buffer_candidates allocations for each and keeps the one the row pattern is fastest on)")
@@ -238,16 +240,8 @@ def main():
     from cachedembedding_amd.functional import pick_fast_buffer
     lottery = None
     out_static = None
-    if not args.no_buffer_lottery and not args.unchanged_trainer and L == 1:
-        out_static, lo_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="write")
-        grad, lg_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="read")
-        lottery = {"what": "functional.pick_fast_buffer: us per pass of the hook-folded row pattern over every candidate "
-                           "allocation (ce_probe_rows), the fastest kept", "forward_output_write_us": lo_,
-                   "upstream_gradient_read_us": lg_}
-        grad.normal_()
-        grad.mul_(1e-3)                                              # fixed upstream grad (benchmark_cache.py:64-65)
-    else:
-        grad = torch.randn(B, F, D, device=dev) * 1e-3               # fixed upstream grad (benchmark_cache.py:64-65)
+    want_lottery = not args.no_buffer_lottery and not args.unchanged_trainer and L == 1
+    grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
     # ... with zero mean over the batch, per feature and element.  The reference draws a fresh randn every iteration;
     # ONE tensor reused for thousands of steps at lr = 1 otherwise pushes the rows of the 3-row tables (a third of every
     # batch each) linearly to |w| ~ 460, where one fp32 ulp is 3e-5 and ANY summation order -- torch's included --
@@ -277,6 +271,37 @@ def main():
     layout = None if args.tile_keys else (offsets, embed.include_last_offset, F)
     win = PrefetchWindow(embed, P, overlap=args.overlap and args.no_graph, cache_cus=args.cache_cus, presort=presort,
                          transport=None, bag_layout=layout)
+
+    if want_lottery:
+        # candidates timed on the step's own kernels over the first window's first batch (one more untimed cache op), the
+        # update switched off meanwhile (lr = 0 adds -0.0 x 0 to the rows it touches); plain probe pattern with --probe_lottery
+        if args.probe_lottery or not presort:
+            out_static, lo_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="write")
+            gbuf, lg_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="read")
+            how = "us per pass of the hook-folded row pattern (ce_probe_rows)"
+        else:
+            s0 = win.prepare([windows[0][i] for i in range(P)])
+            k0 = win.keys[0] if win.keys else None
+            lr_, embed.fused_sgd.lr = embed.fused_sgd.lr, 0.0
+
+            def fwd_work(buf):
+                with torch.no_grad():
+                    embed(s0[0], offsets, hook_features=F, presorted=k0, out=buf)
+
+            out_static, lo_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="write",
+                                               work=fwd_work)
+
+            def step_work(buf):
+                embed(s0[0], offsets, hook_features=F, presorted=k0, out=out_static).backward(buf)
+
+            gbuf, lg_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="read", work=step_work)
+            embed.fused_sgd.lr = lr_
+            del s0, k0
+            how = "us per forward (output candidates) / per forward + backward at lr = 0 (gradient candidates), as hipGraph replays"
+        lottery = {"what": "functional.pick_fast_buffer: " + how + " over every candidate allocation, the fastest kept",
+                   "forward_output_us": lo_, "upstream_gradient_us": lg_}
+        gbuf.copy_(grad)
+        grad = gbuf                                                  # (train_step reads the name when it is called)
 
     def train_step(slots_i, i, keys_i=None):
         out = embed(slots_i, offsets, hook_features=F, presorted=keys_i, out=out_static)

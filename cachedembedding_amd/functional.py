@@ -402,21 +402,55 @@ def probe_rows(buf: torch.Tensor, fold: int, reps: int = 6):
     return w.value, r.value
 
 
-def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "write"):
+def _time_work(work, buf: torch.Tensor, reps: int) -> float:
+    """us per call of work(buf): `reps` calls captured in one hipGraph, replayed twice between two events"""
+    dev = buf.device
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        work(buf)                                # eager once: lazy initialisation must not happen during capture
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            work(buf)
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    g.replay()
+    e1.record()
+    e1.synchronize()
+    del g
+    return e0.elapsed_time(e1) * 1e3 / (2 * reps)
+
+
+def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "write", work=None, reps: int = 8):
     """A contiguous fp32 tensor of `shape` ([..., D]) that is FAST for the hook-folded access pattern: rows visited
     `fold` rows apart, every row on another page -- what the forward's stores into a [B, F, D] output (fold = F) and the
     streaming backward's loads of the upstream gradient do.  How fast depends on how the allocation happens to be
     mapped, not on its address: the same forward launch takes 38 or 45 us on two buffers of one process
     (profiles/r05_alloc_lottery.txt), which is also why the same bench line differed by 15 % in its forward between
-    processes.  So: allocate `candidates` buffers, time the pattern on each (ce_probe_rows, a few passes), keep the
-    fastest, give the others back.  use = "write" (an output buffer) or "read" (a gradient buffer).
+    processes.  So: allocate `candidates` buffers, time each, keep the fastest, give the others back.
+    use = "write" (an output buffer) or "read" (a gradient buffer): what is timed is the pattern alone (ce_probe_rows,
+    a few passes; the search stops at the first candidate clearly of the fast kind).  work = callable(buf): what is
+    timed is the caller's own work on the candidate instead -- work(buf) enqueues it on the current stream, free of
+    side effects, capturable; `reps` calls are replayed as one hipGraph -- and every candidate is tried ("read"
+    candidates are zero-filled first: a gradient buffer must not hold the allocator's leftovers).
     Returns (tensor, {"us": [...], "picked": i}).  For static buffers of graph-captured steps; torch decides where
     everything else lives."""
     assert use in ("write", "read")
-    bufs, us = [], []
+    bufs, us, fresh = [], [], []
     for _ in range(max(1, int(candidates))):
+        r0 = torch.cuda.memory_reserved(device)
         b = torch.empty(shape, dtype=torch.float32, device=device)       # (all candidates stay alive while the search runs:
         bufs.append(b)                                                  # every one is another allocation)
+        fresh.append(int(torch.cuda.memory_reserved(device) > r0))
+        if work is not None:
+            if use == "read":
+                b.zero_()
+            us.append(_time_work(work, b, reps))
+            continue
         w, r = probe_rows(b, fold)
         us.append(w if use == "write" else r)
         if len(us) >= 4:
@@ -426,7 +460,7 @@ def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "
     best = min(range(len(bufs)), key=lambda i: us[i])
     keep = bufs[best]
     del bufs
-    return keep, {"us": [round(u, 2) for u in us], "picked": best}
+    return keep, {"us": [round(u, 2) for u in us], "picked": best, "new_segment": fresh}
 
 
 def is_identity_layout(offsets: torch.Tensor, include_last_offset: bool) -> bool:

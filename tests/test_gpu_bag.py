@@ -887,6 +887,26 @@ def test_out_argument_and_the_buffer_picker(hook):
     wr, rd = probe_rows(torch.empty(shape, device="cuda"), F)
     assert wr > 0 and rd > 0
     kw = dict(mode="sum", include_last_offset=True, hook_features=F if hook else 0)
+    # work=: the candidates are timed on the caller's own launches (a hipGraph of `reps` calls) and all of them are tried;
+    # "read" candidates arrive zero-filled
+    wk = w.cuda()
+    seen = []
+
+    def fwd(b):
+        seen.append(b.data_ptr())
+        with torch.no_grad():
+            ce.embedding_bag(idx, wk, off, out=b, **kw)
+
+    buf2, rep2 = pick_fast_buffer(shape, torch.device("cuda"), F, candidates=3, use="write", work=fwd, reps=4)
+    assert len(rep2["us"]) == 3 and len(set(seen)) == 3 and buf2.data_ptr() in seen and min(rep2["us"]) > 0
+    assert rep2["us"][rep2["picked"]] == min(rep2["us"]) and len(rep2["new_segment"]) == 3
+    torch.cuda.synchronize()
+    assert torch.equal(buf2, ce.embedding_bag(idx, wk, off, **kw))
+    zeros = []
+    buf3, _ = pick_fast_buffer(shape, torch.device("cuda"), F, candidates=2, use="read", reps=2,
+                               work=lambda b: zeros.append(b) or b.add_(0.0))
+    torch.cuda.synchronize()
+    assert all(float(z.abs().max()) == 0.0 for z in zeros)
     w1 = w.cuda().requires_grad_(True)
     ref = ce.embedding_bag(idx, w1, off, **kw)
     w2 = w.cuda().requires_grad_(True)
@@ -895,6 +915,8 @@ def test_out_argument_and_the_buffer_picker(hook):
     go = torch.randn(shape, generator=g).cuda()
     ref.backward(go)
     got.backward(go)
-    assert torch.equal(w1.grad, w2.grad)
+    # (the dense backward folds a row's lookups with fp32 atomics: rows with three or more lookups may differ by an ulp
+    # or two between two launches -- tolerance 1e-6 absolute on gradients of size ~1)
+    torch.testing.assert_close(w1.grad, w2.grad, rtol=0, atol=1e-6)
     with pytest.raises(ValueError):
         ce.embedding_bag(idx, w2, off, out=torch.empty(3, 3, device="cuda"), **kw)
