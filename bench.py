@@ -126,7 +126,7 @@ def parse():
     ap.add_argument("--no_buffer_lottery", action="store_true",
                     help="let torch place the forward's output and the upstream gradient (default: the library tries "
                          "--buffer_candidates allocations for each and keeps the one the row pattern is fastest on)")
-    ap.add_argument("--buffer_candidates", type=int, default=8)
+    ap.add_argument("--buffer_candidates", type=int, default=12)
     ap.add_argument("--no_reference_semantics", action="store_true",
                     help="skip the extra block that runs the same steps with the reference's window semantics (one "
                          "synchronous cache op per window, no protect_depth) next to the headline")
