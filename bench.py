@@ -275,7 +275,7 @@ def main():
     if want_lottery:
         # candidates timed on the step's own kernels over the first window's first batch (one more untimed cache op), the
         # update switched off meanwhile (lr = 0 adds -0.0 x 0 to the rows it touches); plain probe pattern with --probe_lottery
-        if args.probe_lottery or not presort:
+        if args.probe_lottery or not presort or not use_graph or args.deterministic:
             out_static, lo_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="write")
             gbuf, lg_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="read")
             how = "us per pass of the hook-folded row pattern (ce_probe_rows)"
