@@ -1177,8 +1177,26 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
     cap = (int(cap_t.item()) + 255) // 256 * 256
     bucket_mean = float(st_.mean())
     tr = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or pick_transport("auto", P * world * cap))
+    lottery = {}
+    want_lottery = not args.no_buffer_lottery and L == 1 and args.buffer_candidates > 0
+
+    def pick_gradient(w):
+        # the fixed upstream gradient in the fastest of a few candidate buffers for this window's own table update
+        # (as the unsharded path does: functional.pick_fast_buffer(work=...))
+        nonlocal grad
+        from cachedembedding_amd.functional import pick_fast_buffer
+        gbuf, rep = pick_fast_buffer(tuple(grad.shape), dev, F, candidates=args.buffer_candidates, use="read",
+                                     work=w.enqueue_update_lr0)
+        gbuf.copy_(grad)
+        grad = gbuf
+        lottery["upstream_gradient_us"] = rep
+
     gw = GraphedShardedWindow(embed, P, B * F * L, offsets, lambda out, i: grad, cap, hook_features=F, overlap=args.overlap,
-                              transport=tr if args.overlap else None, warmup_ids=[windows[0][i] for i in range(P)])
+                              transport=tr if args.overlap else None, warmup_ids=[windows[0][i] for i in range(P)],
+                              static_out_candidates=args.buffer_candidates if want_lottery else 0,
+                              before_capture=pick_gradient if want_lottery else None)
+    if gw.out_lottery is not None:
+        lottery["forward_output_us"] = gw.out_lottery
     state = {"submitted": -1}
     verify = not args.no_verify and (world == 1 or args.verify_sharded)
     trained_windows = [0] if verify else None        # GraphedShardedWindow trained its warm-up window once, eagerly
@@ -1268,7 +1286,7 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                    "launch": "hipGraph per window" if gw._graphs is not None else
                              "fixed-capacity steps launched one by one (world > 1: CE_SHARDED_GRAPH=1 captures them)",
                    "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
-                   "windows_on_the_variable_size_path": gw.fallback_windows,
+                   "windows_on_the_variable_size_path": gw.fallback_windows, "static_buffers": lottery or None,
                    "arrangement": (gw.trial.report() | {"mode": gw.arrangement}) if gw.trial is not None else {"mode": gw.arrangement},
                    "exchange_split": ({"on": True, "rows_per_peer_and_step": dict(zip(("early", "late", "deferred", "urgent"), gw.split_caps)),
                                        "measured_on_the_warmup_window": gw.split_stats,

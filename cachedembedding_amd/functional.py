@@ -411,8 +411,8 @@ def _time_work(work, buf: torch.Tensor, reps: int) -> float:
         work(buf)                                # eager once: lazy initialisation must not happen during capture
     torch.cuda.current_stream(dev).wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(reps):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (other threads -- a process group's watchdog --
+        for _ in range(reps):                                        # may talk to the runtime meanwhile)
             work(buf)
     g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

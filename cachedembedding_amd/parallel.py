@@ -325,12 +325,15 @@ class HipShardOps(ShardOps):
                                  _MODES[mode], hook_features, ptr(out), stream_ptr()))
         return out
 
-    def pool_from_keys(self, table, keys: "SrcKeys", nnz: int):
+    def pool_from_keys(self, table, keys: "SrcKeys", nnz: int, out: Optional[torch.Tensor] = None):
         """pooled output of a one-id-per-bag batch straight from its source-row keys over `table` (cache + exchange
-        buffer): a row is loaded once per run of equal rows (ce_bag_forward_src_keys)"""
+        buffer): a row is loaded once per run of equal rows (ce_bag_forward_src_keys); into `out` when given"""
         hf, nb = int(keys.hook_features), int(keys.num_bags)
         shape = (nb // hf, hf, self.dim) if hf else (nb, self.dim)
-        out = torch.empty(shape, dtype=torch.float32, device=table.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=table.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError(f"out= must be a contiguous fp32 tensor of shape {shape}")
         check(lib.ce_bag_forward_src_keys(ptr(table), table.shape[0], self.dim, int(nnz), ptr(keys.keys), ptr(out),
                                           stream_ptr()))
         return out
@@ -715,7 +718,14 @@ class GraphedShardedWindow:
                  use_graph: Optional[bool] = None,
                  transport: Optional[str] = None, warmup_ids: Optional[Sequence[torch.Tensor]] = None,
                  split: Optional[bool] = None, split_caps: Optional[Sequence[int]] = None,
-                 arrangement: Optional[str] = None, arrangement_trial: Optional[dict] = None):
+                 arrangement: Optional[str] = None, arrangement_trial: Optional[dict] = None,
+                 static_out_candidates: int = 0, before_capture=None):
+        # static_out_candidates > 0 (one-id-per-bag layouts; needs warmup_ids): the pooled output of every step is ONE
+        # static buffer, the fastest of that many candidate allocations for this window's own forward
+        # (functional.pick_fast_buffer(work=...): the same launch takes 37 or 45 us depending on how its output is
+        # mapped); `out_lottery` reports what was measured.  before_capture(window): called once, after the warm-up
+        # window has trained and before the steps are captured -- e.g. to choose the tensor dense_fn returns the same
+        # way (enqueue_update_lr0 is the work to time on a gradient candidate).
         # arrangement (overlap=True): where the NEXT window's plan runs -- "overlap": on the two side streams beside this
         # window's steps; "interleaved": on the training stream, the owner-side cache op in two halves around this
         # window's steps (ce_cache_prepare_ids_begin_padded / _finish), so that no kernel of the plan runs beside a bag
@@ -800,6 +810,8 @@ class GraphedShardedWindow:
         self._split = bool(split) and W > 1
         self._force_late = self._split and os.environ.get("CE_SPLIT_FORCE", "") == "late"
         self._graphs = None
+        self._out_static = None
+        self.out_lottery = None
         self.fallback_windows = 0
         self.split_stats = None
         if self._split:
@@ -835,8 +847,29 @@ class GraphedShardedWindow:
             # never run on hardware here -- the launched-one-by-one form is the one the world-2/3 tests exercise
             if use_graph is None:
                 use_graph = W == 1 or os.environ.get("CE_SHARDED_GRAPH", "0") == "1"
+            if static_out_candidates > 0 and self._identity and FORWARD_FROM_KEYS:
+                from .functional import pick_fast_buffer
+                k0 = self._keys0()
+                shape = (self.num_bags // self.hook, self.hook, embed.embedding_dim) if self.hook \
+                    else (self.num_bags, embed.embedding_dim)
+                self._out_static, self.out_lottery = pick_fast_buffer(
+                    shape, dev, max(1, self.hook), candidates=int(static_out_candidates), use="write",
+                    work=lambda b: self.ops.pool_from_keys(self._table, k0, self.n, out=b))
+            if before_capture is not None:
+                before_capture(self)
             if use_graph and not (W > 1 and dist.get_backend(self.ex.group) == "gloo"):     # gloo stages through the host
                 self._capture()
+
+    def _keys0(self) -> "SrcKeys":
+        """source-row keys of the warm-up window's first batch (valid once that window has been planned)"""
+        return SrcKeys(self._keys[0][0], self.num_bags, self.incl, self.hook, None, self._identity)
+
+    def enqueue_update_lr0(self, grad_buf: torch.Tensor) -> None:
+        """The table update of the warm-up window's first batch with `grad_buf` as the upstream gradient and lr = 0
+        (nothing changes): the work to time on a candidate gradient buffer (functional.pick_fast_buffer(work=...))."""
+        keys = SrcKeys(self._keys_b[0][0], self.num_bags, self.incl, self.hook, None, self._identity) if self._split \
+            else self._keys0()
+        self.ops.update_table(self._table, grad_buf, keys, self.n, 0.0)
 
     # ---- planning (per window, no host wait)
     @torch.no_grad()
@@ -1142,7 +1175,7 @@ class GraphedShardedWindow:
             cur.wait_event(ev_l)
             keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
             if self._identity and FORWARD_FROM_KEYS and hasattr(ops, "pool_from_keys"):
-                out = ops.pool_from_keys(self._table, keys, self.n)
+                out = ops.pool_from_keys(self._table, keys, self.n, out=self._out_static)
             else:
                 out = ops.pool(self._table, self._idx[buf][i], self.offsets, None, "sum", self.incl, self.hook)
             grad = self.dense_fn(out, i)
@@ -1204,7 +1237,7 @@ class GraphedShardedWindow:
             _a2a(self._tail, rows, None, None, ex.group)
         keys = SrcKeys(self._keys[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
         if self._identity and FORWARD_FROM_KEYS and hasattr(ops, "pool_from_keys"):
-            out = ops.pool_from_keys(self._table, keys, self.n)     # one id per bag: the forward runs from the keys too
+            out = ops.pool_from_keys(self._table, keys, self.n, out=self._out_static)      # one id per bag: from the keys too
         else:
             out = ops.pool(self._table, idx, self.offsets, None, "sum", self.incl, self.hook)
         grad = self.dense_fn(out, i)
