@@ -297,7 +297,7 @@ def main():
             gbuf, lg_ = pick_fast_buffer((B, F, D), dev, F, candidates=args.buffer_candidates, use="read", work=step_work)
             embed.fused_sgd.lr = lr_
             del s0, k0
-            how = "us per forward (output candidates) / per forward + backward at lr = 0 (gradient candidates), as hipGraph replays"
+            how = "us per forward (output candidates) / per forward + backward at lr = 0 (gradient candidates), back to back behind a spin kernel"
         lottery = {"what": "functional.pick_fast_buffer: " + how + " over every candidate allocation, the fastest kept",
                    "forward_output_us": lo_, "upstream_gradient_us": lg_}
         gbuf.copy_(grad)

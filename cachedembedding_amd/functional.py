@@ -403,26 +403,20 @@ def probe_rows(buf: torch.Tensor, fold: int, reps: int = 6):
 
 
 def _time_work(work, buf: torch.Tensor, reps: int) -> float:
-    """us per call of work(buf): `reps` calls captured in one hipGraph, replayed twice between two events"""
-    dev = buf.device
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        work(buf)                                # eager once: lazy initialisation must not happen during capture
-    torch.cuda.current_stream(dev).wait_stream(side)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (other threads -- a process group's watchdog --
-        for _ in range(reps):                                        # may talk to the runtime meanwhile)
-            work(buf)
-    g.replay()
+    """us per call of work(buf): `reps` calls enqueued while the GPU is kept busy by a spin kernel (so that they run
+    back to back however long the host takes to launch them), timed by two events.  Deliberately NOT a captured
+    hipGraph: two dozen capture / destroy cycles leave the runtime with a different assignment of streams to hardware
+    queues for everything created afterwards (measured: a prefetch_num = 1 pipeline built after them ran 5 % slower)."""
+    work(buf)                                    # once, untimed: lazy initialisation, first-touch of the candidate
+    torch.cuda.synchronize(buf.device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(6e5) * reps)           # ~0.3 ms per call at 2 GHz: room for an autograd step's host time
     e0.record()
-    g.replay()
-    g.replay()
+    for _ in range(reps):
+        work(buf)
     e1.record()
     e1.synchronize()
-    del g
-    return e0.elapsed_time(e1) * 1e3 / (2 * reps)
+    return e0.elapsed_time(e1) * 1e3 / reps
 
 
 def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "write", work=None, reps: int = 8):
@@ -435,7 +429,7 @@ def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "
     use = "write" (an output buffer) or "read" (a gradient buffer): what is timed is the pattern alone (ce_probe_rows,
     a few passes; the search stops at the first candidate clearly of the fast kind).  work = callable(buf): what is
     timed is the caller's own work on the candidate instead -- work(buf) enqueues it on the current stream, free of
-    side effects, capturable; `reps` calls are replayed as one hipGraph -- and every candidate is tried ("read"
+    side effects; `reps` calls run back to back behind a spin kernel -- and every candidate is tried ("read"
     candidates are zero-filled first: a gradient buffer must not hold the allocator's leftovers).
     Returns (tensor, {"us": [...], "picked": i}).  For static buffers of graph-captured steps; torch decides where
     everything else lives."""
@@ -459,7 +453,10 @@ def pick_fast_buffer(shape, device, fold: int, candidates: int = 5, use: str = "
                 break
     best = min(range(len(bufs)), key=lambda i: us[i])
     keep = bufs[best]
-    del bufs
+    del bufs, b
+    # the losers go back to the DRIVER, not into torch's cache: whatever is allocated next would otherwise be carved
+    # out of them (measured: a window object built after a 12-candidate search ran 7 % slower at prefetch_num = 1)
+    torch.cuda.empty_cache()
     return keep, {"us": [round(u, 2) for u in us], "picked": best, "new_segment": fresh}
 
 
