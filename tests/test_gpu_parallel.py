@@ -175,10 +175,25 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
 
     ref_w = w_full.clone()
     # window 0 doubles as the warm-up (it trains once eagerly inside the constructor): account for it
+    hook_ran = []
+
+    def before_capture(w):
+        # the work a caller times on candidate gradient buffers: the table update at lr = 0 must leave the table as it is
+        before = w._table.clone()
+        w.enqueue_update_lr0(torch.randn(B_loc, F, D, device="cuda"))
+        torch.cuda.synchronize()
+        assert torch.equal(before, w._table)
+        hook_ran.append(w.out_lottery)
+
+    # (the pooled output of every step in ONE static buffer picked among three candidates; before_capture as above)
     gw = GraphedShardedWindow(emb, P, F * B_loc, offsets, dense_fn, capacity=capacity, hook_features=F,
                               overlap=overlap, warmup_ids=[i.cuda() for i in all_ids[0]],
-                              use_graph=True if force_graph else None) if capacity >= 64 else \
+                              use_graph=True if force_graph else None, static_out_candidates=3,
+                              before_capture=before_capture) if capacity >= 64 else \
         GraphedShardedWindow(emb, P, F * B_loc, offsets, dense_fn, capacity=capacity, hook_features=F, overlap=overlap)
+    if capacity >= 64:
+        assert len(hook_ran) == 1 and hook_ran[0] is not None and len(hook_ran[0]["us"]) == 3
+        assert gw._out_static is not None and tuple(gw._out_static.shape) == (B_loc, F, D)
     if force_graph and rank == 0:
         print("window steps with RCCL all-to-alls inside:", "captured as hipGraphs" if gw._graphs is not None
               else "capture refused -> launched one by one", flush=True)
