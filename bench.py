@@ -319,7 +319,7 @@ def main():
     if use_graph:
         from cachedembedding_amd.pipeline import GraphedWindow
         plan_ahead = args.plan_ahead if args.overlap else 1
-        can_switch = args.overlap and plan_ahead == 1 and not args.graph_cache_op
+        can_switch = args.overlap and plan_ahead in (1, 2) and not args.graph_cache_op
         # the arrangement is the LIBRARY's choice (GraphedWindow(arrangement="auto"), its default): bench.py only says
         # which one it wants to see (--arrangement overlap / interleaved) and reports what the library chose
         gw = GraphedWindow(embed, P, B * F * L, train_step, overlap=args.overlap,

@@ -200,7 +200,7 @@ def _resolve_arrangement(arrangement: Optional[str], switchable: bool) -> Option
     if arrangement is not None and arrangement not in ("auto",) + ARRANGEMENTS:
         raise ValueError(f"arrangement={arrangement!r}: 'auto', 'overlap' or 'interleaved'")
     if arrangement is not None and not switchable:
-        raise ValueError("arrangement= needs a window built with overlap=True (plan_ahead 1, no cache-op graph)")
+        raise ValueError("arrangement= needs a window built with overlap=True (no cache-op graph)")
     return arrangement
 
 
@@ -401,8 +401,13 @@ class GraphedWindow:
             "interleaved replaces overlap (one stream, plan_ahead 1)"
         self.interleaved = interleaved
         # both arrangements on one object: built with overlap=True (the side stream exists), set_arrangement() then
-        # moves the NEXT window's cache op between the side stream and the two halves on the training stream
-        self.switchable = overlap and plan_ahead == 1 and not graph_cache_op
+        # moves the NEXT window's cache op between the side stream and the two halves on the training stream.
+        # plan_ahead 2 (what prefetch_num = 1 pipelines use) can switch too: the caller keeps submitting two windows
+        # ahead; 'interleaved' then runs begin(k+2), steps(k), finish(k+2) on the training stream -- the same two halves
+        # around one window's steps, the slots one window earlier than needed.  Which one a prefetch_num = 1 pipeline wants
+        # depends on the workload (round 5, one box: Kaggle 5 % DATASET 1.55 G interleaved against 1.29 G two windows
+        # ahead on the side stream; LFU 1.44 against 1.58 G; Avazu B = 2048 188 against 215 M): the trial decides.
+        self.switchable = overlap and plan_ahead in (1, 2) and not graph_cache_op
         arrangement = _resolve_arrangement(arrangement, self.switchable and not interleaved) \
             if (arrangement is not None or (self.switchable and not interleaved)) else None
         self.trial: Optional[ArrangementTrial] = None
@@ -569,6 +574,10 @@ class GraphedWindow:
         self._finish_begun()
         self.interleaved = mode == "interleaved"
         self.overlap = not self.interleaved
+        if self.overlap and self.plan_ahead > 1:
+            # two windows ahead, submit() does not make the side stream wait for the training stream -- but the cache ops
+            # issued there while the arrangement was 'interleaved' come first (the cache manager's calls are ordered)
+            self._side.wait_stream(torch.cuda.current_stream(self.mgr.device))
 
     def _finish_begun(self) -> None:
         if self._begun is not None:

@@ -234,12 +234,16 @@ def test_prefetch_window_modes_train_identically_to_plain_embedding_bag(mode, pr
     torch.testing.assert_close(emb.weight, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("arr", ["overlap", "interleaved", "switching", "auto"])
 @pytest.mark.parametrize("P,lfu,presort,transport", [(1, False, False, "worker"), (1, True, False, "zerocopy"),
                                                     (3, False, "src", "worker")])
-def test_cache_op_two_windows_ahead(P, lfu, presort, transport):
+def test_cache_op_two_windows_ahead(P, lfu, presort, transport, arr):
     """GraphedWindow(plan_ahead=2): three slot buffers, protect_depth 2, the cache op of window k+2 only waits for the
     training of window k-1 (the last reader of its buffer).  Same training trajectory as a plain full-table
-    EmbeddingBag with SGD, and no row of a window that still trains is evicted (the table after flush says so)."""
+    EmbeddingBag with SGD, and no row of a window that still trains is evicted (the table after flush says so).
+    arr: where those cache ops run -- on the side stream ('overlap'), in two halves on the training stream around the
+    steps of the window in training ('interleaved': what a prefetch_num = 1 pipeline on Kaggle 5 % prefers), changed
+    by the caller before every window ('switching') or by the library's own trial ('auto', the default)."""
     import cachedembedding_amd as ce
     from cachedembedding_amd.pipeline import GraphedWindow
     torch.manual_seed(0)
@@ -262,15 +266,28 @@ def test_cache_op_two_windows_ahead(P, lfu, presort, transport):
         out.backward(grad)
 
     gw = GraphedWindow(emb, P, F * B, step, overlap=True, warmup_values=windows[0], presort=bool(presort),
-                       transport=transport, bag_layout=layout, plan_ahead=2)
-    assert gw.nbuf == 3
+                       transport=transport, bag_layout=layout, plan_ahead=2,
+                       arrangement=None if arr == "auto" else ("overlap" if arr == "switching" else arr),
+                       arrangement_trial=dict(block_windows=4, rounds=1, settle=0) if arr == "auto" else None)
+    assert gw.nbuf == 3 and gw.switchable
+    plan = ["interleaved", "interleaved", "overlap", "interleaved", "overlap", "overlap", "overlap", "interleaved"]
     torch.cuda.synchronize()
     submitted = -1
+    seen = set()
     for w in range(nwin):
+        if arr == "switching":
+            gw.set_arrangement(plan[w % len(plan)])
+        seen.add(gw.arrangement)
         for w2 in range(submitted + 1, min(nwin, w + 3)):
             gw.submit(windows[w2], w2 % 3)
             submitted = w2
         gw.run(w % 3)
+    if arr in ("switching", "auto"):
+        assert seen == {"overlap", "interleaved"}
+    else:
+        assert seen == {arr}
+    if arr == "auto":
+        assert gw.settle_arrangement(wait=True) in ("overlap", "interleaved") and gw.trial.trials == 1
     torch.cuda.synchronize()
     assert emb.cache_weight_mgr.sync_stats().status == 0
     emb.flush()
