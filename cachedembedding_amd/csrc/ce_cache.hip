@@ -1918,6 +1918,7 @@ struct SwapEngine {
   uint32_t evt_mask = 0;
   long long in_probed = 0;         // admissions that ran while the previous write-back was still on its way
   int out_delay_us = 0;            // test hook (CE_WORKER_OUT_DELAY_US): every write-back job starts this much late
+  long long fail_in_job = 0;       // test hook (CE_WORKER_FAIL_IN_JOB): this admission job reports a failed HIP call
   const int32_t* miss_list_dev = nullptr;
   const void* table_dev = nullptr;
   int rowlen = 0, g_log2 = 0, vec = 0, admit_blocks = 0, admit_threads = 1024;      // admit_blocks 0 = by job size
@@ -2074,6 +2075,7 @@ struct SwapEngine {
       long long n = mail[2].count;
       CE_TRACE("in job %lld: earlier write-backs landed; mail job %lld count %lld", job, mail[2].job, n);
       if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
+      if (fail_in_job > 0 && job == fail_in_job) fail("admission (injected: CE_WORKER_FAIL_IN_JOB)", hipErrorUnknown);
       if (n > 0 && !failed() && admit_by_kernel) {
         // small jobs (prefetch_num 1-2: the cache-op stream is the critical path and waits for every microsecond of
         // this) get 32 workgroups, window-sized jobs 16 (training is the critical path: see the table above).
@@ -2700,6 +2702,7 @@ static int ensure_writeback(ce_cache* h) {
       }
       w->relax = h->evt_keys[0] != nullptr;
       if (const char* e = getenv("CE_WORKER_OUT_DELAY_US")) w->out_delay_us = std::max(0, atoi(e));
+      if (const char* e = getenv("CE_WORKER_FAIL_IN_JOB")) w->fail_in_job = atoll(e);
       for (int b = 0; b < 2; ++b) {
         w->evt_keys[b] = h->evt_keys[b];
         w->evt_pos[b] = h->evt_pos[b];

@@ -325,3 +325,59 @@ def test_worker_transport_empty_and_ragged_calls(strategy):
     mgr.flush()
     ora.flush()
     np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
+
+
+@pytest.mark.parametrize("early", [False, True])
+@pytest.mark.parametrize("strict", [True, False])
+def test_a_failed_admission_releases_the_stream_and_admits_nothing(early, strict, monkeypatch):
+    """The admission worker reports a failed HIP call for job 3 (test hook CE_WORKER_FAIL_IN_JOB): the parked cache-op
+    stream must be released all the same (no hang), the call's record must say CE_ERR_HIP, every slot of the call is -1,
+    NONE of the rows it missed may be resident afterwards (their payload never arrived: a later flush would write garbage
+    home) -- in both orders of the second half (maps after / before the wait: the early order takes its entries back) --
+    and the engine stays failed: the next call raises instead of training on a table that has lost rows."""
+    ce = _ce()
+    from cachedembedding_amd import _lib
+    from oracle.cache_oracle import DATASET, OracleCachedParamMgr
+    monkeypatch.setenv("CE_WORKER_ADMIT", "kernel")
+    monkeypatch.setenv("CE_WORKER_FAIL_IN_JOB", "3")
+    monkeypatch.setenv("CE_EARLY_MAPS", "1" if early else "0")
+    rng = np.random.default_rng(17)
+    N, C, D = 6000, 500, 64
+    w = rng.standard_normal((N, D)).astype(np.float32)
+    ora = OracleCachedParamMgr(w.copy(), C, DATASET)
+    ora.reorder(None, 0.5)
+    mgr = ce.CachedParamMgr(torch.from_numpy(w.copy()), C)
+    mgr.reorder(None, 0.5)
+    mgr.set_transport("worker")
+    mgr.strict = strict
+    ids = [rng.integers(0, N, size=300) for _ in range(5)]
+    for c in range(2):
+        eslots = ora.prepare_ids(ids[c])
+        slots = mgr.prepare_ids(torch.from_numpy(ids[c]).cuda())
+        assert np.array_equal(slots.cpu().numpy(), eslots)
+    _state_equal(mgr, ora, False)
+    resident_before = ora.cached_idx_map.copy()
+    ora.prepare_ids(ids[2])                                       # what the call WOULD have done
+    missed, evicted = ora.traces[-1].miss_rows, ora.traces[-1].evicted_rows
+    assert len(missed) > 50 and len(evicted) > 50
+    if strict:
+        with pytest.raises(_lib.CeError) as ei:
+            mgr.prepare_ids(torch.from_numpy(ids[2]).cuda())
+        assert ei.value.code == _lib.CE_ERR_HIP
+    else:
+        slots = mgr.prepare_ids(torch.from_numpy(ids[2]).cuda())
+        torch.cuda.synchronize()                                  # returns: the stream was released
+        assert (slots.cpu().numpy() == -1).all()
+        with pytest.raises(_lib.CeError) as ei:
+            mgr.raise_on_failed_calls()
+        assert ei.value.code == _lib.CE_ERR_HIP
+    torch.cuda.synchronize()
+    inv = mgr.inverted_cached_idx.cpu().numpy()
+    cmap = mgr.cached_idx_map.cpu().numpy().astype(np.int64)
+    assert (inv[missed] == -1).all(), "a row whose payload never arrived is marked resident"
+    assert (inv[evicted] == -1).all()                             # the victims did leave
+    assert not np.isin(cmap[cmap >= 0], missed).any()
+    kept = np.setdiff1d(resident_before[resident_before >= 0], evicted)
+    assert np.array_equal(np.sort(cmap[cmap >= 0]), np.sort(kept)), "rows the call did not touch stay where they were"
+    with pytest.raises(_lib.CeError, match="injected"):           # the engine stays failed
+        mgr.prepare_ids(torch.from_numpy(ids[3]).cuda())
