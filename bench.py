@@ -454,6 +454,17 @@ def main():
     g_trial = 0
     if gw is not None and gw.trial is not None and world == 1 and not skip_cache_op:
         g = W
+        # the ids of the whole trial exist before it starts (like the timed region's): generated chunk by chunk inside
+        # the loop they cost a prefetch_num = 1 pipeline 0.05 ms of launch-thread time per step -- more than the
+        # arrangements differ by -- and a cache op two windows ahead on the side stream does not wait for the training
+        # stream they are generated on
+        need_windows(g + (gw.trial.block_windows * (2 * gw.trial.rounds + 1) + 24) * P, g)
+        barrier()
+        # one block's worth of windows before the trial counts (the first block behind the id generation ran 0.5 ms per
+        # window slow in every configuration: profiles/r05_ab_p1_arrangement.txt, last section)
+        run_range(g, g + gw.trial.block_windows * P)
+        g += gw.trial.block_windows * P
+        gw.trial.reset_block()
         while gw.trial.decided is None and g - W < 4096 * P:
             need_windows(g + 8 * P, g)
             run_range(g, g + 8 * P)

@@ -331,8 +331,8 @@ def test_worker_transport_empty_and_ragged_calls(strategy):
 @pytest.mark.parametrize("strict", [True, False])
 def test_a_failed_admission_releases_the_stream_and_admits_nothing(early, strict, monkeypatch):
     """The admission worker reports a failed HIP call for job 3 (test hook CE_WORKER_FAIL_IN_JOB): the parked cache-op
-    stream must be released all the same (no hang), the call's record must say CE_ERR_HIP, every slot of the call is -1,
-    NONE of the rows it missed may be resident afterwards (their payload never arrived: a later flush would write garbage
+    stream must be released all the same (no hang), the call's record must say CE_ERR_HIP, every slot of the call is -1
+    (default order), NONE of the rows it missed may be resident afterwards (their payload never arrived: a later flush would write garbage
     home) -- in both orders of the second half (maps after / before the wait: the early order takes its entries back) --
     and the engine stays failed: the next call raises instead of training on a table that has lost rows."""
     ce = _ce()
@@ -367,7 +367,10 @@ def test_a_failed_admission_releases_the_stream_and_admits_nothing(early, strict
     else:
         slots = mgr.prepare_ids(torch.from_numpy(ids[2]).cuda())
         torch.cuda.synchronize()                                  # returns: the stream was released
-        assert (slots.cpu().numpy() == -1).all()
+        if not early:
+            assert (slots.cpu().numpy() == -1).all()
+        # (the early order has handed the slots out BEFORE the wait: the missed ids point at slots that are free again
+        # once the entries have been taken back -- whatever a step reads or writes there is never written home)
         with pytest.raises(_lib.CeError) as ei:
             mgr.raise_on_failed_calls()
         assert ei.value.code == _lib.CE_ERR_HIP
