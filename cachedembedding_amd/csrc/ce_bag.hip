@@ -515,7 +515,12 @@ constexpr unsigned kExclFlag = 0x80000000u;
 // ROWS (the cache op's fused form, presort_window_from_rows): slots_io holds the table ROW of every lookup; its slot
 // is inverted[row] (one random 4-byte gather per lookup, all 16 of a thread in flight before anything else happens)
 // and is written back in place.
-template <bool SRC, bool EXCL, bool ROWS>
+// STAGED (round 5, every form but EXCL, which stages anyway): the keys go to their grouped positions in LDS first and
+// leave with 16 coalesced 512-byte stores per wave instead of 16 x 64 scattered 8-byte ones -- one workgroup is one
+// CU's store path, and 16384 single-line writes through it were most of the kernel's 43 us (it is latency-bound: 26-208
+// workgroups).  Same positions, bit-identical keys.  128 KB of LDS instead of 32 (a 1024-thread workgroup per CU
+// either way).  CE_PRESORT_STAGED=0: the direct scatter.
+template <bool SRC, bool EXCL, bool ROWS, bool STAGED = false>
 __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz_per_batch,
                                                          int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
                                                          unsigned long long* __restrict__ keys_out, BagParams lay,
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
                                                          int64_t* __restrict__ ids_minmax, int64_t* slots_io,
                                                          const int32_t* __restrict__ inverted,
                                                          const int* __restrict__ status) {
-  __shared__ unsigned long long lk[EXCL ? kSegLen : (kSegBuckets + 2) / 2];   // EXCL: the segment's keys by position
+  __shared__ unsigned long long lk[(EXCL || STAGED) ? kSegLen : (kSegBuckets + 2) / 2];   // EXCL / STAGED: the segment's keys by position
   int* const cnt = (int*)lk;                            // [kSegBuckets + 1] bucket counters ([kSegBuckets] = ignored)
   __shared__ int wsum[16];
   __shared__ long long mm_s[2][16];
@@ -619,6 +624,19 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     for (int q = 0; q < kPer; ++q) { cnt[tid * kPer + q] = pre; pre += c4[q]; }
     if (tid == 0) cnt[kSegBuckets] = total;
     __syncthreads();
+    if (!EXCL && STAGED) {
+      int pos[kSegKeys];
+#pragma unroll
+      for (int r = 0; r < kSegKeys; ++r) pos[r] = cnt[bkt[r]] + place[r];
+      __syncthreads();                   // the counters are dead: their LDS becomes the key buffer
+#pragma unroll
+      for (int r = 0; r < kSegKeys; ++r) lk[pos[r]] = key[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kSegKeys; ++r) keys_out[base + r * 1024 + tid] = lk[r * 1024 + tid];
+      __syncthreads();
+      continue;
+    }
     if (!EXCL) {
       if (CE_DBG(lay.debug) & 4) {       // ablation: coalesced stores (wrong places)
 #pragma unroll
@@ -1454,6 +1472,11 @@ extern "C" int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, in
 
 extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }
 
+static bool presort_staged() {
+  static const bool v = [] { const char* e = getenv("CE_PRESORT_STAGED"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
+
 static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
                                uint64_t* keys_out, const BagParams* lay, int64_t off_stride, const int64_t* ids,
                                int64_t* ids_minmax, ce_stream_t stream) {
@@ -1468,13 +1491,22 @@ static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, in
   int64_t* const no_io = nullptr;
   const int32_t* const no_inv = nullptr;
   const int* const no_st = nullptr;
+  const bool staged = presort_staged();
   if (lay && ids_minmax)
     hipLaunchKernelGGL((k_bag_presort_seg<true, true, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride, ids,
                        ids_minmax, no_io, no_inv, no_st);
+  else if (lay && staged)
+    hipLaunchKernelGGL((k_bag_presort_seg<true, false, false, true>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride,
+                       (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
   else if (lay)
     hipLaunchKernelGGL((k_bag_presort_seg<true, false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride,
+                       (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
+  else if (staged)
+    hipLaunchKernelGGL((k_bag_presort_seg<false, false, false, true>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
+                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{}, 0ll,
                        (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
   else
     hipLaunchKernelGGL((k_bag_presort_seg<false, false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
@@ -1507,9 +1539,18 @@ int presort_window_from_rows(int64_t* slots_io, int64_t nnz_per_batch, int64_t n
     int rc = fill_params(lay, 4, nullptr, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset, nullptr,
                          CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_bag_presort_seg<true, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
-                       nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
-                       offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
+    if (presort_staged())
+      hipLaunchKernelGGL((k_bag_presort_seg<true, false, true, true>), grid, block, 0, stream, (const int64_t*)nullptr,
+                         nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
+                         offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
+    else
+      hipLaunchKernelGGL((k_bag_presort_seg<true, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
+                         nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
+                         offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
+  } else if (presort_staged()) {
+    hipLaunchKernelGGL((k_bag_presort_seg<false, false, true, true>), grid, block, 0, stream, (const int64_t*)nullptr,
+                       nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{},
+                       0ll, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
   } else {
     hipLaunchKernelGGL((k_bag_presort_seg<false, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
                        nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{},
