@@ -1,11 +1,11 @@
 run() { timeout 600 python bench.py --no_cpu_baseline "$@" 2>gpurun_out/err.txt | tail -1 | python -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); c=d['cache']; v=d.get('verified') or {}; print('| \`%s\` | %.0f M | %.3f | %.0f | %.3f | %d / %d | %s |' % ('$*', d['value']/1e6, d['ms_per_step'], d['it_per_s'], c['unique_hit_rate'], c['rows_in'], c['rows_out'], ('%d rows, %d violations, max err/bound %.2f' % (v['rows'], v['bound_violations'] + v.get('untouched_mismatch', 0), v['max_err_over_bound'])) if v else 'not run'))
+    d=json.loads(sys.stdin.read()); c=d['cache']; v=d.get('verified') or {}; print('| \`%s\` | %.0f M | %.3f | %.0f | %.3f | %d / %d | %s | %s |' % ('$*', d['value']/1e6, d['ms_per_step'], d['it_per_s'], c['unique_hit_rate'], c['rows_in'], c['rows_out'], ('%d rows, %d violations, max err/bound %.2f' % (v['rows'], v['bound_violations'] + v.get('untouched_mismatch', 0), v['max_err_over_bound'])) if v else 'not run', (d['config'].get('arrangement') or {}).get('mode')))
 except Exception as e:
     print('  FAILED $*', e)" ; grep -E "Error|error" gpurun_out/err.txt | tail -2; }
-echo "| bench.py flags | lookups/s | ms/step | it/s | unique-row hit rate | rows in / out (timed+warmup) | end-of-run check (closed form of SGD) |"
-echo "|---|---|---|---|---|---|---|"
+echo "| bench.py flags | lookups/s | ms/step | it/s | unique-row hit rate | rows in / out (timed+warmup) | end-of-run check (closed form of SGD) | arrangement (the library's choice unless pinned) |"
+echo "|---|---|---|---|---|---|---|---|"
 run --workload criteo_kaggle --cache_ratio 0.05 --prefetch_num 1
 run --workload criteo_kaggle --cache_ratio 0.05 --prefetch_num 1 --use_lfu
 run --workload criteo_kaggle --cache_ratio 0.05 --prefetch_num 8
