@@ -7,9 +7,11 @@ from cachedembedding_amd import pipeline as pl
 
 class _FakeEvent:
     clock = [0.0]
+    made = [0]
 
     def __init__(self, enable_timing=True):
         self.at = None
+        _FakeEvent.made[0] += 1
 
     def record(self, stream=None):
         self.at = _FakeEvent.clock[0]
@@ -46,6 +48,19 @@ def test_trial_alternates_blocks_then_keeps_the_faster_arrangement(monkeypatch):
     assert tr.decided == "overlap" and set(modes[18:]) == {"overlap"} and tr.trials == 1
     rep = tr.report()
     assert rep["mode"] == "overlap" and rep["trial_ms_per_window"] == {"overlap": [1.1, 1.1], "interleaved": [1.3, 1.3]}
+
+
+def test_trial_records_two_events_per_block_not_one_per_window(monkeypatch):
+    """a mark per window cost a prefetch_num = 1 pipeline whose launch thread is the bottleneck 10 us of every step (and
+    the trial then measured its own marks): only the marks a block reads are recorded -- behind its `settle`-th window
+    and behind its last one"""
+    _FakeEvent.made[0] = 0
+    tr, modes = _run_trial(monkeypatch, {"interleaved": 1.0, "overlap": 1.2}, 700, block_windows=100, rounds=3, settle=4,
+                           retrial_every=0)
+    assert tr.decided == "interleaved" and tr.trials == 1
+    assert _FakeEvent.made[0] == 2 * 6                     # six blocks, two marks each -- not 600
+    ms = tr.history[0]["ms_per_window"]
+    assert ms == {"overlap": [1.2, 1.2, 1.2], "interleaved": [1.0, 1.0, 1.0]}
 
 
 def test_trial_with_three_rounds_decides_by_the_median_block(monkeypatch):
