@@ -132,6 +132,9 @@ SIGNATURES = {
     "ce_cache_prepare_ids_finish": (c_int, [c_void_p, c_void_p]),
     "ce_cache_prepare_ids_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ce_cache_prepare_ids_begin_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ce_cache_set_deferred_rows": (c_int, [c_void_p, c_int32]),
+    "ce_cache_rows_ticket": (c_int64, [c_void_p]),
+    "ce_cache_wait_rows": (c_int, [c_void_p, c_int64, c_void_p]),
     "ce_cache_last_stats": (c_int, [c_void_p, POINTER(CeCallStats)]),
     "ce_cache_totals": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
                                 POINTER(c_int64), POINTER(c_int64)]),

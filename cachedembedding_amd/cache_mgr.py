@@ -502,6 +502,25 @@ class CachedParamMgr(torch.nn.Module):
     def writeback_wait(self):
         check(lib.ce_cache_writeback_wait(self._handle))
 
+    def set_deferred_rows(self, on: bool = True):
+        """Worker transport (chained admission): prepare_ids no longer ends by making its stream wait for the missed rows
+        (they travel on a stream of the library's own); the caller orders the first reader of the cache behind them
+        with wait_rows() -- what a pipeline does that issues the next cache op on the same stream before anything trains
+        on this one's slots (ce_cache_set_deferred_rows)."""
+        check(lib.ce_cache_set_deferred_rows(self._handle, int(bool(on))))
+
+    def rows_ticket(self) -> int:
+        """ticket of the most recent cache op for wait_rows (0: none yet / another transport)"""
+        return int(lib.ce_cache_rows_ticket(self._handle))
+
+    def wait_rows(self, ticket: int = 0):
+        """the CURRENT stream waits until the rows of cache op `ticket` (0: the most recent) are in their slots"""
+        if torch.cuda.current_device() == self.device.index:
+            check(lib.ce_cache_wait_rows(self._handle, int(ticket), stream_ptr()))
+        else:
+            with torch.cuda.device(self.device):
+                check(lib.ce_cache_wait_rows(self._handle, int(ticket), stream_ptr()))
+
     def writeback_stats(self) -> dict:
         """Worker-transport accounting: rows / jobs / seconds of the write-back (out) and admission (in) workers."""
         sec = (ctypes.c_double * 6)()

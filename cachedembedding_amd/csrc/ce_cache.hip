@@ -95,11 +95,12 @@ struct WbMail {              // pinned host mailbox: how many rows a worker job 
 
 struct Layout {              // byte offsets inside the caller-provided workspace
   size_t ctl, bitmap, blk_unique, blk_miss, coarse, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      stage_idx, stage, stage_idx2, stage2, in_stage, total;
+      coop, miss_list2, free_list2, stage_idx, stage, stage_idx2, stage2, in_stage, total;
   int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
 
 constexpr int64_t kStageRowsMax = 262144;   // write-back staging: 128 MB at D = 128
+constexpr size_t kCoopBytes = 4096;         // struct Coop (ce_cache_fused.h; static_assert there)
 
 static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   Layout L{};
@@ -121,6 +122,11 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
   L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
   L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
+  // chained admission (worker transport): the fused kernels' scratch, and a second miss / free list -- the admission
+  // and unpack kernels of call w read theirs on the admission stream while call w + 1's front fills the other pair
+  L.coop = o;       o = al(o + kCoopBytes);
+  L.miss_list2 = o; o = al(o + (size_t)L.list_cap * 4);
+  L.free_list2 = o; o = al(o + (size_t)L.list_cap * 4);
   L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
   L.stage_idx = o;  o = al(o + (size_t)L.stage_rows * 4);
   L.stage = o;      o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
@@ -264,27 +270,24 @@ __device__ __forceinline__ uint32_t miss_mask_stamp(const int32_t* __restrict__ 
 // and one lane issues the atomicOr for all of them.
 // (Round 3 tried to count the unique / missing rows here as well -- the thread whose atomicOr sets a bit first owns
 // the row -- so that the bitmap would be scanned once instead of twice: the returning atomics that needs cost 40 us,
-// more than the k_count pass they replaced; ablations in profiles/r03_mark_ablations.txt.)
+// more than the k_count pass they replaced; round 5 folded the repeats of every 8192-id chunk in an LDS hash table
+// first: 7x slower, the same-word atomics of the hot rows that the LDS window below absorbs.  docs/history.md.)
 // U ids per thread are in flight (a chain of three dependent random accesses per id).
 // rows_out: the row of every id (-1 = bad id), as int64 in the caller's slots buffer -- k_slots turns it into the
 // slot in place, so idx_map is gathered once per id per call.
-#ifdef CE_ABLATIONS
-#define CE_MDBG(x) (dbg & (x))
-#else
-#define CE_MDBG(x) (0 && (x))
-#endif
+// The body of k_mark and of k_front's first phase: a grid-stride pass of the calling grid over the ids.  *cold += this
+// thread's lookups of rows that are not resident; *bad = it met an id outside [0, N) that is not accepted padding.
 template <bool MERGE, int U>
-__global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
-                                              const int32_t* __restrict__ idx_map,
-                                              const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out, int dbg,
-                                              int allow_pad) {
-  extern __shared__ uint32_t hot[];
+__device__ __forceinline__ void mark_pass(const int64_t* __restrict__ ids, int64_t n,
+                                          const int32_t* __restrict__ idx_map, const int32_t* __restrict__ inverted,
+                                          int64_t N, int word_bits, int hot_words, uint32_t* hot, uint32_t* bitmap,
+                                          int64_t* rows_out, int allow_pad, int* cold_out, bool* bad_out) {
   for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
   int cold = 0;
+  bool bad = false;
   // wave-uniform trip count: a wave owns U * 64 consecutive ids per iteration
   for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * U; i0 < n; i0 += stride) {
     int32_t row[U], inv[U];
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
         if ((unsigned long long)id >= (unsigned long long)N) {
           // ce_cache_prepare_ids_padded only: -1 = padding (fixed-capacity exchange), no lookup, slot -1.  On the
           // plain entry point a -1 is a bad id like any other (upstream's idx_map.index_select raises on it).
-          if (!(allow_pad && id == -1)) ctl->status = CE_ERR_RANGE;
+          if (!(allow_pad && id == -1)) bad = true;
           valid[u] = false;
           rows_out[i] = -1;
         } else {
@@ -314,8 +317,8 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
       inv[u] = 0;
       cur[u] = ~0u;
       if (valid[u]) {
-        if (!CE_MDBG(4)) rows_out[i] = row[u];
-        if (!CE_MDBG(2)) inv[u] = inverted[row[u]];
+        rows_out[i] = row[u];
+        inv[u] = inverted[row[u]];
         const int word = row[u] >> 5;
         // (looking at hot[word] first and skipping the LDS atomic when the bit is set -- what the cold path does with
         // the global bitmap -- measured in round 4: 67.2 against 65.1 us, no gain.  Also round 4: a RESIDENCY BITMAP
@@ -323,8 +326,8 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
         // kernel, k_count and k_emit: k_count 13.6 -> 7.8 us, but k_mark 65 -> 69, k_emit 31 -> 37 and the slots +
         // keys kernel 32 -> 38 -- every lookup needs inverted[row] once anyway (its slot), and this kernel's gather is
         // what has it in L2 when the later kernels ask; 328 GPU tests green, no net gain, not kept.)
-        if (word < hot_words) { if (!CE_MDBG(1)) atomicOr(&hot[word], 1u << (row[u] & 31)); }
-        else if (!CE_MDBG(8)) cur[u] = *(volatile uint32_t*)(bitmap + word);
+        if (word < hot_words) atomicOr(&hot[word], 1u << (row[u] & 31));
+        else cur[u] = *(volatile uint32_t*)(bitmap + word);
       }
     }
 #pragma unroll
@@ -352,125 +355,28 @@ __global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, 
       }
     }
   }
-  cold = wave_sum(cold);
-  if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
   __syncthreads();
   for (int w = threadIdx.x; w < hot_words; w += blockDim.x) {
     const uint32_t v = hot[w];
     if (v && ((*(volatile uint32_t*)(bitmap + w)) & v) != v) atomicOr(bitmap + w, v);
   }
+  *cold_out += cold;
+  *bad_out = *bad_out || bad;
 }
 
-// k_mark with the repeats of a chunk of ids folded in LDS first (round 5).  A Criteo window is 3.4 M ids of which
-// ~90 % repeat inside their own batch (whole features draw from tables of 3 ... 100 rows; the large tables' heads), and
-// k_mark above pays three random accesses per ID: idx_map, inverted, the bitmap word -- 10 M of them, which is what its
-// 66 us are (the memory system's random-access rate: profiles/r03_mark_ablations.txt).  Here a workgroup takes chunks
-// of kMarkChunk consecutive ids, enters them into an open-addressing table in LDS (key = id, looked at before the
-// compare-and-swap, so the lanes that hold a hot id read one broadcast word instead of serialising on an atomic) and
-// only the lane that ENTERED an id does the global work for it -- one idx_map gather, one inverted gather (the miss
-// statistic, and what has the entry in L2 when k_count / k_emit / the slot kernel ask), one look at the bitmap word and
-// the atomic if the bit is clear -- and leaves the row (bit 31: not resident) beside the key.  After a barrier every id
-// of the chunk reads its row out of the table.  ~0.4 M distinct (chunk, id) pairs per window instead of 3.4 M ids; no
-// LDS window for the hot bitmap words and no ballot merge are needed: a hot row costs one access per chunk.
-// CHUNK ids per workgroup pass, THREADS threads, table of 2 * CHUNK entries (load factor <= 0.5 whatever the ids):
-// 8192 / 1024 -> 128 KB of LDS (one workgroup per CU), 4096 / 512 -> 64 KB, 2048 / 256 -> 32 KB.
-template <int CHUNK, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_mark_dedupe(const int64_t* __restrict__ ids, int64_t n,
-                                                        const int32_t* __restrict__ idx_map,
-                                                        const int32_t* __restrict__ inverted, int64_t N, uint32_t* bitmap,
-                                                        Ctl* ctl, int64_t* rows_out, int allow_pad, int dbg) {
-  constexpr int U = CHUNK / THREADS;
-  constexpr int TAB = 2 * CHUNK;
-  constexpr int TAB_LOG2 = CHUNK == 8192 ? 14 : (CHUNK == 4096 ? 13 : 12);
-  static_assert(CHUNK == 8192 || CHUNK == 4096 || CHUNK == 2048, "table size");
-  __shared__ uint32_t tkey[TAB];           // id + 1 (0 = free)
-  __shared__ uint32_t tval[TAB];           // row | (not resident) << 31
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t nchunks = (n + CHUNK - 1) / CHUNK;
+template <bool MERGE, int U>
+__global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
+                                              const int32_t* __restrict__ idx_map,
+                                              const int32_t* __restrict__ inverted, int64_t N, int word_bits,
+                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out,
+                                              int allow_pad) {
+  extern __shared__ uint32_t hot[];
   int cold = 0;
-  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    for (int e = tid; e < TAB; e += THREADS) tkey[e] = 0;
-    __syncthreads();
-    const int64_t base = chunk * CHUNK;
-    uint32_t key[U];
-    int hh[U];
-    bool own[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = base + u * THREADS + tid;
-      key[u] = 0;
-      own[u] = false;
-      hh[u] = 0;
-      if (i < n) {
-        const int64_t id = ids[i];
-        if ((unsigned long long)id >= (unsigned long long)N) {
-          if (!(allow_pad && id == -1)) ctl->status = CE_ERR_RANGE;     // (see k_mark)
-          rows_out[i] = -1;
-        } else {
-          key[u] = (uint32_t)id + 1u;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!key[u]) continue;
-      if (CE_MDBG(8)) { own[u] = true; continue; }               // ablation: no table, every id does its own global work
-      uint32_t h = (key[u] * 2654435761u) >> (32 - TAB_LOG2);
-      for (;;) {
-        // (an LDS read proper -- ds_read_b32; a volatile access through a plain pointer compiles to a FLAT load here)
-        uint32_t cur = __hip_atomic_load(&tkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (cur == 0) cur = atomicCAS(&tkey[h], 0u, key[u]);
-        if (cur == 0) { own[u] = true; break; }
-        if (cur == key[u]) break;
-        h = (h + 1) & (TAB - 1);
-      }
-      hh[u] = (int)h;
-    }
-    // ---- the lanes that entered an id: the global accesses, all U in flight per step
-    int32_t row[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      row[u] = 0;
-      if (own[u]) row[u] = (idx_map && !CE_MDBG(1)) ? idx_map[key[u] - 1u] : (int32_t)(key[u] - 1u);
-    }
-    int32_t inv[U];
-    uint32_t cur[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      inv[u] = 0;
-      cur[u] = ~0u;
-      if (own[u]) {
-        if (!CE_MDBG(2)) inv[u] = inverted[row[u]];
-        if (!CE_MDBG(4)) cur[u] = __hip_atomic_load(bitmap + (row[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (own[u]) {
-        const uint32_t bit = 1u << (row[u] & 31);
-        if (!(cur[u] & bit)) atomicOr(bitmap + (row[u] >> 5), bit);
-        if (CE_MDBG(8)) {
-          rows_out[base + u * THREADS + tid] = (int64_t)row[u];
-          cold += inv[u] < 0;
-        } else {
-          tval[hh[u]] = (uint32_t)row[u] | (inv[u] < 0 ? 0x80000000u : 0u);
-        }
-      }
-    }
-    __syncthreads();
-    if (!CE_MDBG(8)) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!key[u]) continue;
-        const uint32_t v = tval[hh[u]];
-        rows_out[base + u * THREADS + tid] = (int64_t)(v & 0x7fffffffu);
-        cold += (int)(v >> 31);
-      }
-    }
-    __syncthreads();
-  }
+  bool bad = false;
+  mark_pass<MERGE, U>(ids, n, idx_map, inverted, N, word_bits, hot_words, hot, bitmap, rows_out, allow_pad, &cold, &bad);
+  if (bad) ctl->status = CE_ERR_RANGE;
   cold = wave_sum(cold);
-  if (lane == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
+  if ((threadIdx.x & 63) == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
 }
 
 // unique / missing rows per 32768-row chunk of the bitmap (one uint4 = 128 rows per thread), and their sums per 64
@@ -725,19 +631,14 @@ struct SelState {
   int fail;      // fewer evictable slots than k: capacity overflow of the overlapped pipeline
 };
 // Resolves ONE level: the digit of the k-th smallest key at level q from that level's histogram, given the digits
-// and the remaining rank of the levels above (from the control block: left there by the kernel before; the top level
-// starts from k itself).  One wave, 32 bins per lane: a wave scan, the first lane whose running count reaches the
-// rank, then that lane's bins handed round with shuffles.  Every workgroup of a kernel does this in its prologue
-// (8 KB out of L2) and workgroup 0 records the result for the next kernel: no pick kernel between two passes, no
-// dependency between workgroups, one histogram read per kernel.
-__device__ __forceinline__ SelState select_level(const uint32_t* __restrict__ hist, int q, int top_pass, Ctl* ctl,
-                                                 int lane, bool record) {
+// and the remaining rank of the levels above.  One wave, 32 bins per lane: a wave scan, the first lane whose running
+// count reaches the rank, then that lane's bins handed round with shuffles.
+__device__ __forceinline__ SelState select_digit(const uint32_t* hist, int q, unsigned long long prefix_in,
+                                                 int krem_in, int lane) {
   SelState st;
-  st.prefix = q == top_pass ? 0ull : ctl->sel_prefix_after[q + 1];
-  st.krem = q == top_pass ? (int)ctl->sel_krem : (int)ctl->sel_krem_after[q + 1];
-  // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the capacity overflow of
-  // the overlapped pipeline (unique(window k u k+1) > cuda_row_num); evictable slots are counted by k_keys
-  st.fail = ctl->n_eligible < ctl->sel_krem;
+  st.prefix = prefix_in;
+  st.krem = krem_in;
+  st.fail = 0;
   uint4 h[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) h[j] = ((const uint4*)(hist + q * kBins))[lane * 8 + j];
@@ -767,6 +668,21 @@ __device__ __forceinline__ SelState select_level(const uint32_t* __restrict__ hi
   if (!found) before = cum - __shfl((int)h[7].w, L);      // (only on the failure path: k beyond the candidates)
   st.prefix |= ((unsigned long long)(32 * L + dd)) << (q * kDigitBits);
   st.krem = r - before;
+  return st;
+}
+
+// The per-launch form: every workgroup of a kernel resolves the level above its own in its prologue (8 KB out of L2),
+// from the state workgroup 0 of the kernel before left in the control block (the top level starts from k itself), and
+// workgroup 0 records the result for the next kernel: no pick kernel between two passes, no dependency between
+// workgroups, one histogram read per kernel.
+__device__ __forceinline__ SelState select_level(const uint32_t* __restrict__ hist, int q, int top_pass, Ctl* ctl,
+                                                 int lane, bool record) {
+  const unsigned long long prefix_in = q == top_pass ? 0ull : ctl->sel_prefix_after[q + 1];
+  const int krem_in = q == top_pass ? (int)ctl->sel_krem : (int)ctl->sel_krem_after[q + 1];
+  SelState st = select_digit(hist, q, prefix_in, krem_in, lane);
+  // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the capacity overflow of
+  // the overlapped pipeline (unique(window k u k+1) > cuda_row_num); evictable slots are counted by k_keys
+  st.fail = ctl->n_eligible < ctl->sel_krem;
   if (record && lane == 0) {
     ctl->sel_prefix_after[q] = st.prefix;
     ctl->sel_krem_after[q] = st.krem;
@@ -1306,14 +1222,17 @@ __global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows
                     (int)gridDim.x, first);
 }
 
-// Admission kernel of the worker transport when the previous call's write-back has not landed yet: row i comes out
-// of that job's staging buffer if the job evicted it (EvTable above), out of the host table otherwise.
+// Admission kernel of the worker transport: the missed rows of a call, host table -> in_stage, on the admission stream.
+// The previous call's write-back need not have landed: row i comes out of THAT job's staging buffer if the job
+// evicted it (EvTable above; evt_keys == NULL: there is no such job), out of the host table otherwise.  n_ptr: the
+// count the call's plan left on the device (the launch thread never learns it).
 template <typename VT, int R = kSwapRows>
-__global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict__ rows, long long n,
+__global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict__ rows, const long long* n_ptr,
                                                      const VT* __restrict__ host, VT* dst, int rowlen, int g_log2,
                                                      const unsigned long long* __restrict__ evt_keys,
                                                      const int32_t* __restrict__ evt_pos, uint32_t evt_mask,
                                                      uint32_t tag, const VT* __restrict__ prev_stage) {
+  const long long n = *n_ptr;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
@@ -1324,7 +1243,7 @@ __global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict_
       for (int t = 0; t < R; ++t) {
         if (i + t < n) {
           const int32_t row = rows[i + t];
-          const int32_t p = evt_find(evt_keys, evt_pos, evt_mask, tag, row);
+          const int32_t p = evt_keys ? evt_find(evt_keys, evt_pos, evt_mask, tag, row) : -1;
           const VT* src = p >= 0 ? prev_stage + (int64_t)p * rowlen : host + (int64_t)row * rowlen;
           if (gl < rowlen) v[t] = src[gl];
         }
@@ -1335,7 +1254,7 @@ __global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict_
     } else {
       for (int t = 0; t < R && i + t < n; ++t) {
         const int32_t row = rows[i + t];
-        const int32_t p = evt_find(evt_keys, evt_pos, evt_mask, tag, row);
+        const int32_t p = evt_keys ? evt_find(evt_keys, evt_pos, evt_mask, tag, row) : -1;
         copy_row(p >= 0 ? prev_stage + (int64_t)p * rowlen : host + (int64_t)row * rowlen, dst + (i + t) * rowlen,
                  rowlen, gl, G);
       }
@@ -1343,41 +1262,17 @@ __global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict_
   }
 }
 
-// worker transport: rows [0, min(n_miss, cap)) arrived contiguously in `in_stage`; move them to their slots.
-// maps_done != 0 (the early-maps order, see prepare_ids_impl): k_admit_maps and the slot / key kernel have run BEFORE
-// the stream was parked, so this is the call's last kernel: it publishes the call's record, and when the admission
-// worker reports the job lost it takes the rows' map entries back (nothing that never arrived may stay resident --
-// a later flush would write it to the host table).
+// worker transport, host-gather admission: rows [0, min(n_miss, cap)) arrived contiguously in `in_stage`; move them to
+// their slots.  (The chained admission's form is k_unpack_chained, ce_cache_fused.h.)
 template <typename VT>
 __global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restrict__ slots, const long long* n_ptr,
                                                          long long cap, const VT* __restrict__ in_stage, VT* cache,
                                                          int rowlen, int g_log2, Ctl* ctl,
                                                          const unsigned long long* fail_word, long long job,
-                                                         int maps_done, const int32_t* __restrict__ rows,
-                                                         int32_t* cached_idx_map, int32_t* inverted,
-                                                         ce_call_stats_t* ring, long long seq_arg,
+                                                         const int32_t* __restrict__ rows,
                                                          const VT* __restrict__ host_overflow) {
   const bool ok = ctl->status == CE_OK;         // (nothing in this kernel writes ctl->status)
-  bool lost = false;
-  if (maps_done) {
-    // every workgroup asks the pinned word itself (one PCIe read each, all in flight together)
-    __shared__ int lost_s;
-    if (threadIdx.x == 0) lost_s = *(volatile const unsigned long long*)fail_word == (unsigned long long)job;
-    __syncthreads();
-    lost = lost_s != 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const long long seq = call_seq(ctl, seq_arg);
-      ce_call_stats_t* const ring_slot = ring + (seq % kRing);
-      if (lost && ok) {
-        // the victims are gone (written back) but their slots stay free: undo the plan's share of the free count
-        ctl->n_free = ctl->n_free + ctl->n_miss;
-        ring_slot->status = CE_ERR_HIP;
-        ring_slot->n_free_after = ctl->n_free;
-      }
-      __threadfence_system();
-      *(volatile long long*)&ring_slot->seq = seq;
-    }
-  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     // The admission worker flags a job whose rows did not arrive (a HIP call of its own failed or timed out) in a
     // word of pinned host memory.  ONE thread fetches it over PCIe and leaves the verdict in the control block for
     // k_admit_maps, which then marks nothing resident; whatever this kernel copies into the (free) slots meanwhile
@@ -1386,21 +1281,12 @@ __global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restri
   }
   if (!ok) return;
   long long n = *n_ptr;
-  if (lost) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-      cached_idx_map[slots[i]] = -1;
-      inverted[rows[i]] = -1;
-    }
-    return;
-  }
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
   if (host_overflow && n > cap) {
     // more misses than the staging holds (rare): the rest is read zero-copy out of the host table -- here, behind the
-    // parked wait (the worker keeps the stream parked until the previous write-back has landed for such a call), in
-    // this grid instead of a launch of its own
+    // parked wait (the host gather has waited for every earlier write-back), in this grid instead of a launch of its own
     for (int64_t i = cap + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2); i < n; i += gstride)
       copy_row(host_overflow + (int64_t)rows[i] * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
   }
@@ -1448,18 +1334,19 @@ __global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ 
                                                     int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
                                                     int32_t epoch_imm, Ctl* ctl, ce_call_stats_t* ring,
                                                     long long seq_arg, const unsigned long long* fail_word,
-                                                    long long job, int defer_record = 0) {
-  // ring == NULL (preload): no record to publish, the epoch is the caller's constant.  defer_record (the early-maps
-  // order of the worker transport): this runs BEFORE the rows arrive -- k_unpack_admitted publishes the record and
-  // takes the entries back if they never do
+                                                    long long job, long long* n_unpack_out = nullptr) {
+  // ring == NULL (preload): no record to publish, the epoch is the caller's constant
   const long long seq = ring ? call_seq(ctl, seq_arg) : 0;
   const int32_t epoch = ring ? call_epoch(seq) : epoch_imm;
   ce_call_stats_t* const ring_slot = ring ? ring + (seq % kRing) : nullptr;
-  // worker transport: the admission worker reports a job it could not complete (failed / timed-out HIP call): the
-  // rows never arrived, so nothing may be marked resident.
-  const bool lost = !defer_record && fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
+  // host-gather admission: the worker reports a job it could not complete (failed / timed-out HIP call): the rows
+  // never arrived, so nothing may be marked resident.
+  const bool lost = fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
   // last kernel of prepare_ids that can change the call's record: publish it (a slot whose seq matches is complete)
-  if (ring_slot && !defer_record && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (ring_slot && blockIdx.x == 0 && threadIdx.x == 0) {
+    // chained admission: the rows the unpack kernel moves for this call (it runs on the admission stream, possibly
+    // while the next call's front rewrites the control block)
+    if (n_unpack_out) *n_unpack_out = (ctl->status == CE_OK && n_ptr) ? *n_ptr : 0;
     if (lost && ctl->status == CE_OK) {
       // the victims are gone (written back) but their slots stay free: undo the plan's share of the free count
       ctl->n_free = ctl->n_free + ctl->n_miss;
@@ -1668,6 +1555,8 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const int32_t* __restrict__
 
 }  // namespace ce
 
+#include "ce_cache_fused.h"
+
 // ----------------------------------------------------------------------------- handle
 
 namespace ce {
@@ -1768,20 +1657,25 @@ static const char* const kPhaseNames[kPhases] = {"unique_and_miss", "find_evict_
 struct PhaseProf {
   hipEvent_t ev[kProfDepth][kPhases + 1];
   bool pending[kProfDepth];
-  bool early[kProfDepth];            // the call ran slots + keys BEFORE the admission wait (phases 4 and 5 swapped)
   // a call in two halves whose selection / staging part was deferred to the second half: the second phase starts at
-  // `resume` (recorded when the second half begins), not at the mark behind k_emit -- the training steps between the
-  // two halves are no phase of the cache op
+  // `resume` (recorded when the second half begins), not at the mark behind the front -- the training steps between
+  // the two halves are no phase of the cache op
   hipEvent_t resume[kProfDepth];
   bool resumed[kProfDepth];
+  // chained admission: the rows move on the admission stream -- "admit_swap" is the span from the start of the
+  // admission kernel to the end of the unpack kernel THERE (it overlaps with the phases around it on the call's stream)
+  hipEvent_t adm0[kProfDepth], adm1[kProfDepth];
+  bool chained[kProfDepth];
   double ms[kPhases];
   long long calls;
   PhaseProf() : calls(0) {
     for (int i = 0; i < kProfDepth; ++i) {
       pending[i] = false;
-      early[i] = false;
       resumed[i] = false;
+      chained[i] = false;
       (void)hipEventCreate(&resume[i]);
+      (void)hipEventCreate(&adm0[i]);
+      (void)hipEventCreate(&adm1[i]);
       for (int j = 0; j <= kPhases; ++j) (void)hipEventCreate(&ev[i][j]);
     }
     for (int j = 0; j < kPhases; ++j) ms[j] = 0;
@@ -1789,21 +1683,27 @@ struct PhaseProf {
   ~PhaseProf() {
     for (int i = 0; i < kProfDepth; ++i) {
       (void)hipEventDestroy(resume[i]);
+      (void)hipEventDestroy(adm0[i]);
+      (void)hipEventDestroy(adm1[i]);
       for (int j = 0; j <= kPhases; ++j) (void)hipEventDestroy(ev[i][j]);
     }
   }
   void collect(int i) {              // blocks until call slot i has finished
     if (!pending[i]) return;
-    if (hipEventSynchronize(ev[i][kPhases]) == hipSuccess) {
+    if (hipEventSynchronize(ev[i][kPhases]) == hipSuccess &&
+        (!chained[i] || hipEventSynchronize(adm1[i]) == hipSuccess)) {
       for (int j = 0; j < kPhases; ++j) {
         float t = 0;
-        if (hipEventElapsedTime(&t, (j == 1 && resumed[i]) ? resume[i] : ev[i][j], ev[i][j + 1]) == hipSuccess)
-          ms[(early[i] && j >= kPhases - 2) ? (2 * kPhases - 3 - j) : j] += t;
+        hipError_t e;
+        if (chained[i] && j == 4) e = hipEventElapsedTime(&t, adm0[i], adm1[i]);
+        else e = hipEventElapsedTime(&t, (j == 1 && resumed[i]) ? resume[i] : ev[i][j], ev[i][j + 1]);
+        if (e == hipSuccess) ms[j] += t;
       }
       calls += 1;
     }
     pending[i] = false;
     resumed[i] = false;
+    chained[i] = false;
   }
 };
 
@@ -1902,26 +1802,35 @@ struct SwapEngine {
   hipStream_t in_stream = nullptr;
   hipEvent_t in_ev[2] = {nullptr, nullptr};        // miss list of the job complete (by job parity)
   float* in_stage_dev = nullptr;
-  float* in_host = nullptr;                        // pinned gather buffer
-  // admission by kernel (admit_by_kernel): a small grid on in_stream reads the missed rows out of the pinned table
-  // over PCIe into in_stage -- no host gather, no staging copy.  The worker thread still orders it (miss list ready,
-  // earlier write-backs landed) and releases the parked cache-op stream from the host when the kernel has finished.
-  // 16 workgroups x 1024 threads: 28 MB in ~0.6 ms; wider grids finish sooner but slow the training kernels
-  // (round 2: 8: 0.92 ms admission wait, 2.08 G lookups/s; 16: 0.50 ms, 2.63 G; 32: 0.33 ms, 2.46 G; 64: 0.15 ms, 2.18 G.
-  // round 3, with the shorter cache-op chain: 16: 0.61 ms, 2.70 G; 20: 0.55 ms, 2.72 G; 24: 0.53 ms, 2.67 G; 32: 2.5-2.66 G)
-  bool admit_by_kernel = false;
-  // relaxed ordering of the kernel admission: the previous call's write-back need not have LANDED, its rows are
-  // taken from its staging buffer (EvTable); only the one before must be in the table
-  bool relax = false;
+  float* in_host = nullptr;                        // pinned gather buffer (host-gather admission only)
+  // CHAINED admission (round 6; the default: the table has a device mapping): the launch thread itself enqueues, on
+  // in_stream, the admission kernel behind the front's event and the unpack kernel behind the selection's event.  No
+  // library thread takes part and the cache-op stream never parks: what used to be "front -> [event wake-up of a
+  // worker thread, its kernel launch, its polling of the stream, its store to a pinned word the parked stream polls]
+  // -> unpack" is two stream-to-stream event edges.  Ordering: the admission of call w reads the host table for rows
+  // that no write-back in flight carries -- the launch thread has waited for write-back w - 2 before it enqueues
+  // call w (its staging buffer is about to be reused anyway), and rows of write-back w - 1 come out of that job's
+  // staging buffer (EvTable), intact until call w + 1's selection, which waits for call w's rows (ev_rows).
+  // The HOST-GATHER admission (CE_WORKER_ADMIT=sdma, or a table without device mapping) keeps the worker thread
+  // below: helper threads gather the rows into pinned staging, SDMA copies bring them in, the cache-op stream parks in
+  // hipStreamWaitValue64 until the thread releases it.
+  bool chained = false;
+  hipEvent_t ev_miss[2] = {nullptr, nullptr};      // front of the call of either parity complete (cache-op stream)
+  static constexpr int kRowsRing = 4;
+  hipEvent_t ev_rows[kRowsRing] = {nullptr};       // rows of call c in their slots (in_stream), c % kRowsRing
+  long long chain_calls = 0;                       // chained calls issued (1-based ticket of the latest)
+  // write-back jobs below this number are never looked up in their staging buffer: calls of ANOTHER transport ran
+  // since (ce_cache_set_transport), which may have re-admitted and evicted the same rows past that buffer -- the host
+  // table, where every one of those jobs has landed by then, is the up-to-date copy
+  long long probe_floor = 1;
+  bool deferred_rows = false;                      // prepare_ids does not make its stream wait for the rows
   const unsigned long long* evt_keys[2] = {nullptr, nullptr};
   const int32_t* evt_pos[2] = {nullptr, nullptr};
   uint32_t evt_mask = 0;
-  long long in_probed = 0;         // admissions that ran while the previous write-back was still on its way
+  long long in_probed = 0;         // admissions enqueued while the previous write-back was still on its way
   int out_delay_us = 0;            // test hook (CE_WORKER_OUT_DELAY_US): every write-back job starts this much late
-  long long fail_in_job = 0;       // test hook (CE_WORKER_FAIL_IN_JOB): this admission job reports a failed HIP call
-  const int32_t* miss_list_dev = nullptr;
-  const void* table_dev = nullptr;
-  int rowlen = 0, g_log2 = 0, vec = 0, admit_blocks = 0, admit_threads = 1024;      // admit_blocks 0 = by job size
+  long long fail_in_job = 0;       // test hook (CE_WORKER_FAIL_IN_JOB): this host-gather admission job reports a failed HIP call
+  int rowlen = 0, g_log2 = 0, vec = 0;
   int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
   int32_t* miss_host_dev = nullptr;
   unsigned long long* sig = nullptr;               // pinned + mapped: [0] the value the cache-op stream waits for,
@@ -2062,64 +1971,17 @@ struct SwapEngine {
       hipError_t e = hipEventSynchronize(in_ev[job & 1]);
       if (e != hipSuccess) fail("hipEventSynchronize(in)", e);
       CE_TRACE("in job %lld: event done (%s)", job, hipGetErrorString(e));
-      bool probe = false;
       {
-        // rows the earlier calls evicted must be in the table before it is read -- except, with the kernel admission,
-        // those of the call just before: they are still in that job's staging buffer and are taken from there
-        const long long must = (admit_by_kernel && relax) ? need_out - 1 : need_out;
+        // rows the earlier calls evicted must be in the table before the host threads read it
         std::unique_lock<std::mutex> g(m);
-        cv_done.wait(g, [&] { return out_done >= must || err != 0; });
-        probe = admit_by_kernel && relax && out_done < need_out;
+        cv_done.wait(g, [&] { return out_done >= need_out || err != 0; });
       }
       const auto t1 = std::chrono::steady_clock::now();
       long long n = mail[2].count;
       CE_TRACE("in job %lld: earlier write-backs landed; mail job %lld count %lld", job, mail[2].job, n);
       if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
       if (fail_in_job > 0 && job == fail_in_job) fail("admission (injected: CE_WORKER_FAIL_IN_JOB)", hipErrorUnknown);
-      if (n > 0 && !failed() && admit_by_kernel) {
-        // small jobs (prefetch_num 1-2: the cache-op stream is the critical path and waits for every microsecond of
-        // this) get 32 workgroups, window-sized jobs 16 (training is the critical path: see the table above).
-        // Kaggle 5 % P = 1 (25 k rows): 0.93 -> 1.02 G lookups/s; P = 2: 1.38 -> 1.44 G
-        const int blocks = admit_blocks > 0 ? admit_blocks : (n <= 49152 ? 32 : 20);
-        const int pb = (int)(need_out & 1);
-        // rows in flight per lane group (CE_ADMIT_ROWS; 16 unless set): the grid's rows in flight are what occupies the
-        // L2's miss queues for a PCIe round trip each -- see DESIGN.md section 4 (round 5) for the sweep
-        static const int admit_rows_env = [] { const char* e = getenv("CE_ADMIT_ROWS"); return e ? atoi(e) : 0; }();
-#define CE_ADMIT_R(RR)                                                                                                   \
-  do {                                                                                                                   \
-    if (probe)                                                                                                           \
-      hipLaunchKernelGGL((k_admit_probe<f32x4, RR>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,  \
-                         (const f32x4*)table_dev, (f32x4*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],       \
-                         evt_mask, (uint32_t)need_out, (const f32x4*)stage_dev[pb]);                                     \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((k_admit<f32x4, RR>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,           \
-                         (const int32_t*)nullptr, (const long long*)nullptr, n, (const f32x4*)table_dev,                 \
-                         (f32x4*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);                                \
-  } while (0)
-        if (vec && admit_rows_env == 2) CE_ADMIT_R(2);
-        else if (vec && admit_rows_env == 4) CE_ADMIT_R(4);
-        else if (vec && admit_rows_env == 8) CE_ADMIT_R(8);
-        else if (vec && admit_rows_env == 32) CE_ADMIT_R(32);
-        else if (probe && vec)
-          hipLaunchKernelGGL((k_admit_probe<f32x4>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,
-                             (const f32x4*)table_dev, (f32x4*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],
-                             evt_mask, (uint32_t)need_out, (const f32x4*)stage_dev[pb]);
-        else if (probe)
-          hipLaunchKernelGGL((k_admit_probe<float>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev, n,
-                             (const float*)table_dev, (float*)in_stage_dev, rowlen, g_log2, evt_keys[pb], evt_pos[pb],
-                             evt_mask, (uint32_t)need_out, (const float*)stage_dev[pb]);
-        else if (vec)
-          hipLaunchKernelGGL((k_admit<f32x4>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
-                             (const int32_t*)nullptr, (const long long*)nullptr, n, (const f32x4*)table_dev,
-                             (f32x4*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);
-        else
-          hipLaunchKernelGGL((k_admit<float>), dim3(blocks), dim3(admit_threads), 0, in_stream, miss_list_dev,
-                             (const int32_t*)nullptr, (const long long*)nullptr, n, (const float*)table_dev,
-                             (float*)in_stage_dev, rowlen, g_log2, (const Ctl*)nullptr, 0ll);
-#undef CE_ADMIT_R
-        e = hipGetLastError();
-        if (e != hipSuccess) fail("admission kernel launch", e);
-      } else if (n > 0 && !failed()) {
+      if (n > 0 && !failed()) {
         const float* tb = table;
         float* st = in_host;
         float* dv = in_stage_dev;
@@ -2183,16 +2045,6 @@ struct SwapEngine {
       CE_TRACE("in job %lld: rows gathered, copies enqueued", job);
       e = stream_wait_polite(in_stream);
       if (e != hipSuccess) fail(e == hipErrorNotReady ? "admission timed out (CE_WORKER_TIMEOUT_S)" : "waiting for the H2D copies", e);
-      if (probe && n >= stage_rows) {
-        // More misses than the staging holds: the rows past it are read ZERO-COPY out of the host table by the k_admit
-        // behind the parked wait (prepare_ids_second_half), and that kernel knows nothing of the previous call's
-        // staging buffer -- a row the previous call evicted through its staged part and this call misses in its tail
-        // would be read before (or while) its write-back lands.  The relaxed order therefore ends here for such a
-        // call: the stream stays parked until that write-back is in the table (mail[2].count is clamped
-        // to stage_rows, so "== stage_rows" means "possibly more").
-        std::unique_lock<std::mutex> g(m);
-        cv_done.wait(g, [&] { return out_done >= need_out || err != 0; });
-      }
       // a job that did not bring its rows in is flagged BEFORE the stream is released: k_unpack_admitted /
       // k_admit_maps then admit nothing and the call's record says CE_ERR_HIP
       if (n > 0 && failed()) __atomic_store_n(sig + 1, (unsigned long long)job, __ATOMIC_RELEASE);
@@ -2207,7 +2059,6 @@ struct SwapEngine {
         in_gather_s += std::chrono::duration<double>(tg - t1).count();
         in_rows += n;
         in_jobs += 1;
-        in_probed += probe ? 1 : 0;
       }
       cv_done.notify_all();
     }
@@ -2306,6 +2157,11 @@ struct SwapEngine {
     }
     for (int b = 0; b < 2; ++b)
       if (in_ev[b]) (void)hipEventDestroy(in_ev[b]);
+    for (auto& ev : ev_miss)
+      if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ev_rows)
+      if (ev) (void)hipEventDestroy(ev);
+
     for (auto& ev : chunk_ev)
       if (ev) (void)hipEventDestroy(ev);
     if (in_host) (void)hipHostFree(in_host);
@@ -2327,6 +2183,9 @@ struct ce_cache {
   ce::Ctl* ctl;
   uint32_t* bitmap;
   int32_t *blk_unique, *blk_miss, *coarse, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
+  int32_t* miss_list_b[2];     // [0] = miss_list, [1] = the second pair (chained admission: by call parity)
+  int32_t* free_list_b[2];
+  ce::Coop* coop;              // scratch of the fused kernels
   unsigned long long* keys;
   uint32_t* hist;
   ce_call_stats_t* ring;       // pinned host
@@ -2370,6 +2229,7 @@ struct ce_cache {
   // call's victims: no free-list scan, see free_list_from_victims); the device re-checks the premise (k_emit).
   bool free_zero;
   long long free_reset_seq;    // records up to this call number say nothing about the present
+  bool deferred_rows;          // chained admission: calls do not make their stream wait for the rows (ce_cache_wait_rows)
   // a prepare_ids call issued in two halves (ce_cache_prepare_ids_begin / _finish): what the second half needs
   struct Pending {
     bool active = false;
@@ -2379,7 +2239,9 @@ struct ce_cache {
     bool worker = false, capturing = false, has_tail = false;
     long long in_job = 0, seq_arg = 0;
     int cap_groups = 1, swap_threads = 256, pslot = 0, pmark = 0;
-    bool early = false;          // maps + slots / keys were launched before the admission wait (worker transport)
+    bool chained = false;        // chained admission: the second half is chained_second_half
+    long long call = 0;          // its ticket (SwapEngine::chain_calls)
+    int parity = 0;
     bool sel_pending = false;    // the selection / staging part has not been launched yet (select_and_stage)
     hipStream_t sel_s = nullptr;
     int64_t sel_n = 0;
@@ -2403,6 +2265,29 @@ struct ce_cache {
 using namespace ce;
 
 static int ensure_writeback(ce_cache* h);
+
+// ---- cooperative launches of one process are serialised when more than one manager is alive: every fused kernel
+// waits at grid barriers for ALL its workgroups, so two of them must never each hold a part of the chip the other
+// one needs.  One is a quarter of the resident capacity at most (ce_cache_fused.h), so two or three managers could
+// not starve each other anyway; the chain makes it independent of their number.
+static std::mutex g_coop_m;
+static int g_managers = 0;
+static hipEvent_t g_coop_ev = nullptr;
+static hipStream_t g_coop_stream = nullptr;
+static bool g_coop_recorded = false;
+static void coop_before(hipStream_t s) {
+  std::lock_guard<std::mutex> g(g_coop_m);
+  if (g_managers > 1 && g_coop_recorded && g_coop_stream != s) (void)hipStreamWaitEvent(s, g_coop_ev, 0);
+}
+static void coop_after(hipStream_t s) {
+  std::lock_guard<std::mutex> g(g_coop_m);
+  if (g_managers <= 1) return;
+  if (!g_coop_ev && hipEventCreateWithFlags(&g_coop_ev, hipEventDisableTiming) != hipSuccess) return;
+  if (hipEventRecord(g_coop_ev, s) == hipSuccess) {
+    g_coop_stream = s;
+    g_coop_recorded = true;
+  }
+}
 
 static void drain(ce_cache* h) {
   while (h->drained < h->seq) {
@@ -2429,13 +2314,30 @@ static void drain(ce_cache* h) {
       h->cuda_to_cpu_numel += r.n_evict * h->cfg.embedding_dim;
       h->cache_miss += r.miss_lookups;
       h->total_cache += r.n_ids;
+      if (h->wb && h->wb->chained && r.kind == CE_CALL_PREPARE) {      // (no worker job counts them on this path)
+        std::lock_guard<std::mutex> g(h->wb->m);
+        h->wb->in_rows += r.n_miss;
+      }
     }
     h->drained = s;
   }
 }
 
+// chained admission: the rows of the calls issued so far are moved into their slots on the admission stream
+static hipEvent_t last_rows_event(ce_cache* h) {
+  if (!h->wb || !h->wb->chained || h->wb->chain_calls == 0) return nullptr;
+  return h->wb->ev_rows[h->wb->chain_calls % SwapEngine::kRowsRing];
+}
+// ... `s` waits for them (anything that reads or rewrites cache rows / the maps outside prepare_ids)
+static int join_rows(ce_cache* h, hipStream_t s) {
+  if (hipEvent_t ev = last_rows_event(h)) CE_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+  return CE_OK;
+}
+
 static int sync_and_drain(ce_cache* h) {
   CE_HIP_CHECK(hipEventSynchronize(h->ev));
+  // (deferred rows: the call's own stream did not wait for them)
+  if (hipEvent_t ev = last_rows_event(h)) CE_HIP_CHECK(hipEventSynchronize(ev));
   drain(h);
   return CE_OK;
 }
@@ -2485,6 +2387,11 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->victims = (int32_t*)(h->ws + L.victims);
   h->blk_free = (int32_t*)(h->ws + L.blk_free);
   h->free_list = (int32_t*)(h->ws + L.free_list);
+  h->miss_list_b[0] = h->miss_list;
+  h->miss_list_b[1] = (int32_t*)(h->ws + L.miss_list2);
+  h->free_list_b[0] = h->free_list;
+  h->free_list_b[1] = (int32_t*)(h->ws + L.free_list2);
+  h->coop = (Coop*)(h->ws + L.coop);
   h->seq = h->drained = 0;
   h->cpu_to_cuda_numel = h->cuda_to_cpu_numel = h->cache_miss = h->total_cache = 0;
   const int D = cfg->embedding_dim;
@@ -2520,6 +2427,7 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->last_fail_seq = 0;
   h->free_zero = false;
   h->free_reset_seq = 0;
+  h->deferred_rows = false;
   h->stage2 = (float*)(h->ws + L.stage2);
   h->stage_idx2 = (int32_t*)(h->ws + L.stage_idx2);
   h->in_stage = (float*)(h->ws + L.in_stage);
@@ -2574,13 +2482,22 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
       return rc;
     }
   }
+  {
+    std::lock_guard<std::mutex> g(g_coop_m);
+    g_managers += 1;
+  }
   *out = h;
   return CE_OK;
 }
 
 extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
+  {
+    std::lock_guard<std::mutex> g(g_coop_m);
+    g_managers -= 1;
+  }
   (void)hipEventSynchronize(h->ev);
+  if (h->wb && h->wb->in_stream) (void)hipStreamSynchronize(h->wb->in_stream);
   delete h->wb;          // finishes the queued jobs, joins the workers
   for (int b = 0; b < 2; ++b) {
     if (h->evt_keys[b]) (void)hipFree(h->evt_keys[b]);
@@ -2678,8 +2595,13 @@ static int ensure_writeback(ce_cache* h) {
     w->idx_dev[1] = h->stage_idx2;
     w->in_stage_dev = h->in_stage;
     {
-      static const int relax_env = [] { const char* e = getenv("CE_WB_RELAX"); return e ? atoi(e) : 1; }();
-      if (relax_env != 0 && !h->evt_keys[0]) {
+      // admission: chained on the admission stream (a small kernel reads the missed rows out of the mapped table) unless
+      // CE_WORKER_ADMIT=sdma asks for the host gather + staged copy, or the table has no device-visible mapping
+      const char* e = getenv("CE_WORKER_ADMIT");
+      w->chained = !(e && !strcmp(e, "sdma")) && h->cfg.host_weight_dev != nullptr;
+    }
+    {
+      if (w->chained && !h->evt_keys[0]) {
         uint32_t places = 4096;
         while ((int64_t)places < 4 * L.stage_rows && places < (1u << 30)) places <<= 1;
         bool ok = (int64_t)places >= 4 * L.stage_rows;
@@ -2698,9 +2620,10 @@ static int ensure_writeback(ce_cache* h) {
             h->evt_keys[b] = nullptr;
             h->evt_pos[b] = nullptr;
           }
+          rc = CE_ERR_NOMEM;
+          break;
         }
       }
-      w->relax = h->evt_keys[0] != nullptr;
       if (const char* e = getenv("CE_WORKER_OUT_DELAY_US")) w->out_delay_us = std::max(0, atoi(e));
       if (const char* e = getenv("CE_WORKER_FAIL_IN_JOB")) w->fail_in_job = atoll(e);
       for (int b = 0; b < 2; ++b) {
@@ -2745,14 +2668,15 @@ static int ensure_writeback(ce_cache* h) {
     w->miss_host = (int32_t*)p;
     if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) pd = p;
     w->miss_host_dev = (int32_t*)pd;
-    {
-      // admission: by default a small kernel on in_stream reads the missed rows out of the pinned table; CE_WORKER_ADMIT=
-      // sdma selects the host gather + staged copy (also used when the table has no device-visible mapping)
-      const char* e = getenv("CE_WORKER_ADMIT");
-      w->admit_by_kernel = !(e && !strcmp(e, "sdma")) && h->cfg.host_weight_dev != nullptr;
-    }
-    if (!w->admit_by_kernel &&
+    if (!w->chained &&
         hipHostMalloc((void**)&w->in_host, rows_bytes, hipHostMallocDefault) != hipSuccess) { rc = CE_ERR_NOMEM; break; }
+    if (w->chained) {
+      for (auto& ev : w->ev_miss)
+        if (rc == CE_OK && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
+      for (auto& ev : w->ev_rows)
+        if (rc == CE_OK && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc = CE_ERR_HIP;
+      if (rc) break;
+    }
     // the workers sleep in hipEventSynchronize (blocking-sync events): spinning threads would eat the CPU quota
     // the helpers need
     const unsigned evf = hipEventDisableTiming | hipEventBlockingSync;
@@ -2776,25 +2700,18 @@ static int ensure_writeback(ce_cache* h) {
     static const int in_threads = [] { const char* e = getenv("CE_GATHER_THREADS"); return e ? atoi(e) : dflt; }();
     w->out_pool = new RowPool(std::max(1, std::min(out_threads, 64)));
     w->in_pool = new RowPool(std::max(1, std::min(in_threads, 64)));
-    {
-      const char* b = getenv("CE_ADMIT_BLOCKS");
-      if (b && atoi(b) > 0) w->admit_blocks = atoi(b);
-      const char* t = getenv("CE_ADMIT_THREADS");
-      if (t && (atoi(t) == 256 || atoi(t) == 512 || atoi(t) == 1024)) w->admit_threads = atoi(t);
-      w->miss_list_dev = h->miss_list;
-      w->table_dev = h->cfg.host_weight_dev;
-      w->rowlen = h->rowlen;
-      w->g_log2 = h->g_log2;
-      w->vec = h->vec;
-    }
+    w->rowlen = h->rowlen;
+    w->g_log2 = h->g_log2;
+    w->vec = h->vec;
     w->out_thread = std::thread([w] { w->run_out(); });
-    w->in_thread = std::thread([w] { w->run_in(); });
+    if (!w->chained) w->in_thread = std::thread([w] { w->run_in(); });
   } while (0);
   if (rc) {
     delete w;
     set_error("swap worker setup failed (pinned buffers / streams / events)");
     return rc;
   }
+  w->deferred_rows = h->deferred_rows;
   h->wb = w;
   return CE_OK;
 }
@@ -2828,6 +2745,8 @@ extern "C" int ce_cache_preload(ce_cache_t* h, const int32_t* rows, const int64_
   }
   hipStream_t s = (hipStream_t)stream;
   const ce_cache_config_t& c = h->cfg;
+  rc = join_rows(h, s);
+  if (rc) return rc;
   h->seq += 1;
   const int32_t epoch = (int32_t)(h->seq & 0x3fffffff);
   const int64_t groups_per_block = 256 >> h->g_log2;
@@ -2940,13 +2859,12 @@ static int worker_selftest(ce_cache* h, hipStream_t s) {
   return CE_OK;
 }
 
-// the window's keys, written by the call's last kernel (ce_cache_prepare_ids_keys)
 // Second part of a cache op's front: victim selection, staging of the victims (and the write-back job), free-slot list.
-// Runs inline behind k_emit, or -- a call in two halves on the worker transport (SelArgs::deferred) -- at the start of
-// the SECOND half: the admission kernel the worker launches behind k_emit reads the host table over PCIe for ~0.7 ms,
-// and these kernels run 2-3x slower beside it (find_evict_ids 0.042 -> 0.072 ms, evict_stage 0.030 -> 0.065 ms in the
-// bench's phase timers); behind the window's training steps the admission has long finished and they run alone, while
-// the admission itself starts as early as before.
+// Runs inline behind the front, or -- a call in two halves on the worker transport -- at the start of the SECOND half:
+// the admission kernel behind the front reads the host table over PCIe for ~0.7 ms, and these kernels run 2-3x slower
+// beside it (find_evict_ids 0.042 -> 0.072 ms, evict_stage 0.030 -> 0.065 ms in the bench's phase timers); behind the
+// window's training steps the admission has long finished and they run alone, while the admission itself starts as
+// early as before.
 struct SelArgs {
   hipStream_t s;
   int64_t n;
@@ -2954,7 +2872,39 @@ struct SelArgs {
   long long out_job, seq_arg;
   int wbuf, n_vblocks, pslot;
   const void* prof_id;
+  int32_t* free_list;
 };
+
+// radix passes the victim select needs (the top one is taken by the key kernel itself)
+static int select_top_pass(ce_cache* h, int64_t n, bool capturing) {
+  const ce_cache_config_t& c = h->cfg;
+  const int64_t N = c.num_embeddings;
+  // DATASET keys are < N: the digits above the highest digit of N-1 are zero for every eligible slot, so the
+  // radix select starts there (3 passes of 11 bits at N = 178 M).
+  int top_pass = kLevels - 1;
+  if (c.evict_strategy != CE_EVICT_LFU) {
+    top_pass = 0;
+    while (top_pass < kLevels - 1 && ((uint64_t)(N - 1) >> (kDigitBits * (top_pass + 1))) != 0) ++top_pass;
+  } else {
+    // LFU keys are freq << slot_bits | slot.  No counter can exceed the largest value ever preloaded plus the ids
+    // seen so far (a call adds at most its own length to a counter), so the digits above that bound are zero in
+    // every eligible key.  (The key kernel clamps a counter that a caller pushed beyond it -- freq_cnter is the
+    // caller's tensor -- so a key never has bits above the top digit.)
+    // (a captured call is replayed an unknown number of times: its pass count allows for kGraphFreqHeadroom more
+    // ids; ce_cache_graph_replayed keeps the bound and asks for a new capture once it is used up)
+    uint64_t bound = h->freq_bound + (uint64_t)n;
+    if (capturing) {
+      bound = h->freq_bound + kGraphFreqHeadroom;
+      h->graph_freq_limit = bound;
+    } else {
+      h->freq_bound = bound;
+    }
+    const int bits = 64 - __builtin_clzll(bound | 1ull) + h->slot_bits;
+    top_pass = h->freq_bound_known ? std::min(kLevels - 1, std::max(0, (bits + kDigitBits - 1) / kDigitBits - 1))
+                                   : kLevels - 1;
+  }
+  return top_pass;
+}
 
 static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   const ce_cache_config_t& c = h->cfg;
@@ -2973,38 +2923,14 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
 #define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
-  // DATASET keys are < N: the digits above the highest digit of N-1 are zero for every eligible slot, so the
-  // radix select starts there (3 passes of 11 bits at N = 178 M).  The top pass is taken by k_keys itself.
-  int top_pass = kLevels - 1;
-  if (!lfu) {
-    top_pass = 0;
-    while (top_pass < kLevels - 1 && ((uint64_t)(N - 1) >> (kDigitBits * (top_pass + 1))) != 0) ++top_pass;
-  } else {
-    // LFU keys are freq << slot_bits | slot.  No counter can exceed the largest value ever preloaded plus the ids
-    // seen so far (a call adds at most its own length to a counter), so the digits above that bound are zero in
-    // every eligible key.  (k_keys clamps a counter that a caller pushed beyond it -- freq_cnter is the caller's
-    // tensor -- so a key never has bits above the top digit.)
-    // (a captured call is replayed an unknown number of times: its pass count allows for kGraphFreqHeadroom more
-    // ids; ce_cache_graph_replayed keeps the bound and asks for a new capture once it is used up)
-    uint64_t bound = h->freq_bound + (uint64_t)n;
-    if (capturing) {
-      bound = h->freq_bound + kGraphFreqHeadroom;
-      h->graph_freq_limit = bound;
-    } else {
-      h->freq_bound = bound;
-    }
-    const int bits = 64 - __builtin_clzll(bound | 1ull) + h->slot_bits;
-    top_pass = h->freq_bound_known ? std::min(kLevels - 1, std::max(0, (bits + kDigitBits - 1) / kDigitBits - 1))
-                                   : kLevels - 1;
-  }
+  const int top_pass = select_top_pass(h, n, capturing);
   hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
                      seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
-  // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs; one launch per pass with the LAST
-  // workgroup picking the digit: the agent-scope fences it needs write back the L2 of every XCD, 0.22 -> 0.72 ms
-  // beside the training kernels.  What works: every workgroup of pass p recomputes the digits of the passes above
-  // level above it from that level's histogram in its prologue -- select_level -- so there is no pick kernel at all)
+  // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs.  What works per launch: every
+  // workgroup of pass p recomputes the digits of the level above it from that level's histogram in its prologue --
+  // select_level -- so there is no pick kernel at all; the fused form is k_select, ce_cache_fused.h)
   for (int pass = top_pass - 1; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
   hipLaunchKernelGGL(k_victims, dim3((unsigned)n_vblocks), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
@@ -3013,25 +2939,24 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
   int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
   if (c.transport == CE_TRANSPORT_ZEROCOPY || worker) {
-    // ---- victims -> HBM staging (fast); rows beyond the staging capacity (rare) are written back directly
-    // by k_evict; map clear, free-slot list, admit stay on the caller's stream
+    // ---- victims -> HBM staging (fast); rows beyond the staging capacity (rare) are written back directly;
+    // map clear, free-slot list, admit stay on the caller's stream
     const long long scap = (long long)L.stage_rows;
-    static const int stage_blocks = [] { const char* e = getenv("CE_STAGE_BLOCKS"); return e ? atoi(e) : 512; }();
-    const int sgrid = (int)std::min<int64_t>(stage_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    const int sgrid = (int)std::min<int64_t>(512, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
     WbMail* const mail = worker ? h->wb->mail_dev + wbuf : nullptr;
     const dim3 sg(sgrid + (steady ? n_vblocks : 0));        // + the free-list workgroups of the steady-state form
-    const EvTable evt = (worker && h->wb->relax) ? EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask}
-                                                   : EvTable{nullptr, nullptr, 0u};
+    const EvTable evt = (worker && h->wb->chained) ? EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask}
+                                                     : EvTable{nullptr, nullptr, 0u};
     if (h->vec) {
       hipLaunchKernelGGL((k_evict_stage<f32x4>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const f32x4*)c.cache_weight, (f32x4*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list, evt, L.list_cap > L.stage_rows ? (f32x4*)c.host_weight_dev : (f32x4*)nullptr);
+                         a.free_list, evt, L.list_cap > L.stage_rows ? (f32x4*)c.host_weight_dev : (f32x4*)nullptr);
     } else {
       hipLaunchKernelGGL((k_evict_stage<float>), sg, dim3(256), 0, s, h->victims, c.cached_idx_map,
                          c.inverted_cached_idx, (const float*)c.cache_weight, (float*)stage_cur, stage_idx_cur, scap, h->rowlen, h->g_log2,
                          h->ctl, mail, out_job, sgrid, (const unsigned long long*)h->keys, C, (const int32_t*)h->blk_free,
-                         h->free_list, evt, L.list_cap > L.stage_rows ? (float*)c.host_weight_dev : (float*)nullptr);
+                         a.free_list, evt, L.list_cap > L.stage_rows ? (float*)c.host_weight_dev : (float*)nullptr);
     }
     if (worker) {
       // the write-back worker takes it from here: D2H of the packed block + scatter into the table
@@ -3048,12 +2973,12 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   if (steady) {
     // (the list was written by k_evict_stage's free-list workgroups)
   } else if (C <= 16384) {
-    hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, h->free_list, h->ctl);
+    hipLaunchKernelGGL(k_free_single, dim3(1), dim3(1024), 0, s, c.cached_idx_map, C, a.free_list, h->ctl);
   } else {
     hipLaunchKernelGGL(k_free_count, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
                        h->blk_free, h->ctl);
     hipLaunchKernelGGL(k_free_emit, dim3((unsigned)L.n_slot_blocks), dim3(256), 0, s, c.cached_idx_map, C,
-                       h->blk_free, h->free_list, h->ctl);
+                       h->blk_free, a.free_list, h->ctl);
   }
   CE_PHASE();
 #undef CE_PHASE
@@ -3062,6 +2987,7 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   return CE_OK;
 }
 
+// the window's keys, written by the call's last kernel (ce_cache_prepare_ids_keys)
 struct KeysTail {
   int64_t n_batches, nnz_per_batch;
   int32_t src_keys;
@@ -3073,12 +2999,277 @@ struct KeysTail {
   uint64_t* keys_out;
 };
 
-static int prepare_ids_second_half(ce_cache* h);
-static int launch_maps_and_slots(ce_cache* h);
+// how the ids are marked: rows in frequency order (idx_map present) -- the hot rows sit in the lowest bitmap words, an
+// LDS window absorbs them, cold lookups issue their atomicOr directly; rows in id order -- hot rows are scattered,
+// every wave would hammer their words (421 us per 3.4 M ids), so equal words of a wave are merged first.  (rocprofv3,
+// 3.4 M ids per call; the grid / unroll sweeps of rounds 3-5 ended at these values: docs/history.md)
+struct MarkCfg {
+  bool merge;
+  int u, threads, blocks, hot_words;
+};
+static MarkCfg mark_cfg(const ce_cache* h, int64_t n) {
+  const bool ranked = h->cfg.idx_map != nullptr;
+  MarkCfg m;
+  m.merge = !ranked;
+  m.threads = ranked ? 512 : 256;
+  m.hot_words = (int)std::min<int64_t>(h->L.bitmap_words, ranked ? 8192 : 2048);
+  m.u = n >= 65536 ? 4 : 1;
+  m.blocks = std::min(grid_for(n, m.threads * m.u), 256);
+  return m;
+}
 
-// split != 0: only the first half is enqueued -- everything up to and including the staging of the victims and the
-// free-slot list, i.e. all that needs nothing from the host table; ce_cache_prepare_ids_finish enqueues the rest (wait
-// for the admitted rows, unpack, maps, slots / keys).  See ce_api.h.
+// workgroups of the fused kernels: enough to keep the memory system busy for the call's size, never more than
+// kCoopMaxG (residency: ce_cache_fused.h)
+static int front_grid(const ce_cache* h, int64_t n) {
+  static const int env = [] { const char* e = getenv("CE_FRONT_GRID"); return e ? atoi(e) : 0; }();
+  if (env > 0) return std::min(env, kCoopMaxG);
+  const int64_t by_ids = cdiv(n, 8192), by_rows = cdiv(h->L.n_chunks, 16);
+  return (int)std::max<int64_t>(8, std::min<int64_t>(kCoopMaxG, std::max(by_ids, by_rows)));
+}
+static int select_grid(const ce_cache* h) {
+  static const int env = [] { const char* e = getenv("CE_SELECT_GRID"); return e ? atoi(e) : 0; }();
+  if (env > 0) return std::min(env, kCoopMaxG);
+  return (int)std::max<int64_t>(8, std::min<int64_t>(kCoopMaxG, cdiv(h->cfg.cuda_row_num, 16384)));
+}
+
+static void launch_front(ce_cache* h, const int64_t* ids, int64_t n, int64_t* slots_out, hipStream_t s, int allow_pad,
+                         bool steady, int parity, long long seq_arg) {
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  const MarkCfg mc = mark_cfg(h, n);
+  FrontArgs a;
+  a.ids = ids;
+  a.n = n;
+  a.idx_map = c.idx_map;
+  a.inverted = c.inverted_cached_idx;
+  a.N = c.num_embeddings;
+  a.C = c.cuda_row_num;
+  a.word_bits = h->word_bits;
+  a.hot_words = mc.hot_words;
+  a.bitmap = h->bitmap;
+  a.n_vec = L.n_chunks * (kChunkRows / 128);
+  a.ctl = h->ctl;
+  a.coop = h->coop;
+  a.rows_out = slots_out;
+  a.allow_pad = allow_pad;
+  a.assume_free0 = steady ? 1 : 0;
+  a.parity = parity;
+  a.miss_list = h->miss_list_b[parity];
+  a.slot_epoch = h->slot_epoch;
+  a.hist = h->hist;
+  a.seq_arg = seq_arg;
+  a.in_cap = (long long)L.stage_rows;
+  a.ring = h->ring_dev;
+  const dim3 grid(front_grid(h, n)), block(kCoopThreads);
+  const size_t lds = (size_t)mc.hot_words * 4;
+  coop_before(s);
+  if (mc.merge) {
+    if (mc.u == 4) hipLaunchKernelGGL((k_front<true, 4>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_front<true, 1>), grid, block, lds, s, a);
+  } else {
+    if (mc.u == 4) hipLaunchKernelGGL((k_front<false, 4>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_front<false, 1>), grid, block, lds, s, a);
+  }
+  coop_after(s);
+}
+
+static void launch_select(ce_cache* h, int64_t n, hipStream_t s, int parity, long long seq_arg, long long out_job, int wbuf) {
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  SelectArgs a;
+  a.cached_idx_map = c.cached_idx_map;
+  a.inverted = c.inverted_cached_idx;
+  a.freq = c.freq_cnter;
+  a.slot_epoch = h->slot_epoch;
+  a.C = c.cuda_row_num;
+  a.N = c.num_embeddings;
+  a.seq_arg = seq_arg;
+  a.depth = c.protect_depth;
+  a.slot_bits = h->slot_bits;
+  a.lfu = c.evict_strategy == CE_EVICT_LFU;
+  a.top_pass = select_top_pass(h, n, false);
+  a.parity = parity;
+  a.keys = h->keys;
+  a.hist = h->hist;
+  a.ctl = h->ctl;
+  a.coop = h->coop;
+  a.free_list = h->free_list_b[parity];
+  a.miss_list = h->miss_list_b[parity];
+  a.ring = h->ring_dev;
+  a.cache = c.cache_weight;
+  a.stage = wbuf ? h->stage2 : h->stage;
+  a.stage_rows_idx = wbuf ? h->stage_idx2 : h->stage_idx;
+  a.scap = (long long)L.stage_rows;
+  a.rowlen = h->rowlen;
+  a.g_log2 = h->g_log2;
+  a.vec = h->vec;
+  a.mail = h->wb->mail_dev + wbuf;
+  a.job = out_job;
+  a.evt = EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask};
+  a.host_overflow = L.list_cap > L.stage_rows ? (void*)c.host_weight_dev : nullptr;
+  coop_before(s);
+  hipLaunchKernelGGL(k_select, dim3(select_grid(h)), dim3(kCoopThreads), 0, s, a);
+  coop_after(s);
+}
+
+static int prepare_ids_second_half(ce_cache* h);
+static int chained_second_half(ce_cache* h);
+static int launch_slots_keys(ce_cache* h);
+
+// Chained admission, first half: the fused front on the call's stream, the admission kernel behind its event on the
+// admission stream.  (SwapEngine: why no thread and no parked stream.)
+static int chained_first_half(ce_cache* h, const int64_t* ids, int64_t n, int64_t* slots_out, hipStream_t s,
+                              int allow_pad, const KeysTail* tail, int split) {
+  SwapEngine* const w = h->wb;
+  const Layout& L = h->L;
+  const long long out_job = w->out_issued + 1;
+  const int wbuf = (int)(out_job & 1);
+  // write-back out_job - 2 has landed: its staging buffer is this call's, and everything older is in the host table
+  // the admission kernel is about to read (what job out_job - 1 still carries it takes from that job's staging buffer)
+  int rc = w->wait_out(out_job - 2);
+  if (rc) return rc;
+  const long long call = ++w->chain_calls;
+  const int parity = (int)(call & 1);
+  const bool steady = h->free_zero;
+  const long long seq_arg = (long long)h->seq;
+  PhaseProf* const prof = h->prof;
+  const int pslot = (int)(h->seq % kProfDepth);
+  int pmark = 0;
+  if (prof) {
+    prof->collect(pslot);
+    prof->chained[pslot] = true;
+    (void)hipEventRecord(prof->ev[pslot][pmark++], s);
+  }
+  launch_front(h, ids, n, slots_out, s, allow_pad, steady, parity, seq_arg);
+  CE_HIP_CHECK(hipEventRecord(w->ev_miss[parity], s));
+  CE_HIP_CHECK(hipStreamWaitEvent(w->in_stream, w->ev_miss[parity], 0));
+  if (prof) (void)hipEventRecord(prof->adm0[pslot], w->in_stream);
+  {
+    // 32 workgroups for the calls of prefetch_num 1-2 (the rows are waited for almost at once), 20 for window-sized
+    // ones (the admission runs beside the window's training kernels: wider grids finish sooner and slow those --
+    // rounds 2-5: 8 / 16 / 20 / 32 / 64 workgroups)
+    const int blocks = n <= 600000 ? 32 : 20;
+    const long long prev = out_job - 1;                      // the write-back job whose rows may still be on their way
+    const int pb = (int)(prev & 1);
+    const bool has_prev = prev >= w->probe_floor;
+    const unsigned long long* ek = has_prev ? h->evt_keys[pb] : nullptr;
+    const long long* n_ptr = &h->coop->n_admit[parity];
+    if (h->vec)
+      hipLaunchKernelGGL((k_admit_probe<f32x4>), dim3(blocks), dim3(1024), 0, w->in_stream, h->miss_list_b[parity], n_ptr,
+                         (const f32x4*)h->cfg.host_weight_dev, (f32x4*)h->in_stage, h->rowlen, h->g_log2, ek,
+                         (const int32_t*)h->evt_pos[pb], h->evt_mask, (uint32_t)prev,
+                         (const f32x4*)(pb ? h->stage2 : h->stage));
+    else
+      hipLaunchKernelGGL((k_admit_probe<float>), dim3(blocks), dim3(1024), 0, w->in_stream, h->miss_list_b[parity], n_ptr,
+                         (const float*)h->cfg.host_weight_dev, (float*)h->in_stage, h->rowlen, h->g_log2, ek,
+                         (const int32_t*)h->evt_pos[pb], h->evt_mask, (uint32_t)prev,
+                         (const float*)(pb ? h->stage2 : h->stage));
+    std::lock_guard<std::mutex> g(w->m);
+    w->in_jobs += 1;
+    if (w->out_done < prev) w->in_probed += 1;
+  }
+  if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s);
+  ce_cache::Pending& x = h->pend;
+  x.n = n; x.slots_out = slots_out; x.s = s; x.worker = true; x.capturing = false; x.has_tail = tail != nullptr;
+  x.in_job = 0; x.seq_arg = seq_arg; x.pslot = pslot; x.pmark = pmark; x.prof = prof;
+  x.chained = true; x.call = call; x.parity = parity;
+  x.sel_pending = true;
+  x.sel_s = s; x.sel_n = n; x.sel_steady = steady; x.sel_out_job = out_job; x.sel_wbuf = wbuf;
+  x.sel_n_vblocks = (int)cdiv(h->cfg.cuda_row_num, 4096);
+  if (tail)
+    x.tail = {tail->n_batches, tail->nnz_per_batch, tail->src_keys, tail->offsets, tail->offsets_are_i64,
+              tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset, tail->hook_features, tail->keys_out};
+  (void)L;
+  if (split) {
+    x.active = true;
+    CE_LAUNCH_CHECK();
+    return CE_OK;
+  }
+  return chained_second_half(h);
+}
+
+// ... second half: selection + staging (+ the maps of the admitted rows: they need no payload) on the call's stream,
+// the unpack kernel behind it on the admission stream, the slots / keys of the call's ids on the call's stream again.
+static int chained_second_half(ce_cache* h) {
+  ce_cache::Pending& x = h->pend;
+  x.active = false;
+  x.sel_pending = false;
+  SwapEngine* const w = h->wb;
+  const ce_cache_config_t& c = h->cfg;
+  const Layout& L = h->L;
+  hipStream_t s = x.s;
+  const int parity = x.parity, wbuf = x.sel_wbuf, pslot = x.pslot;
+  const long long call = x.call, out_job = x.sel_out_job;
+  PhaseProf* const prof = (h->prof && (const void*)h->prof == x.prof) ? h->prof : nullptr;
+  if (prof) {
+    (void)hipEventRecord(prof->resume[pslot], s);
+    prof->resumed[pslot] = true;
+  }
+  // The selection rewrites the staging buffer and the row table of write-back job out_job - 2 -- which the PREVIOUS
+  // call's admission / unpack kernels read (rows that job carried) -- and the previous-but-one call's miss / free
+  // lists come up for reuse with the next front: this call's selection goes behind the previous call's rows.
+  if (call > 1) CE_HIP_CHECK(hipStreamWaitEvent(s, w->ev_rows[(call - 1) % SwapEngine::kRowsRing], 0));
+  hipEvent_t sel_done = w->out_ev[wbuf];
+  if (x.sel_steady) {
+    launch_select(h, x.sel_n, s, parity, x.seq_arg, out_job, wbuf);
+    CE_HIP_CHECK(hipEventRecord(w->out_ev[wbuf], s));
+    w->push_out();
+    if (prof)
+      for (int j = 0; j < 3; ++j) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);      // (staging, free list: inside)
+  } else {
+    // the cache still has free slots (warm-up): the per-phase kernels, then the maps -- before the rows, which they
+    // do not need -- with the count the unpack kernel moves
+    SelArgs sel{s, x.sel_n, true, false, false, out_job, x.seq_arg, wbuf, x.sel_n_vblocks, pslot, x.prof,
+                h->free_list_b[parity]};
+    int rc0 = select_and_stage(h, sel, &x.pmark);
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list_b[parity],
+                       h->free_list_b[parity], (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map,
+                       c.inverted_cached_idx, c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl,
+                       h->ring_dev, x.seq_arg, (const unsigned long long*)nullptr, 0ll, &h->coop->n_unpack[parity]);
+    CE_HIP_CHECK(hipEventRecord(w->ev_miss[parity], s));
+    sel_done = w->ev_miss[parity];
+  }
+  CE_HIP_CHECK(hipStreamWaitEvent(w->in_stream, sel_done, 0));
+  {
+    const int gpb = 256 >> h->g_log2;
+    const int ugrid = (int)std::min<int64_t>(x.sel_n <= 600000 ? 128 : 512, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    const long long prev = out_job - 1;
+    const int pb = (int)(prev & 1);
+    const unsigned long long* ek = prev >= w->probe_floor ? h->evt_keys[pb] : nullptr;
+    const bool tail_possible = L.list_cap > L.stage_rows;
+    if (h->vec)
+      hipLaunchKernelGGL((k_unpack_chained<f32x4>), dim3(ugrid), dim3(256), 0, w->in_stream, h->free_list_b[parity],
+                         (const long long*)&h->coop->n_unpack[parity], (long long)L.stage_rows,
+                         (const f32x4*)h->in_stage, (f32x4*)c.cache_weight, h->rowlen, h->g_log2,
+                         (const int32_t*)h->miss_list_b[parity],
+                         tail_possible ? (const f32x4*)c.host_weight_dev : (const f32x4*)nullptr, ek,
+                         (const int32_t*)h->evt_pos[pb], h->evt_mask, (uint32_t)prev,
+                         (const f32x4*)(pb ? h->stage2 : h->stage));
+    else
+      hipLaunchKernelGGL((k_unpack_chained<float>), dim3(ugrid), dim3(256), 0, w->in_stream, h->free_list_b[parity],
+                         (const long long*)&h->coop->n_unpack[parity], (long long)L.stage_rows,
+                         (const float*)h->in_stage, (float*)c.cache_weight, h->rowlen, h->g_log2,
+                         (const int32_t*)h->miss_list_b[parity],
+                         tail_possible ? (const float*)c.host_weight_dev : (const float*)nullptr, ek,
+                         (const int32_t*)h->evt_pos[pb], h->evt_mask, (uint32_t)prev,
+                         (const float*)(pb ? h->stage2 : h->stage));
+  }
+  if (prof) (void)hipEventRecord(prof->adm1[pslot], w->in_stream);
+  hipEvent_t rows = w->ev_rows[call % SwapEngine::kRowsRing];
+  CE_HIP_CHECK(hipEventRecord(rows, w->in_stream));
+  if (prof) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);      // ("admit_swap" is timed on the admission stream)
+  int rc = launch_slots_keys(h);
+  if (rc) return rc;
+  if (prof) prof->pending[pslot] = true;
+  CE_LAUNCH_CHECK();
+  // the caller's stream order covers the rows unless it asked to wait for them itself (ce_cache_wait_rows)
+  if (!w->deferred_rows) CE_HIP_CHECK(hipStreamWaitEvent(s, rows, 0));
+  CE_HIP_CHECK(hipEventRecord(h->ev, s));
+  return CE_OK;
+}
+
+// split != 0: only the first half is enqueued -- ce_cache_prepare_ids_finish enqueues the rest.  See ce_api.h.
 static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out, ce_stream_t stream,
                             int allow_pad, const KeysTail* tail = nullptr, int split = 0) {
   CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
@@ -3097,39 +3288,39 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
     CE_REQUIRE(h->cfg.transport == CE_TRANSPORT_ZEROCOPY, CE_ERR_UNSUPPORTED,
                "only the zero-copy transport can be captured in a hipGraph (the others hand rows to host threads)");
     CE_REQUIRE(!h->prof, CE_ERR_UNSUPPORTED, "switch the phase timers off before capturing a cache op");
+    CE_REQUIRE(!split, CE_ERR_UNSUPPORTED, "a cache op in two halves cannot be captured in a hipGraph");
   }
   int rc = capturing ? CE_OK : before_call(h);
   if (rc) return rc;
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
   const int64_t N = c.num_embeddings, C = c.cuda_row_num;
+  bool worker = c.transport == CE_TRANSPORT_WORKER;
+  if (worker) {
+    rc = ensure_writeback(h);
+    if (rc) return rc;
+    if (h->wb->chained) {
+      rc = h->wb->check();
+      if (rc) return rc;
+      h->seq += 1;
+      return chained_first_half(h, ids, n, slots_out, s, allow_pad, tail, split);
+    }
+  }
   if (!capturing) h->seq += 1;
   const long long seq_arg = capturing ? 0ll : (long long)h->seq;     // 0: the device's own count
   ce_call_stats_t* const ring = h->ring_dev;
   // swap kernels: small grid (default 2 workgroups per CU's worth of slots is left to training kernels)
   // protect_depth > 0 means the call overlaps with training kernels on another stream: stay small (32
   // workgroups measured best: 1.43 -> 1.82 G lookups/s); alone on the GPU a wider grid finishes sooner
-  static const int swap_blocks_env = [] {
-    const char* e = getenv("CE_SWAP_BLOCKS");
-    return e ? atoi(e) : 0;
-  }();
-  const int swap_blocks = swap_blocks_env > 0 ? swap_blocks_env : (c.protect_depth > 0 ? 32 : 512);
-  static const int swap_threads = [] {
-    const char* e = getenv("CE_SWAP_THREADS");
-    const int v = e ? atoi(e) : 256;
-    return (v == 256 || v == 512 || v == 1024) ? v : 256;
-  }();
-  const dim3 swap_block(swap_threads);
+  const int swap_blocks = c.protect_depth > 0 ? 32 : 512;
+  const int swap_threads = 256;
   const int cap_groups = (int)std::min<int64_t>(swap_blocks, std::max<int64_t>(1, cdiv(L.list_cap, (swap_threads >> h->g_log2) * kSwapRows)));
 
-  // worker transport: job numbers / staging buffer of this call; the launch thread only waits here when a worker
-  // is two calls behind (its buffers and events are about to be reused)
-  bool worker = c.transport == CE_TRANSPORT_WORKER;
+  // worker transport with the host-gather admission: job numbers / staging buffer of this call; the launch thread only
+  // waits here when a worker is two calls behind (its buffers and events are about to be reused)
   long long out_job = 0, in_job = 0;
   int wbuf = 0;
   if (worker) {
-    rc = ensure_writeback(h);
-    if (rc) return rc;
     rc = worker_selftest(h, s);
     if (rc == CE_ERR_UNSUPPORTED) {
       // loud, once: the environment cannot run this transport; the zero-copy swap kernel needs nothing from it
@@ -3149,8 +3340,8 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
       (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
       if (s != nullptr && prio_hi != prio_lo && hipStreamGetPriority(s, &prio) == hipSuccess)
         CE_REQUIRE(prio != prio_hi, CE_ERR_UNSUPPORTED,
-                   "the worker transport cannot run its cache op on a highest-priority stream (its copy streams "
-                   "use that priority to stay out of the parked stream's hardware queue)");
+                   "the worker transport's host-gather admission cannot run its cache op on a highest-priority stream "
+                   "(its copy streams use that priority to stay out of the parked stream's hardware queue)");
     }
     out_job = h->wb->out_issued + 1;
     in_job = h->wb->in_issued + 1;
@@ -3170,61 +3361,32 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   CE_PHASE();
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, h->coarse,
                      (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist, seq_arg);
-  {
-    // Two shapes (rocprofv3, 3.4 M ids per call).  Rows in frequency order (idx_map present): the hot rows sit in
-    // the lowest bitmap words, the LDS window absorbs them, and cold lookups issue their atomicOr directly.
-    // Rows in id order (no idx_map): hot rows are scattered, every wave would hammer their words (421 us), so
-    // equal words of a wave are merged first.
-    const bool ranked = c.idx_map != nullptr;
-    static const int mark_hot_env = [] { const char* e = getenv("CE_MARK_HOT"); return e ? atoi(e) : 0; }();
-    static const int mark_blocks = [] { const char* e = getenv("CE_MARK_BLOCKS"); return e ? atoi(e) : 256; }();
-    static const int mark_threads_env = [] { const char* e = getenv("CE_MARK_THREADS"); return e ? atoi(e) : 0; }();
-    static const int mark_merge_env = [] { const char* e = getenv("CE_MARK_MERGE"); return e ? atoi(e) : -1; }();
-    static const int mark_u = [] { const char* e = getenv("CE_MARK_U"); return e ? atoi(e) : 4; }();
-    static const int mark_dbg = [] { const char* e = getenv("CE_MARK_DEBUG"); return e ? atoi(e) : 0; }();
-    const int mark_hot = mark_hot_env > 0 ? mark_hot_env : (ranked ? 8192 : 2048);
-    const int mark_threads = mark_threads_env > 0 ? std::min(mark_threads_env, 1024) : (ranked ? 512 : 256);
-    const bool mark_merge = mark_merge_env >= 0 ? mark_merge_env != 0 : !ranked;
-    const int hot_words = (int)std::min<int64_t>(L.bitmap_words, mark_hot);
-    // calls of a window's size: the repeats of every 8192-id chunk folded in LDS first (CE_MARK_DEDUPE=0: the per-id kernel)
-    static const int mark_dedupe = [] { const char* e = getenv("CE_MARK_DEDUPE"); return e ? atoi(e) : 0; }();
-    static const int mark_dd_blocks = [] { const char* e = getenv("CE_MARK_DEDUPE_BLOCKS"); return e ? atoi(e) : 4096; }();
-    if (n >= 65536 && mark_dedupe) {
-#define CE_MARK_DD(CH, TH)                                                                                          \
-  hipLaunchKernelGGL((k_mark_dedupe<CH, TH>), dim3((unsigned)std::min<int64_t>(cdiv(n, CH), mark_dd_blocks)), dim3(TH), \
-                     0, s, ids, n, c.idx_map, c.inverted_cached_idx, N, h->bitmap, h->ctl, slots_out, allow_pad, mark_dbg)
-      if (mark_dedupe == 1) CE_MARK_DD(8192, 1024);
-      else if (mark_dedupe == 2) CE_MARK_DD(4096, 512);
-      else CE_MARK_DD(2048, 256);
-#undef CE_MARK_DD
-    } else if (n > 0) {
-      const int u = (n >= 65536 && mark_u != 1) ? (mark_u == 2 ? 2 : 4) : 1;
-      const dim3 mg(std::min(grid_for(n, mark_threads * u), mark_blocks)), mb(mark_threads);
-#define CE_MARK(M, U_)                                                                                          \
-  hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
-                     h->word_bits, hot_words, h->bitmap, h->ctl, slots_out, mark_dbg, allow_pad)
-      if (mark_merge) { if (u == 4) CE_MARK(true, 4); else if (u == 2) CE_MARK(true, 2); else CE_MARK(true, 1); }
-      else { if (u == 4) CE_MARK(false, 4); else if (u == 2) CE_MARK(false, 2); else CE_MARK(false, 1); }
+  if (n > 0) {
+    const MarkCfg mc = mark_cfg(h, n);
+    const dim3 mg(mc.blocks), mb(mc.threads);
+#define CE_MARK(M, U_)                                                                                             \
+  hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, mc.hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
+                     h->word_bits, mc.hot_words, h->bitmap, h->ctl, slots_out, allow_pad)
+    if (mc.merge) { if (mc.u == 4) CE_MARK(true, 4); else CE_MARK(true, 1); }
+    else { if (mc.u == 4) CE_MARK(false, 4); else CE_MARK(false, 1); }
 #undef CE_MARK
-    }
   }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss, h->coarse);
   hipLaunchKernelGGL(k_emit, dim3((unsigned)cdiv(L.n_chunks, kEmitSub)), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
                      h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, ring,
                      worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
-                     worker && !h->wb->admit_by_kernel ? h->wb->miss_host_dev : (int32_t*)nullptr, steady ? 1 : 0);
-  // the admission worker starts gathering the missed rows (host table -> in_stage) right behind k_emit; it first lets
-  // every earlier write-back land
+                     worker ? h->wb->miss_host_dev : (int32_t*)nullptr, steady ? 1 : 0);
+  // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) right behind
+  // k_emit; it first lets every earlier write-back land
   if (worker) {
     CE_HIP_CHECK(hipEventRecord(h->wb->in_ev[in_job & 1], s));
     h->wb->push_in(out_job - 1);
   }
   CE_PHASE();
-  SelArgs sel{s, n, worker, capturing, steady, out_job, seq_arg, wbuf, n_vblocks, pslot, (const void*)prof};
+  SelArgs sel{s, n, worker, capturing, steady, out_job, seq_arg, wbuf, n_vblocks, pslot, (const void*)prof, h->free_list};
   // a call in two halves on the worker transport: the selection / staging part moves into the second half
-  static const int split_after_emit_env = [] { const char* e = getenv("CE_SPLIT_AFTER_EMIT"); return e ? atoi(e) : 1; }();
-  const bool defer_sel = split && worker && split_after_emit_env != 0;
+  const bool defer_sel = split && worker;
   if (!defer_sel) {
     rc = select_and_stage(h, sel, &pmark);
     if (rc) return rc;
@@ -3236,28 +3398,13 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   x.in_job = in_job; x.seq_arg = seq_arg; x.cap_groups = cap_groups; x.swap_threads = swap_threads; x.pslot = pslot;
   x.pmark = pmark;
   x.prof = prof;
+  x.chained = false;
   x.sel_pending = defer_sel;
   x.sel_s = s; x.sel_n = n; x.sel_steady = steady; x.sel_out_job = out_job; x.sel_wbuf = wbuf; x.sel_n_vblocks = n_vblocks;
   if (tail)
     x.tail = {tail->n_batches, tail->nnz_per_batch, tail->src_keys, tail->offsets, tail->offsets_are_i64,
               tail->offsets_batch_stride, tail->num_bags, tail->include_last_offset, tail->hook_features, tail->keys_out};
-  // Worker transport, the early-maps order (CE_EARLY_MAPS=1; off by default): which slot every missed row gets is
-  // known here, and neither the maps nor the slots / keys of the call's ids need the rows themselves -- so they can be
-  // launched BEFORE the stream parks and run while the admission is on the wire (it started behind k_emit); what is
-  // left behind the wait is the copy of the arrived rows into their slots.  Measured: the slot / key kernel is slower
-  // beside the admission kernel than alone behind it (window-sized calls 0.10 -> 0.15 ms, prefetch_num 1 0.03 ->
-  // 0.08 ms), which eats what the shorter tail gives: the bench line is unchanged within its noise (2.40 against
-  // 2.43 G, four interleaved runs each) and Kaggle 5 % at prefetch_num 1, where the chain IS the step, loses 12 %
-  // (1.08 against 1.22 G).  Kept for hosts whose admission is much slower than this one's.
-  const char* const early_env = getenv("CE_EARLY_MAPS");
-  x.early = worker && early_env && atoi(early_env) != 0;
-  if (prof) prof->early[pslot] = x.early;
-  if (x.early && !defer_sel) {
-    rc = launch_maps_and_slots(h);
-    if (rc) return rc;
-  }
   if (split) {
-    CE_REQUIRE(!capturing, CE_ERR_UNSUPPORTED, "a cache op in two halves cannot be captured in a hipGraph");
     x.active = true;
     CE_LAUNCH_CHECK();
     return CE_OK;
@@ -3265,12 +3412,10 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   return prepare_ids_second_half(h);
 }
 
-// maps of the admitted rows + the slots (and the window's keys) of the call's ids: behind the row transfer, or -- the
-// worker transport's early-maps order -- before it
-static int launch_maps_and_slots(ce_cache* h) {
+// the slots (and the window's keys) of the call's ids: the call's last launch
+static int launch_slots_keys(ce_cache* h) {
   ce_cache::Pending& x = h->pend;
   const ce_cache_config_t& c = h->cfg;
-  const Layout& L = h->L;
   const int64_t C = c.cuda_row_num, n = x.n;
   int64_t* const slots_out = x.slots_out;
   hipStream_t s = x.s;
@@ -3279,12 +3424,6 @@ static int launch_maps_and_slots(ce_cache* h) {
   PhaseProf* const prof = (h->prof && (const void*)h->prof == x.prof) ? h->prof : nullptr;
   const decltype(x.tail)* const tail = x.has_tail ? &x.tail : nullptr;
   int rc = CE_OK;
-  hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
-                     (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
-                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl, h->ring_dev,
-                     x.seq_arg, x.worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, x.in_job,
-                     x.early ? 1 : 0);
-  if (!x.early && prof) (void)hipEventRecord(prof->ev[x.pslot][x.pmark++], s);      // end of "admit_swap"
   if (n > 0 && lfu) {
     // ~8 k lookups per workgroup keep the LDS hash table (8192 entries) below half full
     hipLaunchKernelGGL(k_slots_lfu, dim3(std::min(grid_for(n, 8192), kMaxBlocks)), dim3(1024), 0, s, slots_out, n,
@@ -3314,21 +3453,18 @@ static int launch_maps_and_slots(ce_cache* h) {
 
 static int prepare_ids_second_half(ce_cache* h) {
   ce_cache::Pending& x = h->pend;
+  if (x.chained) return chained_second_half(h);
   x.active = false;
   if (x.sel_pending) {
     x.sel_pending = false;
     SelArgs sel{x.sel_s, x.sel_n, x.worker, x.capturing, x.sel_steady, x.sel_out_job, x.seq_arg, x.sel_wbuf, x.sel_n_vblocks,
-                x.pslot, x.prof};
+                x.pslot, x.prof, h->free_list};
     if (h->prof && (const void*)h->prof == x.prof) {
       (void)hipEventRecord(h->prof->resume[x.pslot], x.sel_s);
       h->prof->resumed[x.pslot] = true;
     }
     int rc0 = select_and_stage(h, sel, &x.pmark);
     if (rc0) return rc0;
-    if (x.early) {
-      rc0 = launch_maps_and_slots(h);
-      if (rc0) return rc0;
-    }
   }
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
@@ -3342,25 +3478,22 @@ static int prepare_ids_second_half(ce_cache* h) {
   const int pslot = x.pslot;
   int rc = CE_OK;
   if (worker) {
-    // the missed rows arrive in in_stage through the admission worker; this stream parks in the command processor
-    // until the worker's store to the pinned word it polls
+    // host-gather admission: the missed rows arrive in in_stage through the admission worker; this stream parks in
+    // the command processor until the worker's store to the pinned word it polls
     const long long scap = (long long)L.stage_rows;
     CE_HIP_CHECK(hipStreamWaitValue64(s, h->wb->sig, (uint64_t)in_job, hipStreamWaitValueGte, ~0ull));
-    static const int unpack_blocks = [] { const char* e = getenv("CE_UNPACK_BLOCKS"); return e ? atoi(e) : 1024; }();
-    const int ugrid = (int)std::min<int64_t>(unpack_blocks, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
+    const int ugrid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(L.stage_rows, gpb)));
     if (h->vec) {
       hipLaunchKernelGGL((k_unpack_admitted<f32x4>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const f32x4*)h->in_stage, (f32x4*)c.cache_weight,
                          h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
-                         in_job, x.early ? 1 : 0, (const int32_t*)h->miss_list, c.cached_idx_map,
-                         c.inverted_cached_idx, h->ring_dev, x.seq_arg,
+                         in_job, (const int32_t*)h->miss_list,
                          L.list_cap > L.stage_rows ? (const f32x4*)c.host_weight_dev : (const f32x4*)nullptr);
     } else {
       hipLaunchKernelGGL((k_unpack_admitted<float>), dim3(ugrid), dim3(256), 0, s, h->free_list,
                          (const long long*)&h->ctl->n_miss, scap, (const float*)h->in_stage, (float*)c.cache_weight,
                          h->rowlen, h->g_log2, h->ctl, (const unsigned long long*)(h->wb->sig_dev + 1),
-                         in_job, x.early ? 1 : 0, (const int32_t*)h->miss_list, c.cached_idx_map,
-                         c.inverted_cached_idx, h->ring_dev, x.seq_arg,
+                         in_job, (const int32_t*)h->miss_list,
                          L.list_cap > L.stage_rows ? (const float*)c.host_weight_dev : (const float*)nullptr);
     }
   } else if (c.transport == CE_TRANSPORT_ZEROCOPY) {
@@ -3368,22 +3501,18 @@ static int prepare_ids_second_half(ce_cache* h) {
     const long long scap = (long long)L.stage_rows;
     // rows in flight per lane group: 16 keeps a window-sized swap (50 k rows) on a small grid; a call of a few thousand
     // rows (B = 2048 shapes) would then fill only a handful of groups -- 4 spreads it (38 -> 21 us per call)
-    static const int swap_rows_env = [] { const char* e = getenv("CE_SWAP_ROWS"); return e ? atoi(e) : 0; }();
-    const int swap_rows = swap_rows_env > 0 ? swap_rows_env : (n <= 131072 ? 4 : kSwapRows);
+    const int swap_rows = n <= 131072 ? 4 : kSwapRows;
     // workgroups of the write-back part: as many as admit when the call has the GPU to itself; half as many when it
     // overlaps with training (protect_depth > 0) -- PCIe writes are what slows the kernels next to them, and fewer
     // rows leave than enter (32 + 16 workgroups: 2.11 -> 2.22 G lookups/s; 32 + 8 makes the write-back the bottleneck)
-    static const int wb_env = [] { const char* e = getenv("CE_SWAP_WB_BLOCKS"); return e ? atoi(e) : 0; }();
-    const int wb_groups = wb_env > 0 ? std::min(wb_env, cap_groups)
-                                     : (c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups);
+    const int wb_groups = c.protect_depth > 0 ? std::max(1, cap_groups / 2) : cap_groups;
 #define CE_SWAP(VT, R)                                                                                          \
   hipLaunchKernelGGL((k_swap<VT, R>), dim3(wb_groups + cap_groups), swap_block, 0, s, h->stage_idx,             \
                      (const VT*)h->stage, scap, wb_groups, h->miss_list, h->free_list,                           \
                      (const long long*)&h->ctl->n_miss,                                                          \
                      (VT*)c.host_weight_dev, (VT*)c.cache_weight, h->rowlen, h->g_log2, (const Ctl*)h->ctl)
     if (h->vec) {
-      if (swap_rows == 2) CE_SWAP(f32x4, 2); else if (swap_rows == 4) CE_SWAP(f32x4, 4);
-      else if (swap_rows == 8) CE_SWAP(f32x4, 8); else CE_SWAP(f32x4, 16);
+      if (swap_rows == 4) CE_SWAP(f32x4, 4); else CE_SWAP(f32x4, 16);
     } else {
       CE_SWAP(float, 16);
     }
@@ -3419,12 +3548,15 @@ static int prepare_ids_second_half(ce_cache* h) {
       }
     }
   }
-  if (x.early) {
-    if (prof) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);                  // end of "admit_swap"
-  } else {
-    rc = launch_maps_and_slots(h);
-    if (rc) return rc;
-  }
+  // map updates + publication of the call's record (the last kernel that can amend it; it also turns a LOST admission
+  // job of the host-gather worker into a failed call with nothing marked resident)
+  hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list, h->free_list,
+                     (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map, c.inverted_cached_idx,
+                     c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl, h->ring_dev,
+                     x.seq_arg, x.worker ? (const unsigned long long*)(h->wb->sig_dev + 1) : nullptr, x.in_job);
+  if (prof) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);      // end of "admit_swap"
+  rc = launch_slots_keys(h);
+  if (rc) return rc;
   if (prof) prof->pending[pslot] = true;
   CE_LAUNCH_CHECK();
   if (!capturing) CE_HIP_CHECK(hipEventRecord(h->ev, s));
@@ -3474,6 +3606,28 @@ extern "C" int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, in
 extern "C" int ce_cache_prepare_ids_begin_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                                  ce_stream_t stream) {
   return prepare_ids_impl(h, ids, n, slots_out, stream, 1, nullptr, 1);
+}
+
+extern "C" int ce_cache_set_deferred_rows(ce_cache_t* h, int32_t on) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  CE_REQUIRE(!h->pend.active, CE_ERR_INVALID, "a cache op begun with ce_cache_prepare_ids_begin has not been finished");
+  h->deferred_rows = on != 0;
+  if (h->wb) h->wb->deferred_rows = h->deferred_rows;
+  return CE_OK;
+}
+
+extern "C" int64_t ce_cache_rows_ticket(ce_cache_t* h) { return (h && h->wb && h->wb->chained) ? h->wb->chain_calls : 0; }
+
+extern "C" int ce_cache_wait_rows(ce_cache_t* h, int64_t ticket, ce_stream_t stream) {
+  CE_REQUIRE(h, CE_ERR_INVALID, "null handle");
+  if (!h->wb || !h->wb->chained || h->wb->chain_calls == 0) return CE_OK;
+  SwapEngine* const w = h->wb;
+  long long t = (ticket <= 0 || ticket > w->chain_calls) ? w->chain_calls : ticket;
+  // the ring holds the last kRowsRing calls' events; an older call's rows are implied by any younger call's (one
+  // stream moves them all, in order)
+  if (t <= w->chain_calls - SwapEngine::kRowsRing) t = w->chain_calls - SwapEngine::kRowsRing + 1;
+  CE_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, w->ev_rows[t % SwapEngine::kRowsRing], 0));
+  return CE_OK;
 }
 
 extern "C" int ce_cache_graph_replayed(ce_cache_t* h, int64_t n_calls, int64_t ids_per_call, ce_stream_t stream) {
@@ -3577,6 +3731,8 @@ extern "C" int ce_cache_flush(ce_cache_t* h, ce_stream_t stream) {
     rc = h->wb->wait_out(h->wb->out_issued);
     if (rc) return rc;
   }
+  rc = join_rows(h, s);
+  if (rc) return rc;
   h->seq += 1;
   h->free_zero = false;            // every slot is free again once this has run
   h->free_reset_seq = h->seq;
@@ -3621,6 +3777,8 @@ extern "C" int ce_cache_set_transport(ce_cache_t* h, int32_t transport) {
     if (rc == CE_OK) rc = h->wb->wait_in(h->wb->in_issued);
     if (rc) return rc;
     CE_HIP_CHECK(hipEventSynchronize(h->ev));
+    if (hipEvent_t ev = last_rows_event(h)) CE_HIP_CHECK(hipEventSynchronize(ev));
+    h->wb->probe_floor = h->wb->out_issued + 1;
   }
   h->cfg.transport = transport;
   if (transport == CE_TRANSPORT_WORKER) return ensure_writeback(h);

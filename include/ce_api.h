@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CE_API_VERSION 5
+#define CE_API_VERSION 6
 
 /* status codes */
 #define CE_OK 0
@@ -388,6 +388,23 @@ int ce_cache_prepare_ids_padded(ce_cache_t* h, const int64_t* ids, int64_t n, in
  * one-stream arrangement (parallel.GraphedShardedWindow(arrangement="interleaved")). */
 int ce_cache_prepare_ids_begin_padded(ce_cache_t* h, const int64_t* ids, int64_t n, int64_t* slots_out,
                                       ce_stream_t stream);
+
+/* Worker transport, chained admission (API 6; the default when the host table has a device mapping): the missed rows
+ * of a call travel on a private admission stream -- admission kernel behind the call's front, unpack kernel behind its
+ * victim selection -- while the call's own stream goes on with selection, maps and slots.  By default a prepare_ids
+ * call (or its _finish half) ENDS by making its stream wait for the rows, so "everything the call did is ordered
+ * before whatever the caller enqueues next on that stream" holds as for every other transport.
+ * A pipeline that issues the next cache op on the same stream before anything reads the cache (prefetch_num = 1 with
+ * the cache op on a side stream) can take that wait out of the cache-op stream's chain:
+ *   ce_cache_set_deferred_rows(h, 1)   calls no longer wait for their rows;
+ *   ce_cache_rows_ticket(h)            ticket of the most recent call (0: no chained call yet);
+ *   ce_cache_wait_rows(h, t, stream)   `stream` waits until the rows of call `t` (and of every call before it) are in
+ *                                      their slots -- before the first kernel that reads the cache rows of that call's
+ *                                      slots.  t <= 0: the most recent call.  A no-op for the other transports.
+ * ce_cache_flush / _preload / _last_stats / _set_transport order themselves behind the rows whatever the setting. */
+int ce_cache_set_deferred_rows(ce_cache_t* h, int32_t on);
+int64_t ce_cache_rows_ticket(ce_cache_t* h);
+int ce_cache_wait_rows(ce_cache_t* h, int64_t ticket, ce_stream_t stream);
 
 /* Blocks until the most recent prepare_ids/preload/flush has finished on the device and
  * returns that call's statistics; returns its status (CE_ERR_CAPACITY ...). */

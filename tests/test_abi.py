@@ -22,7 +22,7 @@ def test_build_and_load():
     g.build()
     import cachedembedding_amd as ce
     assert ce.LIB_PATH.exists()
-    assert ce._lib.lib.ce_version() == 5
+    assert ce._lib.lib.ce_version() == 6
 
 
 def test_library_on_disk_is_the_one_the_sources_describe():

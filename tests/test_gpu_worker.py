@@ -32,13 +32,16 @@ def _state_equal(mgr, ora, lfu):
     np.testing.assert_array_equal(mgr.cuda_cached_weight.detach().cpu().numpy(), ora.cuda_cached_weight)
 
 
-@pytest.mark.parametrize("admit", ["kernel", "kernel_early_maps", "sdma"])
+@pytest.mark.parametrize("admit", ["kernel", "kernel_deferred", "sdma"])
 @pytest.mark.parametrize("name,strategy", [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"),
                                            ("cache_lfu_freq", "lfu"), ("cache_lfu_nofreq", "lfu")])
 def test_golden_streams_worker(name, strategy, admit, monkeypatch):
+    """kernel: the chained admission (fused front / select kernels, admission + unpack on the admission stream);
+    kernel_deferred: the same with ce_cache_set_deferred_rows -- the call's stream does not wait for its rows, the test
+    does (wait_rows) before it touches the cache; sdma: host gather + staged copies behind a parked stream."""
     ce = _ce()
-    if admit == "kernel_early_maps":                  # maps + slots launched before the admission wait (read per call)
-        monkeypatch.setenv("CE_EARLY_MAPS", "1")
+    deferred = admit == "kernel_deferred"
+    if deferred:
         admit = "kernel"
     monkeypatch.setenv("CE_WORKER_ADMIT", admit)      # read when the manager's swap engine is created
     z = np.load(GOLD / f"{name}.npz")
@@ -47,8 +50,12 @@ def test_golden_streams_worker(name, strategy, admit, monkeypatch):
     mgr = ce.CachedParamMgr(torch.from_numpy(z["weight"].copy()), C, evict_strategy=_strat(ce, strategy))
     mgr.reorder(freq, warm / 1000.0)
     mgr.set_transport("worker")
+    if deferred:
+        mgr.set_deferred_rows(True)
     for c in range(calls):
         slots = mgr.prepare_ids(torch.from_numpy(z["ids"][c]).cuda())
+        if deferred:
+            mgr.wait_rows()
         assert np.array_equal(slots.cpu().numpy(), z["slots"][c])
         assert np.array_equal(mgr.cached_idx_map.cpu().numpy().astype(np.int64), z["cached_idx_map"][c])
         if strategy == "lfu":
@@ -76,7 +83,6 @@ def test_readmission_of_rows_still_in_flight(strategy, depth, N, C, D, per_call,
     monkeypatch.setenv("CE_WORKER_ADMIT", "kernel" if slow else admit)
     if slow:
         monkeypatch.setenv("CE_WORKER_OUT_DELAY_US", "2000")
-        monkeypatch.setenv("CE_EARLY_MAPS", "1" if depth else "0")      # (and the early-maps order in half of the cases)
     ce = _ce()
     from oracle.cache_oracle import DATASET, LFU, OracleCachedParamMgr
     rng = np.random.default_rng(N * 7 + C + depth)
@@ -327,20 +333,19 @@ def test_worker_transport_empty_and_ragged_calls(strategy):
     np.testing.assert_array_equal(mgr.weight.numpy(), ora.weight)
 
 
-@pytest.mark.parametrize("early", [False, True])
 @pytest.mark.parametrize("strict", [True, False])
-def test_a_failed_admission_releases_the_stream_and_admits_nothing(early, strict, monkeypatch):
-    """The admission worker reports a failed HIP call for job 3 (test hook CE_WORKER_FAIL_IN_JOB): the parked cache-op
-    stream must be released all the same (no hang), the call's record must say CE_ERR_HIP, every slot of the call is -1
-    (default order), NONE of the rows it missed may be resident afterwards (their payload never arrived: a later flush would write garbage
-    home) -- in both orders of the second half (maps after / before the wait: the early order takes its entries back) --
-    and the engine stays failed: the next call raises instead of training on a table that has lost rows."""
+def test_a_failed_admission_releases_the_stream_and_admits_nothing(strict, monkeypatch):
+    """Host-gather admission (CE_WORKER_ADMIT=sdma: the one form of the worker transport that still has a library
+    thread and a parked stream between a call's front and its rows).  The admission worker reports a failed HIP call
+    for job 3 (test hook CE_WORKER_FAIL_IN_JOB): the parked cache-op stream must be released all the same (no hang), the
+    call's record must say CE_ERR_HIP, every slot of the call is -1, NONE of the rows it missed may be resident
+    afterwards (their payload never arrived: a later flush would write garbage home), and the engine stays failed: the
+    next call raises instead of training on a table that has lost rows."""
     ce = _ce()
     from cachedembedding_amd import _lib
     from oracle.cache_oracle import DATASET, OracleCachedParamMgr
-    monkeypatch.setenv("CE_WORKER_ADMIT", "kernel")
+    monkeypatch.setenv("CE_WORKER_ADMIT", "sdma")
     monkeypatch.setenv("CE_WORKER_FAIL_IN_JOB", "3")
-    monkeypatch.setenv("CE_EARLY_MAPS", "1" if early else "0")
     rng = np.random.default_rng(17)
     N, C, D = 6000, 500, 64
     w = rng.standard_normal((N, D)).astype(np.float32)
@@ -367,10 +372,7 @@ def test_a_failed_admission_releases_the_stream_and_admits_nothing(early, strict
     else:
         slots = mgr.prepare_ids(torch.from_numpy(ids[2]).cuda())
         torch.cuda.synchronize()                                  # returns: the stream was released
-        if not early:
-            assert (slots.cpu().numpy() == -1).all()
-        # (the early order has handed the slots out BEFORE the wait: the missed ids point at slots that are free again
-        # once the entries have been taken back -- whatever a step reads or writes there is never written home)
+        assert (slots.cpu().numpy() == -1).all()
         with pytest.raises(_lib.CeError) as ei:
             mgr.raise_on_failed_calls()
         assert ei.value.code == _lib.CE_ERR_HIP
