@@ -133,6 +133,7 @@ class CachedParamMgr(torch.nn.Module):
         else:
             self.freq_cnter = None
         self._max_ids = 2 ** 31 - 2
+        self._deferred_rows = False
         self._handle = None
         self._workspace = None
         self._create_handle()
@@ -245,14 +246,17 @@ class CachedParamMgr(torch.nn.Module):
 
     # ------------------------------------------------------------------ A.3
     @torch.no_grad()
-    def prepare_ids(self, ids: torch.Tensor, out: Optional[torch.Tensor] = None, padded: bool = False) -> torch.Tensor:
+    def prepare_ids(self, ids: torch.Tensor, out: Optional[torch.Tensor] = None, padded: bool = False,
+                    defer_rows: bool = False) -> torch.Tensor:
         """`out` (int64, same numel, contiguous) lets a caller keep the slots in a static buffer, e.g. one
         a captured hipGraph reads (pipeline.GraphedWindow).  The buffer is SCRATCH for the whole cache op, not only
         written at its end (the call parks every id's row there first): no other stream may read it until the call has
         finished, and it must not alias `ids`.
         padded=True (ce_cache_prepare_ids_padded): entries of -1 are padding -- no lookup, slot -1 -- as the
         fixed-capacity row-wise exchange produces them.  Without it a -1 is a bad id like any other: IndexError under
-        strict=True, a failed call (raise_on_failed_calls) otherwise -- as upstream's idx_map.index_select raises."""
+        strict=True, a failed call (raise_on_failed_calls) otherwise -- as upstream's idx_map.index_select raises.
+        defer_rows (only after set_deferred_rows(True)): the current stream is NOT made to wait for the missed rows; the
+        caller does that with wait_rows(rows_ticket()) on the stream that first reads the cache."""
         assert ids.is_cuda, "ids must live on the GPU (recsys/dlrm_main.py:250 moves the batch first)"
         shape = ids.shape
         # (every tensor method below is microseconds of a prefetch_num = 1 step that the launch thread bounds: the common
@@ -270,6 +274,8 @@ class CachedParamMgr(torch.nn.Module):
         else:
             with torch.cuda.device(self.device):
                 check(fn(self._handle, ptr(flat), flat.numel(), ptr(slots), stream_ptr()))
+        if self._deferred_rows and not defer_rows:
+            self.wait_rows()
         self._strict_check()
         return slots if slots.shape == shape else slots.view(shape)
 
@@ -305,18 +311,21 @@ class CachedParamMgr(torch.nn.Module):
         return out
 
     @torch.no_grad()
-    def prepare_ids_finish(self) -> None:
+    def prepare_ids_finish(self, defer_rows: bool = False) -> None:
         if torch.cuda.current_device() == self.device.index:
             check(lib.ce_cache_prepare_ids_finish(self._handle, stream_ptr()))
         else:
             with torch.cuda.device(self.device):
                 check(lib.ce_cache_prepare_ids_finish(self._handle, stream_ptr()))
+        if self._deferred_rows and not defer_rows:
+            self.wait_rows()
         self._strict_check()
 
     @torch.no_grad()
     def prepare_ids_keys(self, ids: torch.Tensor, out: torch.Tensor, keys_out: Optional[torch.Tensor], *,
                          offsets: Optional[torch.Tensor] = None, include_last_offset: bool = False,
-                         hook_features: int = 0, identity_bags: bool = False, _begin_only: bool = False) -> torch.Tensor:
+                         hook_features: int = 0, identity_bags: bool = False, _begin_only: bool = False,
+                         defer_rows: bool = False) -> torch.Tensor:
         """prepare_ids for a prefetch window of P equal batches (ids [P, n] int64) that also leaves the window's keys in
         keys_out ([P, presort_len(n)] int64) -- functional.presort_window's keys, written by the cache op's last kernel
         together with the slots instead of by a launch of its own (ce_cache_prepare_ids_keys).  offsets given: source-row
@@ -350,6 +359,8 @@ class CachedParamMgr(torch.nn.Module):
             with torch.cuda.device(self.device):
                 check(fn(*args, stream_ptr()))
         if not _begin_only:
+            if self._deferred_rows and not defer_rows:
+                self.wait_rows()
             self._strict_check()
         return out
 
@@ -508,6 +519,7 @@ class CachedParamMgr(torch.nn.Module):
         with wait_rows() -- what a pipeline does that issues the next cache op on the same stream before anything trains
         on this one's slots (ce_cache_set_deferred_rows)."""
         check(lib.ce_cache_set_deferred_rows(self._handle, int(bool(on))))
+        self._deferred_rows = bool(on)
 
     def rows_ticket(self) -> int:
         """ticket of the most recent cache op for wait_rows (0: none yet / another transport)"""

@@ -95,12 +95,19 @@ struct WbMail {              // pinned host mailbox: how many rows a worker job 
 
 struct Layout {              // byte offsets inside the caller-provided workspace
   size_t ctl, bitmap, blk_unique, blk_miss, coarse, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      coop, miss_list2, free_list2, stage_idx, stage, stage_idx2, stage2, in_stage, total;
+      chain, lb_emit, lb_remap, miss_list2, free_list2, stage_idx, stage, stage_idx2, stage2, in_stage, total;
   int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
 
 constexpr int64_t kStageRowsMax = 262144;   // write-back staging: 128 MB at D = 128
-constexpr size_t kCoopBytes = 4096;         // struct Coop (ce_cache_fused.h; static_assert there)
+// Rows the admission kernel reads / the unpack kernel moves for the call of either parity: written by the call's
+// plan (k_emit / k_emit_scan) and by the kernel that knows whether the selection held (k_stage_remap / k_admit_maps).
+// The control block's own per-call fields are rewritten by the NEXT call's front while those two kernels may still be
+// running on the admission stream.
+struct ChainWords {
+  long long n_admit[2];
+  long long n_unpack[2];
+};
 
 static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   Layout L{};
@@ -122,9 +129,12 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
   L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
   L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
-  // chained admission (worker transport): the fused kernels' scratch, and a second miss / free list -- the admission
-  // and unpack kernels of call w read theirs on the admission stream while call w + 1's front fills the other pair
-  L.coop = o;       o = al(o + kCoopBytes);
+  // chained admission (worker transport): the row counts handed to the admission stream, the look-back words of the
+  // single-pass kernels (ce_cache_fused.h), and a second miss / free list -- the admission and unpack kernels of call w
+  // read theirs on the admission stream while call w + 1's front fills the other pair
+  L.chain = o;      o = al(o + sizeof(ChainWords));
+  L.lb_emit = o;    o = al(o + (size_t)(L.n_chunks + 1) * 8);
+  L.lb_remap = o;   o = al(o + (size_t)(cdiv(C, 4096) + 1) * 8);
   L.miss_list2 = o; o = al(o + (size_t)L.list_cap * 4);
   L.free_list2 = o; o = al(o + (size_t)L.list_cap * 4);
   L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
@@ -180,7 +190,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 // per-call reset: the control block's call fields, the coarse chunk sums k_count adds to, the radix histograms
 __global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_coarse2, uint32_t* hist,
                                                long long seq_arg) {
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     ctl->seq = seq_arg ? seq_arg : ctl->seq + 1;
     ctl->n_unique = 0;
     ctl->n_miss = 0;
@@ -194,10 +204,12 @@ __global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_
     ctl->lost = 0;
     ctl->n_free_start = ctl->n_free;
   }
+  // (a few workgroups: one of 256 threads spent 10 us on these 13-18 k stores -- a launch of the chain like any other)
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   if (coarse)
-    for (int i = threadIdx.x; i < n_coarse2; i += blockDim.x) coarse[i] = 0;
+    for (int i = tid; i < n_coarse2; i += nth) coarse[i] = 0;
   if (hist)
-    for (int i = threadIdx.x; i < kHistWords; i += blockDim.x) hist[i] = 0;
+    for (int i = tid; i < kHistWords; i += nth) hist[i] = 0;
 }
 
 // Bits of one bitmap word (32 consecutive rows from row0) whose row is not resident.  The frequency ranking packs
@@ -260,6 +272,43 @@ __device__ __forceinline__ uint32_t miss_mask_stamp(const int32_t* __restrict__ 
   return mm;
 }
 
+// The four words of one uint4 of the bitmap at once (k_emit_scan): the map entries of ALL sparse words are fetched in
+// one batch -- up to 20 loads in flight -- instead of word after word, bit after bit (a chain of up to 20 dependent
+// round trips in miss_mask_stamp's tail loop: 2-3 us each beside the training kernels); dense words take the 16-byte
+// path as before.
+__device__ __forceinline__ void miss_masks4_stamp(const int32_t* __restrict__ inverted, int64_t row0,
+                                                  const uint32_t (&wds)[4], int64_t N, int32_t* slot_epoch,
+                                                  int32_t epoch, uint32_t (&mm)[4]) {
+  int idx[4][5];
+  int32_t val[4][5];
+  bool dense[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    dense[k] = __popc(wds[k]) > 5;      // (miss_mask_stamp: sixteen-byte loads, or bit by bit in the table's last word)
+    uint32_t b = dense[k] ? 0u : wds[k];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      idx[k][j] = b ? __ffs(b) - 1 : -1;
+      b &= b - 1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) val[k][j] = idx[k][j] >= 0 ? inverted[row0 + 32 * k + idx[k][j]] : 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mm[k] = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (idx[k][j] < 0) continue;
+      if (val[k][j] < 0) mm[k] |= 1u << idx[k][j];
+      else slot_epoch[val[k][j]] = epoch;       // evict_backlist membership [A.3-3]
+    }
+    if (dense[k]) mm[k] = miss_mask_stamp(inverted, row0 + 32 * k, wds[k], N, slot_epoch, epoch);
+  }
+}
+
 // ids -> rows -> bits in the row bitmap.
 //
 // Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window sends >100k ids at
@@ -275,7 +324,7 @@ __device__ __forceinline__ uint32_t miss_mask_stamp(const int32_t* __restrict__ 
 // U ids per thread are in flight (a chain of three dependent random accesses per id).
 // rows_out: the row of every id (-1 = bad id), as int64 in the caller's slots buffer -- k_slots turns it into the
 // slot in place, so idx_map is gathered once per id per call.
-// The body of k_mark and of k_front's first phase: a grid-stride pass of the calling grid over the ids.  *cold += this
+// The body of k_mark: a grid-stride pass of the calling grid over the ids.  *cold += this
 // thread's lookups of rows that are not resident; *bad = it met an id outside [0, N) that is not accepted padding.
 template <bool MERGE, int U>
 __device__ __forceinline__ void mark_pass(const int64_t* __restrict__ ids, int64_t n,
@@ -356,9 +405,20 @@ __device__ __forceinline__ void mark_pass(const int64_t* __restrict__ ids, int64
     }
   }
   __syncthreads();
-  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) {
-    const uint32_t v = hot[w];
-    if (v && ((*(volatile uint32_t*)(bitmap + w)) & v) != v) atomicOr(bitmap + w, v);
+  // the window goes out with all of a thread's looks at the bitmap in flight together (one word after the other was up
+  // to 16 dependent round trips: half of this kernel's time at 426 k ids)
+  for (int w0 = threadIdx.x; w0 < hot_words; w0 += (int)blockDim.x * 8) {
+    uint32_t v[8], cur[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int w = w0 + q * (int)blockDim.x;
+      v[q] = w < hot_words ? hot[w] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cur[q] = v[q] ? *(volatile uint32_t*)(bitmap + w0 + q * (int)blockDim.x) : ~0u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (v[q] && (cur[q] & v[q]) != v[q]) atomicOr(bitmap + w0 + q * (int)blockDim.x, v[q]);
   }
   *cold_out += cold;
   *bad_out = *bad_out || bad;
@@ -426,7 +486,7 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
                                               int n_chunks, int32_t* miss_list, int32_t* slot_epoch, long long seq_arg,
                                               Ctl* ctl, int64_t C, int64_t n_ids, ce_call_stats_t* ring,
                                               WbMail* mail_in, long long job, long long in_cap, int32_t* miss_host,
-                                              int assume_free0) {
+                                              int assume_free0, long long* n_admit_out = nullptr) {
   const long long seq_ = call_seq(ctl, seq_arg);
   const int32_t epoch = call_epoch(seq_);
   ce_call_stats_t* const ring_slot = ring + (seq_ % kRing);
@@ -512,6 +572,10 @@ __global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __r
       mail_in->count = mrows < in_cap ? mrows : in_cap;
       mail_in->job = job;
     }
+    if (n_admit_out) {  // chained admission: the same count, for the admission kernel behind this kernel's event
+      const long long mrows = (status == CE_OK) ? tm : 0;
+      *n_admit_out = mrows < in_cap ? mrows : in_cap;
+    }
     // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
     // record (k_victims can turn it into a capacity failure): k_admit_maps
   }
@@ -581,23 +645,38 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
   const int key_bits = (top_pass + 1) * kDigitBits;
   const unsigned long long fmax = (1ull << ((key_bits < 63 ? key_bits : 63) - slot_bits)) - 1;
   int elig = 0;
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
-    const int32_t row = cached_idx_map[s];
-    const bool prot = (epoch - slot_epoch[s]) <= depth;
-    unsigned long long key = ~0ull;
-    if (row >= 0 && !prot) {
-      if (lfu) {
-        long long f = freq[s];
-        unsigned long long uf = f < 0 ? 0ull : (unsigned long long)f;
-        if (uf > fmax) uf = fmax;
-        key = (uf << slot_bits) | (unsigned long long)s;
-      } else {
-        key = (unsigned long long)(N - 1 - row);
-      }
-      ++elig;
+  // four slots per thread in flight (one after the other, a thread of the 512-workgroup grid walked 13 slots of a
+  // 1.7 M-slot cache in 13 dependent round trips)
+  constexpr int UK = 4;
+  for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < C; s0 += stride * UK) {
+    int32_t row[UK], ep[UK];
+    long long fr[UK];
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int64_t s = s0 + (int64_t)u * stride;
+      row[u] = s < C ? cached_idx_map[s] : -1;
+      ep[u] = s < C ? slot_epoch[s] : 0;
+      fr[u] = (lfu && s < C) ? freq[s] : 0;
     }
-    keys[s] = key;
-    atomicAdd(&sh[(key >> shift) & (kBins - 1)], 1u);
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int64_t s = s0 + (int64_t)u * stride;
+      if (s >= C) continue;
+      const bool prot = (epoch - ep[u]) <= depth;
+      unsigned long long key = ~0ull;
+      if (row[u] >= 0 && !prot) {
+        if (lfu) {
+          unsigned long long uf = fr[u] < 0 ? 0ull : (unsigned long long)fr[u];
+          if (uf > fmax) uf = fmax;
+          key = (uf << slot_bits) | (unsigned long long)s;
+        } else {
+          key = (unsigned long long)(N - 1 - row[u]);
+        }
+        ++elig;
+      }
+      keys[s] = key;
+      atomicAdd(&sh[(key >> shift) & (kBins - 1)], 1u);
+    }
   }
   // evictable slots are counted here, not read off the top-digit histogram: a DATASET key N-1-row can share its
   // top digit with the all-ones key of an ineligible slot.
@@ -2185,7 +2264,9 @@ struct ce_cache {
   int32_t *blk_unique, *blk_miss, *coarse, *miss_list, *slot_epoch, *victims, *blk_free, *free_list;
   int32_t* miss_list_b[2];     // [0] = miss_list, [1] = the second pair (chained admission: by call parity)
   int32_t* free_list_b[2];
-  ce::Coop* coop;              // scratch of the fused kernels
+  ce::ChainWords* chain;       // row counts for the admission stream
+  unsigned long long *lb_emit, *lb_remap;      // look-back words (ce_cache_fused.h)
+  unsigned lb_tag;             // calls that used them (every such call rewrites every word under its own tag)
   unsigned long long* keys;
   uint32_t* hist;
   ce_call_stats_t* ring;       // pinned host
@@ -2265,29 +2346,6 @@ struct ce_cache {
 using namespace ce;
 
 static int ensure_writeback(ce_cache* h);
-
-// ---- cooperative launches of one process are serialised when more than one manager is alive: every fused kernel
-// waits at grid barriers for ALL its workgroups, so two of them must never each hold a part of the chip the other
-// one needs.  One is a quarter of the resident capacity at most (ce_cache_fused.h), so two or three managers could
-// not starve each other anyway; the chain makes it independent of their number.
-static std::mutex g_coop_m;
-static int g_managers = 0;
-static hipEvent_t g_coop_ev = nullptr;
-static hipStream_t g_coop_stream = nullptr;
-static bool g_coop_recorded = false;
-static void coop_before(hipStream_t s) {
-  std::lock_guard<std::mutex> g(g_coop_m);
-  if (g_managers > 1 && g_coop_recorded && g_coop_stream != s) (void)hipStreamWaitEvent(s, g_coop_ev, 0);
-}
-static void coop_after(hipStream_t s) {
-  std::lock_guard<std::mutex> g(g_coop_m);
-  if (g_managers <= 1) return;
-  if (!g_coop_ev && hipEventCreateWithFlags(&g_coop_ev, hipEventDisableTiming) != hipSuccess) return;
-  if (hipEventRecord(g_coop_ev, s) == hipSuccess) {
-    g_coop_stream = s;
-    g_coop_recorded = true;
-  }
-}
 
 static void drain(ce_cache* h) {
   while (h->drained < h->seq) {
@@ -2391,7 +2449,10 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->miss_list_b[1] = (int32_t*)(h->ws + L.miss_list2);
   h->free_list_b[0] = h->free_list;
   h->free_list_b[1] = (int32_t*)(h->ws + L.free_list2);
-  h->coop = (Coop*)(h->ws + L.coop);
+  h->chain = (ChainWords*)(h->ws + L.chain);
+  h->lb_emit = (unsigned long long*)(h->ws + L.lb_emit);
+  h->lb_remap = (unsigned long long*)(h->ws + L.lb_remap);
+  h->lb_tag = 0;
   h->seq = h->drained = 0;
   h->cpu_to_cuda_numel = h->cuda_to_cpu_numel = h->cache_miss = h->total_cache = 0;
   const int D = cfg->embedding_dim;
@@ -2482,20 +2543,12 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
       return rc;
     }
   }
-  {
-    std::lock_guard<std::mutex> g(g_coop_m);
-    g_managers += 1;
-  }
   *out = h;
   return CE_OK;
 }
 
 extern "C" int ce_cache_destroy(ce_cache_t* h) {
   if (!h) return CE_OK;
-  {
-    std::lock_guard<std::mutex> g(g_coop_m);
-    g_managers -= 1;
-  }
   (void)hipEventSynchronize(h->ev);
   if (h->wb && h->wb->in_stream) (void)hipStreamSynchronize(h->wb->in_stream);
   delete h->wb;          // finishes the queued jobs, joins the workers
@@ -2930,7 +2983,7 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
   // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs.  What works per launch: every
   // workgroup of pass p recomputes the digits of the level above it from that level's histogram in its prologue --
-  // select_level -- so there is no pick kernel at all; the fused form is k_select, ce_cache_fused.h)
+  // select_level -- so there is no pick kernel at all)
   for (int pass = top_pass - 1; pass >= 0; --pass)
     hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
   hipLaunchKernelGGL(k_victims, dim3((unsigned)n_vblocks), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
@@ -3018,98 +3071,41 @@ static MarkCfg mark_cfg(const ce_cache* h, int64_t n) {
   return m;
 }
 
-// workgroups of the fused kernels: enough to keep the memory system busy for the call's size, never more than
-// kCoopMaxG (residency: ce_cache_fused.h)
-static int front_grid(const ce_cache* h, int64_t n) {
-  static const int env = [] { const char* e = getenv("CE_FRONT_GRID"); return e ? atoi(e) : 0; }();
-  if (env > 0) return std::min(env, kCoopMaxG);
-  const int64_t by_ids = cdiv(n, 8192), by_rows = cdiv(h->L.n_chunks, 16);
-  return (int)std::max<int64_t>(8, std::min<int64_t>(kCoopMaxG, std::max(by_ids, by_rows)));
-}
-static int select_grid(const ce_cache* h) {
-  static const int env = [] { const char* e = getenv("CE_SELECT_GRID"); return e ? atoi(e) : 0; }();
-  if (env > 0) return std::min(env, kCoopMaxG);
-  return (int)std::max<int64_t>(8, std::min<int64_t>(kCoopMaxG, cdiv(h->cfg.cuda_row_num, 16384)));
-}
+// calls the single-pass kernels take (ce_cache_fused.h): their look-back words hold 23-bit counts, and k_emit_scan
+// needs "unique rows <= cache rows" before it has counted them
+constexpr int64_t kScanMaxIds = (1 << 23) - 1;
 
-static void launch_front(ce_cache* h, const int64_t* ids, int64_t n, int64_t* slots_out, hipStream_t s, int allow_pad,
-                         bool steady, int parity, long long seq_arg) {
+// front of a cache op: reset, ids -> bitmap, then the ascending list of the missing rows + the plan
+static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int64_t* slots_out, hipStream_t s,
+                                 int allow_pad, bool steady, long long seq_arg, int32_t* miss_list, WbMail* mail_in,
+                                 long long in_job, int32_t* miss_host, long long* n_admit_out, bool single_pass_ok) {
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
-  const MarkCfg mc = mark_cfg(h, n);
-  FrontArgs a;
-  a.ids = ids;
-  a.n = n;
-  a.idx_map = c.idx_map;
-  a.inverted = c.inverted_cached_idx;
-  a.N = c.num_embeddings;
-  a.C = c.cuda_row_num;
-  a.word_bits = h->word_bits;
-  a.hot_words = mc.hot_words;
-  a.bitmap = h->bitmap;
-  a.n_vec = L.n_chunks * (kChunkRows / 128);
-  a.ctl = h->ctl;
-  a.coop = h->coop;
-  a.rows_out = slots_out;
-  a.allow_pad = allow_pad;
-  a.assume_free0 = steady ? 1 : 0;
-  a.parity = parity;
-  a.miss_list = h->miss_list_b[parity];
-  a.slot_epoch = h->slot_epoch;
-  a.hist = h->hist;
-  a.seq_arg = seq_arg;
-  a.in_cap = (long long)L.stage_rows;
-  a.ring = h->ring_dev;
-  const dim3 grid(front_grid(h, n)), block(kCoopThreads);
-  const size_t lds = (size_t)mc.hot_words * 4;
-  coop_before(s);
-  if (mc.merge) {
-    if (mc.u == 4) hipLaunchKernelGGL((k_front<true, 4>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_front<true, 1>), grid, block, lds, s, a);
-  } else {
-    if (mc.u == 4) hipLaunchKernelGGL((k_front<false, 4>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_front<false, 1>), grid, block, lds, s, a);
+  const int64_t N = c.num_embeddings, C = c.cuda_row_num;
+  hipLaunchKernelGGL(k_begin, dim3(16), dim3(256), 0, s, h->ctl, h->coarse,
+                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist, seq_arg);
+  if (n > 0) {
+    const MarkCfg mc = mark_cfg(h, n);
+    const dim3 mg(mc.blocks), mb(mc.threads);
+#define CE_MARK(M, U_)                                                                                             \
+  hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, mc.hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
+                     h->word_bits, mc.hot_words, h->bitmap, h->ctl, slots_out, allow_pad)
+    if (mc.merge) { if (mc.u == 4) CE_MARK(true, 4); else CE_MARK(true, 1); }
+    else { if (mc.u == 4) CE_MARK(false, 4); else CE_MARK(false, 1); }
+#undef CE_MARK
   }
-  coop_after(s);
-}
-
-static void launch_select(ce_cache* h, int64_t n, hipStream_t s, int parity, long long seq_arg, long long out_job, int wbuf) {
-  const ce_cache_config_t& c = h->cfg;
-  const Layout& L = h->L;
-  SelectArgs a;
-  a.cached_idx_map = c.cached_idx_map;
-  a.inverted = c.inverted_cached_idx;
-  a.freq = c.freq_cnter;
-  a.slot_epoch = h->slot_epoch;
-  a.C = c.cuda_row_num;
-  a.N = c.num_embeddings;
-  a.seq_arg = seq_arg;
-  a.depth = c.protect_depth;
-  a.slot_bits = h->slot_bits;
-  a.lfu = c.evict_strategy == CE_EVICT_LFU;
-  a.top_pass = select_top_pass(h, n, false);
-  a.parity = parity;
-  a.keys = h->keys;
-  a.hist = h->hist;
-  a.ctl = h->ctl;
-  a.coop = h->coop;
-  a.free_list = h->free_list_b[parity];
-  a.miss_list = h->miss_list_b[parity];
-  a.ring = h->ring_dev;
-  a.cache = c.cache_weight;
-  a.stage = wbuf ? h->stage2 : h->stage;
-  a.stage_rows_idx = wbuf ? h->stage_idx2 : h->stage_idx;
-  a.scap = (long long)L.stage_rows;
-  a.rowlen = h->rowlen;
-  a.g_log2 = h->g_log2;
-  a.vec = h->vec;
-  a.mail = h->wb->mail_dev + wbuf;
-  a.job = out_job;
-  a.evt = EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask};
-  a.host_overflow = L.list_cap > L.stage_rows ? (void*)c.host_weight_dev : nullptr;
-  coop_before(s);
-  hipLaunchKernelGGL(k_select, dim3(select_grid(h)), dim3(kCoopThreads), 0, s, a);
-  coop_after(s);
+  if (single_pass_ok && !mail_in && !miss_host && n <= C && n <= kScanMaxIds) {      // (the host gather reads k_emit's mailbox)
+    h->lb_tag = (h->lb_tag + 1) & 0xffffu;
+    hipLaunchKernelGGL(k_emit_scan, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx,
+                       N, (int)L.n_chunks, h->lb_emit, h->lb_tag, miss_list, h->slot_epoch, seq_arg, h->ctl, n,
+                       h->ring_dev, (long long)L.stage_rows, steady ? 1 : 0, n_admit_out);
+    return;
+  }
+  hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
+                     c.inverted_cached_idx, N, h->blk_unique, h->blk_miss, h->coarse);
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)cdiv(L.n_chunks, kEmitSub)), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
+                     h->blk_miss, h->coarse, (int)L.n_chunks, miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, h->ring_dev,
+                     mail_in, in_job, (long long)L.stage_rows, miss_host, steady ? 1 : 0, n_admit_out);
 }
 
 static int prepare_ids_second_half(ce_cache* h);
@@ -3140,7 +3136,8 @@ static int chained_first_half(ce_cache* h, const int64_t* ids, int64_t n, int64_
     prof->chained[pslot] = true;
     (void)hipEventRecord(prof->ev[pslot][pmark++], s);
   }
-  launch_front(h, ids, n, slots_out, s, allow_pad, steady, parity, seq_arg);
+  launch_front_kernels(h, ids, n, slots_out, s, allow_pad, steady, seq_arg, h->miss_list_b[parity], (WbMail*)nullptr, 0ll,
+                       (int32_t*)nullptr, &h->chain->n_admit[parity], true);
   CE_HIP_CHECK(hipEventRecord(w->ev_miss[parity], s));
   CE_HIP_CHECK(hipStreamWaitEvent(w->in_stream, w->ev_miss[parity], 0));
   if (prof) (void)hipEventRecord(prof->adm0[pslot], w->in_stream);
@@ -3151,9 +3148,18 @@ static int chained_first_half(ce_cache* h, const int64_t* ids, int64_t n, int64_
     const int blocks = n <= 600000 ? 32 : 20;
     const long long prev = out_job - 1;                      // the write-back job whose rows may still be on their way
     const int pb = (int)(prev & 1);
-    const bool has_prev = prev >= w->probe_floor;
+    // rows the previous call evicted come out of that job's staging buffer only while the job has not landed (the
+    // look-up costs every row of the admission a dependent round trip before its PCIe read can start)
+    bool landed;
+    {
+      std::lock_guard<std::mutex> g(w->m);
+      landed = w->out_done >= prev;
+      w->in_jobs += 1;
+      if (!landed) w->in_probed += 1;
+    }
+    const bool has_prev = prev >= w->probe_floor && !landed;
     const unsigned long long* ek = has_prev ? h->evt_keys[pb] : nullptr;
-    const long long* n_ptr = &h->coop->n_admit[parity];
+    const long long* n_ptr = &h->chain->n_admit[parity];
     if (h->vec)
       hipLaunchKernelGGL((k_admit_probe<f32x4>), dim3(blocks), dim3(1024), 0, w->in_stream, h->miss_list_b[parity], n_ptr,
                          (const f32x4*)h->cfg.host_weight_dev, (f32x4*)h->in_stage, h->rowlen, h->g_log2, ek,
@@ -3164,9 +3170,6 @@ static int chained_first_half(ce_cache* h, const int64_t* ids, int64_t n, int64_
                          (const float*)h->cfg.host_weight_dev, (float*)h->in_stage, h->rowlen, h->g_log2, ek,
                          (const int32_t*)h->evt_pos[pb], h->evt_mask, (uint32_t)prev,
                          (const float*)(pb ? h->stage2 : h->stage));
-    std::lock_guard<std::mutex> g(w->m);
-    w->in_jobs += 1;
-    if (w->out_done < prev) w->in_probed += 1;
   }
   if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s);
   ce_cache::Pending& x = h->pend;
@@ -3210,23 +3213,69 @@ static int chained_second_half(ce_cache* h) {
   // lists come up for reuse with the next front: this call's selection goes behind the previous call's rows.
   if (call > 1) CE_HIP_CHECK(hipStreamWaitEvent(s, w->ev_rows[(call - 1) % SwapEngine::kRowsRing], 0));
   hipEvent_t sel_done = w->out_ev[wbuf];
-  if (x.sel_steady) {
-    launch_select(h, x.sel_n, s, parity, x.seq_arg, out_job, wbuf);
+  if (x.sel_steady && x.sel_n <= kScanMaxIds) {
+    // a full cache: keys, the histogram passes, the victims ranked into the ascending free-slot list, then ONE kernel
+    // for staging + both maps
+    const int64_t N = c.num_embeddings, C = c.cuda_row_num;
+    const int lfu = c.evict_strategy == CE_EVICT_LFU;
+    const int top_pass = select_top_pass(h, x.sel_n, false);
+    hipLaunchKernelGGL(k_keys, dim3(std::min(grid_for(C, 256 * 4), 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter,
+                       h->slot_epoch, C, N, x.seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
+    const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
+    for (int pass = top_pass - 1; pass >= 0; --pass)
+      hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
+    if (prof) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);
+    StageArgs a;
+    a.cached_idx_map = c.cached_idx_map;
+    a.inverted = c.inverted_cached_idx;
+    a.freq = c.freq_cnter;
+    a.slot_epoch = h->slot_epoch;
+    a.C = C;
+    a.seq_arg = x.seq_arg;
+    a.top_pass = top_pass;
+    a.keys = h->keys;
+    a.hist = h->hist;
+    a.ctl = h->ctl;
+    a.lb = h->lb_remap;
+    h->lb_tag = (h->lb_tag + 1) & 0xffffu;
+    a.tag = h->lb_tag;
+    a.free_list = h->free_list_b[parity];
+    a.miss_list = h->miss_list_b[parity];
+    a.ring = h->ring_dev;
+    a.n_unpack_out = &h->chain->n_unpack[parity];
+    a.cache = c.cache_weight;
+    a.stage = wbuf ? h->stage2 : h->stage;
+    a.stage_rows_idx = wbuf ? h->stage_idx2 : h->stage_idx;
+    a.scap = (long long)L.stage_rows;
+    a.rowlen = h->rowlen;
+    a.g_log2 = h->g_log2;
+    a.vec = h->vec;
+    a.mail = w->mail_dev + wbuf;
+    a.job = out_job;
+    a.evt = EvTable{h->evt_keys[wbuf], h->evt_pos[wbuf], h->evt_mask};
+    a.host_overflow = L.list_cap > L.stage_rows ? (void*)c.host_weight_dev : nullptr;
+    hipLaunchKernelGGL(k_rank_victims, dim3((unsigned)cdiv(C, kRemapSlots)), dim3(256), 0, s, a);
+    {
+      const int gpb = 256 >> h->g_log2;
+      const int sgrid = (int)std::min<int64_t>(x.sel_n <= 600000 ? 256 : 512,
+                                               std::max<int64_t>(1, cdiv(L.stage_rows, gpb * kStageRowsInFlight)));
+      hipLaunchKernelGGL(k_stage_maps, dim3(sgrid), dim3(256), 0, s, a);
+    }
     CE_HIP_CHECK(hipEventRecord(w->out_ev[wbuf], s));
     w->push_out();
     if (prof)
-      for (int j = 0; j < 3; ++j) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);      // (staging, free list: inside)
+      for (int j = 0; j < 2; ++j) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);      // (free list: inside)
   } else {
     // the cache still has free slots (warm-up): the per-phase kernels, then the maps -- before the rows, which they
     // do not need -- with the count the unpack kernel moves
-    SelArgs sel{s, x.sel_n, true, false, false, out_job, x.seq_arg, wbuf, x.sel_n_vblocks, pslot, x.prof,
+    SelArgs sel{s, x.sel_n, true, false, x.sel_steady, out_job, x.seq_arg, wbuf, x.sel_n_vblocks, pslot, x.prof,
                 h->free_list_b[parity]};
     int rc0 = select_and_stage(h, sel, &x.pmark);
     if (rc0) return rc0;
     hipLaunchKernelGGL(k_admit_maps, dim3(grid_for(L.list_cap, 256)), dim3(256), 0, s, h->miss_list_b[parity],
                        h->free_list_b[parity], (const long long*)&h->ctl->n_miss, 0ll, c.cached_idx_map,
                        c.inverted_cached_idx, c.freq_cnter, (const int64_t*)nullptr, h->slot_epoch, 0, h->ctl,
-                       h->ring_dev, x.seq_arg, (const unsigned long long*)nullptr, 0ll, &h->coop->n_unpack[parity]);
+                       h->ring_dev, x.seq_arg, (const unsigned long long*)nullptr, 0ll, &h->chain->n_unpack[parity]);
     CE_HIP_CHECK(hipEventRecord(w->ev_miss[parity], s));
     sel_done = w->ev_miss[parity];
   }
@@ -3240,7 +3289,7 @@ static int chained_second_half(ce_cache* h) {
     const bool tail_possible = L.list_cap > L.stage_rows;
     if (h->vec)
       hipLaunchKernelGGL((k_unpack_chained<f32x4>), dim3(ugrid), dim3(256), 0, w->in_stream, h->free_list_b[parity],
-                         (const long long*)&h->coop->n_unpack[parity], (long long)L.stage_rows,
+                         (const long long*)&h->chain->n_unpack[parity], (long long)L.stage_rows,
                          (const f32x4*)h->in_stage, (f32x4*)c.cache_weight, h->rowlen, h->g_log2,
                          (const int32_t*)h->miss_list_b[parity],
                          tail_possible ? (const f32x4*)c.host_weight_dev : (const f32x4*)nullptr, ek,
@@ -3248,7 +3297,7 @@ static int chained_second_half(ce_cache* h) {
                          (const f32x4*)(pb ? h->stage2 : h->stage));
     else
       hipLaunchKernelGGL((k_unpack_chained<float>), dim3(ugrid), dim3(256), 0, w->in_stream, h->free_list_b[parity],
-                         (const long long*)&h->coop->n_unpack[parity], (long long)L.stage_rows,
+                         (const long long*)&h->chain->n_unpack[parity], (long long)L.stage_rows,
                          (const float*)h->in_stage, (float*)c.cache_weight, h->rowlen, h->g_log2,
                          (const int32_t*)h->miss_list_b[parity],
                          tail_possible ? (const float*)c.host_weight_dev : (const float*)nullptr, ek,
@@ -3359,24 +3408,10 @@ static int prepare_ids_impl(ce_cache_t* h, const int64_t* ids, int64_t n, int64_
   if (prof) prof->collect(pslot);
 #define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   CE_PHASE();
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, s, h->ctl, h->coarse,
-                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist, seq_arg);
-  if (n > 0) {
-    const MarkCfg mc = mark_cfg(h, n);
-    const dim3 mg(mc.blocks), mb(mc.threads);
-#define CE_MARK(M, U_)                                                                                             \
-  hipLaunchKernelGGL((k_mark<M, U_>), mg, mb, mc.hot_words * 4, s, ids, n, c.idx_map, c.inverted_cached_idx, N,    \
-                     h->word_bits, mc.hot_words, h->bitmap, h->ctl, slots_out, allow_pad)
-    if (mc.merge) { if (mc.u == 4) CE_MARK(true, 4); else CE_MARK(true, 1); }
-    else { if (mc.u == 4) CE_MARK(false, 4); else CE_MARK(false, 1); }
-#undef CE_MARK
-  }
-  hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
-                     c.inverted_cached_idx, N, h->blk_unique, h->blk_miss, h->coarse);
-  hipLaunchKernelGGL(k_emit, dim3((unsigned)cdiv(L.n_chunks, kEmitSub)), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx, N,
-                     h->blk_miss, h->coarse, (int)L.n_chunks, h->miss_list, h->slot_epoch, seq_arg, h->ctl, C, n, ring,
-                     worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job, (long long)L.stage_rows,
-                     worker ? h->wb->miss_host_dev : (int32_t*)nullptr, steady ? 1 : 0);
+  // (a captured call keeps the two-pass front: its look-back tag would be frozen into the graph)
+  launch_front_kernels(h, ids, n, slots_out, s, allow_pad, steady, seq_arg, h->miss_list,
+                       worker ? h->wb->mail_dev + 2 : (WbMail*)nullptr, in_job,
+                       worker ? h->wb->miss_host_dev : (int32_t*)nullptr, (long long*)nullptr, !capturing);
   // the admission worker starts gathering the missed rows (host table -> pinned staging -> in_stage) right behind
   // k_emit; it first lets every earlier write-back land
   if (worker) {

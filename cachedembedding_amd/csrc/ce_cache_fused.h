@@ -1,271 +1,187 @@
-// Fused forms of the cache op's index kernels (round 6).  Included by ce_cache.hip behind the per-phase kernels it
-// re-uses helpers from (miss_mask, miss_mask_stamp, mark_pass, select_digit, EvTable, copy_row).
+// Merged forms of the cache op's index kernels (round 6).  Included by ce_cache.hip behind the per-phase kernels whose
+// helpers they use (miss masks, select_level, EvTable, copy_row).
 //
 // One prepare_ids used to be 11-13 dependent launches (reference: one torch op + a device sync per phase,
 // recsys/dlrm_main.py:259 -> upstream CachedParamMgr.prepare_ids).  At prefetch_num = 1 and in the
-// reference's own micro-benchmark shape (benchmark/benchmark_cache.py:58-72) every one of those launches is a few
-// microseconds of work behind a 5-12 us dependent boundary, and the chain -- not the bag kernels -- is the step.  Here
-// the phases that only depend on each other through grid-wide sums run as ONE launch each, the boundaries replaced by
-// a grid barrier between co-resident workgroups:
+// reference's own micro-benchmark shape (benchmark/benchmark_cache.py:58-72) the chain -- not the bag kernels -- is
+// the step, and what a kernel of the chain costs there is its number of DEPENDENT memory round trips (2-3 us each
+// beside the training kernels), not its bytes.  Two merges take round trips out without putting anything in:
 //
-//   k_front    ctl reset | mark ids -> bitmap | count unique / missing per workgroup range | plan + ordered emission
-//              of the missing rows + epoch stamps + bitmap clear                                     (2 barriers)
-//   k_select   keys + top digit | (levels - 1) x histogram pass | victim counts | ascending victim list = the free
-//              slots of a full cache, victims staged, BOTH maps rewritten for the rows that take their slots, the
-//              call's record published                                                          (levels + 1 barriers)
+//   k_emit_scan     count + emit in ONE pass over the bitmap and the map entries of the rows seen: a workgroup's place
+//                   in the miss list is the number of missing rows in the chunks before it -- single-pass scan with
+//                   decoupled look-back (every workgroup publishes its count in a tagged 64-bit word and adds up its
+//                   predecessors' words), so there is no count kernel and no second gather of the map.  Needs the
+//                   call's verdict before the first stamp, i.e. "unique rows <= cache rows" known up front: calls of at
+//                   most cuda_row_num ids (prefetch_num 1-2; a window of 8 batches takes k_count + k_emit).
+//   k_rank_victims  for a FULL cache (the call evicts exactly as many rows as it misses and the slots to fill are its
+//   k_stage_maps    victims): victims per 4096-slot block counted and ranked by the same look-back, written as the
+//                   ascending free-slot list; then, over that list, their rows staged for the write-back AND both maps
+//                   rewritten for the rows that take their slots -- k_victims + k_evict_stage + its free-list
+//                   workgroups + k_admit_maps in two launches, no returning atomic.
 //
-// Residency: <= kCoopMaxG workgroups of 1024 threads, <= 64 VGPRs and <= 48 KB of LDS each, i.e. two fit a CU and a
-// grid is at most a quarter of the chip's resident capacity -- whatever else runs (the bag kernels' workgroups
-// retire by themselves) all workgroups of a launch become resident, and up to four such launches (other managers,
-// other processes sharing the GPU) can wait for each other's barriers at once without starving one another.  The
-// barrier's spin is bounded all the same: a grid that never becomes resident traps instead of hanging the device.
+// (Tried first and measured slower, alone and beside training: the same phases as ONE launch each with a grid barrier
+// between co-resident workgroups -- begin + mark + count + emit 107 us against 69 for the four launches, keys + passes
+// + victims + staging 244 against 87 at Kaggle 5 %: a software barrier costs a release (the XCD's L2 written back), a
+// returning atomic, a poll and an acquire -- two kernel boundaries' worth -- and the few fat workgroups that can be
+// co-resident keep fewer loads in flight than the launch-sized grids.  docs/history.md.)
 #pragma once
 
 namespace ce {
 
-constexpr int kCoopMaxG = 128;
-constexpr int kCoopThreads = 1024;
-constexpr unsigned long long kBarrierTimeoutTicks = 400000000ull;      // wall_clock64 runs at 100 MHz: 4 s
-
-// device scratch of the fused kernels, one per manager; the barrier words and the hand-over counts on lines of their own
-struct Coop {
-  unsigned bar_count;
-  unsigned pad0[31];
-  unsigned bar_gen;
-  unsigned pad1[31];
-  // rows the admission kernel reads / the unpack kernel moves for the call of either parity: written by the plan
-  // (k_front) and by the kernel that knows whether the selection held (k_select / k_admit_maps); the control block's
-  // own per-call fields are rewritten by the NEXT call's front while these two kernels may still be running
-  long long n_admit[2];
-  long long n_unpack[2];
-  long long pad2[12];
-  // per-workgroup partial sums (the grid-wide totals every workgroup adds up for itself behind a barrier)
-  int32_t part_unique[kCoopMaxG];
-  int32_t part_miss[kCoopMaxG];
-  int32_t part_cold[kCoopMaxG];
-  int32_t part_bad[kCoopMaxG];
-  int32_t part_elig[kCoopMaxG];
-  int32_t part_vic[kCoopMaxG];
-};
-static_assert(sizeof(Coop) <= kCoopBytes, "Coop must fit the workspace region make_layout reserves for it");
-
-// Grid barrier between the co-resident workgroups of one launch: arrival counter + generation word; the last arriver
-// resets the counter and bumps the generation (self-resetting: no per-launch base, so a launch needs no argument that
-// depends on the launches before it).  Release by the arriving lane before its arrival (its workgroup's stores leave
-// the XCD's L2), acquire after the generation moved (this CU's L1 dropped); the poll itself is a relaxed agent-scope
-// load (an acquire per poll would invalidate the L1 of every waiting CU per iteration).
-__device__ __forceinline__ void grid_sync(Coop* co, unsigned nblocks) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned gen = __hip_atomic_load(&co->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned old = __hip_atomic_fetch_add(&co->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == nblocks - 1) {
-      __hip_atomic_store(&co->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // (release: the reset is performed before the generation moves -- a workgroup that sees the new generation may
-      // arrive at the NEXT barrier at once)
-      __hip_atomic_fetch_add(&co->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(&co->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > kBarrierTimeoutTicks) __builtin_trap();      // not all workgroups resident: loud, not a hang
+// ---- decoupled look-back.  One 64-bit word per workgroup: tag (which call wrote it) | state | two counts.  A word of
+// another tag is "not there yet"; every call of this form rewrites every word, so no kernel ever clears them.  Written
+// and polled with relaxed agent-scope accesses: the payload IS the word, nothing else is handed over.
+constexpr unsigned long long kLbAggregate = 1ull, kLbPrefix = 2ull;
+__device__ __forceinline__ unsigned long long lb_pack(unsigned tag, unsigned long long state, unsigned a, unsigned b) {
+  return ((unsigned long long)(tag & 0xffffu) << 48) | (state << 46) | ((unsigned long long)(a & 0x7fffffu) << 23) |
+         (unsigned long long)(b & 0x7fffffu);
+}
+// Called by the 64 lanes of ONE wave of workgroup j after the workgroup's counts (a, b) are final: publishes them, adds
+// up the counts of the workgroups before it -- 256 words per round trip, four loads in flight per lane: all workgroups of
+// these launches are resident at once, so what a late workgroup finds are mostly aggregates, hundreds of them -- and
+// publishes the inclusive prefix.  Workgroups are dispatched in index order, so every predecessor is running or done;
+// the spin is bounded all the same (a trap instead of a hung device).  Every lane returns the exclusive prefix.
+__device__ __forceinline__ void lb_scan_wave(unsigned long long* words, int j, unsigned tag, unsigned a, unsigned b,
+                                             unsigned* base_a, unsigned* base_b) {
+  const int lane = threadIdx.x & 63;
+  unsigned sa = 0, sb = 0;
+  if (j > 0) {
+    if (lane == 0)
+      __hip_atomic_store(&words[j], lb_pack(tag, kLbAggregate, a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    int i = j - 1;                       // nearest predecessor not yet consumed
+    bool done = false;
+    while (!done) {
+      unsigned long long w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = i - 64 * q - lane;
+        // (below index 0: "an inclusive prefix of zero" ends the walk)
+        w[q] = idx >= 0 ? __hip_atomic_load(&words[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : lb_pack(tag, kLbPrefix, 0u, 0u);
+      }
+      bool again = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (done || again) continue;
+        const unsigned long long st = (w[q] >> 46) & 3ull;
+        const bool valid = (unsigned)(w[q] >> 48) == (tag & 0xffffu) && st != 0;
+        const unsigned long long m_inv = __ballot(!valid), m_pre = __ballot(valid && st == kLbPrefix);
+        const unsigned long long m_stop = m_inv | m_pre;
+        const int stop = m_stop ? __ffsll((long long)m_stop) - 1 : 64;      // nearest lane that ends or stalls the walk
+        const bool stop_is_prefix = m_stop && ((m_pre >> stop) & 1ull);
+        const bool take = lane < stop || (lane == stop && stop_is_prefix);
+        unsigned xa = take ? (unsigned)(w[q] >> 23) & 0x7fffffu : 0u, xb = take ? (unsigned)w[q] & 0x7fffffu : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          xa += __shfl_xor(xa, d);
+          xb += __shfl_xor(xb, d);
+        }
+        sa += xa;
+        sb += xb;
+        if (stop_is_prefix) {
+          done = true;
+        } else if (m_stop) {             // a word that is not there yet: come back for it
+          i = i - 64 * q - stop;
+          again = true;
+        }
+      }
+      if (!done && !again) i -= 256;
+      if (again) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 400000000ull) __builtin_trap();
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  __syncthreads();
+  if (lane == 0)
+    __hip_atomic_store(&words[j], lb_pack(tag, kLbPrefix, sa + a, sb + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *base_a = sa;
+  *base_b = sb;
 }
 
-__device__ __forceinline__ int coop_load(const int32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// sum of one int per thread over the 1024-thread workgroup (every thread gets it); `tmp` = 16 ints of LDS
-__device__ __forceinline__ int block_sum_1024(int v, int* tmp) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
-  __syncthreads();
-  int t = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t += tmp[i];
-  return t;
-}
-
-// exclusive scan of one int per thread over the 1024-thread workgroup; *total = workgroup sum.  `tmp` = 16 ints.
-__device__ __forceinline__ int block_excl_scan_1024(int v, int* tmp, int* total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int inc = wave_incl_scan(v, lane);
-  __syncthreads();
-  if (lane == 63) tmp[w] = inc;
-  __syncthreads();
-  int pre = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (i < w) pre += tmp[i];
-    tot += tmp[i];
-  }
-  *total = tot;
-  return pre + inc - v;
-}
-
-struct FrontArgs {
-  const int64_t* ids;
-  int64_t n;
-  const int32_t* idx_map;
-  const int32_t* inverted;
-  int64_t N, C;
-  int word_bits, hot_words;
-  uint32_t* bitmap;
-  int64_t n_vec;               // uint4 words of the bitmap (n_chunks * 256)
-  Ctl* ctl;
-  Coop* coop;
-  int64_t* rows_out;
-  int allow_pad, assume_free0, parity;
-  int32_t* miss_list;
-  int32_t* slot_epoch;
-  uint32_t* hist;
-  long long seq_arg, in_cap;
-  ce_call_stats_t* ring;
-};
-
-// begin + mark + count + emit.  Workgroup g owns the uint4 words [g * per, (g + 1) * per) of the bitmap (per a multiple
-// of the workgroup size): contiguous and ascending in g, so the place of its first missing row in the miss list is the
-// number of missing rows of the workgroups before it -- G <= 128 partial counts, added up by every workgroup for
-// itself behind the second barrier, together with the call's totals: every workgroup reaches the same verdict,
-// workgroup 0 records it (what k_emit's workgroup 0 did).
-template <bool MERGE, int U>
-__global__ __launch_bounds__(kCoopThreads) void k_front(const FrontArgs a) {
-  extern __shared__ uint32_t hot[];
-  __shared__ int tmp_s[16];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int g = (int)blockIdx.x, G = (int)gridDim.x;
-  Ctl* const ctl = a.ctl;
-  Coop* const co = a.coop;
-  // ---- per-call reset (k_begin): nothing below reads these before the first barrier
-  if (g == 0 && tid == 0) {
-    ctl->seq = a.seq_arg ? a.seq_arg : ctl->seq + 1;
-    ctl->n_unique = 0;
-    ctl->n_miss = 0;
-    ctl->k_evict = 0;
-    ctl->miss_lookups = 0;
-    ctl->sel_prefix = 0;
-    ctl->sel_krem = 0;
-    ctl->n_eligible = 0;
-    ctl->victims_count = 0;
-    ctl->status = CE_OK;
-    ctl->lost = 0;
-    ctl->n_free_start = ctl->n_free;
-  }
-  for (int i = g * kCoopThreads + tid; i < kHistWords; i += G * kCoopThreads) a.hist[i] = 0;
-  // ---- mark
-  int cold = 0;
-  bool bad = false;
-  mark_pass<MERGE, U>(a.ids, a.n, a.idx_map, a.inverted, a.N, a.word_bits, a.hot_words, hot, a.bitmap, a.rows_out,
-                      a.allow_pad, &cold, &bad);
-  cold = block_sum_1024(cold, tmp_s);
-  const int any_bad = __syncthreads_or(bad ? 1 : 0);
-  if (tid == 0) {
-    co->part_cold[g] = cold;
-    co->part_bad[g] = any_bad;
-  }
-  grid_sync(co, (unsigned)G);
-  // ---- count
-  const int64_t per = ((a.n_vec + G - 1) / G + kCoopThreads - 1) / kCoopThreads * kCoopThreads;
-  const int64_t v0 = (int64_t)g * per, v1 = v0 + per < a.n_vec ? v0 + per : a.n_vec;
-  const uint4* const bitmap4 = (const uint4*)a.bitmap;
-  int u = 0, m = 0;
-  for (int64_t v = v0 + tid; v < v1; v += kCoopThreads) {
-    const uint4 q = bitmap4[v];
-    const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!wds[k]) continue;
-      u += __popc(wds[k]);
-      m += __popc(miss_mask(a.inverted, v * 128 + k * 32, wds[k], a.N));
-    }
-  }
-  u = block_sum_1024(u, tmp_s);
-  m = block_sum_1024(m, tmp_s);
-  if (tid == 0) {
-    co->part_unique[g] = u;
-    co->part_miss[g] = m;
-  }
-  grid_sync(co, (unsigned)G);
-  // ---- totals, this workgroup's base, the verdict
-  int pu = 0, pm = 0, pc = 0, pb = 0, pbase = 0;
-  if (tid < G) {
-    pu = coop_load(&co->part_unique[tid]);
-    pm = coop_load(&co->part_miss[tid]);
-    pc = coop_load(&co->part_cold[tid]);
-    pb = coop_load(&co->part_bad[tid]);
-    if (tid < g) pbase = pm;
-  }
-  const long long tu = block_sum_1024(pu, tmp_s);
-  const long long tm = block_sum_1024(pm, tmp_s);
-  const long long tcold = block_sum_1024(pc, tmp_s);
-  const int tbad = block_sum_1024(pb, tmp_s);
-  const long long base = block_sum_1024(pbase, tmp_s);
-  const long long n_free = __hip_atomic_load(&ctl->n_free, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // assume_free0: the host launched the call in its steady-state form (the slots to fill are the call's victims)
-  // because the last record it has seen said "no free slot left"; a call launched before the record of a lost
-  // admission arrived fails here, state untouched.  (Workgroup 0's plan below leaves n_free alone in exactly the two
-  // cases this test tells apart, so it does not matter whether it has run yet.)
-  const bool stale = a.assume_free0 && n_free != 0;
-  int status = tbad ? CE_ERR_RANGE : CE_OK;
-  if (status == CE_OK && tu > a.C) status = CE_ERR_CAPACITY;
-  if (status == CE_OK && stale) status = CE_ERR_HIP;
-  const bool ok = status == CE_OK;
-  const long long seq_ = call_seq(ctl, a.seq_arg);
+// count + emit + plan in one pass (see the header).  One workgroup per 32768-row chunk of the bitmap; the LAST one
+// holds the call's totals when its look-back ends and records the plan (what k_emit's workgroup 0 does from k_count's
+// sums).  The bad-id verdict is k_mark's, a launch ago; unique <= n <= C by the caller's choice of this kernel.
+// (One workgroup of 1024 threads per four chunks -- a quarter of the pollers, look-backs of one or two rounds -- was
+// slower: 44 against 37 us at the Kaggle table.  What the kernel waits for is the workgroups of the table's dense head,
+// whose threads fetch 128 map entries each before they can publish a count.)
+__global__ __launch_bounds__(256) void k_emit_scan(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
+                                                   int n_chunks, unsigned long long* lb, unsigned tag,
+                                                   int32_t* miss_list, int32_t* slot_epoch, long long seq_arg, Ctl* ctl,
+                                                   int64_t n_ids, ce_call_stats_t* ring, long long in_cap,
+                                                   int assume_free0, long long* n_admit_out) {
+  __shared__ int su[4], sm[4], wsub[4];
+  __shared__ unsigned base_s[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = (int)blockIdx.x;
+  const long long seq_ = call_seq(ctl, seq_arg);
   const int32_t epoch = call_epoch(seq_);
-  if (g == 0 && tid == 0) {
-    ce_call_stats_t* const ring_slot = a.ring + (seq_ % kRing);
-    long long k = 0;
-    if (ok) {
-      k = tm - n_free;
-      if (k < 0) k = 0;
-      ctl->n_free = n_free + k - tm;
-    }
-    __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ctl->n_unique = tu;
-    ctl->n_miss = tm;
-    ctl->k_evict = k;
-    ctl->sel_krem = k;
-    ctl->miss_lookups = ok ? tcold : 0;
-    ring_slot->n_ids = a.n;
-    ring_slot->n_unique = tu;
-    ring_slot->n_miss = tm;
-    ring_slot->n_evict = k;
-    ring_slot->miss_lookups = ok ? tcold : 0;
-    ring_slot->n_free_after = ok ? n_free + k - tm : n_free;
-    ring_slot->status = status;
-    ring_slot->kind = CE_CALL_PREPARE;
-    const long long rows = ok ? tm : 0;
-    co->n_admit[a.parity] = rows < a.in_cap ? rows : a.in_cap;
-    // (the record's seq -- "complete" -- is published by the last kernel that can amend it: k_select / k_admit_maps)
-  }
-  // ---- ordered emission, epoch stamps of the resident rows, bitmap clear
-  uint4* const bitmap4w = (uint4*)a.bitmap;
-  long long run = base;
-  for (int64_t vb = v0; vb < v1; vb += kCoopThreads) {
-    const int64_t v = vb + tid;
-    uint4 q = make_uint4(0, 0, 0, 0);
-    if (v < v1) q = bitmap4[v];
-    const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-    uint32_t mm[4];
-    int mt = 0;
+  const int st_in = ctl->status;                                     // (k_mark's, a launch ago)
+  const bool stale = assume_free0 && ctl->n_free_start != 0;
+  const bool ok = st_in == CE_OK && !stale;
+  const int64_t v = (int64_t)c * 256 + threadIdx.x;
+  const uint4 q = bitmap4[v];
+  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+  uint32_t mm[4];
+  int u = 0, m = 0;
+  if (ok) miss_masks4_stamp(inverted, v * 128, wds, N, slot_epoch, epoch, mm);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      mm[k] = 0;
-      if (ok && wds[k]) {
-        mm[k] = miss_mask_stamp(a.inverted, v * 128 + k * 32, wds[k], a.N, a.slot_epoch, epoch);
-        mt += __popc(mm[k]);
+  for (int k = 0; k < 4; ++k) {
+    if (!ok) mm[k] = 0;
+    u += __popc(wds[k]);
+    m += __popc(mm[k]);
+  }
+  const int inc = wave_incl_scan(m, lane);
+  const int uw = wave_sum(u);
+  if (lane == 63) {
+    su[wv] = uw;
+    sm[wv] = inc;
+    wsub[wv] = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const unsigned tu_c = (unsigned)(su[0] + su[1] + su[2] + su[3]), tm_c = (unsigned)(sm[0] + sm[1] + sm[2] + sm[3]);
+    unsigned bu = 0, bm = 0;
+    lb_scan_wave(lb, c, tag, tu_c, tm_c, &bu, &bm);
+    if (threadIdx.x == 0) {
+      base_s[0] = bu;
+      base_s[1] = bm;
+    }
+    if (threadIdx.x == 0 && c == n_chunks - 1) {
+      // ---- the plan: this workgroup's inclusive prefix is the call's total
+      const long long tu = (long long)bu + tu_c, tm = (long long)bm + tm_c;
+      ce_call_stats_t* const ring_slot = ring + (seq_ % kRing);
+      int status = st_in;
+      if (status == CE_OK && stale) status = CE_ERR_HIP;
+      long long k = 0;
+      if (status == CE_OK) {
+        k = tm - ctl->n_free;
+        if (k < 0) k = 0;
+        ctl->n_free = ctl->n_free + k - tm;
+      }
+      __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ctl->n_unique = tu;
+      ctl->n_miss = tm;
+      ctl->k_evict = k;
+      ctl->sel_krem = k;
+      ring_slot->n_ids = n_ids;
+      ring_slot->n_unique = tu;
+      ring_slot->n_miss = tm;
+      ring_slot->n_evict = k;
+      ring_slot->miss_lookups = (status == CE_OK) ? ctl->miss_lookups : 0;
+      ring_slot->n_free_after = ctl->n_free;
+      ring_slot->status = status;
+      ring_slot->kind = CE_CALL_PREPARE;
+      if (n_admit_out) {
+        const long long mrows = (status == CE_OK) ? tm : 0;
+        *n_admit_out = mrows < in_cap ? mrows : in_cap;
       }
     }
-    int tot;
-    long long pos = run + block_excl_scan_1024(mt, tmp_s, &tot);
+  }
+  __syncthreads();
+  if (ok) {
+    int pos = (int)base_s[1] + inc - m;
+    for (int k = 0; k < wv; ++k) pos += wsub[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       uint32_t bits = mm[k];
@@ -273,31 +189,30 @@ __global__ __launch_bounds__(kCoopThreads) void k_front(const FrontArgs a) {
       while (bits) {
         const int b = __ffs(bits) - 1;
         bits &= bits - 1;
-        a.miss_list[pos++] = (int32_t)(row0 + b);
+        miss_list[pos++] = (int32_t)(row0 + b);
       }
     }
-    if (q.x | q.y | q.z | q.w) bitmap4w[v] = make_uint4(0, 0, 0, 0);
-    run += tot;
   }
+  if (q.x | q.y | q.z | q.w) bitmap4[v] = make_uint4(0, 0, 0, 0);
 }
 
-struct SelectArgs {
+struct StageArgs {
   int32_t* cached_idx_map;
   int32_t* inverted;
   int64_t* freq;
   int32_t* slot_epoch;
-  int64_t C, N;
+  int64_t C;
   long long seq_arg;
-  int32_t depth;
-  int slot_bits, lfu, top_pass, parity;
-  unsigned long long* keys;
-  uint32_t* hist;
+  int top_pass;
+  const unsigned long long* keys;
+  const uint32_t* hist;
   Ctl* ctl;
-  Coop* coop;
+  unsigned long long* lb;
+  unsigned tag;
   int32_t* free_list;            // out: the victims ascending = the slots the missing rows take
   const int32_t* miss_list;
   ce_call_stats_t* ring;
-  // staging of the victims (k_evict_stage's arguments)
+  long long* n_unpack_out;
   const void* cache;
   void* stage;
   int32_t* stage_rows_idx;
@@ -309,223 +224,153 @@ struct SelectArgs {
   void* host_overflow;
 };
 
-template <typename VT>
-__device__ __forceinline__ void stage_and_remap(const SelectArgs& a, long long first, long long end, int32_t epoch) {
-  const VT* const cache = (const VT*)a.cache;
-  VT* const stage = (VT*)a.stage;
-  VT* const host = (VT*)a.host_overflow;
-  const int rowlen = a.rowlen;
-  const int Gl = 1 << a.g_log2;
-  const int gl = threadIdx.x & (Gl - 1);
-  const int grp = threadIdx.x >> a.g_log2, ngrp = kCoopThreads >> a.g_log2;
-  constexpr int R = kStageRowsInFlight;
-  for (long long i = first + (long long)grp * R; i < end; i += (long long)ngrp * R) {
-    int32_t slot[R], old[R];
-    VT v[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) slot[t] = i + t < end ? a.free_list[i + t] : -1;
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      old[t] = -1;
-      if (slot[t] < 0) continue;
-      if (gl == 0) {
-        // the victim's row leaves both maps, the missing row of the same rank takes its slot (A.4 pairs the missing
-        // rows with the free slots in ascending order of both; a full cache's free slots are its victims)
-        const int32_t row = a.cached_idx_map[slot[t]];
-        const int32_t in_row = a.miss_list[i + t];
-        old[t] = row;
-        a.inverted[row] = -1;
-        a.cached_idx_map[slot[t]] = in_row;
-        a.inverted[in_row] = slot[t];
-        a.slot_epoch[slot[t]] = epoch;
-        if (a.freq) a.freq[slot[t]] = 0;
-        if (i + t < a.scap) {
-          a.stage_rows_idx[i + t] = row;
-          if (a.evt.keys) evt_insert(a.evt, (uint32_t)a.job, row, (int32_t)(i + t));
-        }
-      }
-      if (rowlen <= Gl) {
-        if (gl < rowlen) v[t] = cache[(int64_t)slot[t] * rowlen + gl];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      if (slot[t] < 0) continue;
-      const bool staged = i + t < a.scap;
-      int32_t row = 0;
-      if (!staged || rowlen > Gl) row = __shfl(old[t], (threadIdx.x & 63) & ~(Gl - 1));      // the group's lane 0 has it
-      if (rowlen <= Gl) {
-        if (gl < rowlen) {
-          if (staged) stage[(i + t) * rowlen + gl] = v[t];
-          else if (host) host[(int64_t)row * rowlen + gl] = v[t];      // beyond the staging: straight to the host table
-        }
-      } else {
-        VT* const dst = staged ? stage + (i + t) * rowlen : (host ? host + (int64_t)row * rowlen : nullptr);
-        if (dst) copy_row(cache + (int64_t)slot[t] * rowlen, dst, rowlen, gl, Gl);
-      }
-    }
-  }
-}
+constexpr int kRemapSlots = 4096;      // slots per workgroup of k_rank_victims (k_victims' blocks)
 
-// keys + radix select + victims + staging + maps, for a FULL cache (the call began with no free slot, so it evicts
-// exactly as many rows as it misses and the slots to fill are its victims).  Workgroup g owns the slots
-// [g * per, (g + 1) * per): the victims it finds, written in slot order at (victims of the workgroups before it) +
-// rank, ARE the ascending list k_victims + free_list_from_victims produced with an atomic and a second pass.
-__global__ __launch_bounds__(kCoopThreads) void k_select(const SelectArgs a) {
-  __shared__ uint32_t sh[kBins];
-  __shared__ int tmp_s[16];
+// Victims of a FULL cache in ascending slot order = the call's free-slot list.  Workgroup j owns the slots
+// [4096 j, 4096 j + 4096): its victims (key <= the threshold the level-0 histogram gives, like k_victims), their count
+// handed round by look-back, their slots written at (victims of the blocks before) + rank -- no returning atomic, no
+// second pass over the keys (k_victims + k_evict_stage's free-list workgroups).
+// (One kernel for ranks AND staging AND maps, every workgroup moving the victims of its own 4096 slots, was 147 us
+// against 20: the slots a full cache turns over are the ones its coldest rows sit in, a few blocks hold most of them.)
+__global__ __launch_bounds__(256) void k_rank_victims(const StageArgs a) {
   __shared__ unsigned long long prefix_s;
-  __shared__ int krem_s;
-  const int tid = threadIdx.x;
-  const int g = (int)blockIdx.x, G = (int)gridDim.x;
+  __shared__ int fail_s, go_s;
+  __shared__ unsigned long long mask_s[64];
+  __shared__ int pre_s[65];
+  __shared__ unsigned base_s;
   Ctl* const ctl = a.ctl;
-  Coop* const co = a.coop;
-  const long long seq = call_seq(ctl, a.seq_arg);
-  const int32_t epoch = call_epoch(seq);
-  ce_call_stats_t* const ring_slot = a.ring + (seq % kRing);
-  const long long k = ctl->k_evict;                       // (written by the launch before this one)
-  const bool call_ok = ctl->status == CE_OK;
-  if (!call_ok || k == 0) {                               // grid-uniform: nothing to select
-    if (g == 0 && tid == 0) {
-      co->n_unpack[a.parity] = 0;
-      if (a.mail) {
-        a.mail->count = 0;
-        a.mail->job = a.job;
-      }
-      __threadfence_system();
-      *(volatile long long*)&ring_slot->seq = seq;
-    }
-    return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = (int)blockIdx.x;
+  // wave wv holds the 64-slot groups wv, wv + 4, ... (in flight while wave 0 works out the threshold)
+  const int64_t s0 = (int64_t)j * kRemapSlots;
+  unsigned long long key[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int64_t sl = s0 + (int64_t)(wv + 4 * u) * 64 + lane;
+    key[u] = sl < a.C ? a.keys[sl] : ~0ull;
   }
-  const int64_t per = ((a.C + G - 1) / G + kCoopThreads - 1) / kCoopThreads * kCoopThreads;
-  const int64_t s0 = (int64_t)g * per, s1 = s0 + per < a.C ? s0 + per : a.C;
-  // ---- keys (k_keys) + the top digit's histogram
-  for (int i = tid; i < kBins; i += kCoopThreads) sh[i] = 0;
+  if (threadIdx.x < 64) {
+    const SelState st = select_level(a.hist, 0, a.top_pass, ctl, threadIdx.x, false);
+    if (threadIdx.x == 0) {
+      prefix_s = st.prefix;
+      fail_s = st.fail;
+      go_s = (ctl->k_evict != 0 && ctl->status == CE_OK) ? 1 : 0;
+    }
+  }
   __syncthreads();
-  {
-    const int shift = a.top_pass * kDigitBits;
-    const int key_bits = (a.top_pass + 1) * kDigitBits;
-    const unsigned long long fmax = (1ull << ((key_bits < 63 ? key_bits : 63) - a.slot_bits)) - 1;
-    int elig = 0;
-    for (int64_t s = s0 + tid; s < s1; s += kCoopThreads) {
-      const int32_t row = a.cached_idx_map[s];
-      const bool prot = (epoch - a.slot_epoch[s]) <= a.depth;
-      unsigned long long key = ~0ull;
-      if (row >= 0 && !prot) {
-        if (a.lfu) {
-          const long long f = a.freq[s];
-          unsigned long long uf = f < 0 ? 0ull : (unsigned long long)f;
-          if (uf > fmax) uf = fmax;
-          key = (uf << a.slot_bits) | (unsigned long long)s;
-        } else {
-          key = (unsigned long long)(a.N - 1 - row);
-        }
-        ++elig;
-      }
-      a.keys[s] = key;
-      atomicAdd(&sh[(key >> shift) & (kBins - 1)], 1u);
-    }
-    elig = block_sum_1024(elig, tmp_s);
-    if (tid == 0) co->part_elig[g] = elig;
-    uint32_t* const mine = a.hist + a.top_pass * kBins;
-    for (int i = tid; i < kBins; i += kCoopThreads)
-      if (sh[i]) atomicAdd(&mine[i], sh[i]);
-  }
-  grid_sync(co, (unsigned)G);
-  const long long n_elig = block_sum_1024(tid < G ? coop_load(&co->part_elig[tid]) : 0, tmp_s);
-  if (n_elig < k) {
-    // fewer evictable slots than rows to admit (the protected window holds them): the capacity overflow of the
-    // overlapped pipeline.  Nothing is evicted or admitted; the record says so (k_victims' failure path).
-    if (g == 0 && tid == 0) {
+  if (!go_s) return;                     // no miss / a failed call: k_stage_maps publishes the record
+  if (fail_s) {
+    // fewer evictable slots than rows to admit -- the capacity overflow of the overlapped pipeline: nothing is evicted
+    // or admitted, the record says so.  Every workgroup sees the same; ONE thread records it.
+    if (j == 0 && threadIdx.x == 0) {
+      ce_call_stats_t* const ring_slot = a.ring + (call_seq(ctl, a.seq_arg) % kRing);
       ctl->n_free = ctl->n_free - ctl->k_evict + ctl->n_miss;
       ctl->k_evict = 0;
       ctl->status = CE_ERR_CAPACITY;
       ring_slot->status = CE_ERR_CAPACITY;
       ring_slot->n_evict = 0;
       ring_slot->n_free_after = ctl->n_free;
-      co->n_unpack[a.parity] = 0;
-      if (a.mail) {
-        a.mail->count = 0;
-        a.mail->job = a.job;
-      }
-      __threadfence_system();
-      *(volatile long long*)&ring_slot->seq = seq;
     }
     return;
   }
-  // ---- the digits below the top one: every workgroup resolves the level above from its (complete) histogram, then
-  // adds its slots' share to the next one
-  if (tid == 0) {
-    prefix_s = 0;
-    krem_s = (int)k;
-  }
-  __syncthreads();
-  for (int pass = a.top_pass - 1; pass >= 0; --pass) {
-    for (int i = tid; i < kBins; i += kCoopThreads) sh[i] = 0;
-    if (tid < 64) {
-      const SelState st = select_digit(a.hist, pass + 1, prefix_s, krem_s, tid);
-      if (tid == 0) {
-        prefix_s = st.prefix;
-        krem_s = st.krem;
-      }
-    }
-    __syncthreads();
-    const unsigned long long prefix = prefix_s;
-    const int shift = pass * kDigitBits;
-    constexpr int UK = 4;
-    for (int64_t sb = s0 + tid; sb < s1; sb += (int64_t)kCoopThreads * UK) {
-      unsigned long long key[UK];
-#pragma unroll
-      for (int q = 0; q < UK; ++q) {
-        const int64_t s = sb + (int64_t)q * kCoopThreads;
-        key[q] = s < s1 ? a.keys[s] : 0ull;
-      }
-#pragma unroll
-      for (int q = 0; q < UK; ++q) {
-        const int64_t s = sb + (int64_t)q * kCoopThreads;
-        const bool match = (key[q] >> (shift + kDigitBits)) == (prefix >> (shift + kDigitBits));
-        if (s < s1 && match) atomicAdd(&sh[(key[q] >> shift) & (kBins - 1)], 1u);
-      }
-    }
-    __syncthreads();
-    uint32_t* const mine = a.hist + pass * kBins;
-    for (int i = tid; i < kBins; i += kCoopThreads)
-      if (sh[i]) atomicAdd(&mine[i], sh[i]);
-    grid_sync(co, (unsigned)G);
-  }
-  if (tid < 64) {
-    const SelState st = select_digit(a.hist, 0, prefix_s, krem_s, tid);
-    if (tid == 0) prefix_s = st.prefix;
-  }
-  __syncthreads();
   const unsigned long long T = prefix_s;       // the k-th smallest key; keys are unique
-  // ---- victims of this workgroup's slots
-  int cnt = 0;
-  for (int64_t s = s0 + tid; s < s1; s += kCoopThreads) {
-    const unsigned long long key = a.keys[s];
-    cnt += (key <= T && key != ~0ull);
-  }
-  cnt = block_sum_1024(cnt, tmp_s);
-  if (tid == 0) co->part_vic[g] = cnt;
-  grid_sync(co, (unsigned)G);
-  const long long base = block_sum_1024(tid < g ? coop_load(&co->part_vic[tid]) : 0, tmp_s);
-  long long run = base;
-  for (int64_t sb = s0; sb < s1; sb += kCoopThreads) {
-    const int64_t s = sb + tid;
-    const unsigned long long key = s < s1 ? a.keys[s] : ~0ull;
-    const int hit = (key <= T && key != ~0ull);
-    int tot;
-    const long long pos = run + block_excl_scan_1024(hit, tmp_s, &tot);
-    if (hit && pos < k) a.free_list[pos] = (int32_t)s;
-    run += tot;
+  const long long k = ctl->k_evict;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const unsigned long long mk = __ballot(key[u] <= T && key[u] != ~0ull);
+    if (lane == 0) mask_s[wv + 4 * u] = mk;
   }
   __syncthreads();
-  long long end = base + cnt;
-  if (end > k) end = k;
-  if (a.vec) stage_and_remap<f32x4>(a, base, end, epoch);
-  else stage_and_remap<float>(a, base, end, epoch);
-  if (g == 0 && tid == 0) {
-    co->n_unpack[a.parity] = k;
+  if (threadIdx.x < 64) {
+    const int cgrp = __popcll(mask_s[threadIdx.x]);
+    const int inc = wave_incl_scan(cgrp, lane);
+    pre_s[threadIdx.x] = inc - cgrp;
+    unsigned b0 = 0, b1 = 0;
+    lb_scan_wave(a.lb, j, a.tag, (unsigned)__shfl(inc, 63), 0u, &b0, &b1);
+    if (threadIdx.x == 0) base_s = b0;
+  }
+  __syncthreads();
+  const long long base = base_s;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int g = wv + 4 * u;
+    const unsigned long long mk = mask_s[g];
+    if ((mk >> lane) & 1) {
+      const long long pos = base + pre_s[g] + __popcll(mk & lt);
+      if (pos < k) a.free_list[pos] = (int32_t)(s0 + (int64_t)g * 64 + lane);
+    }
+  }
+}
+
+// victims [0, k) of the call, grid-stride, a lane group per R of them
+template <typename VT>
+__device__ __forceinline__ void stage_and_remap(const StageArgs& a, long long k, int32_t epoch) {
+  const VT* const cache = (const VT*)a.cache;
+  VT* const stage = (VT*)a.stage;
+  VT* const host = (VT*)a.host_overflow;
+  const int rowlen = a.rowlen;
+  const int Gl = 1 << a.g_log2;
+  const int gl = threadIdx.x & (Gl - 1);
+  const long long gstride = ((long long)gridDim.x * blockDim.x) >> a.g_log2;
+  constexpr int R = kStageRowsInFlight;
+  for (long long i0 = ((((long long)blockIdx.x * blockDim.x + threadIdx.x)) >> a.g_log2) * R; i0 < k; i0 += gstride * R) {
+    int32_t slot[R], old[R], in_row[R];
+    VT v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      slot[t] = i0 + t < k ? a.free_list[i0 + t] : -1;
+      in_row[t] = (i0 + t < k && gl == 0) ? a.miss_list[i0 + t] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < R; ++t) {            // every victim's old row and payload in flight before the first store
+      old[t] = (slot[t] >= 0 && gl == 0) ? a.cached_idx_map[slot[t]] : -1;
+      if (slot[t] >= 0 && rowlen <= Gl && gl < rowlen) v[t] = cache[(int64_t)slot[t] * rowlen + gl];
+    }
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      if (slot[t] < 0) continue;
+      const long long i = i0 + t;
+      const bool staged = i < a.scap;
+      if (gl == 0) {
+        // the victim's row leaves both maps, the missing row of the same rank takes its slot (A.4 pairs the missing
+        // rows with the free slots in ascending order of both; a full cache's free slots are its victims)
+        a.inverted[old[t]] = -1;
+        a.cached_idx_map[slot[t]] = in_row[t];
+        a.inverted[in_row[t]] = slot[t];
+        a.slot_epoch[slot[t]] = epoch;
+        if (a.freq) a.freq[slot[t]] = 0;
+        if (staged) {
+          a.stage_rows_idx[i] = old[t];
+          if (a.evt.keys) evt_insert(a.evt, (uint32_t)a.job, old[t], (int32_t)i);
+        }
+      }
+      int32_t row = 0;
+      if (!staged) row = __shfl(old[t], (threadIdx.x & 63) & ~(Gl - 1));      // the group's lane 0 has it
+      if (rowlen <= Gl) {
+        if (gl < rowlen) {
+          if (staged) stage[i * rowlen + gl] = v[t];
+          else if (host) host[(int64_t)row * rowlen + gl] = v[t];      // beyond the staging: straight to the host table
+        }
+      } else {
+        VT* const dst = staged ? stage + i * rowlen : (host ? host + (int64_t)row * rowlen : nullptr);
+        if (dst) copy_row(cache + (int64_t)slot[t] * rowlen, dst, rowlen, gl, Gl);
+      }
+    }
+  }
+}
+
+// ... and what happens to them, over the whole list, a lane group per four victims: rows staged for the write-back, the
+// victims' rows out of both maps, the missing rows of the same rank in (k_evict_stage + k_admit_maps; the payload of
+// the admitted rows follows on the admission stream: k_unpack_chained).  Publishes the call's record.
+__global__ __launch_bounds__(256) void k_stage_maps(const StageArgs a) {
+  Ctl* const ctl = a.ctl;
+  const long long seq = call_seq(ctl, a.seq_arg);
+  const int32_t epoch = call_epoch(seq);
+  const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ce_call_stats_t* const ring_slot = a.ring + (seq % kRing);
+    *a.n_unpack_out = k;
     if (a.mail) {                              // read by the write-back worker after this kernel's event
       a.mail->count = k < a.scap ? k : a.scap;
       a.mail->job = a.job;
@@ -533,6 +378,8 @@ __global__ __launch_bounds__(kCoopThreads) void k_select(const SelectArgs a) {
     __threadfence_system();
     *(volatile long long*)&ring_slot->seq = seq;
   }
+  if (a.vec) stage_and_remap<f32x4>(a, k, epoch);
+  else stage_and_remap<float>(a, k, epoch);
 }
 
 // The rows of call w arrived in in_stage (the admission kernel, on the admission stream); move them to the slots the

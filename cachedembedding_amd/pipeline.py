@@ -258,7 +258,11 @@ class PrefetchWindow:
             self.mgr.strict = False   # no host sync inside the pipelined cache op
             if transport and transport != "auto":
                 self.mgr.set_transport(transport)
+            # (worker transport: the cache op's stream does not wait for the missed rows, collect() makes the
+            # training stream wait for them -- GraphedWindow._wait_rows)
+            self.mgr.set_deferred_rows(True)
         self._auto = overlap and transport == "auto"
+        self._ticket_tmp = 0
         self.trial: Optional[ArrangementTrial] = None
         self._mode = "overlap" if overlap else "sequential"
         arrangement = _resolve_arrangement(arrangement, overlap) if (overlap or arrangement is not None) else None
@@ -297,9 +301,11 @@ class PrefetchWindow:
                 P_, n_ = len(counts), counts[0]
                 slots = torch.empty(P_ * n_, dtype=torch.int64, device=cat.device)
                 kbuf = torch.empty(P_, presort_len(n_), dtype=torch.int64, device=cat.device) if fused else None
-                self.mgr.prepare_ids_keys(cat.view(P_, n_), slots, kbuf, **(lay if fused else {}), _begin_only=begin_only)
+                self.mgr.prepare_ids_keys(cat.view(P_, n_), slots, kbuf, **(lay if fused else {}), _begin_only=begin_only,
+                                          defer_rows=self.overlap)
             else:
-                slots = self.mgr.prepare_ids(cat)
+                slots = self.mgr.prepare_ids(cat, defer_rows=self.overlap)
+            self._ticket_tmp = self.mgr.rows_ticket() if self.overlap else 0
         # split by per-batch id counts (torch.chunk in the reference is only right for equal sizes, B#13)
         parts = list(torch.split(slots, counts))
         self._keys_tmp = None
@@ -328,6 +334,8 @@ class PrefetchWindow:
         """Synchronous window op on the current stream (reference behaviour)."""
         assert 1 <= len(values) <= self.P
         slots = self._cache_op(values)
+        if self._ticket_tmp:
+            self.mgr.wait_rows(self._ticket_tmp)
         self.keys = self._keys_tmp
         return slots
 
@@ -339,7 +347,7 @@ class PrefetchWindow:
         if self._mode == "interleaved":
             slots = self._cache_op(values, begin_only=True)
             if slots is not None:
-                self._pending = (None, slots, self._keys_tmp)
+                self._pending = (None, slots, self._keys_tmp, self._ticket_tmp)
                 return
         self._side.wait_stream(cur)          # ids were produced on the current stream
         with torch.cuda.stream(self._side):
@@ -349,19 +357,19 @@ class PrefetchWindow:
             ev.record(self._side)
         for v in values:
             v.record_stream(self._side)
-        self._pending = (ev, slots, keys)
+        self._pending = (ev, slots, keys, self._ticket_tmp)
 
     def collect(self) -> List[torch.Tensor]:
         """Slots of the submitted window; the current stream waits for the side stream."""
         assert self._pending is not None
-        ev, slots, keys = self._pending
+        ev, slots, keys, ticket = self._pending
         self._pending = None
         # strict=False: a cache op that overflowed (unique(window k U k+1) > cuda_row_num) or met a bad id handed
         # back slots of -1; raise like the reference as soon as its record has arrived (no host wait)
         self.mgr.raise_on_failed_calls()
         cur = torch.cuda.current_stream(self.mgr.device)
         if ev is None:                       # interleaved: the second half, on the stream the first one went to
-            self.mgr.prepare_ids_finish()
+            self.mgr.prepare_ids_finish(defer_rows=True)
         else:
             cur.wait_event(ev)
             for s in slots:
@@ -370,6 +378,8 @@ class PrefetchWindow:
                 (k.keys if isinstance(k, SrcKeys) else k).record_stream(cur)
                 if isinstance(k, SrcKeys) and k.ranges is not None:
                     k.ranges.record_stream(cur)
+        if ticket:
+            self.mgr.wait_rows(ticket)       # the missed rows of this window, before anything reads its slots
         self.keys = keys
         if self.trial is not None:           # a window boundary on the training stream: the trial's clock
             self._mode = self.trial.window_done(cur)
@@ -463,6 +473,7 @@ class GraphedWindow:
                 r[..., 1] = torch.iinfo(torch.int64).max
         self._side = make_side_stream(dev, cache_cus) if overlap else None
         self._events = [None] * nbuf
+        self._tickets = [0] * nbuf             # rows ticket of the cache op that filled buffer b (deferred rows)
         self._read_done = [None] * nbuf        # event behind the last training run that read buffer b
         self._step_fn = step_fn
         if overlap or interleaved:
@@ -471,6 +482,10 @@ class GraphedWindow:
             transport = pick_transport(transport, prefetch_num * ids_per_batch)
             if transport:
                 self.mgr.set_transport(transport)
+            # worker transport: the missed rows of a window travel on the library's admission stream; the cache op's own
+            # stream does not wait for them (the next window's cache op may follow it at once) -- the TRAINING stream
+            # does, right before the first step that reads the window's slots (_wait_rows)
+            self.mgr.set_deferred_rows(True)
         # eager warm-up on real slots (lazy initialisation must not happen during capture), then capture
         if warmup_values is not None:
             wcat = torch.cat(list(warmup_values))
@@ -485,6 +500,7 @@ class GraphedWindow:
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
+            self._wait_rows(0)
             for i in range(self.P):
                 self._call(step_fn, 0, i)
         torch.cuda.current_stream(dev).wait_stream(s)
@@ -594,7 +610,7 @@ class GraphedWindow:
 
     def _finish_begun(self) -> None:
         if self._begun is not None:
-            self.mgr.prepare_ids_finish()
+            self.mgr.prepare_ids_finish(defer_rows=True)
             self._begun = None
 
     def _cache_op(self, cat: torch.Tensor, buf: int, begin_only: bool = False) -> None:
@@ -604,13 +620,23 @@ class GraphedWindow:
                                        self._keys[buf] if self.presort else None,
                                        **((self._layout or {}) if self.presort else {}))
             self._begun = buf
+            self._tickets[buf] = self.mgr.rows_ticket()
             return
         if self.presort and FUSED_WINDOW_KEYS and self._ranges is None and cat.dtype == torch.int64 and cat.is_contiguous():
-            self.mgr.prepare_ids_keys(cat.view(self.P, self.n), self._bufs[buf], self._keys[buf], **(self._layout or {}))
+            self.mgr.prepare_ids_keys(cat.view(self.P, self.n), self._bufs[buf], self._keys[buf], defer_rows=True,
+                                      **(self._layout or {}))
+            self._tickets[buf] = self.mgr.rows_ticket()
             return
-        self.mgr.prepare_ids(cat, out=self._bufs[buf])
+        self.mgr.prepare_ids(cat, out=self._bufs[buf], defer_rows=True)
+        self._tickets[buf] = self.mgr.rows_ticket()
         if self.presort:
             self._presort(buf, cat)
+
+    def _wait_rows(self, buf: int) -> None:
+        """the current (training) stream waits for the rows the cache op of buffer `buf` missed"""
+        if self._tickets[buf]:
+            self.mgr.wait_rows(self._tickets[buf])
+            self._tickets[buf] = 0
 
     def _presort(self, buf: int, ids: torch.Tensor) -> None:
         # one launch for the window: every batch's 16384-lookup segments grouped by row
@@ -674,6 +700,7 @@ class GraphedWindow:
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
+        self._wait_rows(buf)
         for i in range(first, last):
             if self._step_graphs[buf]:
                 self._step_graphs[buf][i].replay()
@@ -700,6 +727,7 @@ class GraphedWindow:
         if self._events[buf] is not None:
             cur.wait_event(self._events[buf])
             self._events[buf] = None
+        self._wait_rows(buf)
         self.mgr.raise_on_failed_calls()
         dst = self._ids[1 - buf].view(-1)
         if len(next_values) == 1:
@@ -731,6 +759,7 @@ class GraphedWindow:
         if self._events[buf] is not None:
             torch.cuda.current_stream(self.mgr.device).wait_event(self._events[buf])
             self._events[buf] = None
+        self._wait_rows(buf)
         if not self.mgr.strict:
             self.mgr.raise_on_failed_calls()     # non-blocking; see PrefetchWindow.collect
         whole = steps is None or steps >= self.P
