@@ -760,7 +760,7 @@ class GraphedShardedWindow:
         self._ovf = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
         self._ovf_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
         self._ovf_event = [None, None]               # behind the flag's copy to the host
-        self._ovf_pending = [False, False]
+        self._planned = [False, False]               # a plan has been submitted into the buffer and not trained yet
         self._events = [None, None]
         self._ids = [None, None]
         self._side = torch.cuda.Stream(device=dev) if overlap else None        # dedupe + id exchange
@@ -772,15 +772,16 @@ class GraphedShardedWindow:
                 self.mgr.set_transport(transport)
         from .pipeline import ARRANGEMENTS, ArrangementTrial, DEFAULT_ARRANGEMENT
         if arrangement is None:
-            arrangement = (DEFAULT_ARRANGEMENT if W == 1 else "overlap") if overlap else None
+            arrangement = DEFAULT_ARRANGEMENT if overlap else None
         if arrangement is not None:
             if arrangement not in ("auto",) + ARRANGEMENTS:
                 raise ValueError(f"arrangement={arrangement!r}: 'auto', 'overlap' or 'interleaved'")
             if not overlap:
                 raise ValueError("arrangement= needs overlap=True (the next window planned while this one trains)")
-            if arrangement == "auto" and W > 1:
-                raise ValueError("arrangement='auto' needs the ranks to agree on a verdict: W = 1 only for now")
-        self.trial = ArrangementTrial(P, **(arrangement_trial or {})) if arrangement == "auto" else None
+        # W > 1: the trial's verdict is COLLECTIVE -- every rank's block times, MAX over the ranks (the step is as slow as
+        # its slowest rank), reduced at the same window on every rank, so that all of them switch in the same window
+        self.trial = ArrangementTrial(P, reduce_fn=self._reduce_max if W > 1 else None, **(arrangement_trial or {})) \
+            if arrangement == "auto" else None
         self._mode = self.trial.mode if self.trial is not None else (arrangement or "sequential")
         self._begun: Optional[int] = None            # interleaved: buffer whose owner-side cache op is begun, not finished
         self._begun_slots = None
@@ -914,6 +915,41 @@ class GraphedShardedWindow:
             self._serve[buf].copy_(got)
         else:
             self._serve[buf].copy_(self._req[buf].permute(1, 0, 2))
+        if self._split and getattr(self, "_caps", None) is not None:
+            self._plan_classify(buf)
+
+    @torch.no_grad()
+    def _plan_classify(self, buf: int) -> None:
+        """The split's share of the plan that needs only what every peer asked for (not the slots): classification,
+        the flags' all-to-all, the places of every row in the four messages of a step, the ranks' agreement on the
+        overflow flag.  HERE, right behind the id exchange and BEFORE the owner-side cache op: a process
+        group issues its collectives on one internal stream in host order, and submit(k+1) comes before run(k) -- with
+        these two collectives behind the cache op, window k's row exchanges would queue behind window k+1's PCIe
+        admission."""
+        W, P, cap, r = self.W, self.P, self.cap, self.rank
+        sp = stream_ptr()
+        self._classify(buf)
+        got = torch.empty_like(self._flags_o[buf])
+        _a2a(got, self._flags_o[buf], None, None, self.ex.group)                     # [owner, P, cap]
+        self._flags_r[buf].copy_(got.permute(1, 0, 2))
+        serve_pwc = self._serve[buf].permute(1, 0, 2).contiguous()
+        flags_o_pwc = self._flags_o[buf].permute(1, 0, 2).contiguous()
+        check(lib.ce_split_places(ptr(serve_pwc), ptr(flags_o_pwc), P, W, cap, r, ptr(self._caps), ptr(self._pf_srv[buf]),
+                                  ptr(self._pb_srv[buf]), None, ptr(self._ovf[buf]), sp))
+        check(lib.ce_split_places(ptr(self._req[buf]), ptr(self._flags_r[buf]), P, W, cap, r, ptr(self._caps),
+                                  ptr(self._pf_req[buf]), ptr(self._pb_req[buf]), None, ptr(self._ovf[buf]), sp))
+        self._agree_on_overflow(buf)
+
+    def _reduce_max(self, values):
+        """MAX over the ranks of a short list of floats (the arrangement trial's block times)"""
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if dist.get_backend(self.ex.group) == "gloo":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.ex.group)
+        else:
+            d = t.to(self.mgr.device)
+            dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.ex.group)
+            t = d.cpu()
+        return [float(v) for v in t]
 
     def _agree_on_overflow(self, buf: int) -> None:
         """the ranks must agree on which path a window takes (its collectives differ): MAX over the ranks' flags, then
@@ -1078,23 +1114,12 @@ class GraphedShardedWindow:
 
     @torch.no_grad()
     def _plan_split(self, buf: int) -> None:
-        """owner: classify what every peer asks for, tell the peers, lay out the gather / update lists of every
-        step; requester: the same places from the flags the owners sent, then the two lookup indices and their keys"""
+        """behind the owner-side cache op (the slots are known): the gather / update lists of every step from the
+        places _plan_classify worked out, then the two lookup indices and their keys"""
         from .functional import presort_window
         W, P, cap, n, r = self.W, self.P, self.cap, self.n, self.rank
         ne, nl, nd, nu = self._n
         sp = stream_ptr()
-        self._classify(buf)
-        got = torch.empty_like(self._flags_o[buf])
-        _a2a(got, self._flags_o[buf], None, None, self.ex.group)                     # [owner, P, cap]
-        self._flags_r[buf].copy_(got.permute(1, 0, 2))
-        serve_pwc = self._serve[buf].permute(1, 0, 2).contiguous()
-        flags_o_pwc = self._flags_o[buf].permute(1, 0, 2).contiguous()
-        check(lib.ce_split_places(ptr(serve_pwc), ptr(flags_o_pwc), P, W, cap, r, ptr(self._caps), ptr(self._pf_srv[buf]),
-                                  ptr(self._pb_srv[buf]), None, ptr(self._ovf[buf]), sp))
-        check(lib.ce_split_places(ptr(self._req[buf]), ptr(self._flags_r[buf]), P, W, cap, r, ptr(self._caps),
-                                  ptr(self._pf_req[buf]), ptr(self._pb_req[buf]), None, ptr(self._ovf[buf]), sp))
-        self._agree_on_overflow(buf)
         # owner lists: the slot of every served row at its place in the step's messages (early | late, deferred | urgent)
         slots = self._slots[buf]                                                     # [P, W * cap]
         caps = self._caps.long()
@@ -1194,6 +1219,7 @@ class GraphedShardedWindow:
         """Plan of a window into buffer `buf` (0/1); call it before run() of the previous window so they overlap."""
         dev = self.mgr.device
         self._ids[buf] = list(ids_list)
+        self._planned[buf] = True
         if not self.overlap:
             self._plan(ids_list, buf)
             self._plan_owner(buf)
@@ -1281,6 +1307,7 @@ class GraphedShardedWindow:
     def run(self, buf: int) -> None:
         """Train the P batches of the window in buffer `buf` (waits for its plan)."""
         dev = self.mgr.device
+        self._planned[buf] = False
         if self._begun == buf:             # (no window trained in between: the two halves back to back)
             self._finish_begun()
         ev = self._events[buf]
@@ -1288,10 +1315,10 @@ class GraphedShardedWindow:
             ev.synchronize()               # the plan was enqueued a whole window ago: the flag is there
             torch.cuda.current_stream(dev).wait_event(ev)
             self._events[buf] = None
-        elif self._mode == "interleaved" or self._ovf_pending[buf]:
-            # interleaved: the plan ran on this stream; its overflow flag was copied to the host behind it
-            if self._ovf_event[buf] is not None:
-                self._ovf_event[buf].synchronize()
+        elif self._ovf_event[buf] is not None:
+            # the plan ran on THIS stream (submitted under 'interleaved' -- whatever the arrangement is by now: it can
+            # change between submit and run): its overflow flag was copied to the host behind it
+            self._ovf_event[buf].synchronize()
         if not self.mgr.strict:
             self.mgr.raise_on_failed_calls()
         if int(self._ovf_host[buf][0]) != 0:
@@ -1309,6 +1336,17 @@ class GraphedShardedWindow:
                 g = self.ops.grad_rows(grad_like, p_.perm, self.offsets, None, self.embed.mode, self.incl, self.hook,
                                        p_.n, p_.keys)
                 self.ops.owner_update(p_.slots, self.ex.return_grads(p_, g), self.embed._lr[0])
+            nbuf = 1 - buf
+            if self._planned[nbuf]:
+                # The NEXT window's plan ran before this fallback's cache op, so its rows are no longer "the call
+                # before" when the window after it is planned: protect_depth 1 would let that plan evict rows the next
+                # window has not trained on yet.  Its owner-side cache op is issued again (every row it names is
+                # stamped again, and re-admitted if the fallback evicted it) and the indices that depend on the slots
+                # are rebuilt.  Rare by construction (a bucket beyond mean + 4.5 sigma), so the cost does not matter.
+                if self._events[nbuf] is not None:
+                    torch.cuda.current_stream(dev).wait_event(self._events[nbuf])
+                slots = self.mgr.prepare_ids(self._serve[nbuf].view(-1), padded=True)
+                self._plan_owner_rest(nbuf, slots)
             return
         if self._graphs is not None:
             self._graphs[buf].replay()

@@ -82,7 +82,15 @@ class ArrangementTrial:
     on one unlucky block of the other).  Every window of the trial trains for real.  `retrial_every` windows later the trial runs again."""
 
     def __init__(self, steps_per_window: int, block_windows: int = 0, rounds: int = 3, settle: int = 4,
-                 retrial_every: int = 16384):
+                 retrial_every: int = 16384, reduce_fn=None, decide_lag: int = 2, event_factory=None):
+        # reduce_fn (several ranks training one model, parallel.GraphedShardedWindow): a COLLECTIVE that takes the
+        # 2 x rounds block times of this rank and returns their maximum over the ranks.  The verdict is then reached
+        # from the same numbers on every rank, and at the same window: `decide_lag` windows behind the last block (by
+        # then its events have long completed, so the wait for them costs nothing), never "whenever this rank happens
+        # to find its events done" -- the ranks would call the collective in different windows.
+        self.reduce_fn, self.decide_lag = reduce_fn, int(decide_lag)
+        self._event = event_factory or (lambda: torch.cuda.Event(enable_timing=True))
+        self._lag = 0
         self.block_windows = int(block_windows) if block_windows else max(8, -(-256 // max(1, steps_per_window)))
         self.settle = min(int(settle), self.block_windows - 2)
         self.rounds, self.retrial_every = int(rounds), int(retrial_every)
@@ -102,6 +110,7 @@ class ArrangementTrial:
         self._first: Optional[torch.cuda.Event] = None
         self._blocks: List[tuple] = []            # (mode, first timed event, last event, windows between them)
         self._since = 0
+        self._lag = 0
 
     @property
     def mode(self) -> str:
@@ -133,7 +142,7 @@ class ArrangementTrial:
             idx = self._n
             self._n += 1
             if idx == self.settle or idx == self.block_windows:
-                ev = torch.cuda.Event(enable_timing=True)
+                ev = self._event()
                 ev.record(stream)
                 if idx == self.settle:
                     self._first = ev
@@ -144,7 +153,12 @@ class ArrangementTrial:
                     self._first = ev if self.settle == 0 else None
                     self._blk += 1
         elif self.decided is None:
-            self.poll()
+            if self.reduce_fn is None:
+                self.poll()
+            else:
+                self._lag += 1
+                if self._lag >= self.decide_lag:
+                    self.poll(wait=True)
         else:
             self._since += 1
             if self.retrial_every and self._since >= self.retrial_every:
@@ -157,13 +171,18 @@ class ArrangementTrial:
         """decide once every block's events have completed (wait=True: synchronise on them)"""
         if self.decided is not None or self._blk < len(self._order):
             return self.decided
+        if self.reduce_fn is not None and not wait:
+            return None                      # (a collective verdict is only ever reached in window_done's own window)
         if wait:
             self._blocks[-1][2].synchronize()
         if not all(b[2].query() for b in self._blocks):
             return None
+        per_block = [e0.elapsed_time(e1) / n for _, e0, e1, n in self._blocks]
+        if self.reduce_fn is not None:
+            per_block = list(self.reduce_fn(per_block))
         ms = {m: [] for m in ARRANGEMENTS}
-        for mode, e0, e1, n in self._blocks:
-            ms[mode].append(e0.elapsed_time(e1) / n)
+        for (mode, _, _, _), v in zip(self._blocks, per_block):
+            ms[mode].append(v)
         # three blocks per arrangement: the MEDIAN decides (one block in five is off by 20-40 % on these shared hosts,
         # whichever arrangement it is: the minimum picks a lucky block, the maximum an unlucky one); two: the slower
         def score(v):

@@ -150,3 +150,60 @@ def test_get_partition_matches_tensor_split():
                 lo, hi, _ = get_partition(D, r, W)
                 assert (lo, hi) == (off, off + sizes[r])
                 off += sizes[r]
+
+
+class _ClockEvent:
+    """stand-in for torch.cuda.Event on a rank-local fake clock (tests/test_pipeline_cpu.py has the single-rank form)"""
+    clock = [0.0]
+
+    def __init__(self):
+        self.at = None
+
+    def record(self, stream=None):
+        self.at = _ClockEvent.clock[0]
+
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+    def elapsed_time(self, other):
+        return other.at - self.at
+
+
+def _collective_trial(rank, world):
+    """VERDICT r5 #2a: the arrangement trial at W > 1.  Every rank times its own blocks -- here rank 0 finds 'interleaved'
+    faster and the others 'overlap' -- but the verdict comes from the MAX over the ranks, reduced in the same window on
+    every rank: all of them must run every window in the same arrangement and switch in the same window."""
+    from cachedembedding_amd.pipeline import ArrangementTrial
+
+    def reduce_max(values):
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    cost = {"interleaved": 1.0, "overlap": 1.3} if rank == 0 else {"interleaved": 1.6, "overlap": 1.2}
+    tr = ArrangementTrial(8, block_windows=4, rounds=3, settle=1, retrial_every=40, reduce_fn=reduce_max, decide_lag=2,
+                          event_factory=_ClockEvent)
+    modes = []
+    for _ in range(120):                       # two trials (retrial_every = 40 windows after the first verdict)
+        m = tr.mode
+        _ClockEvent.clock[0] += cost[m]
+        modes.append(m)
+        tr.window_done(None)
+    mine = torch.tensor([0 if m == "interleaved" else 1 for m in modes])
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    for g in gathered:
+        assert torch.equal(g, mine), "the ranks trained a window in different arrangements"
+    # MAX over the ranks: interleaved 1.6, overlap 1.3 per window -> overlap, whatever this rank measured itself
+    assert tr.decided == "overlap" and tr.trials == 2
+    assert tr.history[-1]["ms_per_window"] == {"overlap": [1.3] * 3, "interleaved": [1.6] * 3}
+    first_switch = modes.index("overlap", 6 * 4 + 1)           # the first window after the trial's blocks
+    assert all(m == "overlap" for m in modes[first_switch:first_switch + 30])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_arrangement_trial_reaches_one_verdict_on_all_ranks(world):
+    _spawn(_collective_trial, world)

@@ -114,7 +114,7 @@ def _rowwise(rank, world, strategy, with_freq, overlap=False):
 
 
 def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=(5003, 64, 4, 32, 3, 1000),
-                     force_graph=False, stream="random", expect_split=None):
+                     force_graph=False, stream="random", expect_split=None, flip=False):
     # stream: how consecutive batches relate -- "random" draws; "same": every batch of a window looks up the SAME rows
     # (every row late and urgent: what the split must not overtake); "disjoint": consecutive batches share no row (all
     # early / deferred: everything may travel ahead)
@@ -149,6 +149,11 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
     elif stream == "same":
         gs = torch.Generator().manual_seed(7)              # (the same rows on EVERY rank, too)
         all_ids = [[torch.randint(0, N, (F * B_loc,), generator=gs)] * P for _ in range(nwin + 1)]
+    elif stream == "alternating":
+        # even windows look up 50 rows (every bucket fits the capacity), odd windows ~250 distinct rows per batch (every
+        # bucket overflows it): with `flip` the arrangement changes between a window's submit() and its run()
+        all_ids = [[torch.randint(0, 50 if w_ % 2 == 0 else N, (F * B_loc,), generator=g) for _ in range(P)]
+                   for w_ in range(nwin + 1)]
     elif stream == "disjoint":
         # batch b of a window draws from the rows congruent to b modulo P + 1 (and the first batch of the next window
         # from another class than the last batch of this one): on every rank, so no row is touched in two consecutive steps
@@ -231,6 +236,8 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
             gw.submit([i.cuda() for i in all_ids[w]], w % 2)
         elif w + 1 <= nwin:
             gw.submit([i.cuda() for i in all_ids[w + 1]], (w + 1) % 2)
+            if flip:       # a plan submitted under one arrangement, trained under the other
+                gw.set_arrangement("overlap" if gw.arrangement == "interleaved" else "interleaved")
         gw.run(w % 2)
         torch.cuda.synchronize()
         exp = reference_window(all_ids[w])
@@ -254,7 +261,9 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
             assert bool((fl[:, 1:][valid[:, 1:]] & 1).bool().all()) and bool((fl[valid] & 2).bool().all())
         else:
             assert not bool((fl[valid] & 1).bool().any()) and not bool((fl[:, :-1][valid[:, :-1]] & 2).bool().any())
-    if capacity < 64:
+    if stream == "alternating":
+        assert gw.fallback_windows == nwin // 2, gw.fallback_windows      # windows 1 and 3 of 1..4
+    elif capacity < 64:
         assert gw.fallback_windows == nwin
     else:
         assert gw.fallback_windows == 0
@@ -278,6 +287,15 @@ def _rowwise_graphed(rank, world, strategy, with_freq, capacity, overlap, sizes=
 @pytest.mark.parametrize("capacity,overlap", [(256, True), (256, False), (8, True)])
 def test_rowwise_graphed_fixed_capacity_window(world, strategy, with_freq, capacity, overlap):
     _spawn(_rowwise_graphed, world, strategy, with_freq, capacity, overlap)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_arrangement_flips_between_submit_and_run_of_an_overflowing_window(world):
+    """run() must wait for the overflow flag of a plan that ran on the training stream (submitted under
+    'interleaved') even when the arrangement has changed to 'overlap' by the time the window trains -- otherwise it reads
+    the flag of the window before (here: "fits" for a window that overflows, i.e. rows pooled as zeros and their
+    gradients dropped).  Every second window overflows its buckets; the arrangement flips after every submit()."""
+    _spawn(_rowwise_graphed, world, "dataset", True, 64, True, (5003, 64, 4, 64, 3, 1000), False, "alternating", None, True)
 
 
 @pytest.mark.parametrize("world", [2, 3])
