@@ -1064,6 +1064,7 @@ __global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__
     for (int64_t i = cap + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2); i < k_all; i += gs0) {
       const int32_t slot = victims[i];
       const int32_t row = cached_idx_map[slot];
+      if (row < 0) continue;             // (group-uniform; an unmapped victim slot writes nothing: ADVICE r5)
       copy_row(cache + (int64_t)slot * rowlen, host_overflow + (int64_t)row * rowlen, rowlen, gl0, G0);
       __builtin_amdgcn_wave_barrier();
       if (gl0 == 0) {

@@ -282,6 +282,7 @@ class PrefetchWindow:
             self.mgr.set_deferred_rows(True)
         self._auto = overlap and transport == "auto"
         self._ticket_tmp = 0
+        self._begin_stream = None
         self.trial: Optional[ArrangementTrial] = None
         self._mode = "overlap" if overlap else "sequential"
         arrangement = _resolve_arrangement(arrangement, overlap) if (overlap or arrangement is not None) else None
@@ -366,6 +367,7 @@ class PrefetchWindow:
         if self._mode == "interleaved":
             slots = self._cache_op(values, begin_only=True)
             if slots is not None:
+                self._begin_stream = cur             # (the second half goes to the SAME stream: ADVICE r5)
                 self._pending = (None, slots, self._keys_tmp, self._ticket_tmp)
                 return
         self._side.wait_stream(cur)          # ids were produced on the current stream
@@ -388,7 +390,14 @@ class PrefetchWindow:
         self.mgr.raise_on_failed_calls()
         cur = torch.cuda.current_stream(self.mgr.device)
         if ev is None:                       # interleaved: the second half, on the stream the first one went to
-            self.mgr.prepare_ids_finish(defer_rows=True)
+            bs = self._begin_stream
+            if bs is not None and bs != cur:     # the caller changed streams between submit() and collect()
+                bs.wait_stream(cur)
+                with torch.cuda.stream(bs):
+                    self.mgr.prepare_ids_finish(defer_rows=True)
+                cur.wait_stream(bs)
+            else:
+                self.mgr.prepare_ids_finish(defer_rows=True)
         else:
             cur.wait_event(ev)
             for s in slots:
