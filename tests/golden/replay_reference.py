@@ -31,6 +31,9 @@ import numpy as np
 GOLD = Path(__file__).resolve().parent
 STREAMS = [("cache_dataset_freq", "dataset"), ("cache_dataset_nofreq", "dataset"), ("cache_lfu_freq", "lfu"),
            ("cache_lfu_nofreq", "lfu")]
+# where upstream's manager runs: "cuda" (it needs one); tests/test_oracle.py sets "cpu" to drive main() end to end
+# through a stand-in module with upstream's names and signatures
+DEVICE = "cuda"
 LFU_SCRIPT = [[2], [1, 2], [0, 2], [0, 1, 2], [0, 1, 2], [0, 1, 2], [0, 1, 2], [0, 2], [0, 2], [0, 2], [0, 2],
               [0], [0], [0], [0], [0, 1, 2], [0, 1, 2], [3], [2], [4], [2], [0]]
 
@@ -39,7 +42,7 @@ def upstream():
     """(CachedParamMgr, CachedEmbeddingBag, EvictionStrategy) of an importable ColossalAI, or None"""
     try:
         import torch
-        if not torch.cuda.is_available():
+        if DEVICE == "cuda" and not torch.cuda.is_available():
             return None
         try:
             from colossalai.nn.parallel.layers.cache_embedding import (CachedEmbeddingBag, CachedParamMgr,
@@ -66,11 +69,11 @@ def _upstream_factory(strategy: str):
         return mgr
 
     def prepare(mgr, ids: np.ndarray) -> np.ndarray:
-        return _np(mgr.prepare_ids(torch.from_numpy(ids).cuda()))
+        return _np(mgr.prepare_ids(torch.from_numpy(ids).to(DEVICE)))
 
     def touch(mgr, slots: np.ndarray):
         with torch.no_grad():
-            mgr.cuda_cached_weight[torch.from_numpy(np.unique(slots)).cuda()] += 0.5
+            mgr.cuda_cached_weight[torch.from_numpy(np.unique(slots)).to(DEVICE)] += 0.5
 
     return make, prepare, touch
 
@@ -138,9 +141,9 @@ def lfu_known_answer() -> Optional[bool]:
         bag = CachedEmbeddingBag(5, 5, cache_ratio=3 / 5, buffer_size=0, pin_weight=True, _weight=torch.randn(5, 5),
                                  ids_freq_mapping=[4, 2, 1, 3, 1] if init_freq else None, warmup_ratio=1.0,
                                  evict_strategy=EvictionStrategy.LFU)
-        offsets = torch.tensor([0], device="cuda")
+        offsets = torch.tensor([0], device=DEVICE)
         for ids in LFU_SCRIPT:
-            bag(torch.tensor(ids, device="cuda"), offsets)
+            bag(torch.tensor(ids, device=DEVICE), offsets)
         if list(bag.num_hits_history[-6:]) != [3, 0, 1, 0, 1, 1]:
             return False
     return True

@@ -302,3 +302,89 @@ def test_parity_pin_kit_comparison_logic(name, strategy):
 
     rep = rr.replay(strategy, z, factory(evict_a_wrong_row))
     assert rep["different"] == 1, rep
+
+
+def _stand_in_colossalai():
+    """module objects `colossalai`, `.nn`, `.nn.parallel`, `.nn.parallel.layers` holding upstream's three names with
+    upstream's constructor signatures, backed by the op-sequence-literal restatement"""
+    import enum
+    import types
+    from oracle.cache_oracle_torch import TorchCachedParamMgr
+
+    class EvictionStrategy(enum.Enum):
+        LFU = 1
+        DATASET = 2
+
+    class CachedParamMgr(TorchCachedParamMgr):
+        def __init__(self, weight, cuda_row_num=0, buffer_size=0, pin_weight=True,
+                     evict_strategy=EvictionStrategy.DATASET, async_copy=False):
+            super().__init__(weight, cuda_row_num, "lfu" if evict_strategy is EvictionStrategy.LFU else "dataset")
+
+    class CachedEmbeddingBag(torch.nn.Module):
+        def __init__(self, num_embeddings, embedding_dim, padding_idx=None, max_norm=None, norm_type=2.0,
+                     scale_grad_by_freq=False, sparse=False, _weight=None, mode="mean", include_last_offset=False,
+                     dtype=None, device=None, cache_ratio=0.01, ids_freq_mapping=None, warmup_ratio=0.7,
+                     buffer_size=0, pin_weight=False, evict_strategy=EvictionStrategy.DATASET):
+            super().__init__()
+            rows = max(int(num_embeddings * cache_ratio), 1)
+            self.cache_weight_mgr = CachedParamMgr(_weight, rows, buffer_size, pin_weight, evict_strategy)
+            self.cache_weight_mgr.reorder(ids_freq_mapping, warmup_ratio)
+
+        def forward(self, ids, offsets=None, per_sample_weights=None, shape_hook=None):
+            with torch.no_grad():
+                slots = self.cache_weight_mgr.prepare_ids(ids)
+            return torch.nn.functional.embedding_bag(slots, self.cache_weight_mgr.cuda_cached_weight, offsets)
+
+        @property
+        def num_hits_history(self):
+            return self.cache_weight_mgr.num_hits_history
+
+    mods = {}
+    for name in ("colossalai", "colossalai.nn", "colossalai.nn.parallel", "colossalai.nn.parallel.layers"):
+        mods[name] = types.ModuleType(name)
+        mods[name].__path__ = []                      # a package: `import a.b.c` walks through it
+    layers = mods["colossalai.nn.parallel.layers"]
+    layers.CachedParamMgr, layers.CachedEmbeddingBag, layers.EvictionStrategy = (CachedParamMgr, CachedEmbeddingBag,
+                                                                                  EvictionStrategy)
+    return mods
+
+
+def test_parity_pin_kit_runs_end_to_end_through_a_stand_in_upstream_module(monkeypatch, capsys):
+    """the part of tests/golden/replay_reference.py that will run on the day -- the
+    `import colossalai.nn.parallel.layers` branch (the `.cache_embedding` sub-package absent, as in the pinned
+    commit's neighbours), upstream's constructor signatures and attribute names, all FOUR streams and the LFU
+    known-answer script through `main()` -- executed here with the restatement injected under upstream's module name.
+    A wrong answer from the stand-in must come out as exit code 1."""
+    rr = _replay_module()
+    for name, mod in _stand_in_colossalai().items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setattr(rr, "DEVICE", "cpu")
+    up = rr.upstream()
+    assert up is not None and up[0].__name__ == "CachedParamMgr"
+    assert rr.lfu_known_answer() is True
+    assert rr.main([]) == 0
+    out = capsys.readouterr().out
+    assert "SKIPPED" not in out and "IDENTICAL up to tie order" in out
+    for name, _ in rr.STREAMS:
+        assert f"{name}: " in out and "'different': 0" in out
+    assert out.count("'histories_equal': True") == 4
+
+    # a manager that evicts a wrong row on its sixth call: main() must say so and return 1
+    layers = sys.modules["colossalai.nn.parallel.layers"]
+    good = layers.CachedParamMgr
+
+    class Wrong(good):
+        def prepare_ids(self, ids):
+            out = super().prepare_ids(ids)
+            self._n = getattr(self, "_n", 0) + 1
+            if self._n == 6:
+                s = int((self.cached_idx_map >= 0).nonzero().view(-1)[0])
+                old = int(self.cached_idx_map[s])
+                new = int((self.inverted_cached_idx < 0).nonzero().view(-1)[0])
+                self.cached_idx_map[s] = new
+                self.inverted_cached_idx[old], self.inverted_cached_idx[new] = -1, s
+            return out
+
+    monkeypatch.setattr(layers, "CachedParamMgr", Wrong)
+    assert rr.main([]) == 1
+    assert "REAL DIFFERENCE" in capsys.readouterr().out
