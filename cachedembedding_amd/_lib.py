@@ -15,7 +15,8 @@ from pathlib import Path
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libce_hip.so"
+# CE_LIBRARY: another build of the same sources (tests load libce_hip_testhooks.so, the -DCE_TEST_HOOKS twin, this way)
+LIB_PATH = Path(os.environ["CE_LIBRARY"]) if os.environ.get("CE_LIBRARY") else _PKG / "libce_hip.so"
 
 CE_OK = 0
 CE_ERR_INVALID = 1

@@ -12,6 +12,10 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libce_hip.so"
+# the same library with the fault / delay injection of tests/test_gpu_worker.py compiled in (-DCE_TEST_HOOKS): loaded
+# only by the child process of tests/test_gpu_worker.py::test_hook_tests_on_the_test_hooks_build (CE_LIBRARY=...)
+LIB_TEST_HOOKS = PKG / "libce_hip_testhooks.so"
+HOOKED_SOURCES = ["ce_cache.hip"]          # the sources that read CE_TEST_HOOKS
 SOURCES = ["ce_host.hip", "ce_bag.hip", "ce_bag_extra.hip", "ce_cache.hip", "ce_sort.hip", "ce_rowcopy.cpp"]
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++"]       # plain C++ sources (host only)
 HEADERS = [ROOT / "include" / "ce_api.h", CSRC / "ce_common.h", CSRC / "ce_cache_fused.h"]
@@ -83,5 +87,36 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_test_hooks(force: bool = False) -> Path:
+    """libce_hip_testhooks.so: the objects of build() with HOOKED_SOURCES recompiled under -DCE_TEST_HOOKS"""
+    build(force=force)
+    objdir = PKG / "csrc" / "build"
+    hook_stamp = objdir / "lib_testhooks.stamp"
+    dig = _digest()
+    if LIB_TEST_HOOKS.exists() and not force and hook_stamp.exists() and hook_stamp.read_text().strip() == dig:
+        return LIB_TEST_HOOKS
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        stem = src.rsplit(".", 1)[0]
+        if src in HOOKED_SOURCES:
+            obj = objdir / (stem + "_testhooks.o")
+            cmd = [hipcc, *FLAGS, *_extra_flags(), "-DCE_TEST_HOOKS", "-c", str(CSRC / src), "-o", str(obj)]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src} (-DCE_TEST_HOOKS):\n{r.stdout}")
+        else:
+            obj = objdir / (stem + ".o")
+        objs.append(str(obj))
+    link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(LIB_TEST_HOOKS), "-lpthread",
+            "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    hook_stamp.write_text(dig)
+    return LIB_TEST_HOOKS
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_test_hooks(force="--force" in sys.argv))

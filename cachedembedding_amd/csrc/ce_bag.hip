@@ -76,15 +76,9 @@ __device__ __forceinline__ int64_t share_of(const BagParams& p, int grp, int ngr
   return p.interleave ? (int64_t)grp * gridDim.x + blockIdx.x : (int64_t)blockIdx.x * ngroups + grp;
 }
 
-// cache policies of the two big streams (CE_FWD_NT / CE_BWD_NT, default on): see DESIGN.md section 4
-static int bag_policy() {
-  static const int v = [] {
-    const char* f = getenv("CE_FWD_NT");
-    const char* b = getenv("CE_BWD_NT");
-    return ((f ? atoi(f) : 1) ? 1 : 0) | ((b ? atoi(b) : 1) ? 2 : 0);
-  }();
-  return v;
-}
+// cache policies of the two big streams: both non-temporal (the sweeps of rounds 3-5 that said so
+// are in profiles/ and docs/history.md, their switches are gone)
+constexpr int kBagPolicy = 3;
 
 // offsets == nullptr: the caller states one id per bag, in order (offsets = arange; ce_bag_forward, the presorts)
 __device__ __forceinline__ int ld_off(const BagParams& p, int i) {
@@ -104,16 +98,13 @@ __device__ __forceinline__ int64_t out_row(const BagParams& p, int g) {
 
 constexpr int kIdxStage = 2048;   // indices of one 64-bag tile staged in LDS (8 KB per wave)
 
-// Output store of the forward by cache policy (CE_FWD_STORE): 0 plain, 1 nt (default), 2 sc1 (write-through: the line
-// is not kept in the XCD's L2), 3 sc0 sc1, 4 sc1 nt.  The output is written once and read by another kernel; what
-// matters is how much of the L2 / Infinity Cache it takes from the cache rows the gather wants to find there.
+// Output store of the forward: non-temporal (SP = 1).  The output is written once and read by another kernel; what
+// matters is how much of the L2 / Infinity Cache it takes from the cache rows the gather wants to find there (the
+// sc1 / sc0 sc1 / sc1 nt forms measured the same or slower: profiles/r03_probe_fwd_xcd.txt, docs/history.md).
 template <int SP>
 __device__ __forceinline__ void store_out(f32x4* p, f32x4 v) {
   if (SP == 0) *p = v;
-  else if (SP == 1) __builtin_nontemporal_store(v, p);
-  else if (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else if (SP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+  else __builtin_nontemporal_store(v, p);
 }
 template <int SP>
 __device__ __forceinline__ void store_out(float* p, float v) {
@@ -515,12 +506,11 @@ constexpr unsigned kExclFlag = 0x80000000u;
 // ROWS (the cache op's fused form, presort_window_from_rows): slots_io holds the table ROW of every lookup; its slot
 // is inverted[row] (one random 4-byte gather per lookup, all 16 of a thread in flight before anything else happens)
 // and is written back in place.
-// STAGED (round 5, every form but EXCL, which stages anyway): the keys go to their grouped positions in LDS first and
-// leave with 16 coalesced 512-byte stores per wave instead of 16 x 64 scattered 8-byte ones -- one workgroup is one
-// CU's store path, and 16384 single-line writes through it were most of the kernel's 43 us (it is latency-bound: 26-208
-// workgroups).  Same positions, bit-identical keys.  128 KB of LDS instead of 32 (a 1024-thread workgroup per CU
-// either way).  CE_PRESORT_STAGED=0: the direct scatter.
-template <bool SRC, bool EXCL, bool ROWS, bool STAGED = false>
+// Every form stages: the keys go to their grouped positions in LDS first and leave with 16 coalesced 512-byte stores
+// per wave instead of 16 x 64 scattered 8-byte ones -- one workgroup is one CU's store path, and 16384 single-line
+// writes through it were most of the kernel's 43 us (it is latency-bound: 26-208 workgroups; the direct scatter it
+// replaced: profiles/r05_ab_presort_staged.txt).  128 KB of LDS: the library needs gfx950's 160 KB per CU.
+template <bool SRC, bool EXCL, bool ROWS>
 __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restrict__ indices, int64_t nnz_per_batch,
                                                          int32_t segs_per_batch, int64_t n_segs, uint32_t num_rows,
                                                          unsigned long long* __restrict__ keys_out, BagParams lay,
@@ -528,7 +518,8 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
                                                          int64_t* __restrict__ ids_minmax, int64_t* slots_io,
                                                          const int32_t* __restrict__ inverted,
                                                          const int* __restrict__ status) {
-  __shared__ unsigned long long lk[(EXCL || STAGED) ? kSegLen : (kSegBuckets + 2) / 2];   // EXCL / STAGED: the segment's keys by position
+  __shared__ unsigned long long lk[kSegLen];          // the segment's keys by position (the counters first)
+  static_assert(sizeof(unsigned long long) * kSegLen <= 160 * 1024 - 1024, "gfx950: 160 KB of LDS per CU");
   int* const cnt = (int*)lk;                            // [kSegBuckets + 1] bucket counters ([kSegBuckets] = ignored)
   __shared__ int wsum[16];
   __shared__ long long mm_s[2][16];
@@ -624,7 +615,7 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
     for (int q = 0; q < kPer; ++q) { cnt[tid * kPer + q] = pre; pre += c4[q]; }
     if (tid == 0) cnt[kSegBuckets] = total;
     __syncthreads();
-    if (!EXCL && STAGED) {
+    if (!EXCL) {
       int pos[kSegKeys];
 #pragma unroll
       for (int r = 0; r < kSegKeys; ++r) pos[r] = cnt[bkt[r]] + place[r];
@@ -634,18 +625,6 @@ __global__ __launch_bounds__(1024) void k_bag_presort_seg(const int64_t* __restr
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < kSegKeys; ++r) keys_out[base + r * 1024 + tid] = lk[r * 1024 + tid];
-      __syncthreads();
-      continue;
-    }
-    if (!EXCL) {
-      if (CE_DBG(lay.debug) & 4) {       // ablation: coalesced stores (wrong places)
-#pragma unroll
-        for (int r = 0; r < kSegKeys; ++r) keys_out[base + r * 1024 + tid] = key[r];
-        __syncthreads();
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < kSegKeys; ++r) keys_out[base + cnt[bkt[r]] + place[r]] = key[r];
       __syncthreads();
       continue;
     }
@@ -1147,7 +1126,7 @@ static int fill_params(BagParams& p, int32_t dim, const int64_t* indices, int64_
   p.hookB = hookF ? (int32_t)(num_bags / hookF) : 0;
   p.alpha = 1.f;
   p.num_rows = 0xffffffffu;
-  p.policy = bag_policy();
+  p.policy = kBagPolicy;
   return CE_OK;
 }
 
@@ -1160,19 +1139,19 @@ static int bag_grid(int64_t num_bags) {
 // the kernel sorts 1024-lookup tiles itself
 static int launch_bwd_scatter(const BagParams& p, bool vec, int nch, hipStream_t s) {
   BagParams q = p;
-  const char* dbg = getenv("CE_BWD_DEBUG");
-  q.debug = dbg ? atoi(dbg) : 0;
+#ifdef CE_ABLATIONS
+  { const char* dbg = getenv("CE_BWD_DEBUG"); q.debug = dbg ? atoi(dbg) : 0; }
+#endif
   // sorted keys: a tile count that is a multiple of the CU count (425,984 keys -> 512 tiles of 832, two per CU,
   // instead of 416 tiles = one or two per CU): 80 -> 72.5 us.  More, smaller tiles lose to the per-tile prologue
   // (3/CU 77 us, 4/CU 85 us, 8/CU 94 us), and the self-sorting path does not gain (92 us either way).
   q.tile_len = kBwdTile;
   if (p.presorted) {
-    static const int per_cu = [] { const char* e = getenv("CE_BWD_TILES_PER_CU"); return e ? atoi(e) : 2; }();
+    constexpr int per_cu = 2;
     const int64_t total = cdiv(p.nnz, kSegLen) * kSegLen;
     if (per_cu > 0 && total > (int64_t)kNumCU * 256)
       q.tile_len = (int)std::min<int64_t>(kBwdTile, (cdiv(total, (int64_t)kNumCU * per_cu) + 15) & ~15ll);
   }
-  static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
   const int ntiles = (int)cdiv(p.presorted ? cdiv(p.nnz, kSegLen) * kSegLen : p.nnz, q.tile_len);
   dim3 grid(std::min(ntiles, kMaxBlocks)), block(256);
   const bool k32 = q.num_rows <= (1u << 22) - 2;
@@ -1182,7 +1161,7 @@ static int launch_bwd_scatter(const BagParams& p, bool vec, int nch, hipStream_t
     else hipLaunchKernelGGL((k_bag_bwd_tile<VT, N, unsigned long long, R>), grid, block, 0, s, q);    \
   } while (0)
   if (vec) {
-    if (nch == 1) { if (r_env == 8) CE_BWT(f32x4, 1, 8); else CE_BWT(f32x4, 1, 16); }
+    if (nch == 1) CE_BWT(f32x4, 1, 16);
     else if (nch == 2) CE_BWT(f32x4, 2, 4); else CE_BWT(f32x4, 4, 2);
   } else {
     if (nch == 1) CE_BWT(float, 1, 8); else if (nch == 2) CE_BWT(float, 2, 4); else CE_BWT(float, 4, 2);
@@ -1231,36 +1210,17 @@ extern "C" int ce_bag_forward(const float* weight, int64_t num_rows, int32_t dim
   dim3 grid(bag_grid(num_bags)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const bool stage = nnz != num_bags;      // multi-id bags possible
-  static const int u_env = [] { const char* e = getenv("CE_FWD_U"); return e ? atoi(e) : 16; }();
 #define CE_FWD(VT, N, U)                                                                          \
   do {                                                                                            \
     if (stage) hipLaunchKernelGGL((k_bag_fwd<VT, N, true, U, 1>), grid, block, 0, s, p);          \
-    else if (sp == 0) hipLaunchKernelGGL((k_bag_fwd<VT, N, false, U, 0>), grid, block, 0, s, p);  \
     else hipLaunchKernelGGL((k_bag_fwd<VT, N, false, U, 1>), grid, block, 0, s, p);               \
   } while (0)
-#define CE_FWD_SP(U)                                                                                        \
-  do {                                                                                                      \
-    if (sp == 2) hipLaunchKernelGGL((k_bag_fwd<f32x4, 1, false, U, 2>), grid, block, 0, s, p);              \
-    else if (sp == 3) hipLaunchKernelGGL((k_bag_fwd<f32x4, 1, false, U, 3>), grid, block, 0, s, p);         \
-    else if (sp == 4) hipLaunchKernelGGL((k_bag_fwd<f32x4, 1, false, U, 4>), grid, block, 0, s, p);         \
-    else CE_FWD(f32x4, 1, U);                                                                               \
-  } while (0)
-  static const int sp_env = [] { const char* e = getenv("CE_FWD_STORE"); return e ? atoi(e) : -1; }();
-  const int sp = sp_env >= 0 ? sp_env : ((p.policy & 1) ? 1 : 0);
-  static const int bpc_env = [] { const char* e = getenv("CE_FWD_WAVES"); return e ? atoi(e) : 0; }();
-  if (bpc_env > 0) grid = dim3((unsigned)std::min<int64_t>(cdiv(cdiv(num_bags, 64), 4), (int64_t)kNumCU * bpc_env));
   if (vec) {
-    if (nch == 1 && !stage) {
-      if (u_env == 4) CE_FWD_SP(4); else if (u_env == 8) CE_FWD_SP(8);
-      else if (u_env == 32) CE_FWD_SP(32); else CE_FWD_SP(16);
-    } else if (nch == 1) {
-      if (u_env == 4) CE_FWD(f32x4, 1, 4); else if (u_env == 8) CE_FWD(f32x4, 1, 8);
-      else if (u_env == 32) CE_FWD(f32x4, 1, 32); else CE_FWD(f32x4, 1, 16);
-    } else if (nch == 2) CE_FWD(f32x4, 2, 4); else CE_FWD(f32x4, 4, 2);
+    if (nch == 1) CE_FWD(f32x4, 1, 16);
+    else if (nch == 2) CE_FWD(f32x4, 2, 4); else CE_FWD(f32x4, 4, 2);
   } else {
     if (nch == 1) CE_FWD(float, 1, 8); else if (nch == 2) CE_FWD(float, 2, 4); else CE_FWD(float, 4, 2);
   }
-#undef CE_FWD_SP
 #undef CE_FWD
   CE_LAUNCH_CHECK();
   return CE_OK;
@@ -1370,31 +1330,27 @@ static int launch_bwd_stream(float* dst, int64_t num_rows, int32_t dim, int64_t 
   p.alpha = alpha;
   p.num_rows = (uint32_t)num_rows;
   p.presorted = keys;
+#ifdef CE_ABLATIONS
   { const char* dbg = getenv("CE_BWD_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
-  static const int il_env = [] { const char* e = getenv("CE_BWD_INTERLEAVE"); return e ? atoi(e) : 1; }();
-  p.interleave = il_env;
+#endif
+  p.interleave = 1;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
   // 6 workgroups per CU, i.e. 12288 shares of ~35 keys at the bench shape.  Alone on the GPU the share size matters
   // little (2 / 3 / 4 / 5 / 6 / 8 / 12 per CU: 55.5 / 54 / 58.5 / 56 / 53.7 / 55.8 / 58.6 us); beside the cache op's
   // kernels it does -- a workgroup that gets its CU late holds the whole launch back by its share: 77 / 74 / 70.5 /
   // 67.5 / 67 / 68 / 70.5 us (profiles/r04_late/grid_sweep_*.txt: forward 16/CU + backward 6 or 8/CU take the bench
   // line from 2.91 to 3.02-3.03 G over 10 runs each; 6 is the one that is also fastest alone)
-  static const int per_cu = [] { const char* e = getenv("CE_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 6; }();
-  static const int excl_env = [] { const char* e = getenv("CE_BWD_EXCL"); return e ? atoi(e) : 1; }();
+  // (re-checked in the one-stream arrangement: profiles/r05_ab_grid_interleaved.txt)
+  constexpr int per_cu = 6;
   const int ngroups = 256 >> p.g_log2;
   // small inputs: one share of >= 16 keys per lane group
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));
   dim3 g(grid), b(256);
   const long long* rg = (const long long*)seg_ranges;
-  const bool excl = seg_ranges != nullptr && excl_env != 0 && vec && nch == 1;
+  const bool excl = seg_ranges != nullptr && vec && nch == 1;
   if (vec) {
-    static const int r_env = [] { const char* e = getenv("CE_BWD_R"); return e ? atoi(e) : 16; }();
-    if (nch == 1 && excl && r_env == 8) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 8, true, true>), g, b, 0, s, p, total, rg);
-    else if (nch == 1 && excl && (p.policy & 2)) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, true, true>), g, b, 0, s, p, total, rg);
-    else if (nch == 1 && excl) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, false, true>), g, b, 0, s, p, total, rg);
-    else if (nch == 1 && r_env == 8) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 8, true, false>), g, b, 0, s, p, total, rg);
-    else if (nch == 1 && (p.policy & 2)) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, true, false>), g, b, 0, s, p, total, rg);
-    else if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, false, false>), g, b, 0, s, p, total, rg);
+    if (nch == 1 && excl) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, true, true>), g, b, 0, s, p, total, rg);
+    else if (nch == 1) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 1, 16, true, false>), g, b, 0, s, p, total, rg);
     else if (nch == 2) hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 2, 8, true, false>), g, b, 0, s, p, total, rg);
     else hipLaunchKernelGGL((k_bag_bwd_stream<f32x4, 4, 4, true, false>), g, b, 0, s, p, total, rg);
   } else {
@@ -1441,26 +1397,19 @@ extern "C" int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, in
   p.dst = out;
   p.num_rows = (uint32_t)num_rows;
   p.presorted = (const unsigned long long*)src_keys;
-  static const int il_env = [] { const char* e = getenv("CE_FWDK_INTERLEAVE"); return e ? atoi(e) : 0; }();
-  p.interleave = il_env;
+  p.interleave = 0;
   const int64_t total = cdiv(nnz, kSegLen) * kSegLen;
   // 16 workgroups per CU: more than fit at once (97 VGPRs: 5), so the dispatcher hands the shares out as CUs free up
   // (measured at the bench shape beside the cache op: 4/CU 72-74 us per launch, 8/CU 66-70, 16/CU 63-64, 32/CU 62-65;
   // alone: 8/CU 48, 16/CU 46.7, 5/CU -- exactly resident -- 43 but 66 beside the cache op)
-  static const int per_cu = [] { const char* e = getenv("CE_FWDK_BLOCKS_PER_CU"); return e ? atoi(e) : 16; }();
-  static const int r_env = [] { const char* e = getenv("CE_FWDK_R"); return e ? atoi(e) : 16; }();
+  constexpr int per_cu = 16;
   const int ngroups = 256 >> p.g_log2;
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kNumCU * per_cu, cdiv(total, (int64_t)ngroups * 16)));
   dim3 g(grid), b(256);
   hipStream_t s = (hipStream_t)stream;
-  const int nts = (p.policy & 1) ? 1 : 0;
-#define CE_FWK(VT, N, R)                                                                    \
-  do {                                                                                      \
-    if (nts) hipLaunchKernelGGL((k_bag_fwd_keys<VT, N, R, 1>), g, b, 0, s, p, total);       \
-    else hipLaunchKernelGGL((k_bag_fwd_keys<VT, N, R, 0>), g, b, 0, s, p, total);           \
-  } while (0)
+#define CE_FWK(VT, N, R) hipLaunchKernelGGL((k_bag_fwd_keys<VT, N, R, 1>), g, b, 0, s, p, total)
   if (vec) {
-    if (nch == 1) { if (r_env == 8) CE_FWK(f32x4, 1, 8); else if (r_env == 32) CE_FWK(f32x4, 1, 32); else CE_FWK(f32x4, 1, 16); }
+    if (nch == 1) CE_FWK(f32x4, 1, 16);
     else if (nch == 2) CE_FWK(f32x4, 2, 8); else CE_FWK(f32x4, 4, 4);
   } else {
     if (nch == 1) CE_FWK(float, 1, 16); else if (nch == 2) CE_FWK(float, 2, 8); else CE_FWK(float, 4, 4);
@@ -1471,11 +1420,6 @@ extern "C" int ce_bag_forward_src_keys(const float* weight, int64_t num_rows, in
 }
 
 extern "C" int64_t ce_bag_presort_len(int64_t nnz) { return nnz <= 0 ? 0 : cdiv(nnz, kSegLen) * kSegLen; }
-
-static bool presort_staged() {
-  static const bool v = [] { const char* e = getenv("CE_PRESORT_STAGED"); return e ? atoi(e) != 0 : true; }();
-  return v;
-}
 
 static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, int64_t n_batches, int64_t num_rows,
                                uint64_t* keys_out, const BagParams* lay, int64_t off_stride, const int64_t* ids,
@@ -1491,22 +1435,13 @@ static int presort_window_impl(const int64_t* indices, int64_t nnz_per_batch, in
   int64_t* const no_io = nullptr;
   const int32_t* const no_inv = nullptr;
   const int* const no_st = nullptr;
-  const bool staged = presort_staged();
   if (lay && ids_minmax)
     hipLaunchKernelGGL((k_bag_presort_seg<true, true, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride, ids,
                        ids_minmax, no_io, no_inv, no_st);
-  else if (lay && staged)
-    hipLaunchKernelGGL((k_bag_presort_seg<true, false, false, true>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
-                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride,
-                       (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
   else if (lay)
     hipLaunchKernelGGL((k_bag_presort_seg<true, false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
                        (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, *lay, off_stride,
-                       (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
-  else if (staged)
-    hipLaunchKernelGGL((k_bag_presort_seg<false, false, false, true>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
-                       (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{}, 0ll,
                        (const int64_t*)nullptr, (int64_t*)nullptr, no_io, no_inv, no_st);
   else
     hipLaunchKernelGGL((k_bag_presort_seg<false, false, false>), grid, block, 0, (hipStream_t)stream, indices, nnz_per_batch,
@@ -1539,18 +1474,9 @@ int presort_window_from_rows(int64_t* slots_io, int64_t nnz_per_batch, int64_t n
     int rc = fill_params(lay, 4, nullptr, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset, nullptr,
                          CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    if (presort_staged())
-      hipLaunchKernelGGL((k_bag_presort_seg<true, false, true, true>), grid, block, 0, stream, (const int64_t*)nullptr,
-                         nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
-                         offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
-    else
-      hipLaunchKernelGGL((k_bag_presort_seg<true, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
-                         nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
-                         offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
-  } else if (presort_staged()) {
-    hipLaunchKernelGGL((k_bag_presort_seg<false, false, true, true>), grid, block, 0, stream, (const int64_t*)nullptr,
-                       nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{},
-                       0ll, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
+    hipLaunchKernelGGL((k_bag_presort_seg<true, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
+                       nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, lay,
+                       offsets_batch_stride, (const int64_t*)nullptr, (int64_t*)nullptr, slots_io, inverted, status);
   } else {
     hipLaunchKernelGGL((k_bag_presort_seg<false, false, true>), grid, block, 0, stream, (const int64_t*)nullptr,
                        nnz_per_batch, (int32_t)spb, nseg, (uint32_t)num_rows, (unsigned long long*)keys_out, BagParams{},
@@ -1580,7 +1506,9 @@ static int presort_window_src_impl(const int64_t* indices, int64_t nnz_per_batch
   int rc = fill_params(lay, 4, indices, nnz_per_batch, offsets, offsets_are_i64, num_bags, include_last_offset,
                        nullptr, CE_MODE_SUM, hook_features, &vec, &nch, nullptr, nullptr, nullptr);
   if (rc) return rc;
+#ifdef CE_ABLATIONS
   { const char* dbg = getenv("CE_PRESORT_DEBUG"); lay.debug = dbg ? atoi(dbg) : 0; }
+#endif
   return presort_window_impl(indices, nnz_per_batch, n_batches, num_rows, keys_out, &lay, offsets_batch_stride, ids,
                              seg_id_ranges, stream);
 }

@@ -1908,8 +1908,12 @@ struct SwapEngine {
   const int32_t* evt_pos[2] = {nullptr, nullptr};
   uint32_t evt_mask = 0;
   long long in_probed = 0;         // admissions enqueued while the previous write-back was still on its way
-  int out_delay_us = 0;            // test hook (CE_WORKER_OUT_DELAY_US): every write-back job starts this much late
-  long long fail_in_job = 0;       // test hook (CE_WORKER_FAIL_IN_JOB): this host-gather admission job reports a failed HIP call
+#ifdef CE_TEST_HOOKS
+  // fault / delay injection for tests/test_gpu_worker.py: only in libce_hip_testhooks.so (build.py, -DCE_TEST_HOOKS);
+  // the product library has neither the fields nor the strings (tests/test_abi.py)
+  int out_delay_us = 0;            // CE_WORKER_OUT_DELAY_US: every write-back job starts this much late
+  long long fail_in_job = 0;       // CE_WORKER_FAIL_IN_JOB: this host-gather admission job reports a failed HIP call
+#endif
   int rowlen = 0, g_log2 = 0, vec = 0;
   int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
   int32_t* miss_host_dev = nullptr;
@@ -1966,7 +1970,9 @@ struct SwapEngine {
       const auto t1 = std::chrono::steady_clock::now();
       long long k = mail[b].count;
       double copy_wait = 0, scatter = 0, wait0 = 0;
+#ifdef CE_TEST_HOOKS
       if (out_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(out_delay_us));
+#endif
       CE_TRACE("out job %lld: event done (%s), mail job %lld count %lld", job, hipGetErrorString(e), mail[b].job, k);
       if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record moves nothing
       if (k > 0 && !failed()) {
@@ -2060,7 +2066,9 @@ struct SwapEngine {
       long long n = mail[2].count;
       CE_TRACE("in job %lld: earlier write-backs landed; mail job %lld count %lld", job, mail[2].job, n);
       if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
+#ifdef CE_TEST_HOOKS
       if (fail_in_job > 0 && job == fail_in_job) fail("admission (injected: CE_WORKER_FAIL_IN_JOB)", hipErrorUnknown);
+#endif
       if (n > 0 && !failed()) {
         const float* tb = table;
         float* st = in_host;
@@ -2678,8 +2686,10 @@ static int ensure_writeback(ce_cache* h) {
           break;
         }
       }
+#ifdef CE_TEST_HOOKS
       if (const char* e = getenv("CE_WORKER_OUT_DELAY_US")) w->out_delay_us = std::max(0, atoi(e));
       if (const char* e = getenv("CE_WORKER_FAIL_IN_JOB")) w->fail_in_job = atoll(e);
+#endif
       for (int b = 0; b < 2; ++b) {
         w->evt_keys[b] = h->evt_keys[b];
         w->evt_pos[b] = h->evt_pos[b];

@@ -692,16 +692,8 @@ static int dedupe_bucket_impl(const int64_t* ids, int64_t n, const int32_t* idx_
   if (n > 0) {
     hipLaunchKernelGGL(k_dedupe_mark_w, dim3(grid_for(n, 256), nb), dim3(256), 0, s, ids, n, idx_map, num_rows, bits,
                        stamp, rows32, sstride);
-    const char* it_e = getenv("CE_DEDUPE_IT");      // 1 / 2 / 4 lookups per thread in the claim pass (default 4)
-    const int it_env = it_e ? atoi(it_e) : 4;
-    if (it_env == 1)
-      hipLaunchKernelGGL((k_dedupe_claim_w<1>), dim3(grid_for(n, 256), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
-                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts, num_rows, sstride);
-    else if (it_env == 2)
-      hipLaunchKernelGGL((k_dedupe_claim_w<2>), dim3(grid_for(n, 512), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
-                         world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts, num_rows, sstride);
-    else
-      hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
+    // 4 lookups per thread in the claim pass (1 and 2 measured slower)
+    hipLaunchKernelGGL((k_dedupe_claim_w<4>), dim3(grid_for(n, 1024), nb), dim3(256), 0, s, (const int32_t*)rows32, n,
                          world, (const int32_t*)stamp, slot_of_row, bucket_rows, counts, num_rows, sstride);
   }
   if (cap > 0)

@@ -56,6 +56,31 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert getattr(_lib.lib, n) is not None
 
 
+def test_product_library_has_no_test_hooks_and_few_switches():
+    """the fault / delay injection the worker tests need is compiled only into libce_hip_testhooks.so
+    (-DCE_TEST_HOOKS); the product library carries neither the switches' names nor more than 20 environment switches
+    in all; both libraries export the same C ABI."""
+    from cachedembedding_amd import build as b
+    lib, hooks = b.build(), b.build_test_hooks()
+    blob, hblob = lib.read_bytes(), hooks.read_bytes()
+    for name in (b"CE_WORKER_FAIL_IN_JOB", b"CE_WORKER_OUT_DELAY_US"):
+        assert name not in blob, name
+        assert name in hblob, name
+    for gone in (b"CE_MARK_DEDUPE", b"CE_EARLY_MAPS", b"CE_SPLIT_AFTER_EMIT", b"CE_FWD_STORE", b"CE_BWD_BLOCKS_PER_CU",
+                 b"CE_FWDK_BLOCKS_PER_CU", b"CE_PRESORT_STAGED", b"CE_DEDUPE_IT", b"CE_BWD_DEBUG"):
+        assert gone not in blob, gone
+    switches = set()
+    for src in sorted((b.PKG / "csrc").glob("*.*")):
+        if src.suffix in (".hip", ".h", ".cpp"):
+            switches |= set(re.findall(r'getenv\("(CE_[A-Z0-9_]+)"\)', src.read_text()))
+    assert len(switches) <= 20, sorted(switches)
+
+    def exports(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True).stdout
+        return set(re.findall(r" T (ce_[a-z0-9_]+)", out))
+    assert exports(lib) == exports(hooks)
+
+
 def _struct_fields(name):
     m = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (name, name), HEADER, flags=re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)

@@ -381,9 +381,7 @@ def test_bucketize_rows_stable_and_counts():
         assert torch.equal(perm, exp_perm)
 
 
-@pytest.mark.parametrize("it", ["1", "4"])
-def test_dedupe_bucket_rows_properties(it, monkeypatch):
-    monkeypatch.setenv("CE_DEDUPE_IT", it)
+def test_dedupe_bucket_rows_properties():
     """ce_dedupe_bucket_rows: the unique rows of the batch, grouped by owner; pos maps every lookup to its row
     (the order inside a bucket is not specified, so the check is on the properties the exchange relies on)."""
     from cachedembedding_amd._lib import check, lib, ptr, stream_ptr
