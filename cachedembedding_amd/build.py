@@ -18,7 +18,8 @@ LIB_TEST_HOOKS = PKG / "libce_hip_testhooks.so"
 HOOKED_SOURCES = ["ce_cache.hip"]          # the sources that read CE_TEST_HOOKS
 SOURCES = ["ce_host.hip", "ce_bag.hip", "ce_bag_extra.hip", "ce_cache.hip", "ce_sort.hip", "ce_rowcopy.cpp"]
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++"]       # plain C++ sources (host only)
-HEADERS = [ROOT / "include" / "ce_api.h", CSRC / "ce_common.h", CSRC / "ce_cache_fused.h"]
+HEADERS = [ROOT / "include" / "ce_api.h", CSRC / "ce_common.h", CSRC / "ce_cache_index.h", CSRC / "ce_cache_select.h",
+           CSRC / "ce_cache_rows.h", CSRC / "ce_cache_fused.h", CSRC / "ce_cache_worker.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
          f"--offload-arch={ARCH}", f"-I{ROOT / 'include'}", f"-I{CSRC}"]

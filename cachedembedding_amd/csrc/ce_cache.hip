@@ -43,2226 +43,12 @@
 
 #include "ce_common.h"
 
-namespace ce {
-
-constexpr int kChunkShift = 15;
-constexpr int kChunkRows = 1 << kChunkShift;   // rows covered by one 256-thread workgroup of the bitmap scan (uint4/thread)
-constexpr int kCoarseShift = 6;                 // k_count also sums its chunk counts per 64 chunks (k_emit adds those up)
-constexpr int kCoarsePad = 32;                  // ints between two coarse counters: a 128-byte line each (device atomics to one
-                                                // line serialise whatever the address: packed counters cost k_count 15 us)
-constexpr int kSlotsPerBlock = 1024;  // slots covered by one block of the slot-space scans (4/thread)
-constexpr int kRing = 1024;           // pinned host ring of per-call stats
-constexpr unsigned long long kGraphFreqHeadroom = 1ull << 31;   // ids a captured LFU call may see before a new capture
-constexpr int kDigitBits = 11;         // radix select: 11-bit digits (28-bit DATASET keys of a 178 M-row table: 3 passes)
-constexpr int kBins = 1 << kDigitBits;
-constexpr int kLevels = 6;             // 6 x 11 >= 64 bits
-constexpr int kHistWords = kLevels * kBins;   // one histogram per radix pass
-constexpr int32_t kEpochNever = -(1 << 30);
-constexpr int64_t kHistoryKeep = 1 << 16;   // per-call records kept on the host side
-
-struct Ctl {                 // device control block (one per manager)
-  long long n_free;          // persistent: free slots
-  long long n_unique;        // per call
-  long long n_miss;
-  long long k_evict;
-  long long miss_lookups;
-  unsigned long long sel_prefix;   // (unused)
-  long long sel_krem;              // k of the current select (set by the plan)
-  long long n_eligible;      // slots that may be evicted in this call (resident and not protected)
-  int victims_count;
-  int status;
-  int lost;                  // per call: the admission worker reported that the rows did not arrive (see k_admit_maps)
-  int pad_;
-  long long n_free_start;    // per call: n_free when the call began (k_begin; read-only for the rest of the call)
-  // radix select: digits and remaining rank after level q was resolved (written by workgroup 0 of the kernel that
-  // resolves level q -- every workgroup of that kernel computes the same thing for itself --, read by later kernels)
-  unsigned long long sel_prefix_after[8];
-  long long sel_krem_after[8];
-  // number of the call in flight (= the host's h->seq).  A launched call brings it along (k_begin stores it); a call
-  // replayed from a captured hipGraph has no per-launch arguments, so there k_begin counts it up itself -- the
-  // epoch of the eviction backlist and the record slot in the stats ring are both derived from it on the device.
-  long long seq;
-};
-
-// call number -> what the kernels need from it (seq_arg != 0: launched with its number; 0: replayed, see Ctl::seq)
-__device__ __forceinline__ long long call_seq(const Ctl* ctl, long long seq_arg) { return seq_arg ? seq_arg : ctl->seq; }
-__device__ __forceinline__ int32_t call_epoch(long long seq) { return (int32_t)(seq & 0x3fffffff); }
-
-struct WbMail {              // pinned host mailbox: how many rows a worker job moves (written by the device)
-  long long job;
-  long long count;
-};
-
-struct Layout {              // byte offsets inside the caller-provided workspace
-  size_t ctl, bitmap, blk_unique, blk_miss, coarse, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      chain, lb_emit, lb_remap, miss_list2, free_list2, stage_idx, stage, stage_idx2, stage2, in_stage, total;
-  int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
-};
-
-constexpr int64_t kStageRowsMax = 262144;   // write-back staging: 128 MB at D = 128
-// Rows the admission kernel reads / the unpack kernel moves for the call of either parity: written by the call's
-// plan (k_emit / k_emit_scan) and by the kernel that knows whether the selection held (k_stage_remap / k_admit_maps).
-// The control block's own per-call fields are rewritten by the NEXT call's front while those two kernels may still be
-// running on the admission stream.
-struct ChainWords {
-  long long n_admit[2];
-  long long n_unpack[2];
-};
-
-static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
-  Layout L{};
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  L.n_chunks = cdiv(N, kChunkRows);
-  L.bitmap_words = L.n_chunks * (kChunkRows / 32);
-  L.n_slot_blocks = cdiv(C, kSlotsPerBlock);
-  L.list_cap = std::max<int64_t>(1, std::min<int64_t>(C, std::max<int64_t>(max_ids, 1)));
-  size_t o = 0;
-  L.ctl = o;        o = al(o + sizeof(Ctl));
-  L.bitmap = o;     o = al(o + (size_t)L.bitmap_words * 4);
-  L.blk_unique = o; o = al(o + (size_t)(L.n_chunks + 1) * 4);
-  L.blk_miss = o;   o = al(o + (size_t)(L.n_chunks + 1) * 4);
-  L.coarse = o;     o = al(o + (size_t)((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad * 4);   // [unique, missing] per 64 chunks
-  L.miss_list = o;  o = al(o + (size_t)L.list_cap * 4);
-  L.slot_epoch = o; o = al(o + (size_t)C * 4);
-  L.keys = o;       o = al(o + (size_t)C * 8);
-  L.hist = o;       o = al(o + (size_t)kHistWords * 4);
-  L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
-  L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
-  L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
-  // chained admission (worker transport): the row counts handed to the admission stream, the look-back words of the
-  // single-pass kernels (ce_cache_fused.h), and a second miss / free list -- the admission and unpack kernels of call w
-  // read theirs on the admission stream while call w + 1's front fills the other pair
-  L.chain = o;      o = al(o + sizeof(ChainWords));
-  L.lb_emit = o;    o = al(o + (size_t)(L.n_chunks + 1) * 8);
-  L.lb_remap = o;   o = al(o + (size_t)(cdiv(C, 4096) + 1) * 8);
-  L.miss_list2 = o; o = al(o + (size_t)L.list_cap * 4);
-  L.free_list2 = o; o = al(o + (size_t)L.list_cap * 4);
-  L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
-  L.stage_idx = o;  o = al(o + (size_t)L.stage_rows * 4);
-  L.stage = o;      o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
-  // worker transport (CE_TRANSPORT_WORKER): the eviction staging is double-buffered -- the victims of call w stay
-  // in HBM until the host worker has copied them out, while call w+1 stages into the other buffer -- and the
-  // admitted rows arrive in `in_stage` (one pinned hipMemcpyAsync per chunk) before a kernel moves them to their slots
-  L.stage_idx2 = o; o = al(o + (size_t)L.stage_rows * 4);
-  L.stage2 = o;     o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
-  L.in_stage = o;   o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
-  L.total = o;
-  return L;
-}
-
-// ----------------------------------------------------------------------------- device helpers
-
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
-
-// exclusive scan of one int per thread over a 256-thread block; returns exclusive prefix, *total = block sum
-__device__ __forceinline__ int block_excl_scan_256(int v, int* total) {
-  __shared__ int wsum[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = wave_incl_scan(v, lane);
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int base = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < w) base += wsum[i];
-    tot += wsum[i];
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
-
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-}
-
-// ----------------------------------------------------------------------------- kernels
-
-// per-call reset: the control block's call fields, the coarse chunk sums k_count adds to, the radix histograms
-__global__ __launch_bounds__(256) void k_begin(Ctl* ctl, int32_t* coarse, int n_coarse2, uint32_t* hist,
-                                               long long seq_arg) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctl->seq = seq_arg ? seq_arg : ctl->seq + 1;
-    ctl->n_unique = 0;
-    ctl->n_miss = 0;
-    ctl->k_evict = 0;
-    ctl->miss_lookups = 0;
-    ctl->sel_prefix = 0;
-    ctl->sel_krem = 0;
-    ctl->n_eligible = 0;
-    ctl->victims_count = 0;
-    ctl->status = CE_OK;
-    ctl->lost = 0;
-    ctl->n_free_start = ctl->n_free;
-  }
-  // (a few workgroups: one of 256 threads spent 10 us on these 13-18 k stores -- a launch of the chain like any other)
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-  if (coarse)
-    for (int i = tid; i < n_coarse2; i += nth) coarse[i] = 0;
-  if (hist)
-    for (int i = tid; i < kHistWords; i += nth) hist[i] = 0;
-}
-
-// Bits of one bitmap word (32 consecutive rows from row0) whose row is not resident.  The frequency ranking packs
-// the hot rows into the lowest words, where nearly every bit is set: a lookup per set bit would be up to 128
-// dependent-latency loads in one thread (the tail of k_emit), so dense words fetch the 32 map entries
-// as eight 16-byte loads instead.
-__device__ __forceinline__ bool dense_word(uint32_t bits, int64_t row0, int64_t N) {
-  return __popc(bits) >= 6 && row0 + 32 <= N;
-}
-__device__ __forceinline__ uint32_t miss_mask(const int32_t* __restrict__ inverted, int64_t row0, uint32_t bits,
-                                              int64_t N) {
-  uint32_t mm = 0;
-  if (dense_word(bits, row0, N)) {
-    const int4* p = (const int4*)(inverted + row0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int4 x = p[j];
-      mm |= ((uint32_t)(x.x < 0) | ((uint32_t)(x.y < 0) << 1) | ((uint32_t)(x.z < 0) << 2) |
-             ((uint32_t)(x.w < 0) << 3)) << (4 * j);
-    }
-    return mm & bits;
-  }
-  while (bits) {
-    const int b = __ffs(bits) - 1;
-    bits &= bits - 1;
-    if (inverted[row0 + b] < 0) mm |= 1u << b;
-  }
-  return mm;
-}
-
-// The same, and every resident row's slot gets the call's stamp on the way (k_emit: the slot is in hand here, a second
-// pass over the map just for the stamps was k_emit's tail).
-__device__ __forceinline__ uint32_t miss_mask_stamp(const int32_t* __restrict__ inverted, int64_t row0, uint32_t bits,
-                                                    int64_t N, int32_t* slot_epoch, int32_t epoch) {
-  uint32_t mm = 0;
-  if (dense_word(bits, row0, N)) {
-    const int4* p = (const int4*)(inverted + row0);
-    int4 x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = p[j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int32_t sl[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (!((bits >> (4 * j + c)) & 1)) continue;
-        if (sl[c] < 0) mm |= 1u << (4 * j + c);
-        else slot_epoch[sl[c]] = epoch;       // evict_backlist membership [A.3-3]
-      }
-    }
-    return mm;
-  }
-  while (bits) {
-    const int b = __ffs(bits) - 1;
-    bits &= bits - 1;
-    const int32_t sl = inverted[row0 + b];
-    if (sl < 0) mm |= 1u << b;
-    else slot_epoch[sl] = epoch;
-  }
-  return mm;
-}
-
-// The four words of one uint4 of the bitmap at once (k_emit_scan): the map entries of ALL sparse words are fetched in
-// one batch -- up to 20 loads in flight -- instead of word after word, bit after bit (a chain of up to 20 dependent
-// round trips in miss_mask_stamp's tail loop: 2-3 us each beside the training kernels); dense words take the 16-byte
-// path as before.
-__device__ __forceinline__ void miss_masks4_stamp(const int32_t* __restrict__ inverted, int64_t row0,
-                                                  const uint32_t (&wds)[4], int64_t N, int32_t* slot_epoch,
-                                                  int32_t epoch, uint32_t (&mm)[4]) {
-  int idx[4][5];
-  int32_t val[4][5];
-  bool dense[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    dense[k] = __popc(wds[k]) > 5;      // (miss_mask_stamp: sixteen-byte loads, or bit by bit in the table's last word)
-    uint32_t b = dense[k] ? 0u : wds[k];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      idx[k][j] = b ? __ffs(b) - 1 : -1;
-      b &= b - 1;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) val[k][j] = idx[k][j] >= 0 ? inverted[row0 + 32 * k + idx[k][j]] : 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    mm[k] = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      if (idx[k][j] < 0) continue;
-      if (val[k][j] < 0) mm[k] |= 1u << idx[k][j];
-      else slot_epoch[val[k][j]] = epoch;       // evict_backlist membership [A.3-3]
-    }
-    if (dense[k]) mm[k] = miss_mask_stamp(inverted, row0 + 32 * k, wds[k], N, slot_epoch, epoch);
-  }
-}
-
-// ids -> rows -> bits in the row bitmap.
-//
-// Hot rows share bitmap words (rank order puts the hottest 32 rows in word 0) and a Criteo window sends >100k ids at
-// a 3-row table, so a global atomicOr per id would serialise.  Rows in frequency order (idx_map present): the
-// lowest `hot_words` words live in an LDS window per workgroup and are flushed once at the end; a cold id first
-// LOOKS at its word and only issues the (fire-and-forget) atomic when its bit is still clear.  Rows in id order
-// (MERGE): hot rows are scattered, so the lanes of a wave that still aim at the same word are merged with ballots
-// and one lane issues the atomicOr for all of them.
-// (Round 3 tried to count the unique / missing rows here as well -- the thread whose atomicOr sets a bit first owns
-// the row -- so that the bitmap would be scanned once instead of twice: the returning atomics that needs cost 40 us,
-// more than the k_count pass they replaced; round 5 folded the repeats of every 8192-id chunk in an LDS hash table
-// first: 7x slower, the same-word atomics of the hot rows that the LDS window below absorbs.  docs/history.md.)
-// U ids per thread are in flight (a chain of three dependent random accesses per id).
-// rows_out: the row of every id (-1 = bad id), as int64 in the caller's slots buffer -- k_slots turns it into the
-// slot in place, so idx_map is gathered once per id per call.
-// The body of k_mark: a grid-stride pass of the calling grid over the ids.  *cold += this
-// thread's lookups of rows that are not resident; *bad = it met an id outside [0, N) that is not accepted padding.
-template <bool MERGE, int U>
-__device__ __forceinline__ void mark_pass(const int64_t* __restrict__ ids, int64_t n,
-                                          const int32_t* __restrict__ idx_map, const int32_t* __restrict__ inverted,
-                                          int64_t N, int word_bits, int hot_words, uint32_t* hot, uint32_t* bitmap,
-                                          int64_t* rows_out, int allow_pad, int* cold_out, bool* bad_out) {
-  for (int w = threadIdx.x; w < hot_words; w += blockDim.x) hot[w] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
-  int cold = 0;
-  bool bad = false;
-  // wave-uniform trip count: a wave owns U * 64 consecutive ids per iteration
-  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * U; i0 < n; i0 += stride) {
-    int32_t row[U], inv[U];
-    uint32_t cur[U];
-    bool valid[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * 64 + lane;
-      valid[u] = i < n;
-      row[u] = 0;
-      if (valid[u]) {
-        const int64_t id = ids[i];
-        if ((unsigned long long)id >= (unsigned long long)N) {
-          // ce_cache_prepare_ids_padded only: -1 = padding (fixed-capacity exchange), no lookup, slot -1.  On the
-          // plain entry point a -1 is a bad id like any other (upstream's idx_map.index_select raises on it).
-          if (!(allow_pad && id == -1)) bad = true;
-          valid[u] = false;
-          rows_out[i] = -1;
-        } else {
-          row[u] = idx_map ? idx_map[id] : (int32_t)id;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * 64 + lane;
-      inv[u] = 0;
-      cur[u] = ~0u;
-      if (valid[u]) {
-        rows_out[i] = row[u];
-        inv[u] = inverted[row[u]];
-        const int word = row[u] >> 5;
-        // (looking at hot[word] first and skipping the LDS atomic when the bit is set -- what the cold path does with
-        // the global bitmap -- measured in round 4: 67.2 against 65.1 us, no gain.  Also round 4: a RESIDENCY BITMAP
-        // (bit r = row r is resident, kept by the admit / evict kernels) in place of the inverted[] gathers of this
-        // kernel, k_count and k_emit: k_count 13.6 -> 7.8 us, but k_mark 65 -> 69, k_emit 31 -> 37 and the slots +
-        // keys kernel 32 -> 38 -- every lookup needs inverted[row] once anyway (its slot), and this kernel's gather is
-        // what has it in L2 when the later kernels ask; 328 GPU tests green, no net gain, not kept.)
-        if (word < hot_words) atomicOr(&hot[word], 1u << (row[u] & 31));
-        else cur[u] = *(volatile uint32_t*)(bitmap + word);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int word = row[u] >> 5;
-      const int bidx = row[u] & 31;
-      const bool need = valid[u] && (cur[u] & (1u << bidx)) == 0;
-      if (valid[u]) cold += inv[u] < 0;
-      if (!MERGE) {
-        if (need) atomicOr(bitmap + word, 1u << bidx);
-      } else if (__any(need)) {
-        unsigned long long pm = __ballot(need);
-        if (!need) pm = 0;
-        for (int b = 0; b < word_bits; ++b) {
-          const unsigned long long m = __ballot((word >> b) & 1);
-          pm &= ((word >> b) & 1) ? m : ~m;
-        }
-        uint32_t orbits = 0;
-#pragma unroll
-        for (int b = 0; b < 32; ++b) {
-          const unsigned long long m = __ballot(need && bidx == b);
-          if (m & pm) orbits |= (1u << b);
-        }
-        if (need && (__ffsll((long long)pm) - 1) == lane) atomicOr(bitmap + word, orbits);
-      }
-    }
-  }
-  __syncthreads();
-  // the window goes out with all of a thread's looks at the bitmap in flight together (one word after the other was up
-  // to 16 dependent round trips: half of this kernel's time at 426 k ids)
-  for (int w0 = threadIdx.x; w0 < hot_words; w0 += (int)blockDim.x * 8) {
-    uint32_t v[8], cur[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int w = w0 + q * (int)blockDim.x;
-      v[q] = w < hot_words ? hot[w] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) cur[q] = v[q] ? *(volatile uint32_t*)(bitmap + w0 + q * (int)blockDim.x) : ~0u;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (v[q] && (cur[q] & v[q]) != v[q]) atomicOr(bitmap + w0 + q * (int)blockDim.x, v[q]);
-  }
-  *cold_out += cold;
-  *bad_out = *bad_out || bad;
-}
-
-template <bool MERGE, int U>
-__global__ __launch_bounds__(1024) void k_mark(const int64_t* __restrict__ ids, int64_t n,
-                                              const int32_t* __restrict__ idx_map,
-                                              const int32_t* __restrict__ inverted, int64_t N, int word_bits,
-                                              int hot_words, uint32_t* bitmap, Ctl* ctl, int64_t* rows_out,
-                                              int allow_pad) {
-  extern __shared__ uint32_t hot[];
-  int cold = 0;
-  bool bad = false;
-  mark_pass<MERGE, U>(ids, n, idx_map, inverted, N, word_bits, hot_words, hot, bitmap, rows_out, allow_pad, &cold, &bad);
-  if (bad) ctl->status = CE_ERR_RANGE;
-  cold = wave_sum(cold);
-  if ((threadIdx.x & 63) == 0 && cold) atomicAdd((unsigned long long*)&ctl->miss_lookups, (unsigned long long)cold);
-}
-
-// unique / missing rows per 32768-row chunk of the bitmap (one uint4 = 128 rows per thread), and their sums per 64
-// chunks (two device atomics per workgroup on ~85 addresses: k_emit adds those up instead of 5431 chunk counts)
-__global__ __launch_bounds__(256) void k_count(const uint4* __restrict__ bitmap4,
-                                               const int32_t* __restrict__ inverted, int64_t N,
-                                               int32_t* blk_unique, int32_t* blk_miss, int32_t* coarse) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint4 q = bitmap4[v];
-  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-  int u = 0, m = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (!wds[k]) continue;
-    u += __popc(wds[k]);
-    m += __popc(miss_mask(inverted, v * 128 + k * 32, wds[k], N));
-  }
-  __shared__ int su[4], sm[4];
-  u = wave_sum(u);
-  m = wave_sum(m);
-  if ((threadIdx.x & 63) == 0) {
-    su[threadIdx.x >> 6] = u;
-    sm[threadIdx.x >> 6] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int tu = su[0] + su[1] + su[2] + su[3], tm = sm[0] + sm[1] + sm[2] + sm[3];
-    blk_unique[blockIdx.x] = tu;
-    blk_miss[blockIdx.x] = tm;
-    if (tu) atomicAdd(&coarse[(2 * (blockIdx.x >> kCoarseShift)) * kCoarsePad], tu);
-    if (tm) atomicAdd(&coarse[(2 * (blockIdx.x >> kCoarseShift) + 1) * kCoarsePad], tm);
-  }
-}
-
-// Ordered emission of the missing rows + the plan.  The bitmap is scanned in 32768-row chunks (one uint4 = 128 rows
-// per thread of a 256-thread workgroup); a workgroup takes kEmitSub chunks, strided by the grid size, with all its
-// loads in flight at once: the whole grid is then resident at the same time (1358 workgroups at N = 178 M) instead of
-// running in 2.7 rounds of short latency-bound workgroups, and the dense chunks of the hot rows (the lowest ones)
-// land in different workgroups.  A chunk's place in the miss list is the number of missing rows in the chunks
-// before it; every workgroup adds that up itself -- k_count's sums per 64 chunks plus the chunk counts of the
-// chunk's own group of 64: ~150 values out of L2 -- so there is neither a scan kernel (k_plan: 13.6 us + a launch)
-// nor a chain between workgroups.  The same sums give every workgroup the call's totals and hence the same verdict;
-// workgroup 0 also records it: capacity check, k = misses - free slots, the stats record, the mailbox.
-constexpr int kEmitSub = 1;      // (4 chunks per workgroup, contiguous or strided, measured SLOWER: 111 / 56 us against 46)
-__global__ __launch_bounds__(256) void k_emit(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
-                                              const int32_t* __restrict__ blk_miss, const int32_t* __restrict__ coarse,
-                                              int n_chunks, int32_t* miss_list, int32_t* slot_epoch, long long seq_arg,
-                                              Ctl* ctl, int64_t C, int64_t n_ids, ce_call_stats_t* ring,
-                                              WbMail* mail_in, long long job, long long in_cap, int32_t* miss_host,
-                                              int assume_free0, long long* n_admit_out = nullptr) {
-  const long long seq_ = call_seq(ctl, seq_arg);
-  const int32_t epoch = call_epoch(seq_);
-  ce_call_stats_t* const ring_slot = ring + (seq_ % kRing);
-  __shared__ long long red[2 + kEmitSub][4];
-  __shared__ int wsub[kEmitSub][4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int bid = (int)blockIdx.x, G = (int)gridDim.x;
-  const int st_in = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int chunk[kEmitSub];
-  uint4 q[kEmitSub];
-#pragma unroll
-  for (int j = 0; j < kEmitSub; ++j) {
-    chunk[j] = bid + j * G;
-    q[j] = make_uint4(0, 0, 0, 0);
-    if (chunk[j] < n_chunks) q[j] = bitmap4[(int64_t)chunk[j] * 256 + threadIdx.x];
-  }
-  // totals, and every chunk's base, from the coarse sums + the chunk counts of the chunk's own group of 64
-  const int n_coarse = (n_chunks >> kCoarseShift) + 1;
-  long long tu_p = 0, tm_p = 0, base_p[kEmitSub];
-#pragma unroll
-  for (int j = 0; j < kEmitSub; ++j) base_p[j] = 0;
-  for (int g = threadIdx.x; g < n_coarse; g += 256) {
-    const int cu = coarse[(2 * g) * kCoarsePad], cm = coarse[(2 * g + 1) * kCoarsePad];
-    tu_p += cu;
-    tm_p += cm;
-#pragma unroll
-    for (int j = 0; j < kEmitSub; ++j)
-      if (g < (chunk[j] >> kCoarseShift)) base_p[j] += cm;
-  }
-#pragma unroll
-  for (int j = 0; j < kEmitSub; ++j) {
-    const int i = ((chunk[j] >> kCoarseShift) << kCoarseShift) + (int)(threadIdx.x & 63);
-    if ((int)(threadIdx.x >> 6) == j && i < chunk[j] && chunk[j] < n_chunks) base_p[j] += blk_miss[i];      // wave j: chunk j
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    tu_p += __shfl_xor(tu_p, d);
-    tm_p += __shfl_xor(tm_p, d);
-#pragma unroll
-    for (int j = 0; j < kEmitSub; ++j) base_p[j] += __shfl_xor(base_p[j], d);
-  }
-  if (lane == 0) {
-    red[0][wv] = tu_p;
-    red[1][wv] = tm_p;
-#pragma unroll
-    for (int j = 0; j < kEmitSub; ++j) red[2 + j][wv] = base_p[j];
-  }
-  __syncthreads();
-  const long long tu = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  const long long tm = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-  // assume_free0: the host launched the call in its steady-state form (no free-list scan: the slots to fill are the
-  // victims, see k_evict_stage) because the last record it has seen said "no free slot left".  Nothing but a flush or
-  // a lost admission raises the count again and the host knows of both -- but a call launched before the record of
-  // a lost admission arrived must not pair missing rows with a stale list: it fails, state untouched.
-  const bool stale = assume_free0 && ctl->n_free_start != 0;
-  // workgroup 0 may already have turned CE_OK into CE_ERR_CAPACITY below: the verdict is the same either way
-  const bool ok = st_in == CE_OK && tu <= C && !stale;
-  if (bid == 0 && threadIdx.x == 0) {
-    int status = st_in;
-    if (status == CE_OK && tu > C) status = CE_ERR_CAPACITY;
-    if (status == CE_OK && stale) status = CE_ERR_HIP;
-    long long k = 0;
-    if (status == CE_OK) {
-      k = tm - ctl->n_free;
-      if (k < 0) k = 0;
-      ctl->n_free = ctl->n_free + k - tm;
-    }
-    __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ctl->n_unique = tu;
-    ctl->n_miss = tm;
-    ctl->k_evict = k;
-    ctl->sel_krem = k;
-    ring_slot->n_ids = n_ids;
-    ring_slot->n_unique = tu;
-    ring_slot->n_miss = tm;
-    ring_slot->n_evict = k;
-    ring_slot->miss_lookups = (status == CE_OK) ? ctl->miss_lookups : 0;
-    ring_slot->n_free_after = ctl->n_free;
-    ring_slot->status = status;
-    ring_slot->kind = CE_CALL_PREPARE;
-    if (mail_in) {      // rows the admission worker gathers for this call (read after the event behind this kernel)
-      const long long mrows = (status == CE_OK) ? tm : 0;
-      mail_in->count = mrows < in_cap ? mrows : in_cap;
-      mail_in->job = job;
-    }
-    if (n_admit_out) {  // chained admission: the same count, for the admission kernel behind this kernel's event
-      const long long mrows = (status == CE_OK) ? tm : 0;
-      *n_admit_out = mrows < in_cap ? mrows : in_cap;
-    }
-    // seq (the "record complete" marker) is published by the last kernel of the call that may still amend the
-    // record (k_victims can turn it into a capacity failure): k_admit_maps
-  }
-  // ONE pass over the map entries of the rows seen: which of them are missing, and the call's stamp on the slots of
-  // the others (a failed call stamps nothing and emits nothing)
-  uint32_t mm[kEmitSub][4];
-  int m[kEmitSub], inc[kEmitSub];
-#pragma unroll
-  for (int j = 0; j < kEmitSub; ++j) {
-    m[j] = 0;
-    const uint32_t wds[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-    const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      mm[j][k] = 0;
-      if (ok && wds[k]) {
-        mm[j][k] = miss_mask_stamp(inverted, v * 128 + k * 32, wds[k], N, slot_epoch, epoch);
-        m[j] += __popc(mm[j][k]);
-      }
-    }
-    inc[j] = wave_incl_scan(m[j], lane);
-    if (lane == 63) wsub[j][wv] = inc[j];
-  }
-  __syncthreads();
-  if (ok) {
-#pragma unroll
-    for (int j = 0; j < kEmitSub; ++j) {
-      if (chunk[j] >= n_chunks) continue;
-      int pos = (int)(red[2 + j][0] + red[2 + j][1] + red[2 + j][2] + red[2 + j][3]) + inc[j] - m[j];
-      for (int k = 0; k < wv; ++k) pos += wsub[j][k];
-      const int64_t v = (int64_t)chunk[j] * 256 + threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t bits = mm[j][k];
-        const int64_t row0 = v * 128 + k * 32;
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          if (miss_host && pos < in_cap) miss_host[pos] = (int32_t)(row0 + b);      // the admission worker's copy
-          miss_list[pos++] = (int32_t)(row0 + b);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kEmitSub; ++j)
-    if (chunk[j] < n_chunks && (q[j].x | q[j].y | q[j].z | q[j].w))
-      bitmap4[(int64_t)chunk[j] * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0);
-}
-
-// selection keys: smaller = evicted first.  Ineligible (empty / protected) = all ones.  The histogram of the TOP digit
-// is taken here too (the keys are in registers): one pass over the keys less.
-__global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached_idx_map,
-                                              const int64_t* __restrict__ freq,
-                                              const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
-                                              long long seq_arg, int32_t depth, int slot_bits, int lfu, int top_pass,
-                                              unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
-  if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin)
-  const int32_t epoch = call_epoch(call_seq(ctl, seq_arg));
-  __shared__ uint32_t sh[kBins];
-  for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
-  __syncthreads();
-  const int shift = top_pass * kDigitBits;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // LFU: a counter is clamped so that the key stays inside the digits the select looks at (the host derives
-  // top_pass from an upper bound of the counters; freq_cnter is the caller's tensor, so nothing else guarantees it)
-  const int key_bits = (top_pass + 1) * kDigitBits;
-  const unsigned long long fmax = (1ull << ((key_bits < 63 ? key_bits : 63) - slot_bits)) - 1;
-  int elig = 0;
-  // four slots per thread in flight (one after the other, a thread of the 512-workgroup grid walked 13 slots of a
-  // 1.7 M-slot cache in 13 dependent round trips)
-  constexpr int UK = 4;
-  for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < C; s0 += stride * UK) {
-    int32_t row[UK], ep[UK];
-    long long fr[UK];
-#pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      const int64_t s = s0 + (int64_t)u * stride;
-      row[u] = s < C ? cached_idx_map[s] : -1;
-      ep[u] = s < C ? slot_epoch[s] : 0;
-      fr[u] = (lfu && s < C) ? freq[s] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      const int64_t s = s0 + (int64_t)u * stride;
-      if (s >= C) continue;
-      const bool prot = (epoch - ep[u]) <= depth;
-      unsigned long long key = ~0ull;
-      if (row[u] >= 0 && !prot) {
-        if (lfu) {
-          unsigned long long uf = fr[u] < 0 ? 0ull : (unsigned long long)fr[u];
-          if (uf > fmax) uf = fmax;
-          key = (uf << slot_bits) | (unsigned long long)s;
-        } else {
-          key = (unsigned long long)(N - 1 - row[u]);
-        }
-        ++elig;
-      }
-      keys[s] = key;
-      atomicAdd(&sh[(key >> shift) & (kBins - 1)], 1u);
-    }
-  }
-  // evictable slots are counted here, not read off the top-digit histogram: a DATASET key N-1-row can share its
-  // top digit with the all-ones key of an ineligible slot.
-  // One atomic per WORKGROUP on a grid of at most 512: same-address device atomics serialise at ~7 ns each, and
-  // one per wave of a 1738-workgroup grid cost this kernel 50 us.
-  __shared__ int wsum[4];
-  elig = wave_sum(elig);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = elig;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (tot) atomicAdd((unsigned long long*)&ctl->n_eligible, (unsigned long long)tot);
-  }
-  uint32_t* const mine = hist + top_pass * kBins;
-  for (int i = threadIdx.x; i < kBins; i += blockDim.x)
-    if (sh[i]) atomicAdd(&mine[i], sh[i]);
-}
-
-// Few, fat workgroups: every workgroup ends with one device atomic per non-empty bin and same-address atomics
-// serialise (~7 ns each), so 1738 workgroups of 256 cost 12 us per pass in the histogram flush alone; 256
-// workgroups of 1024 threads with 4 independent key loads per thread read the 14 MB of keys just as fast.
-// Digits of the k-th smallest key decided so far, from the per-pass histograms hist[q][2048] of the passes q > lowest
-// (what a single-thread pick kernel between two histogram passes would compute): one wave, 32 bins per lane, per
-// level a wave scan, the first lane whose running count reaches k, then that lane's bins handed round with
-// shuffles.  Every workgroup of the NEXT kernel recomputes it in its prologue (8 KB per level out of L2) -- that
-// removes one launch per pass.  The inputs (k in ctl->sel_krem, the histograms) are read-only while it runs, so all
-// workgroups agree.
-struct SelState {
-  unsigned long long prefix;
-  int krem;
-  int fail;      // fewer evictable slots than k: capacity overflow of the overlapped pipeline
-};
-// Resolves ONE level: the digit of the k-th smallest key at level q from that level's histogram, given the digits
-// and the remaining rank of the levels above.  One wave, 32 bins per lane: a wave scan, the first lane whose running
-// count reaches the rank, then that lane's bins handed round with shuffles.
-__device__ __forceinline__ SelState select_digit(const uint32_t* hist, int q, unsigned long long prefix_in,
-                                                 int krem_in, int lane) {
-  SelState st;
-  st.prefix = prefix_in;
-  st.krem = krem_in;
-  st.fail = 0;
-  uint4 h[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) h[j] = ((const uint4*)(hist + q * kBins))[lane * 8 + j];
-  int sum = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) sum += (int)(h[j].x + h[j].y + h[j].z + h[j].w);
-  const int inc = wave_incl_scan(sum, lane);
-  const unsigned long long m = __ballot(inc >= st.krem);
-  const int L = m ? __ffsll((long long)m) - 1 : 63;
-  const int r = st.krem - __shfl(inc - sum, L);          // rank inside lane L's 32 bins
-  int dd = 31, before = 0, cum = 0;
-  bool found = false;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int vals[4] = {(int)h[j].x, (int)h[j].y, (int)h[j].z, (int)h[j].w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int val = __shfl(vals[c], L);
-      if (!found && r <= cum + val) {
-        dd = 4 * j + c;
-        before = cum;
-        found = true;
-      }
-      cum += val;
-    }
-  }
-  if (!found) before = cum - __shfl((int)h[7].w, L);      // (only on the failure path: k beyond the candidates)
-  st.prefix |= ((unsigned long long)(32 * L + dd)) << (q * kDigitBits);
-  st.krem = r - before;
-  return st;
-}
-
-// The per-launch form: every workgroup of a kernel resolves the level above its own in its prologue (8 KB out of L2),
-// from the state workgroup 0 of the kernel before left in the control block (the top level starts from k itself), and
-// workgroup 0 records the result for the next kernel: no pick kernel between two passes, no dependency between
-// workgroups, one histogram read per kernel.
-__device__ __forceinline__ SelState select_level(const uint32_t* __restrict__ hist, int q, int top_pass, Ctl* ctl,
-                                                 int lane, bool record) {
-  const unsigned long long prefix_in = q == top_pass ? 0ull : ctl->sel_prefix_after[q + 1];
-  const int krem_in = q == top_pass ? (int)ctl->sel_krem : (int)ctl->sel_krem_after[q + 1];
-  SelState st = select_digit(hist, q, prefix_in, krem_in, lane);
-  // With protect_depth > 0 the protected set can leave fewer than k candidates: that is the capacity overflow of
-  // the overlapped pipeline (unique(window k u k+1) > cuda_row_num); evictable slots are counted by k_keys
-  st.fail = ctl->n_eligible < ctl->sel_krem;
-  if (record && lane == 0) {
-    ctl->sel_prefix_after[q] = st.prefix;
-    ctl->sel_krem_after[q] = st.krem;
-  }
-  return st;
-}
-
-__global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restrict__ keys, int64_t C, int pass,
-                                               int top_pass, uint32_t* hist, Ctl* ctl) {
-  if (ctl->k_evict == 0) return;
-  __shared__ uint32_t sh[kBins];
-  __shared__ unsigned long long prefix_s;
-  __shared__ int fail_s;
-  for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
-  if (threadIdx.x < 64) {
-    const SelState st = select_level(hist, pass + 1, top_pass, ctl, threadIdx.x, blockIdx.x == 0);
-    if (threadIdx.x == 0) {
-      prefix_s = st.prefix;
-      fail_s = st.fail;
-    }
-  }
-  __syncthreads();
-  if (fail_s) return;                  // k_victims records the failure
-  const int shift = pass * kDigitBits;
-  const unsigned long long prefix = prefix_s;
-  constexpr int U = 4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
-  for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; s0 < C; s0 += stride) {
-    unsigned long long key[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t s = s0 + (int64_t)u * blockDim.x;
-      key[u] = s < C ? keys[s] : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t s = s0 + (int64_t)u * blockDim.x;
-      // (only passes below the top one get here: shift + kDigitBits <= 55)
-      const bool match = (key[u] >> (shift + kDigitBits)) == (prefix >> (shift + kDigitBits));
-      if (s < C && match) atomicAdd(&sh[(key[u] >> shift) & (kBins - 1)], 1u);
-    }
-  }
-  __syncthreads();
-  uint32_t* const mine = hist + pass * kBins;
-  for (int i = threadIdx.x; i < kBins; i += blockDim.x)
-    if (sh[i]) atomicAdd(&mine[i], sh[i]);
-}
-
-// blk_vic (steady-state calls only): victims among this workgroup's 4096 slots -- k_evict_stage's free-list
-// workgroups turn them into the ascending list of slots to fill without another scan of cached_idx_map; the
-// threshold key goes to ctl->sel_prefix_after[0] for them.
-__global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
-                                                 int32_t* victims, int64_t cap, Ctl* ctl, const uint32_t* hist,
-                                                 int top_pass, ce_call_stats_t* ring, long long seq_arg,
-                                                 int32_t* blk_vic) {
-  ce_call_stats_t* const ring_slot = ring + (call_seq(ctl, seq_arg) % kRing);
-  __shared__ unsigned long long prefix_s;
-  __shared__ int fail_s, go_s;
-  // this workgroup's 4096 slots (16 per thread, strided by 256): in flight while wave 0 works out the threshold
-  // (every workgroup recomputes it from the histograms: few, fat workgroups keep that redundant work small)
-  constexpr int KV = 16;
-  const int64_t s0 = (int64_t)blockIdx.x * (256 * KV) + threadIdx.x;
-  unsigned long long key[KV];
-#pragma unroll
-  for (int u = 0; u < KV; ++u) {
-    const int64_t sl = s0 + u * 256;
-    key[u] = sl < C ? keys[sl] : ~0ull;
-  }
-  if (blk_vic && threadIdx.x == 0) blk_vic[blockIdx.x] = 0;
-  if (threadIdx.x < 64) {
-    const SelState st = select_level(hist, 0, top_pass, ctl, threadIdx.x, blk_vic != nullptr && blockIdx.x == 0);
-    if (threadIdx.x == 0) {
-      prefix_s = st.prefix;
-      fail_s = st.fail;
-      // k_evict is cleared by workgroup 0 of THIS kernel when the call fails: it is read once per workgroup, by one
-      // thread, so that all threads of a workgroup take the same way around the barrier below
-      go_s = ctl->k_evict != 0;
-    }
-  }
-  __syncthreads();
-  if (!go_s) return;
-  if (fail_s) {
-    // every workgroup sees the same failure (read-only inputs); ONE thread turns the call into a capacity failure:
-    // nothing is evicted or admitted, the record says so.  The kernels that follow read k_evict / status.
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      ctl->n_free = ctl->n_free - ctl->k_evict + ctl->n_miss;
-      ctl->k_evict = 0;
-      ctl->status = CE_ERR_CAPACITY;
-      ring_slot->status = CE_ERR_CAPACITY;
-      ring_slot->n_evict = 0;
-      ring_slot->n_free_after = ctl->n_free;
-      __threadfence_system();
-    }
-    return;
-  }
-  const unsigned long long T = prefix_s;   // k-th smallest key; keys are unique
-  // the workgroup's victims are counted with a block scan and reserve their places with ONE returning atomic (a returning device atomic is a ~2 us round trip; one
-  // per wave with a victim in it was ~24 k of them on one address per call)
-  __shared__ int base_s;
-  int hits = 0;
-#pragma unroll
-  for (int u = 0; u < KV; ++u) hits += (key[u] <= T && key[u] != ~0ull);
-  int tot;
-  int pos = block_excl_scan_256(hits, &tot);
-  if (tot == 0) return;                     // block-uniform
-  if (threadIdx.x == 0) {
-    base_s = atomicAdd(&ctl->victims_count, tot);
-    if (blk_vic) blk_vic[blockIdx.x] = tot;
-  }
-  __syncthreads();
-  pos += base_s;
-#pragma unroll
-  for (int u = 0; u < KV; ++u) {
-    if (key[u] <= T && key[u] != ~0ull) {
-      if (pos < cap) victims[pos] = (int32_t)(s0 + u * 256);
-      ++pos;
-    }
-  }
-}
-
-// group of G lanes per row, 16 B per lane (or 4 B when the row is not 16-B sized)
-template <typename VT>
-__device__ __forceinline__ void copy_row(const VT* __restrict__ src, VT* __restrict__ dst, int rowlen, int gl, int G) {
-  for (int c = gl; c < rowlen; c += G) dst[c] = src[c];
-}
-
-constexpr int kSwapRows = 16;   // rows in flight per lane group in the PCIe swap kernels
-
-template <typename VT>
-__global__ __launch_bounds__(1024) void k_evict(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
-                                               int32_t* inverted, const VT* __restrict__ cache, VT* host,
-                                               long long first, int rowlen, int g_log2, const Ctl* ctl) {
-  const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
-  if (k <= first) return;
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  if (!host) return;
-  // kSwapRows rows in flight per lane group: the kernel is PCIe-latency bound, so it is launched on a SMALL grid
-  // (it must not occupy the wave slots of the training kernels it overlaps with) and gets its
-  // memory-level parallelism from unrolling instead
-  for (int64_t i = first + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * kSwapRows; i < k;
-       i += gstride * kSwapRows) {
-    if (rowlen <= G) {
-      VT v[kSwapRows];
-      int64_t dst[kSwapRows];
-#pragma unroll
-      for (int t = 0; t < kSwapRows; ++t) {
-        dst[t] = -1;
-        if (i + t < k) {
-          const int32_t slot = victims[i + t];
-          dst[t] = cached_idx_map[slot];
-          if (gl < rowlen) v[t] = cache[(int64_t)slot * rowlen + gl];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < kSwapRows; ++t) {
-        if (dst[t] < 0) continue;
-        if (gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
-        if (gl == 0) {                      // maps of the victims this kernel moves (k_evict_stage does its own)
-          inverted[dst[t]] = -1;
-          cached_idx_map[victims[i + t]] = -1;
-        }
-      }
-    } else {
-      for (int t = 0; t < kSwapRows && i + t < k; ++t) {
-        const int32_t slot = victims[i + t];
-        const int32_t row = cached_idx_map[slot];
-        copy_row(cache + (int64_t)slot * rowlen, host + (int64_t)row * rowlen, rowlen, gl, G);
-        __builtin_amdgcn_wave_barrier();
-        if (gl == 0) {
-          inverted[row] = -1;
-          cached_idx_map[slot] = -1;
-        }
-      }
-    }
-  }
-}
-// Full-duplex swap: victims' rows are first copied cache -> HBM staging (fast); k_swap then writes them to the
-// host table from the staging buffer while its other workgroups read the missed rows -- PCIe carries both
-// directions at once.  Victims beyond the staging capacity (rare) are
-// written back directly by k_evict (`first` = staging capacity).
-constexpr int kStageRowsInFlight = 4;   // rows in flight per lane group of the HBM-to-HBM row movers
-
-// Steady state (the call began with no free slot: every missing row takes a victim's place): the free-slot list IS
-// the victim list in ascending slot order.  Workgroup j of this role owns the 4096 slots k_victims' workgroup j
-// counted (blk_vic[j]), adds up the counts before its own (<= a few hundred values out of L2), finds its victims again
-// from the keys (key <= the threshold k_victims recorded) and writes their slots at base + rank: no scan of
-// cached_idx_map, no launch of its own -- it rides in k_evict_stage's grid (which clears cached_idx_map meanwhile:
-// nothing here reads it).
-__device__ __forceinline__ void free_list_from_victims(const unsigned long long* __restrict__ keys, int64_t C,
-                                                       const int32_t* __restrict__ blk_vic, int32_t* free_list,
-                                                       const Ctl* ctl, int j) {
-  if (ctl->status != CE_OK || ctl->k_evict == 0) return;
-  const unsigned long long T = ctl->sel_prefix_after[0];
-  const long long need = ctl->n_miss;
-  __shared__ int part_s[4];
-  __shared__ unsigned long long mask_s[64];
-  __shared__ int pre_s[65];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int part = 0;
-  for (int i = threadIdx.x; i < j; i += 256) part += blk_vic[i];
-  part = wave_sum(part);
-  if (lane == 0) part_s[wv] = part;
-  // victims among 64 consecutive slots -> one 64-bit mask (wave wv takes the 64-slot groups wv, wv + 4, ...)
-  const int64_t s0 = (int64_t)j * 4096;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int g = wv + 4 * u;
-    const int64_t sl = s0 + (int64_t)g * 64 + lane;
-    const unsigned long long key = sl < C ? keys[sl] : ~0ull;
-    const unsigned long long m = __ballot(key <= T && key != ~0ull);
-    if (lane == 0) mask_s[g] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int c = __popcll(mask_s[threadIdx.x]);
-    const int inc = wave_incl_scan(c, lane);
-    pre_s[threadIdx.x] = inc - c;
-  }
-  __syncthreads();
-  const long long base = (long long)part_s[0] + part_s[1] + part_s[2] + part_s[3];
-  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int g = wv + 4 * u;
-    const unsigned long long m = mask_s[g];
-    if ((m >> lane) & 1) {
-      const long long pos = base + pre_s[g] + __popcll(m & lt);
-      if (pos < need) free_list[pos] = (int32_t)(s0 + (int64_t)g * 64 + lane);
-    }
-  }
-}
-
-// Worker transport: "which rows did write-back job j stage, and where" -- so that the NEXT call's admission can take a
-// row that job j evicted out of j's staging buffer (still intact in HBM) instead of waiting until the host has
-// scattered it into the table.  One open-addressing table per job parity; an entry is tag << 32 | row with tag = the
-// low 32 bits of the job number (never 0), its staging position in a parallel array.  A job treats every entry of
-// another tag as free, so the tables are never cleared: job j's entries form gap-free probe runs (j only ever skips
-// entries of its own) until job j + 2 starts overwriting them, by which time job j + 1's admission -- their only
-// reader -- has finished.  At most stage_rows entries per job in >= 4 x stage_rows places.
-struct EvTable {
-  unsigned long long* keys;
-  int32_t* pos;
-  uint32_t mask;
-};
-__device__ __forceinline__ uint32_t evt_hash(int32_t row, uint32_t mask) {
-  return (((uint32_t)row * 2654435761u) >> 7) & mask;
-}
-__device__ __forceinline__ void evt_insert(const EvTable t, uint32_t tag, int32_t row, int32_t pos) {
-  const unsigned long long mine = ((unsigned long long)tag << 32) | (uint32_t)row;
-  uint32_t h = evt_hash(row, t.mask);
-  for (;;) {
-    const unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(cur >> 32) == tag) {          // taken by this job
-      h = (h + 1) & t.mask;
-      continue;
-    }
-    if (atomicCAS(&t.keys[h], cur, mine) == cur) {
-      t.pos[h] = pos;
-      return;
-    }
-  }
-}
-__device__ __forceinline__ int32_t evt_find(const unsigned long long* __restrict__ keys,
-                                            const int32_t* __restrict__ pos, uint32_t mask, uint32_t tag,
-                                            int32_t row) {
-  uint32_t h = evt_hash(row, mask);
-  for (;;) {
-    const unsigned long long cur = keys[h];
-    if ((uint32_t)(cur >> 32) != tag) return -1;
-    if ((uint32_t)cur == (uint32_t)row) return pos[h];
-    h = (h + 1) & mask;
-  }
-}
-
-template <typename VT>
-__global__ __launch_bounds__(256) void k_evict_stage(const int32_t* __restrict__ victims,
-                                                     int32_t* cached_idx_map, int32_t* inverted,
-                                                     const VT* __restrict__ cache, VT* stage, int32_t* stage_rows_idx,
-                                                     long long cap, int rowlen, int g_log2, const Ctl* ctl,
-                                                     WbMail* mail, long long job, int stage_grid,
-                                                     const unsigned long long* __restrict__ keys, int64_t C,
-                                                     const int32_t* __restrict__ blk_vic, int32_t* free_list,
-                                                     EvTable evt, VT* host_overflow) {
-  if ((int)blockIdx.x >= stage_grid) {       // (only launched with these workgroups in the steady-state form)
-    free_list_from_victims(keys, C, blk_vic, free_list, ctl, (int)blockIdx.x - stage_grid);
-    return;
-  }
-  const long long k_all = (ctl->status == CE_OK) ? ctl->k_evict : 0;
-  long long k = k_all;
-  if (k > cap) k = cap;
-  if (host_overflow && k_all > cap) {
-    // More victims than the staging holds (a cache larger than 262144 slots turning over in one call: never at the
-    // bench sizes): the rest goes to the host table directly, a row per lane group at a time -- a loop in this grid
-    // instead of a kernel of its own that every call launched to find nothing to do (round 5: -1 launch per call).
-    const int G0 = 1 << g_log2;
-    const int gl0 = threadIdx.x & (G0 - 1);
-    const int64_t gs0 = ((int64_t)stage_grid * blockDim.x) >> g_log2;
-    for (int64_t i = cap + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2); i < k_all; i += gs0) {
-      const int32_t slot = victims[i];
-      const int32_t row = cached_idx_map[slot];
-      if (row < 0) continue;             // (group-uniform; an unmapped victim slot writes nothing: ADVICE r5)
-      copy_row(cache + (int64_t)slot * rowlen, host_overflow + (int64_t)row * rowlen, rowlen, gl0, G0);
-      __builtin_amdgcn_wave_barrier();
-      if (gl0 == 0) {
-        inverted[row] = -1;
-        cached_idx_map[slot] = -1;
-      }
-    }
-  }
-  if (mail && blockIdx.x == 0 && threadIdx.x == 0) {      // read by the worker after this kernel's event
-    mail->count = k;
-    mail->job = job;
-  }
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)stage_grid * blockDim.x) >> g_log2;
-  constexpr int R = kStageRowsInFlight;
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < k; i += gstride * R) {
-    if (rowlen <= G) {          // R rows in flight per lane group (one row at a time left this kernel latency bound)
-      int32_t slot[R];
-      VT v[R];
-#pragma unroll
-      for (int t = 0; t < R; ++t) slot[t] = i + t < k ? victims[i + t] : -1;
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        if (slot[t] < 0) continue;
-        if (gl == 0) {                      // the victim's host row, then both maps cleared (was k_evict_maps)
-          const int32_t row = cached_idx_map[slot[t]];
-          stage_rows_idx[i + t] = row;
-          inverted[row] = -1;
-          cached_idx_map[slot[t]] = -1;
-          if (evt.keys) evt_insert(evt, (uint32_t)job, row, (int32_t)(i + t));
-        }
-        if (gl < rowlen) v[t] = cache[(int64_t)slot[t] * rowlen + gl];
-      }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        if (slot[t] >= 0 && gl < rowlen) stage[(i + t) * rowlen + gl] = v[t];
-    } else {
-      for (int t = 0; t < R && i + t < k; ++t) {
-        const int32_t slot = victims[i + t];
-        if (gl == 0) {
-          const int32_t row = cached_idx_map[slot];
-          stage_rows_idx[i + t] = row;
-          inverted[row] = -1;
-          cached_idx_map[slot] = -1;
-          if (evt.keys) evt_insert(evt, (uint32_t)job, row, (int32_t)(i + t));
-        }
-        copy_row(cache + (int64_t)slot * rowlen, stage + (i + t) * rowlen, rowlen, gl, G);
-      }
-    }
-  }
-}
-
-template <typename VT, int R>
-__device__ __forceinline__ void writeback_rows(const int32_t* __restrict__ stage_rows_idx,
-                                               const VT* __restrict__ stage, VT* host, long long cap, int rowlen,
-                                               int g_log2, const Ctl* ctl, int block, int nblocks) {
-  long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
-  if (k > cap) k = cap;
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * R; i < k;
-       i += gstride * R) {
-    if (rowlen <= G) {
-      VT v[R];
-      int64_t dst[R];
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        dst[t] = -1;
-        if (i + t < k) {
-          dst[t] = stage_rows_idx[i + t];
-          if (gl < rowlen) v[t] = stage[(i + t) * rowlen + gl];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        if (dst[t] >= 0 && gl < rowlen) host[dst[t] * rowlen + gl] = v[t];
-    } else {
-      for (int t = 0; t < R && i + t < k; ++t)
-        copy_row(stage + (i + t) * rowlen, host + (int64_t)stage_rows_idx[i + t] * rowlen, rowlen, gl, G);
-    }
-  }
-}
-
-// map updates run after the payload pass (rows read cached_idx_map above)
-__global__ __launch_bounds__(256) void k_evict_maps(const int32_t* __restrict__ victims, int32_t* cached_idx_map,
-                                                    int32_t* inverted, int32_t* evicted_rows, const Ctl* ctl) {
-  const long long k = (ctl->status == CE_OK) ? ctl->k_evict : 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) {
-    const int32_t slot = victims[i];
-    const int32_t row = cached_idx_map[slot];
-    if (evicted_rows) evicted_rows[i] = row;
-    inverted[row] = -1;
-    cached_idx_map[slot] = -1;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_free_count(const int32_t* __restrict__ cached_idx_map, int64_t C,
-                                                    int32_t* blk_free, const Ctl* ctl) {
-  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
-  const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  int f = 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    if (s0 + t < C) f += (cached_idx_map[s0 + t] < 0);
-  __shared__ int sf[4];
-  f = wave_sum(f);
-  if ((threadIdx.x & 63) == 0) sf[threadIdx.x >> 6] = f;
-  __syncthreads();
-  if (threadIdx.x == 0) blk_free[blockIdx.x] = sf[0] + sf[1] + sf[2] + sf[3];
-}
-
-// every workgroup adds up the free counts of the blocks before its own (a few KB out of L2): no scan kernel
-__global__ __launch_bounds__(256) void k_free_emit(const int32_t* __restrict__ cached_idx_map, int64_t C,
-                                                   const int32_t* __restrict__ blk_free, int32_t* free_list,
-                                                   const Ctl* ctl) {
-  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
-  const long long need = ctl->n_miss;
-  __shared__ int wsum4[4];
-  int part = 0;                       // free slots before this block: < cuda_row_num < 2^31
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += blk_free[i];
-  part = wave_sum(part);
-  if ((threadIdx.x & 63) == 0) wsum4[threadIdx.x >> 6] = part;
-  __syncthreads();
-  const long long before = (long long)wsum4[0] + wsum4[1] + wsum4[2] + wsum4[3];
-  if (before >= need) return;   // block-uniform
-  const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  int fl[4];
-  int f = 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    fl[t] = (s0 + t < C) && (cached_idx_map[s0 + t] < 0);
-    f += fl[t];
-  }
-  int tot;
-  long long pos = block_excl_scan_256(f, &tot) + before;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (fl[t]) {
-      if (pos < need) free_list[pos] = (int32_t)(s0 + t);
-      ++pos;
-    }
-  }
-}
-
-// small caches: count, scan and emit of the free-slot list in ONE workgroup (three launches otherwise; a
-// prefetch_num = 1 step is a chain of such launches).  Walks the slots in order, 4096 per round, and stops as soon
-// as the first n_miss free slots are out.
-__global__ __launch_bounds__(1024) void k_free_single(const int32_t* __restrict__ cached_idx_map, int64_t C,
-                                                      int32_t* free_list, const Ctl* ctl) {
-  if (ctl->status != CE_OK || ctl->n_miss == 0) return;
-  const long long need = ctl->n_miss;
-  __shared__ int wtot[16];
-  __shared__ long long base_s;
-  if (threadIdx.x == 0) base_s = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t s0 = 0; s0 < C; s0 += 4096) {
-    const long long base = base_s;
-    if (base >= need) break;                       // block-uniform
-    const int64_t i0 = s0 + (int64_t)threadIdx.x * 4;
-    int fl[4], f = 0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      fl[t] = (i0 + t < C) && (cached_idx_map[i0 + t] < 0);
-      f += fl[t];
-    }
-    const int inc = wave_incl_scan(f, lane);
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
-    int pre = 0, tot = 0;
-    for (int k = 0; k < 16; ++k) {
-      if (k < w) pre += wtot[k];
-      tot += wtot[k];
-    }
-    long long pos = base + pre + inc - f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (fl[t]) {
-        if (pos < need) free_list[pos] = (int32_t)(i0 + t);
-        ++pos;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) base_s = base + tot;
-    __syncthreads();
-  }
-}
-
-// rows[i] -> slots[i] for first <= i < n (slots == nullptr: slot i; rows == nullptr: row i)
-template <typename VT, int R>
-__device__ __forceinline__ void admit_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
-                                           const long long* n_ptr, long long n_imm, const VT* __restrict__ host,
-                                           VT* cache, int rowlen, int g_log2, const Ctl* ctl, int block, int nblocks,
-                                           long long first = 0) {
-  if (ctl && ctl->status != CE_OK) return;
-  const long long n = n_ptr ? *n_ptr : n_imm;
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)nblocks * blockDim.x) >> g_log2;
-  for (int64_t i = first + (((int64_t)block * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
-    if (rowlen <= G) {          // R host rows in flight per lane group (see k_evict)
-      VT v[R];
-      int64_t dst[R];
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        dst[t] = -1;
-        if (i + t < n) {
-          const int64_t row = rows ? rows[i + t] : i + t;
-          dst[t] = slots ? slots[i + t] : i + t;
-          if (gl < rowlen) v[t] = host[row * rowlen + gl];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        if (dst[t] >= 0 && gl < rowlen) cache[dst[t] * rowlen + gl] = v[t];
-    } else {
-      for (int t = 0; t < R && i + t < n; ++t) {
-        const int64_t row = rows ? rows[i + t] : i + t;
-        const int64_t slot = slots ? slots[i + t] : i + t;
-        copy_row(host + row * rowlen, cache + slot * rowlen, rowlen, gl, G);
-      }
-    }
-  }
-}
-
-template <typename VT, int R = kSwapRows>
-__global__ __launch_bounds__(1024) void k_admit(const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
-                                               const long long* n_ptr, long long n_imm,
-                                               const VT* __restrict__ host, VT* cache, int rowlen, int g_log2,
-                                               const Ctl* ctl, long long first) {
-  admit_rows<VT, R>(rows, slots, n_ptr, n_imm, host, cache, rowlen, g_log2, ctl, (int)blockIdx.x,
-                    (int)gridDim.x, first);
-}
-
-// Admission kernel of the worker transport: the missed rows of a call, host table -> in_stage, on the admission stream.
-// The previous call's write-back need not have landed: row i comes out of THAT job's staging buffer if the job
-// evicted it (EvTable above; evt_keys == NULL: there is no such job), out of the host table otherwise.  n_ptr: the
-// count the call's plan left on the device (the launch thread never learns it).
-template <typename VT, int R = kSwapRows>
-__global__ __launch_bounds__(1024) void k_admit_probe(const int32_t* __restrict__ rows, const long long* n_ptr,
-                                                     const VT* __restrict__ host, VT* dst, int rowlen, int g_log2,
-                                                     const unsigned long long* __restrict__ evt_keys,
-                                                     const int32_t* __restrict__ evt_pos, uint32_t evt_mask,
-                                                     uint32_t tag, const VT* __restrict__ prev_stage) {
-  const long long n = *n_ptr;
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
-    if (rowlen <= G) {
-      VT v[R];
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        if (i + t < n) {
-          const int32_t row = rows[i + t];
-          const int32_t p = evt_keys ? evt_find(evt_keys, evt_pos, evt_mask, tag, row) : -1;
-          const VT* src = p >= 0 ? prev_stage + (int64_t)p * rowlen : host + (int64_t)row * rowlen;
-          if (gl < rowlen) v[t] = src[gl];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        if (i + t < n && gl < rowlen) dst[(i + t) * rowlen + gl] = v[t];
-    } else {
-      for (int t = 0; t < R && i + t < n; ++t) {
-        const int32_t row = rows[i + t];
-        const int32_t p = evt_keys ? evt_find(evt_keys, evt_pos, evt_mask, tag, row) : -1;
-        copy_row(p >= 0 ? prev_stage + (int64_t)p * rowlen : host + (int64_t)row * rowlen, dst + (i + t) * rowlen,
-                 rowlen, gl, G);
-      }
-    }
-  }
-}
-
-// worker transport, host-gather admission: rows [0, min(n_miss, cap)) arrived contiguously in `in_stage`; move them to
-// their slots.  (The chained admission's form is k_unpack_chained, ce_cache_fused.h.)
-template <typename VT>
-__global__ __launch_bounds__(256) void k_unpack_admitted(const int32_t* __restrict__ slots, const long long* n_ptr,
-                                                         long long cap, const VT* __restrict__ in_stage, VT* cache,
-                                                         int rowlen, int g_log2, Ctl* ctl,
-                                                         const unsigned long long* fail_word, long long job,
-                                                         const int32_t* __restrict__ rows,
-                                                         const VT* __restrict__ host_overflow) {
-  const bool ok = ctl->status == CE_OK;         // (nothing in this kernel writes ctl->status)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // The admission worker flags a job whose rows did not arrive (a HIP call of its own failed or timed out) in a
-    // word of pinned host memory.  ONE thread fetches it over PCIe and leaves the verdict in the control block for
-    // k_admit_maps, which then marks nothing resident; whatever this kernel copies into the (free) slots meanwhile
-    // is never looked at.
-    ctl->lost = *(volatile const unsigned long long*)fail_word == (unsigned long long)job;
-  }
-  if (!ok) return;
-  long long n = *n_ptr;
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  if (host_overflow && n > cap) {
-    // more misses than the staging holds (rare): the rest is read zero-copy out of the host table -- here, behind the
-    // parked wait (the host gather has waited for every earlier write-back), in this grid instead of a launch of its own
-    for (int64_t i = cap + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2); i < n; i += gstride)
-      copy_row(host_overflow + (int64_t)rows[i] * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
-  }
-  if (n > cap) n = cap;
-  constexpr int R = kStageRowsInFlight;
-  for (int64_t i = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2) * R; i < n; i += gstride * R) {
-    if (rowlen <= G) {
-      int32_t slot[R];
-      VT v[R];
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        slot[t] = i + t < n ? slots[i + t] : -1;
-        if (slot[t] >= 0 && gl < rowlen) v[t] = in_stage[(i + t) * rowlen + gl];
-      }
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        if (slot[t] >= 0 && gl < rowlen) cache[(int64_t)slot[t] * rowlen + gl] = v[t];
-    } else {
-      for (int t = 0; t < R && i + t < n; ++t)
-        copy_row(in_stage + (i + t) * rowlen, cache + (int64_t)slots[i + t] * rowlen, rowlen, gl, G);
-    }
-  }
-}
-
-// Full-duplex swap in ONE launch: the first wb_blocks workgroups stream the staged victims to the host table,
-// the others read the missed rows from it.  (An earlier version ran the write-back on an auxiliary stream; HIP
-// multiplexes streams onto a few hardware queues and that stream could land on the TRAINING stream's queue,
-// stalling training for the whole write-back -- seen in a rocprofv3 timeline.  One kernel needs no extra stream.)
-template <typename VT, int R>
-__global__ __launch_bounds__(1024) void k_swap(const int32_t* __restrict__ stage_rows_idx,
-                                              const VT* __restrict__ stage, long long cap, int wb_blocks,
-                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ slots,
-                                              const long long* n_ptr, VT* host, VT* cache, int rowlen, int g_log2,
-                                              const Ctl* ctl) {
-  if ((int)blockIdx.x < wb_blocks)
-    writeback_rows<VT, R>(stage_rows_idx, stage, host, cap, rowlen, g_log2, ctl, (int)blockIdx.x, wb_blocks);
-  else
-    admit_rows<VT, R>(rows, slots, n_ptr, 0ll, (const VT*)host, cache, rowlen, g_log2, ctl,
-                      (int)blockIdx.x - wb_blocks, (int)gridDim.x - wb_blocks);
-}
-
-__global__ __launch_bounds__(256) void k_admit_maps(const int32_t* __restrict__ rows,
-                                                    const int32_t* __restrict__ slots, const long long* n_ptr,
-                                                    long long n_imm, int32_t* cached_idx_map, int32_t* inverted,
-                                                    int64_t* freq, const int64_t* freq_vals, int32_t* slot_epoch,
-                                                    int32_t epoch_imm, Ctl* ctl, ce_call_stats_t* ring,
-                                                    long long seq_arg, const unsigned long long* fail_word,
-                                                    long long job, long long* n_unpack_out = nullptr) {
-  // ring == NULL (preload): no record to publish, the epoch is the caller's constant
-  const long long seq = ring ? call_seq(ctl, seq_arg) : 0;
-  const int32_t epoch = ring ? call_epoch(seq) : epoch_imm;
-  ce_call_stats_t* const ring_slot = ring ? ring + (seq % kRing) : nullptr;
-  // host-gather admission: the worker reports a job it could not complete (failed / timed-out HIP call): the rows
-  // never arrived, so nothing may be marked resident.
-  const bool lost = fail_word && ctl->lost != 0;      // left by k_unpack_admitted (the kernel before this one)
-  // last kernel of prepare_ids that can change the call's record: publish it (a slot whose seq matches is complete)
-  if (ring_slot && blockIdx.x == 0 && threadIdx.x == 0) {
-    // chained admission: the rows the unpack kernel moves for this call (it runs on the admission stream, possibly
-    // while the next call's front rewrites the control block)
-    if (n_unpack_out) *n_unpack_out = (ctl->status == CE_OK && n_ptr) ? *n_ptr : 0;
-    if (lost && ctl->status == CE_OK) {
-      // the victims are gone (written back) but their slots stay free: undo the plan's share of the free count
-      ctl->n_free = ctl->n_free + ctl->n_miss;
-      ring_slot->status = CE_ERR_HIP;
-      ring_slot->n_free_after = ctl->n_free;
-      __hip_atomic_store(&ctl->status, CE_ERR_HIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __threadfence_system();
-    *(volatile long long*)&ring_slot->seq = seq;
-  }
-  if (lost) return;
-  if (ctl && __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != CE_OK) return;
-  const long long n = n_ptr ? *n_ptr : n_imm;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int32_t row = rows ? rows[i] : (int32_t)i;
-    const int32_t slot = slots ? slots[i] : (int32_t)i;
-    cached_idx_map[slot] = row;
-    inverted[row] = slot;
-    if (freq) freq[slot] = freq_vals ? freq_vals[i] : 0;
-    slot_epoch[slot] = epoch;
-  }
-}
-
-// _id_to_cached_cuda_id alone (ce_cache_lookup_slots): inverted[idx_map[id]]
-__global__ __launch_bounds__(256) void k_lookup(const int64_t* __restrict__ ids, int64_t n,
-                                                const int32_t* __restrict__ idx_map,
-                                                const int32_t* __restrict__ inverted, int64_t N, int64_t* slots_out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t id = ids[i];
-    int64_t slot = -1;
-    if ((unsigned long long)id < (unsigned long long)N) slot = inverted[idx_map ? idx_map[id] : (int32_t)id];
-    slots_out[i] = slot;
-  }
-}
-
-// Last kernel of prepare_ids: k_mark left the ROW of every id in `slots` (-1 = bad id); turn it into the slot in
-// place -- one random 4-byte gather per id instead of the two dependent ones of inverted[idx_map[id]] [A.6].
-// A failed call (overflow / bad id) changes nothing but still hands back well-defined slots (-1): callers that skip
-// the status check (strict=False) then gather zero rows instead of garbage.
-__global__ __launch_bounds__(256) void k_slots(int64_t* slots, int64_t n, const int32_t* __restrict__ inverted,
-                                               const Ctl* ctl) {
-  const bool failed = ctl->status != CE_OK;
-  constexpr int U = 4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; i0 < n; i0 += stride) {
-    int64_t row[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + (int64_t)u * blockDim.x;
-      row[u] = i < n ? slots[i] : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + (int64_t)u * blockDim.x;
-      if (i < n) slots[i] = (failed || row[u] < 0) ? -1 : (int64_t)inverted[row[u]];
-    }
-  }
-}
-
-// LFU form of k_slots: slots + `freq[slot] += multiplicity` [A.3-7].  A hot slot collects >100 k lookups per
-// window and same-address device atomics serialise at the memory side (~7 ns each): with one merged atomic per
-// WAVE the hottest counter alone still took 53 k of them (k_slots 381 us per window).  Here every workgroup owns
-// a contiguous range of lookups and counts them in an LDS hash table (slot -> count, open addressing); only the
-// table's entries go to memory, so a counter sees at most one atomic per workgroup.  Four lookups per thread are
-// in flight to cover the random load.
-constexpr int kSlotsHashBits = 13;
-constexpr int kSlotsHash = 1 << kSlotsHashBits;
-__global__ __launch_bounds__(1024) void k_slots_lfu(int64_t* slots, int64_t n, const int32_t* __restrict__ inverted,
-                                                    int64_t* freq, const Ctl* ctl) {
-  __shared__ int hkey[kSlotsHash];
-  __shared__ int hcnt[kSlotsHash];
-  for (int i = threadIdx.x; i < kSlotsHash; i += blockDim.x) { hkey[i] = -1; hcnt[i] = 0; }
-  __syncthreads();
-  const bool failed = ctl->status != CE_OK;
-  const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
-  const int64_t hi = lo + per_block < n ? lo + per_block : n;
-  constexpr int U = 4;
-  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)blockDim.x * U) {
-    int64_t row[U];
-    int slot[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + (int64_t)u * blockDim.x;
-      row[u] = (i < hi && !failed) ? slots[i] : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) slot[u] = row[u] >= 0 ? inverted[row[u]] : -1;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + (int64_t)u * blockDim.x;
-      if (i < hi) slots[i] = slot[u];
-      if (slot[u] < 0) continue;
-      unsigned h = ((unsigned)slot[u] * 2654435761u) >> (32 - kSlotsHashBits);
-      bool done = false;
-      for (int p = 0; p < 16 && !done; ++p) {
-        const int old = atomicCAS(&hkey[h], -1, slot[u]);
-        if (old == -1 || old == slot[u]) {
-          atomicAdd(&hcnt[h], 1);
-          done = true;
-        } else {
-          h = (h + 1) & (kSlotsHash - 1);
-        }
-      }
-      if (!done) atomicAdd((unsigned long long*)&freq[slot[u]], 1ull);      // table crowded: count directly
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kSlotsHash; i += blockDim.x)
-    if (hkey[i] >= 0) atomicAdd((unsigned long long*)&freq[hkey[i]], (unsigned long long)hcnt[i]);
-}
-
-template <typename VT>
-__global__ __launch_bounds__(256) void k_flush_rows(const int32_t* __restrict__ cached_idx_map, int64_t C,
-                                                    const VT* __restrict__ cache, VT* host, int rowlen,
-                                                    int g_log2) {
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; s < C; s += gstride) {
-    const int32_t row = cached_idx_map[s];
-    if (row >= 0) copy_row(cache + s * rowlen, host + (int64_t)row * rowlen, rowlen, gl, G);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_flush_maps(int32_t* cached_idx_map, int64_t C, int32_t* inverted,
-                                                    int64_t* freq, int32_t* slot_epoch, Ctl* ctl) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int n = 0;
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < C; s += stride) {
-    const int32_t row = cached_idx_map[s];
-    if (row >= 0) {
-      inverted[row] = -1;
-      cached_idx_map[s] = -1;
-      ++n;
-    }
-    if (freq) freq[s] = INT64_MAX;
-    slot_epoch[s] = kEpochNever;
-  }
-  n = wave_sum(n);
-  if ((threadIdx.x & 63) == 0 && n) atomicAdd((unsigned long long*)&ctl->k_evict, (unsigned long long)n);
-}
-
-__global__ void k_flush_end(int64_t C, Ctl* ctl, ce_call_stats_t* ring_slot, long long seq) {
-  ctl->seq = seq;
-  ctl->n_free = C;
-  ring_slot->n_ids = 0;
-  ring_slot->n_unique = 0;
-  ring_slot->n_miss = 0;
-  ring_slot->n_evict = ctl->k_evict;
-  ring_slot->miss_lookups = 0;
-  ring_slot->n_free_after = C;
-  ring_slot->status = CE_OK;
-  ring_slot->kind = CE_CALL_FLUSH;
-  __threadfence_system();
-  ring_slot->seq = seq;
-}
-
-__global__ void k_preload_end(long long n, Ctl* ctl, ce_call_stats_t* ring_slot, long long seq) {
-  ctl->seq = seq;
-  ctl->n_free -= n;
-  ring_slot->n_ids = 0;
-  ring_slot->n_unique = n;
-  ring_slot->n_miss = n;
-  ring_slot->n_evict = 0;
-  ring_slot->miss_lookups = 0;
-  ring_slot->n_free_after = ctl->n_free;
-  ring_slot->status = CE_OK;
-  ring_slot->kind = CE_CALL_PRELOAD;
-  __threadfence_system();
-  ring_slot->seq = seq;
-}
-
-__global__ __launch_bounds__(256) void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
-__global__ __launch_bounds__(256) void k_fill_i64(int64_t* p, int64_t n, int64_t v) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
-
-// staged transport helpers: pack rows (by slot list) into / out of a contiguous device buffer
-template <typename VT>
-__global__ __launch_bounds__(256) void k_pack_rows(const int32_t* __restrict__ slots, long long n,
-                                                   const VT* __restrict__ cache, VT* staging, int rowlen,
-                                                   int g_log2) {
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride)
-    copy_row(cache + (int64_t)slots[i] * rowlen, staging + i * rowlen, rowlen, gl, G);
-}
-template <typename VT>
-__global__ __launch_bounds__(256) void k_unpack_rows(const int32_t* __restrict__ slots, long long n,
-                                                     const VT* __restrict__ staging, VT* cache, int rowlen,
-                                                     int g_log2) {
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) >> g_log2;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> g_log2; i < n; i += gstride)
-    copy_row(staging + i * rowlen, cache + (int64_t)slots[i] * rowlen, rowlen, gl, G);
-}
-
-}  // namespace ce
-
+#include "ce_cache_index.h"
+#include "ce_cache_select.h"
+#include "ce_cache_rows.h"
 #include "ce_cache_fused.h"
+#include "ce_cache_worker.h"
 
-// ----------------------------------------------------------------------------- handle
-
-namespace ce {
-
-// persistent worker pool for the staged transport's table gather/scatter (spawning 64 std::threads per call cost
-// more than the copies themselves)
-class RowPool {
- public:
-  explicit RowPool(int n) {
-    // the helpers move rows between the host table and pinned staging: keep them on the GPU's NUMA node
-    cpu_set_t set;
-    const bool near = near_gpu_cpus(&set);
-    for (int i = 0; i < n; ++i)
-      workers_.emplace_back([this, i, near, set] {
-        if (near) (void)sched_setaffinity(0, sizeof set, &set);
-        run(i);
-      });
-  }
-  ~RowPool() {
-    {
-      std::lock_guard<std::mutex> g(m_);
-      stop_ = true;
-      ++gen_;
-    }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-  }
-  void parallel(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
-    const int t = (int)std::min<int64_t>((int64_t)workers_.size(), std::max<int64_t>(1, cdiv(n, 1024)));
-    if (t <= 1) {
-      fn(0, n);
-      return;
-    }
-    start(n, t, fn);
-    wait();
-  }
-  // non-blocking form: worker i < parts runs fn(lo_i, hi_i) over its share of [0, n); `fn` must outlive wait()
-  void start(int64_t n, int parts, const std::function<void(int64_t, int64_t)>& fn) {
-    parts = std::max(1, std::min(parts, (int)workers_.size()));
-    {
-      std::lock_guard<std::mutex> g(m_);
-      fn_ = &fn;
-      n_ = n;
-      parts_ = parts;
-      pending_ = parts;
-      ++gen_;
-    }
-    cv_.notify_all();
-  }
-  void wait() {
-    std::unique_lock<std::mutex> g(m_);
-    done_.wait(g, [this] { return pending_ == 0; });
-  }
-  int size() const { return (int)workers_.size(); }
-
- private:
-  void run(int id) {
-    unsigned long long seen = 0;
-    for (;;) {
-      const std::function<void(int64_t, int64_t)>* fn;
-      int64_t n;
-      int parts;
-      {
-        std::unique_lock<std::mutex> g(m_);
-        cv_.wait(g, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (stop_) return;
-        fn = fn_;
-        n = n_;
-        parts = parts_;
-      }
-      if (id < parts) {
-        const int64_t per = cdiv(n, parts);
-        const int64_t lo = id * per, hi = std::min<int64_t>(n, lo + per);
-        if (lo < hi) (*fn)(lo, hi);
-        std::lock_guard<std::mutex> g(m_);
-        if (--pending_ == 0) done_.notify_all();
-      }
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_, done_;
-  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
-  int64_t n_ = 0;
-  int parts_ = 0, pending_ = 0;
-  unsigned long long gen_ = 0;
-  bool stop_ = false;
-};
-
-// Per-phase timers of prepare_ids (the reference brackets the same phases with its Timer / record_function
-// ranges: recsys/dlrm_main.py:258, upstream CachedParamMgr._elapsed_dict printed by print_comm_stats :294).
-// hipEvents on the call's own stream, read back lazily: no host sync is added to the call.
-constexpr int kPhases = 6;
-constexpr int kProfDepth = 8;
-static const char* const kPhaseNames[kPhases] = {"unique_and_miss", "find_evict_ids", "evict_stage",
-                                                  "free_slots", "admit_swap", "ids_to_slots"};
-struct PhaseProf {
-  hipEvent_t ev[kProfDepth][kPhases + 1];
-  bool pending[kProfDepth];
-  // a call in two halves whose selection / staging part was deferred to the second half: the second phase starts at
-  // `resume` (recorded when the second half begins), not at the mark behind the front -- the training steps between
-  // the two halves are no phase of the cache op
-  hipEvent_t resume[kProfDepth];
-  bool resumed[kProfDepth];
-  // chained admission: the rows move on the admission stream -- "admit_swap" is the span from the start of the
-  // admission kernel to the end of the unpack kernel THERE (it overlaps with the phases around it on the call's stream)
-  hipEvent_t adm0[kProfDepth], adm1[kProfDepth];
-  bool chained[kProfDepth];
-  double ms[kPhases];
-  long long calls;
-  PhaseProf() : calls(0) {
-    for (int i = 0; i < kProfDepth; ++i) {
-      pending[i] = false;
-      resumed[i] = false;
-      chained[i] = false;
-      (void)hipEventCreate(&resume[i]);
-      (void)hipEventCreate(&adm0[i]);
-      (void)hipEventCreate(&adm1[i]);
-      for (int j = 0; j <= kPhases; ++j) (void)hipEventCreate(&ev[i][j]);
-    }
-    for (int j = 0; j < kPhases; ++j) ms[j] = 0;
-  }
-  ~PhaseProf() {
-    for (int i = 0; i < kProfDepth; ++i) {
-      (void)hipEventDestroy(resume[i]);
-      (void)hipEventDestroy(adm0[i]);
-      (void)hipEventDestroy(adm1[i]);
-      for (int j = 0; j <= kPhases; ++j) (void)hipEventDestroy(ev[i][j]);
-    }
-  }
-  void collect(int i) {              // blocks until call slot i has finished
-    if (!pending[i]) return;
-    if (hipEventSynchronize(ev[i][kPhases]) == hipSuccess &&
-        (!chained[i] || hipEventSynchronize(adm1[i]) == hipSuccess)) {
-      for (int j = 0; j < kPhases; ++j) {
-        float t = 0;
-        hipError_t e;
-        if (chained[i] && j == 4) e = hipEventElapsedTime(&t, adm0[i], adm1[i]);
-        else e = hipEventElapsedTime(&t, (j == 1 && resumed[i]) ? resume[i] : ev[i][j], ev[i][j + 1]);
-        if (e == hipSuccess) ms[j] += t;
-      }
-      calls += 1;
-    }
-    pending[i] = false;
-    resumed[i] = false;
-    chained[i] = false;
-  }
-};
-
-// host-side row copies of the swap workers: csrc/ce_rowcopy.cpp (widest streaming store the CPU has)
-void row_copy_stream(float* dst, const float* src, size_t floats);
-void row_copy_fence();
-
-// waiting for a copy stream without burning a CPU of a quota-limited host and without any packet in a hardware
-// queue: poll hipStreamQuery with short sleeps
-// seconds a swap worker (or the launch thread waiting for one) gives a copy / a job before it declares it lost:
-// the parked cache-op stream is then released with the job flagged as failed instead of hanging the GPU for ever
-// (what would happen if a copy stream ever shared a hardware queue with the parked stream -- ensure_writeback)
-static double worker_timeout_s() {
-  static const double v = [] { const char* e = getenv("CE_WORKER_TIMEOUT_S"); const double t = e ? atof(e) : 30.0; return t > 0 ? t : 30.0; }();
-  return v;
-}
-// The workers wait with short sleeps (no queue packets, see run_in).  A thread's default timer slack is 50 us, so
-// sleep_for(15 us) returns after ~65 us: at prefetch_num 1 a write-back job is a few hundred microseconds of which
-// those overshoots were a third (Kaggle 5 % P = 1: 0.327 ms per job).  Worker threads ask for 1 us of slack.
-static inline void tight_timer_slack() { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul); }
-
-static inline hipError_t stream_wait_polite(hipStream_t st, double timeout_s = worker_timeout_s()) {
-  const auto t0 = std::chrono::steady_clock::now();
-  for (int spins = 0;; ++spins) {
-    const hipError_t e = hipStreamQuery(st);
-    if (e != hipErrorNotReady) return e;
-    if (spins < 50) std::this_thread::yield();
-    else std::this_thread::sleep_for(std::chrono::microseconds(15));
-    if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-      return hipErrorNotReady;      // timed out: the caller reports it
-  }
-}
-
-static inline hipError_t event_wait_polite(hipEvent_t ev, double timeout_s = worker_timeout_s()) {
-  const auto t0 = std::chrono::steady_clock::now();
-  for (int spins = 0;; ++spins) {
-    const hipError_t e = hipEventQuery(ev);
-    if (e != hipErrorNotReady) return e;
-    if (spins < 50) std::this_thread::yield();
-    else std::this_thread::sleep_for(std::chrono::microseconds(15));
-    if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-      return hipErrorNotReady;      // timed out: the caller reports it
-  }
-}
-
-static const bool g_trace = [] { const char* e = getenv("CE_WORKER_TRACE"); return e && atoi(e) != 0; }();
-#define CE_TRACE(...)                                                                            \
-  do {                                                                                           \
-    if (ce::g_trace) {                                                                           \
-      const double t_ = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); \
-      fprintf(stderr, "[ce %.6f %p] ", t_, (void*)this);                                         \
-      fprintf(stderr, __VA_ARGS__);                                                              \
-      fputc('\n', stderr);                                                                       \
-    }                                                                                            \
-  } while (0)
-
-// Worker transport (CE_TRANSPORT_WORKER): both directions of the row swap leave the CUs.
-//
-// Measured on the box (profiles/r02_probe_sdma.txt): a pinned hipMemcpyAsync runs on an SDMA engine at ~51 GB/s per
-// direction and does NOT slow an HBM-bound kernel running beside it (x1.02), whereas rows moved by waves over the
-// mapped host table (round 1's k_swap) held the training kernels back by 40-47 % for as long as they ran.  So:
-//
-//   out  k_evict_stage packs the victims of call w into an HBM staging buffer; the `out` worker waits for that
-//        kernel's event ON ITS OWN THREAD, copies the block out in chunks (hipMemcpyAsync, private stream) and
-//        scatters each chunk into the host table with helper threads while the next one is in flight.
-//   in   k_emit leaves the ascending list of missed rows in pinned host memory; the `in` worker waits for that
-//        kernel's event, lets helper threads gather the rows out of the table into pinned staging, each helper
-//        the worker copying each gathered chunk to the device at once (hipMemcpyAsync), and finally releases the
-//        cache-op stream, which has been parked in a hipStreamWaitValue64 (no CU involved), with a plain store to the
-//        pinned word the stream polls, once the copies have completed.  k_unpack_admitted then moves the rows to
-//        their slots.
-//
-// Ordering: a row evicted by call w-1 and missed by call w must be read back with the payload w-1 staged.  The host
-// gather of call w therefore starts only after the write-back of call w-1 has reached the table; the admission
-// KERNEL waits for the write-back of call w-2 only and, while that of w-1 is still on its way, looks every missed
-// row up in the table of rows w-1 staged (EvTable) and takes a hit out of w-1's staging buffer -- intact until call
-// w+1 stages its own victims, which happens behind call w's admission wait.  (Waiting for w-1 put a 1 ms
-// write-back, the slower PCIe direction beside the admission's reads, on the cache-op stream's cycle: front ->
-// write-back -> admission of the next call.)  Rows evicted by call w itself are never in its miss list.
-// The launch thread blocks only when a worker is two calls behind.  A failing HIP call inside a worker still
-// releases the stream (the error surfaces at the next call / wait) so the GPU is never left parked.
-struct SwapEngine {
-  int device = 0;
-  int64_t D = 0, stage_rows = 0;
-  float* table = nullptr;
-  // ---- out (evictions)
-  hipStream_t out_stream = nullptr, out_stream2 = nullptr;      // alternating D2H copy streams
-  hipEvent_t out_ev[2] = {nullptr, nullptr};       // staging of the job complete (recorded on the cache-op stream)
-  static constexpr int kOutChunks = 8;
-  hipEvent_t chunk_ev[kOutChunks + 1] = {nullptr};      // behind every chunk copy of the job being written back
-  const float* stage_dev[2] = {nullptr, nullptr};
-  const int32_t* idx_dev[2] = {nullptr, nullptr};
-  float* rows_host[2] = {nullptr, nullptr};        // pinned landing buffers
-  int32_t* idx_host[2] = {nullptr, nullptr};
-  // ---- in (admissions)
-  hipStream_t in_stream = nullptr;
-  hipEvent_t in_ev[2] = {nullptr, nullptr};        // miss list of the job complete (by job parity)
-  float* in_stage_dev = nullptr;
-  float* in_host = nullptr;                        // pinned gather buffer (host-gather admission only)
-  // CHAINED admission (round 6; the default: the table has a device mapping): the launch thread itself enqueues, on
-  // in_stream, the admission kernel behind the front's event and the unpack kernel behind the selection's event.  No
-  // library thread takes part and the cache-op stream never parks: what used to be "front -> [event wake-up of a
-  // worker thread, its kernel launch, its polling of the stream, its store to a pinned word the parked stream polls]
-  // -> unpack" is two stream-to-stream event edges.  Ordering: the admission of call w reads the host table for rows
-  // that no write-back in flight carries -- the launch thread has waited for write-back w - 2 before it enqueues
-  // call w (its staging buffer is about to be reused anyway), and rows of write-back w - 1 come out of that job's
-  // staging buffer (EvTable), intact until call w + 1's selection, which waits for call w's rows (ev_rows).
-  // The HOST-GATHER admission (CE_WORKER_ADMIT=sdma, or a table without device mapping) keeps the worker thread
-  // below: helper threads gather the rows into pinned staging, SDMA copies bring them in, the cache-op stream parks in
-  // hipStreamWaitValue64 until the thread releases it.
-  bool chained = false;
-  hipEvent_t ev_miss[2] = {nullptr, nullptr};      // front of the call of either parity complete (cache-op stream)
-  static constexpr int kRowsRing = 4;
-  hipEvent_t ev_rows[kRowsRing] = {nullptr};       // rows of call c in their slots (in_stream), c % kRowsRing
-  long long chain_calls = 0;                       // chained calls issued (1-based ticket of the latest)
-  // write-back jobs below this number are never looked up in their staging buffer: calls of ANOTHER transport ran
-  // since (ce_cache_set_transport), which may have re-admitted and evicted the same rows past that buffer -- the host
-  // table, where every one of those jobs has landed by then, is the up-to-date copy
-  long long probe_floor = 1;
-  bool deferred_rows = false;                      // prepare_ids does not make its stream wait for the rows
-  const unsigned long long* evt_keys[2] = {nullptr, nullptr};
-  const int32_t* evt_pos[2] = {nullptr, nullptr};
-  uint32_t evt_mask = 0;
-  long long in_probed = 0;         // admissions enqueued while the previous write-back was still on its way
-#ifdef CE_TEST_HOOKS
-  // fault / delay injection for tests/test_gpu_worker.py: only in libce_hip_testhooks.so (build.py, -DCE_TEST_HOOKS);
-  // the product library has neither the fields nor the strings (tests/test_abi.py)
-  int out_delay_us = 0;            // CE_WORKER_OUT_DELAY_US: every write-back job starts this much late
-  long long fail_in_job = 0;       // CE_WORKER_FAIL_IN_JOB: this host-gather admission job reports a failed HIP call
-#endif
-  int rowlen = 0, g_log2 = 0, vec = 0;
-  int32_t* miss_host = nullptr;                    // pinned + mapped: written by k_emit
-  int32_t* miss_host_dev = nullptr;
-  unsigned long long* sig = nullptr;               // pinned + mapped: [0] the value the cache-op stream waits for,
-                                                   // [1] the last admission job that was LOST (k_admit_maps reads it)
-  unsigned long long* sig_dev = nullptr;
-  // ---- mailboxes (pinned + mapped): [0], [1] = out staging buffers, [2] = in
-  WbMail* mail = nullptr;
-  WbMail* mail_dev = nullptr;
-  std::thread out_thread, in_thread;
-  std::mutex m;
-  std::condition_variable cv_job, cv_done;
-  long long out_issued = 0, out_done = 0, in_issued = 0, in_done = 0;
-  bool stop = false;
-  int err = 0;
-  char errmsg[256] = {0};
-  RowPool* out_pool = nullptr;
-  RowPool* in_pool = nullptr;
-  // statistics (what upstream's swap_in_bandwidth / swap_out_bandwidth report)
-  double out_wait_s = 0, out_busy_s = 0, in_wait_s = 0, in_busy_s = 0, in_gather_s = 0;
-  double out_wait0_s = 0;
-  double out_copy_wait_s = 0, out_scatter_s = 0;       // parts of out_busy_s (CE_WORKER_PROFILE=1 prints them at exit)
-  long long out_rows = 0, out_jobs = 0, in_rows = 0, in_jobs = 0;
-
-  void fail(const char* what, hipError_t e) {
-    std::lock_guard<std::mutex> g(m);
-    if (!err) {
-      err = CE_ERR_HIP;
-      snprintf(errmsg, sizeof errmsg, "swap worker: %s failed: %s", what, hipGetErrorString(e));
-    }
-  }
-  bool failed() {
-    std::lock_guard<std::mutex> g(m);
-    return err != 0;
-  }
-
-  void run_out() {
-    (void)hipSetDevice(device);
-    bind_thread_near_gpu();
-    tight_timer_slack();
-    for (;;) {
-      long long job;
-      {
-        std::unique_lock<std::mutex> g(m);
-        cv_job.wait(g, [&] { return stop || out_done < out_issued; });
-        if (out_done >= out_issued) return;
-        job = out_done + 1;
-      }
-      const int b = (int)(job & 1);
-      const auto t0 = std::chrono::steady_clock::now();
-      CE_TRACE("out job %lld: waiting for its staging event", job);
-      hipError_t e = hipEventSynchronize(out_ev[b]);
-      if (e != hipSuccess) fail("hipEventSynchronize(out)", e);
-      const auto t1 = std::chrono::steady_clock::now();
-      long long k = mail[b].count;
-      double copy_wait = 0, scatter = 0, wait0 = 0;
-#ifdef CE_TEST_HOOKS
-      if (out_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(out_delay_us));
-#endif
-      CE_TRACE("out job %lld: event done (%s), mail job %lld count %lld", job, hipGetErrorString(e), mail[b].job, k);
-      if (mail[b].job != job || k < 0 || k > stage_rows) k = 0;     // a failed / foreign record moves nothing
-      if (k > 0 && !failed()) {
-        // The packed block leaves in kOutChunks copies, ALL issued at once on the two copy streams in turn, each with
-        // an event behind it; chunk c is scattered into the table while the later ones are on the wire.  (Issuing
-        // chunk c + 1 only when chunk c was being waited for left the copies and the scatters back to back:
-        // 0.6 + 0.55 ms per 54 k-row job instead of overlapped.)  The host polls the events (no queue packets).
-        e = hipMemcpyAsync(idx_host[b], idx_dev[b], (size_t)k * 4, hipMemcpyDeviceToHost, out_stream);
-        const int64_t per = std::max<int64_t>(4096, cdiv(k, kOutChunks));
-        int nch = 0;
-        for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++nch) {
-          const int64_t cnt = std::min<int64_t>(per, k - off);
-          hipStream_t cs = (nch & 1) ? out_stream2 : out_stream;
-          e = hipMemcpyAsync(rows_host[b] + off * D, stage_dev[b] + off * D, (size_t)cnt * D * 4, hipMemcpyDeviceToHost, cs);
-          if (e == hipSuccess) e = hipEventRecord(chunk_ev[nch], cs);
-        }
-        int c = 0;
-        for (int64_t off = 0; off < k && e == hipSuccess; off += per, ++c) {
-          const int64_t cnt = std::min<int64_t>(per, k - off);
-          const auto tc0 = std::chrono::steady_clock::now();
-          // (chunk 0 also needs the row numbers, which went first on out_stream)
-          hipError_t e2 = event_wait_polite(chunk_ev[c]);
-          const auto tc1 = std::chrono::steady_clock::now();
-          copy_wait += std::chrono::duration<double>(tc1 - tc0).count();
-          if (c == 0) wait0 = std::chrono::duration<double>(tc1 - tc0).count();
-          if (e == hipSuccess) e = e2;
-          if (e != hipSuccess) break;
-          float* tb = table;
-          const float* st = rows_host[b] + off * D;
-          const int32_t* ri = idx_host[b] + off;
-          const int64_t d = D;
-          out_pool->parallel(cnt, [=](int64_t lo, int64_t hi) {
-            // every row lands on a page of its own: a read prefetch of ANOTHER line of the page of the row 8 ahead
-            // starts its page walk early (the row's own lines are streamed past the cache and must not be pulled
-            // in): 71 -> 48 ns per row on 4 KB pages, 18.5 -> 13 on 2 MB pages (profiles/probes/probe_scatter2.cpp)
-            for (int64_t i = lo; i < hi; ++i) {
-              if (i + 8 < hi) __builtin_prefetch((const void*)((uintptr_t)(tb + (size_t)ri[i + 8] * d) ^ 2048u), 0, 0);
-              row_copy_stream(tb + (size_t)ri[i] * d, st + (size_t)i * d, (size_t)d);
-            }
-            row_copy_fence();
-          });
-          scatter += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc1).count();
-        }
-        if (e == hipSuccess) {         // both streams idle again before the staging buffer is reused
-          e = stream_wait_polite(out_stream);
-          if (e == hipSuccess) e = stream_wait_polite(out_stream2);
-        }
-        if (e != hipSuccess) fail(e == hipErrorNotReady ? "write-back copy timed out (CE_WORKER_TIMEOUT_S)" : "D2H copy", e);
-      }
-      const auto t2 = std::chrono::steady_clock::now();
-      CE_TRACE("out job %lld: done", job);
-      {
-        std::lock_guard<std::mutex> g(m);
-        out_done = job;
-        out_wait_s += std::chrono::duration<double>(t1 - t0).count();
-        out_busy_s += std::chrono::duration<double>(t2 - t1).count();
-        out_copy_wait_s += copy_wait;
-        out_wait0_s += wait0;
-        out_scatter_s += scatter;
-        out_rows += k;
-        out_jobs += 1;
-      }
-      cv_done.notify_all();
-    }
-  }
-
-  void run_in() {
-    (void)hipSetDevice(device);
-    bind_thread_near_gpu();
-    tight_timer_slack();
-    for (;;) {
-      long long job, need_out;
-      {
-        std::unique_lock<std::mutex> g(m);
-        cv_job.wait(g, [&] { return stop || in_done < in_issued; });
-        if (in_done >= in_issued) return;
-        job = in_done + 1;
-        need_out = out_issued_at[job & 7];
-      }
-      const auto t0 = std::chrono::steady_clock::now();
-      CE_TRACE("in job %lld: waiting for its miss-list event (needs out job %lld)", job, need_out);
-      hipError_t e = hipEventSynchronize(in_ev[job & 1]);
-      if (e != hipSuccess) fail("hipEventSynchronize(in)", e);
-      CE_TRACE("in job %lld: event done (%s)", job, hipGetErrorString(e));
-      {
-        // rows the earlier calls evicted must be in the table before the host threads read it
-        std::unique_lock<std::mutex> g(m);
-        cv_done.wait(g, [&] { return out_done >= need_out || err != 0; });
-      }
-      const auto t1 = std::chrono::steady_clock::now();
-      long long n = mail[2].count;
-      CE_TRACE("in job %lld: earlier write-backs landed; mail job %lld count %lld", job, mail[2].job, n);
-      if (mail[2].job != job || n < 0 || n > stage_rows) n = 0;
-#ifdef CE_TEST_HOOKS
-      if (fail_in_job > 0 && job == fail_in_job) fail("admission (injected: CE_WORKER_FAIL_IN_JOB)", hipErrorUnknown);
-#endif
-      if (n > 0 && !failed()) {
-        const float* tb = table;
-        float* st = in_host;
-        float* dv = in_stage_dev;
-        const int32_t* rows = miss_host;
-        const int64_t d = D;
-        hipStream_t cs = in_stream;
-        // ONE wake-up of the helpers per job (a condition-variable round trip per chunk cost more than the chunk):
-        // they pull 2048-row pieces off a shared counter and flag each finished piece; this thread -- the only one
-        // that talks to the runtime -- copies every run of finished pieces to the device as soon as it is 8192 rows
-        // long, so the copies trail the gather by one chunk.
-        constexpr int kAhead = 8;
-        constexpr int64_t kPiece = 2048, kCopyPieces = 4;
-        const int64_t npieces = cdiv(n, kPiece);
-        std::atomic<int64_t> next{0};
-        std::vector<std::atomic<unsigned char>> ready((size_t)npieces);
-        for (auto& r : ready) r.store(0, std::memory_order_relaxed);
-        const std::function<void(int64_t, int64_t)> work = [&](int64_t, int64_t) {
-          for (;;) {
-            const int64_t pc = next.fetch_add(1, std::memory_order_relaxed);
-            if (pc >= npieces) break;
-            const int64_t lo = pc * kPiece, hi = std::min<int64_t>(n, lo + kPiece);
-            for (int64_t i = lo; i < hi; ++i) {
-              if (i + kAhead < hi) {
-                const char* q = (const char*)(tb + (size_t)rows[i + kAhead] * d);
-                for (int64_t l = 0; l < d * 4; l += 64) __builtin_prefetch(q + l);
-              }
-              row_copy_stream(st + (size_t)i * d, tb + (size_t)rows[i] * d, (size_t)d);
-            }
-            row_copy_fence();
-            ready[(size_t)pc].store(1, std::memory_order_release);
-          }
-        };
-        const int helpers = (int)std::min<int64_t>(in_pool->size(), npieces);
-        in_pool->start(helpers, helpers, work);
-        int64_t cursor = 0;
-        int idle = 0;
-        while (cursor < npieces) {
-          int64_t k = 0;
-          while (cursor + k < npieces && ready[(size_t)(cursor + k)].load(std::memory_order_acquire)) ++k;
-          if (k >= kCopyPieces || (k > 0 && cursor + k == npieces)) {
-            const int64_t lo = cursor * kPiece, hi = std::min<int64_t>(n, (cursor + k) * kPiece);
-            e = hipMemcpyAsync(dv + (size_t)lo * d, st + (size_t)lo * d, (size_t)(hi - lo) * d * 4,
-                               hipMemcpyHostToDevice, cs);
-            if (e != hipSuccess) { fail("hipMemcpyAsync(H2D)", e); break; }
-            cursor += k;
-            idle = 0;
-          } else if (++idle < 64) {
-            std::this_thread::yield();
-          } else {
-            std::this_thread::sleep_for(std::chrono::microseconds(10));
-          }
-        }
-        in_pool->wait();
-      }
-      const auto tg = std::chrono::steady_clock::now();
-      // Wait for the copies on the host (their completion signals: no packet goes through a hardware queue), then
-      // release the cache-op stream with a plain store to the pinned word it polls.  Nothing here may depend on a
-      // GPU queue making progress: HIP multiplexes streams onto a few hardware queues (4 by default), so the copy
-      // stream can share one with the parked stream -- a hipStreamWriteValue64 / event marker queued behind the
-      // parked wait would never execute (seen as a hang of the full test suite).
-      CE_TRACE("in job %lld: rows gathered, copies enqueued", job);
-      e = stream_wait_polite(in_stream);
-      if (e != hipSuccess) fail(e == hipErrorNotReady ? "admission timed out (CE_WORKER_TIMEOUT_S)" : "waiting for the H2D copies", e);
-      // a job that did not bring its rows in is flagged BEFORE the stream is released: k_unpack_admitted /
-      // k_admit_maps then admit nothing and the call's record says CE_ERR_HIP
-      if (n > 0 && failed()) __atomic_store_n(sig + 1, (unsigned long long)job, __ATOMIC_RELEASE);
-      __atomic_store_n(sig, (unsigned long long)job, __ATOMIC_RELEASE);
-      CE_TRACE("in job %lld: released the stream (%s)", job, hipGetErrorString(e));
-      const auto t2 = std::chrono::steady_clock::now();
-      {
-        std::lock_guard<std::mutex> g(m);
-        in_done = job;
-        in_wait_s += std::chrono::duration<double>(t1 - t0).count();
-        in_busy_s += std::chrono::duration<double>(t2 - t1).count();
-        in_gather_s += std::chrono::duration<double>(tg - t1).count();
-        in_rows += n;
-        in_jobs += 1;
-      }
-      cv_done.notify_all();
-    }
-  }
-  long long out_issued_at[8] = {0};      // write-back jobs that must have landed before in-job j gathers
-  hipStream_t tested_stream = nullptr;   // cache-op stream the self-test below has passed on
-  bool tested = false;
-
-  int check() {
-    std::lock_guard<std::mutex> g(m);
-    if (err) {
-      set_error("%s", errmsg);
-      return err;
-    }
-    return CE_OK;
-  }
-  // The launch thread never waits for a worker without a deadline: a worker stuck in the runtime (GPU hang, a copy
-  // that never starts) would otherwise block the caller for ever with the cache-op stream parked.  On a timeout the
-  // pending admission is flagged lost and the stream released from here.
-  int give_up(const char* what) {
-    {
-      std::lock_guard<std::mutex> g(m);
-      if (!err) {
-        err = CE_ERR_HIP;
-        snprintf(errmsg, sizeof errmsg, "swap worker: %s did not finish within %.0f s (CE_WORKER_TIMEOUT_S)", what,
-                 2 * worker_timeout_s());
-      }
-    }
-    if (sig) {
-      __atomic_store_n(sig + 1, (unsigned long long)in_issued, __ATOMIC_RELEASE);
-      __atomic_store_n(sig, ~0ull >> 1, __ATOMIC_RELEASE);
-    }
-    return check();
-  }
-  int wait_out(long long upto) {       // blocks until write-back job `upto` has reached the host table
-    bool ok;
-    {
-      std::unique_lock<std::mutex> g(m);
-      ok = cv_done.wait_for(g, std::chrono::duration<double>(2 * worker_timeout_s()),
-                            [&] { return out_done >= upto || out_done >= out_issued; });
-    }
-    return ok ? check() : give_up("a write-back job");
-  }
-  int wait_in(long long upto) {
-    bool ok;
-    {
-      std::unique_lock<std::mutex> g(m);
-      ok = cv_done.wait_for(g, std::chrono::duration<double>(2 * worker_timeout_s()),
-                            [&] { return in_done >= upto || in_done >= in_issued; });
-    }
-    return ok ? check() : give_up("an admission job");
-  }
-  void push_out() {
-    {
-      std::lock_guard<std::mutex> g(m);
-      ++out_issued;
-      CE_TRACE("push out job %lld", out_issued);
-    }
-    cv_job.notify_all();
-  }
-  void push_in(long long need_out) {
-    {
-      std::lock_guard<std::mutex> g(m);
-      ++in_issued;
-      out_issued_at[in_issued & 7] = need_out;
-      CE_TRACE("push in job %lld (needs out %lld)", in_issued, need_out);
-    }
-    cv_job.notify_all();
-  }
-
-  ~SwapEngine() {
-    {
-      std::lock_guard<std::mutex> g(m);
-      stop = true;
-    }
-    if (const char* e = getenv("CE_WORKER_PROFILE"))
-      if (atoi(e) != 0 && in_jobs > 0)
-        fprintf(stderr, "[libce_hip] admission worker: %lld jobs, %lld of them with the previous write-back still on its "
-                "way (rows it evicted taken from its staging buffer)\n", in_jobs, in_probed);
-    if (const char* e = getenv("CE_WORKER_PROFILE"))
-      if (atoi(e) != 0 && out_jobs > 0)
-        fprintf(stderr, "[libce_hip] write-back worker: %lld jobs, %.3f ms busy per job = %.3f waiting for copies + %.3f "
-                "scattering + %.3f other; %.0f rows per job; first chunk's wait %.3f\n", out_jobs, out_busy_s / out_jobs * 1e3,
-                out_copy_wait_s / out_jobs * 1e3, out_scatter_s / out_jobs * 1e3,
-                (out_busy_s - out_copy_wait_s - out_scatter_s) / out_jobs * 1e3, (double)out_rows / out_jobs,
-                out_wait0_s / out_jobs * 1e3);
-    cv_job.notify_all();
-    if (in_thread.joinable()) in_thread.join();
-    if (out_thread.joinable()) out_thread.join();
-    delete out_pool;
-    delete in_pool;
-    for (int b = 0; b < 2; ++b) {
-      if (out_ev[b]) (void)hipEventDestroy(out_ev[b]);
-      if (rows_host[b]) (void)hipHostFree(rows_host[b]);
-      if (idx_host[b]) (void)hipHostFree(idx_host[b]);
-    }
-    for (int b = 0; b < 2; ++b)
-      if (in_ev[b]) (void)hipEventDestroy(in_ev[b]);
-    for (auto& ev : ev_miss)
-      if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : ev_rows)
-      if (ev) (void)hipEventDestroy(ev);
-
-    for (auto& ev : chunk_ev)
-      if (ev) (void)hipEventDestroy(ev);
-    if (in_host) (void)hipHostFree(in_host);
-    if (miss_host) (void)hipHostFree(miss_host);
-    if (sig) (void)hipHostFree(sig);
-    if (mail) (void)hipHostFree(mail);
-    if (out_stream) (void)hipStreamDestroy(out_stream);
-    if (out_stream2) (void)hipStreamDestroy(out_stream2);
-    if (in_stream) (void)hipStreamDestroy(in_stream);
-  }
-};
-
-}  // namespace ce
 
 struct ce_cache {
   ce_cache_config_t cfg;
