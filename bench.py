@@ -915,12 +915,30 @@ def verify_table(ledger, embed, args, N, D, dev, note):
     res["what"] = ("after the timed region: cache flushed; every row any trained step looked up compared in the host "
                    "table with w0 - lr * (fp64 sum of its lookups' gradient rows); untouched rows (sample) bit-equal "
                    "to w0; hot rows also against the reference's fp32 step-by-step arithmetic")
+    res["in_words"] = hot_rows_in_words(res)
     note(f"verified {res['rows']} rows / {res['lookups']} lookups / {res['steps']} steps in {res['seconds']:.1f}s: "
          f"{res['bound_violations']} bound violations, max err/bound {res['max_err_over_bound']:.3f}, "
          f"untouched mismatches {res.get('untouched_mismatch')}")
     if not res["pass"]:
         print("[bench] VERIFICATION FAILED: the host table is not what SGD should have produced", file=sys.stderr, flush=True)
     return res
+
+
+def hot_rows_in_words(res) -> str:
+    """what the check does and does not say about rows that sum many gradients (VERDICT r5 weak #1b): north_star's
+    '1e-5 relative' is met bit for bit / to 1e-5 by the rows with <= 4 lookups; a row that adds up thousands of fp32
+    gradients in another ORDER than torch does cannot agree with torch to 1e-5, and is held to the fp64 bound that
+    torch's own fp32 result is held to"""
+    s = (f"{res.get('single_lookup_rows', 0)} rows with one lookup are bit-equal to fp32(w0 - lr*g) "
+         f"({res.get('single_lookup_mismatch', 0)} mismatches); the {res.get('cold_rows', 0)} rows with <= 4 lookups agree "
+         f"with the fp64 closed form to {res.get('max_rel_err_cold', 0.0):.1e} relative (bar 1e-5, no absolute floor)")
+    if res.get("hot_rows_checked"):
+        s += (f"; the {res['hot_rows_checked']} hottest rows ({res['hot_rows_min_lookups']}-{res['hot_rows_max_lookups']} "
+              f"lookups each) are NOT held to 1e-5 against torch: they differ from torch's own fp32 step-by-step result by "
+              f"{res['hot_table_vs_torch_fp32_max_diff_rel_to_row_max']:.1e} of the row maximum (another summation order of "
+              f"the same fp32 terms), and both sit inside the fp64 bound -- this table at "
+              f"{res['hot_table_max_err_over_bound']:.2f} of it, torch fp32 at {res['hot_torch_fp32_max_err_over_bound']:.2f}")
+    return s
 
 
 _REAL_STDOUT = None
@@ -1381,6 +1399,7 @@ def verify_shard(embed, windows, trained_windows, grad, args, rank, world, dev, 
     res["what"] = ("rank 0's shard (counts over all ranks in all_ranks): cache flushed; every local row any rank's trained "
                    "step looked up vs w0 - lr * (fp64 sum of its lookups' gradient rows over ALL ranks); untouched rows "
                    "(sample) bit-equal to w0")
+    res["in_words"] = hot_rows_in_words(res)
     if rank == 0:
         print(f"[bench] verified shard of rank 0: {res['rows']} rows / {res['lookups']} lookups / {res['steps']} steps in "
               f"{res['seconds']:.1f}s; all ranks: {res['all_ranks']}", file=sys.stderr, flush=True)
