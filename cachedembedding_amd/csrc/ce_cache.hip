@@ -62,6 +62,10 @@ struct ce_cache {
   ce::ChainWords* chain;       // row counts for the admission stream
   unsigned long long *lb_emit, *lb_remap;      // look-back words (ce_cache_fused.h)
   unsigned lb_tag;             // calls that used them (every such call rewrites every word under its own tag)
+  ce::FrontWords* front;       // [2]: counters of the per-lookup front (k_touch / k_miss_rank), by parity of front_calls
+  int32_t *fine_cnt, *coarse_cnt;
+  long long front_calls;       // calls that took the per-lookup front
+  bool front_cleanup_pending;  // ... and whose k_keys has not been launched yet (it clears the front's bits and counters)
   unsigned long long* keys;
   uint32_t* hist;
   ce_call_stats_t* ring;       // pinned host
@@ -248,6 +252,11 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->lb_emit = (unsigned long long*)(h->ws + L.lb_emit);
   h->lb_remap = (unsigned long long*)(h->ws + L.lb_remap);
   h->lb_tag = 0;
+  h->front = (FrontWords*)(h->ws + L.front);
+  h->fine_cnt = (int32_t*)(h->ws + L.fine_cnt);
+  h->coarse_cnt = (int32_t*)(h->ws + L.coarse_cnt);
+  h->front_calls = 0;
+  h->front_cleanup_pending = false;
   h->seq = h->drained = 0;
   h->cpu_to_cuda_numel = h->cuda_to_cpu_numel = h->cache_miss = h->total_cache = 0;
   const int D = cfg->embedding_dim;
@@ -709,6 +718,19 @@ static int worker_selftest(ce_cache* h, hipStream_t s) {
   return CE_OK;
 }
 
+// k_keys' arguments for what the per-lookup front left behind (all NULL behind the bitmap front)
+struct FrontTail {
+  const int32_t* miss_tmp;
+  const FrontWords* fw;
+  uint32_t* bitmap;
+  int32_t *fine, *coarse;
+};
+static FrontTail take_front_tail(ce_cache* h) {
+  if (!h->front_cleanup_pending) return FrontTail{nullptr, nullptr, nullptr, nullptr, nullptr};
+  h->front_cleanup_pending = false;
+  return FrontTail{h->victims, h->front + (h->front_calls & 1), h->bitmap, h->fine_cnt, h->coarse_cnt};
+}
+
 // Second part of a cache op's front: victim selection, staging of the victims (and the write-back job), free-slot list.
 // Runs inline behind the front, or -- a call in two halves on the worker transport -- at the start of the SECOND half:
 // the admission kernel behind the front reads the host table over PCIe for ~0.7 ms, and these kernels run 2-3x slower
@@ -774,8 +796,10 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
   const int top_pass = select_top_pass(h, n, capturing);
+  const FrontTail ft = take_front_tail(h);
   hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
-                     seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
+                     seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl, ft.miss_tmp, ft.fw,
+                     ft.bitmap, ft.fine, ft.coarse);
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
   // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs.  What works per launch: every
@@ -879,6 +903,36 @@ static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int
   const ce_cache_config_t& c = h->cfg;
   const Layout& L = h->L;
   const int64_t N = c.num_embeddings, C = c.cuda_row_num;
+  if (h->front_cleanup_pending) {
+    // the call before took the per-lookup front and failed on the host before its k_keys was launched
+    hipLaunchKernelGGL(k_front_cleanup, dim3(64), dim3(256), 0, s, (const int32_t*)h->victims,
+                       (const FrontWords*)(h->front + (h->front_calls & 1)), h->bitmap, h->fine_cnt, h->coarse_cnt);
+    h->front_cleanup_pending = false;
+  }
+  if (single_pass_ok && !mail_in && !miss_host && n <= C && n <= kScanMaxIds && L.n_chunks <= kRankMaxChunks) {
+    // the per-lookup front (ce_cache_fused.h): two launches, no reset kernel, nothing proportional to the table
+    // (the host gather reads k_emit's mailbox; a captured call has no call number to stamp with)
+    const long long fc = ++h->front_calls;
+    FrontWords* const fw = h->front + (fc & 1);
+    FrontWords* const fw_next = h->front + ((fc + 1) & 1);
+    if (n > 0) {
+      const int U = n >= 65536 ? 2 : 1;
+      const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(cdiv(n, U), 64) * 64));
+      const dim3 tg((unsigned)cdiv(n, (int64_t)threads * U)), tb(threads);
+#define CE_TOUCH(U_)                                                                                                \
+  hipLaunchKernelGGL((k_touch<U_>), tg, tb, 0, s, ids, n, c.idx_map, c.inverted_cached_idx, N, h->bitmap, h->fine_cnt, \
+                     h->coarse_cnt, h->slot_epoch, seq_arg, fw, h->victims, slots_out, allow_pad)
+      if (U == 2) CE_TOUCH(2); else CE_TOUCH(1);
+#undef CE_TOUCH
+    }
+    const int rgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(std::max(n, C), 4096)));
+    hipLaunchKernelGGL(k_miss_rank, dim3(rgrid), dim3(256), (size_t)L.n_chunks * 4, s, (const int32_t*)h->victims, fw, fw_next,
+                       (const uint32_t*)h->bitmap, (const int32_t*)h->fine_cnt, (const int32_t*)h->coarse_cnt,
+                       (int)L.n_chunks, miss_list, (const int32_t*)h->slot_epoch, C, h->hist, seq_arg, h->ctl, n, h->ring_dev,
+                       (long long)L.stage_rows, steady ? 1 : 0, n_admit_out);
+    h->front_cleanup_pending = true;
+    return;
+  }
   hipLaunchKernelGGL(k_begin, dim3(16), dim3(256), 0, s, h->ctl, h->coarse,
                      (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist, seq_arg);
   if (n > 0) {
@@ -890,13 +944,6 @@ static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int
     if (mc.merge) { if (mc.u == 4) CE_MARK(true, 4); else CE_MARK(true, 1); }
     else { if (mc.u == 4) CE_MARK(false, 4); else CE_MARK(false, 1); }
 #undef CE_MARK
-  }
-  if (single_pass_ok && !mail_in && !miss_host && n <= C && n <= kScanMaxIds) {      // (the host gather reads k_emit's mailbox)
-    h->lb_tag = (h->lb_tag + 1) & 0xffffu;
-    hipLaunchKernelGGL(k_emit_scan, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (uint4*)h->bitmap, c.inverted_cached_idx,
-                       N, (int)L.n_chunks, h->lb_emit, h->lb_tag, miss_list, h->slot_epoch, seq_arg, h->ctl, n,
-                       h->ring_dev, (long long)L.stage_rows, steady ? 1 : 0, n_admit_out);
-    return;
   }
   hipLaunchKernelGGL(k_count, dim3((unsigned)L.n_chunks), dim3(256), 0, s, (const uint4*)h->bitmap,
                      c.inverted_cached_idx, N, h->blk_unique, h->blk_miss, h->coarse);
@@ -1016,8 +1063,10 @@ static int chained_second_half(ce_cache* h) {
     const int64_t N = c.num_embeddings, C = c.cuda_row_num;
     const int lfu = c.evict_strategy == CE_EVICT_LFU;
     const int top_pass = select_top_pass(h, x.sel_n, false);
+    const FrontTail ft = take_front_tail(h);
     hipLaunchKernelGGL(k_keys, dim3(std::min(grid_for(C, 256 * 4), 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter,
-                       h->slot_epoch, C, N, x.seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl);
+                       h->slot_epoch, C, N, x.seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl,
+                       ft.miss_tmp, ft.fw, ft.bitmap, ft.fine, ft.coarse);
     const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
     for (int pass = top_pass - 1; pass >= 0; --pass)
       hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);

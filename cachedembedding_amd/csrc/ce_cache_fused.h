@@ -7,12 +7,9 @@
 // the step, and what a kernel of the chain costs there is its number of DEPENDENT memory round trips (2-3 us each
 // beside the training kernels), not its bytes.  Two merges take round trips out without putting anything in:
 //
-//   k_emit_scan     count + emit in ONE pass over the bitmap and the map entries of the rows seen: a workgroup's place
-//                   in the miss list is the number of missing rows in the chunks before it -- single-pass scan with
-//                   decoupled look-back (every workgroup publishes its count in a tagged 64-bit word and adds up its
-//                   predecessors' words), so there is no count kernel and no second gather of the map.  Needs the
-//                   call's verdict before the first stamp, i.e. "unique rows <= cache rows" known up front: calls of at
-//                   most cuda_row_num ids (prefetch_num 1-2; a window of 8 batches takes k_count + k_emit).
+//   k_touch         the front per LOOKUP instead of per table row, for calls of at most cuda_row_num ids: see below
+//   k_miss_rank     (round 6, first form: k_emit_scan, count + emit in one pass over the bitmap with decoupled
+//                   look-back -- still N / 8 bytes and one workgroup per 32768 rows per call; replaced)
 //   k_rank_victims  for a FULL cache (the call evicts exactly as many rows as it misses and the slots to fill are its
 //   k_stage_maps    victims): victims per 4096-slot block counted and ranked by the same look-back, written as the
 //                   ascending free-slot list; then, over that list, their rows staged for the write-back AND both maps
@@ -99,101 +96,245 @@ __device__ __forceinline__ void lb_scan_wave(unsigned long long* words, int j, u
   *base_b = sb;
 }
 
-// count + emit + plan in one pass (see the header).  One workgroup per 32768-row chunk of the bitmap; the LAST one
-// holds the call's totals when its look-back ends and records the plan (what k_emit's workgroup 0 does from k_count's
-// sums).  The bad-id verdict is k_mark's, a launch ago; unique <= n <= C by the caller's choice of this kernel.
-// (One workgroup of 1024 threads per four chunks -- a quarter of the pollers, look-backs of one or two rounds -- was
-// slower: 44 against 37 us at the Kaggle table.  What the kernel waits for is the workgroups of the table's dense head,
-// whose threads fetch 128 map entries each before they can publish a count.)
-__global__ __launch_bounds__(256) void k_emit_scan(uint4* bitmap4, const int32_t* __restrict__ inverted, int64_t N,
-                                                   int n_chunks, unsigned long long* lb, unsigned tag,
-                                                   int32_t* miss_list, int32_t* slot_epoch, long long seq_arg, Ctl* ctl,
-                                                   int64_t n_ids, ce_call_stats_t* ring, long long in_cap,
-                                                   int assume_free0, long long* n_admit_out) {
-  __shared__ int su[4], sm[4], wsub[4];
-  __shared__ unsigned base_s[2];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = (int)blockIdx.x;
-  const long long seq_ = call_seq(ctl, seq_arg);
-  const int32_t epoch = call_epoch(seq_);
-  const int st_in = ctl->status;                                     // (k_mark's, a launch ago)
-  const bool stale = assume_free0 && ctl->n_free_start != 0;
-  const bool ok = st_in == CE_OK && !stale;
-  const int64_t v = (int64_t)c * 256 + threadIdx.x;
-  const uint4 q = bitmap4[v];
-  const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-  uint32_t mm[4];
-  int u = 0, m = 0;
-  if (ok) miss_masks4_stamp(inverted, v * 128, wds, N, slot_epoch, epoch, mm);
+// ---- the per-lookup front: calls of at most cuda_row_num ids (prefetch_num 1-2, the reference's micro-benchmark shape)
+//
+// k_mark + k_count / k_emit read and rewrite a bitmap of the whole TABLE to learn which rows a call names: N / 8 bytes
+// scanned per call whatever the call's size, one workgroup per 32768 rows with a look-back chain through all of them
+// (83 us of a 426 k-id call on the Kaggle table, most of it waiting).  A small call is better served per LOOKUP:
+//
+//   k_touch      id -> row -> slot.  A resident row's slot gets the call's stamp (a plain store: repeats are harmless, so
+//                the hot rows cost nothing); a missing row is test-and-set in the bitmap -- the thread that finds the
+//                bit clear owns the row, appends it to an unordered list (one returning atomic per WORKGROUP) and
+//                counts it in the 1024-row and 32768-row counters of its place in the table.  Misses are a few per
+//                cent of the lookups and rarely repeat, so the returning atomics that sank "count in k_mark" (round 3:
+//                every lookup of every hot row) are not on this path.
+//   k_miss_rank  the list in ascending order = every row at its RANK: (missing rows in the chunks before its chunk: a
+//                prefix over at most 16384 counters, recomputed by every workgroup in LDS) + (in the 1024-row groups
+//                before its group: <= 31 counters) + (bits below it in its group: <= 32 bitmap words) -- sixteen
+//                independent 16-byte loads per missing row, no sort, no pass over the table.  The distinct resident rows
+//                are counted off the stamps (a pass over the cache's 4-byte stamps), the radix histograms cleared, and
+//                the workgroup that finishes last writes the plan and the record -- what k_begin, k_emit_scan's
+//                look-back and its last workgroup did.
+//
+// The bits, counters of the missing rows are cleared by the next kernel of the call (k_keys' prologue) along the list.
+// A failed call (bad id) keeps its stamps: with protect_depth > 0 its resident rows stay protected for that many
+// calls more, which only ever keeps rows.
+
+// One pass, one iteration: workgroup b owns the ids [b * 1024 * U, (b + 1) * 1024 * U), a wave U * 64 consecutive ones.
+template <int U>
+__global__ __launch_bounds__(1024) void k_touch(const int64_t* __restrict__ ids, int64_t n,
+                                               const int32_t* __restrict__ idx_map,
+                                               const int32_t* __restrict__ inverted, int64_t N, uint32_t* bitmap,
+                                               int32_t* fine, int32_t* coarse, int32_t* slot_epoch, long long seq_arg,
+                                               FrontWords* fw, int32_t* miss_tmp, int64_t* rows_out, int allow_pad) {
+  __shared__ int wcnt[16], wcold[16];
+  __shared__ unsigned base_s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+  const int32_t epoch = call_epoch(seq_arg);
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * U;
+  int32_t row[U], inv[U];
+  bool valid[U], first[U];
+  bool bad = false;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (!ok) mm[k] = 0;
-    u += __popc(wds[k]);
-    m += __popc(mm[k]);
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = i0 + u * 64 + lane;
+    valid[u] = i < n;
+    row[u] = 0;
+    if (valid[u]) {
+      const int64_t id = ids[i];
+      if ((unsigned long long)id >= (unsigned long long)N) {
+        if (!(allow_pad && id == -1)) bad = true;       // (k_mark: -1 is padding on the padded entry point only)
+        valid[u] = false;
+        rows_out[i] = -1;
+      } else {
+        row[u] = idx_map ? idx_map[id] : (int32_t)id;
+      }
+    }
   }
-  const int inc = wave_incl_scan(m, lane);
-  const int uw = wave_sum(u);
-  if (lane == 63) {
-    su[wv] = uw;
-    sm[wv] = inc;
-    wsub[wv] = inc;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    inv[u] = 0;
+    if (valid[u]) {
+      rows_out[i0 + u * 64 + lane] = row[u];
+      inv[u] = inverted[row[u]];
+    }
+  }
+  int cold = 0, mine = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    first[u] = false;
+    if (!valid[u]) continue;
+    if (inv[u] >= 0) {
+      slot_epoch[inv[u]] = epoch;                       // evict_backlist membership [A.3-3]
+    } else {
+      ++cold;
+      const uint32_t bit = 1u << (row[u] & 31);
+      const uint32_t old = atomicOr(bitmap + (row[u] >> 5), bit);
+      first[u] = (old & bit) == 0;
+      mine += first[u] ? 1 : 0;
+    }
+  }
+  const int winc = wave_incl_scan(mine, lane);
+  cold = wave_sum(cold);
+  if (lane == 63) wcnt[wv] = winc;
+  if (lane == 0) wcold[wv] = cold;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0, tc = 0;
+    for (int k = 0; k < nw; ++k) {
+      tot += wcnt[k];
+      tc += wcold[k];
+    }
+    base_s = tot ? atomicAdd(&fw->n_miss, (unsigned)tot) : 0u;
+    if (tc) atomicAdd(&fw->miss_lookups, (unsigned long long)tc);
   }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const unsigned tu_c = (unsigned)(su[0] + su[1] + su[2] + su[3]), tm_c = (unsigned)(sm[0] + sm[1] + sm[2] + sm[3]);
-    unsigned bu = 0, bm = 0;
-    lb_scan_wave(lb, c, tag, tu_c, tm_c, &bu, &bm);
-    if (threadIdx.x == 0) {
-      base_s[0] = bu;
-      base_s[1] = bm;
+  unsigned pos = base_s + (unsigned)(winc - mine);
+  for (int k = 0; k < wv; ++k) pos += (unsigned)wcnt[k];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (!first[u]) continue;
+    miss_tmp[pos++] = row[u];
+    atomicAdd(fine + (row[u] >> kFineShift), 1);
+    atomicAdd(coarse + (row[u] >> kChunkShift), 1);
+  }
+  if (bad) fw->bad = 1;
+}
+
+// (only when a call failed on the host between its front and its k_keys: the next call's front clears up first)
+__global__ __launch_bounds__(256) void k_front_cleanup(const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
+                                                       uint32_t* bitmap, int32_t* fine, int32_t* coarse) {
+  front_cleanup(miss_tmp, fw, bitmap, fine, coarse);
+}
+
+__global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ miss_tmp, FrontWords* fw,
+                                                   FrontWords* fw_next, const uint32_t* __restrict__ bitmap,
+                                                   const int32_t* __restrict__ fine,
+                                                   const int32_t* __restrict__ coarse, int n_chunks,
+                                                   int32_t* miss_list, const int32_t* __restrict__ slot_epoch,
+                                                   int64_t C, uint32_t* hist, long long seq_arg, Ctl* ctl,
+                                                   int64_t n_ids, ce_call_stats_t* ring, long long in_cap,
+                                                   int assume_free0, long long* n_admit_out) {
+  extern __shared__ int cbase[];                       // [n_chunks]: missing rows in the chunks before
+  __shared__ int wtot[4];
+  __shared__ int last_s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned gtid = blockIdx.x * 256u + threadIdx.x, gsize = gridDim.x * 256u;
+  const unsigned m = fw->n_miss;                       // (final: k_touch is a launch ago)
+  const int32_t epoch = call_epoch(seq_arg);
+  // the stamps first: their loads are in flight while the prefix is worked out
+  int hits = 0;
+  {
+    const int64_t c4 = C >> 2;
+    const int4* const e4 = (const int4*)slot_epoch;
+    for (int64_t q = gtid; q < c4; q += gsize) {
+      const int4 x = e4[q];
+      hits += (x.x == epoch) + (x.y == epoch) + (x.z == epoch) + (x.w == epoch);
     }
-    if (threadIdx.x == 0 && c == n_chunks - 1) {
-      // ---- the plan: this workgroup's inclusive prefix is the call's total
-      const long long tu = (long long)bu + tu_c, tm = (long long)bm + tm_c;
-      ce_call_stats_t* const ring_slot = ring + (seq_ % kRing);
-      int status = st_in;
-      if (status == CE_OK && stale) status = CE_ERR_HIP;
+    for (int64_t s_ = (c4 << 2) + gtid; s_ < C; s_ += gsize) hits += slot_epoch[s_] == epoch;
+  }
+  for (unsigned i = gtid; i < (unsigned)kHistWords; i += gsize) hist[i] = 0;
+  if (m) {                                             // (uniform over the grid)
+    const int per = (n_chunks + 255) >> 8;
+    const int c0 = (int)threadIdx.x * per;
+    int sum = 0;
+    for (int j = 0; j < per; ++j)
+      if (c0 + j < n_chunks) sum += coarse[c0 + j];
+    const int inc = wave_incl_scan(sum, lane);
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    int pre = inc - sum;
+    for (int k = 0; k < wv; ++k) pre += wtot[k];
+    for (int j = 0; j < per; ++j)
+      if (c0 + j < n_chunks) {
+        cbase[c0 + j] = pre;
+        pre += coarse[c0 + j];
+      }
+    __syncthreads();
+    for (unsigned i = gtid; i < m; i += gsize) {
+      const int32_t r = miss_tmp[i];
+      const int c = r >> kChunkShift, f = r >> kFineShift;
+      const int nf = f - c * kFinePerChunk;            // 1024-row groups of the chunk before the row's own
+      const int4* const fp = (const int4*)(fine + (int64_t)c * kFinePerChunk);
+      const uint4* const bp = (const uint4*)(bitmap + ((int64_t)f << (kFineShift - 5)));
+      int4 fc[kFinePerChunk / 4];
+      uint4 bw[8];
+#pragma unroll
+      for (int j = 0; j < kFinePerChunk / 4; ++j) fc[j] = fp[j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bw[j] = bp[j];
+      int cnt = cbase[c];
+#pragma unroll
+      for (int j = 0; j < kFinePerChunk / 4; ++j) {
+        cnt += (4 * j + 0 < nf ? fc[j].x : 0) + (4 * j + 1 < nf ? fc[j].y : 0) + (4 * j + 2 < nf ? fc[j].z : 0) +
+               (4 * j + 3 < nf ? fc[j].w : 0);
+      }
+      const int w = (r >> 5) & 31;
+      const uint32_t below = (1u << (r & 31)) - 1u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t wd[4] = {bw[j].x, bw[j].y, bw[j].z, bw[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int wi = 4 * j + q;
+          cnt += wi < w ? __popc(wd[q]) : (wi == w ? __popc(wd[q] & below) : 0);
+        }
+      }
+      miss_list[cnt] = r;
+    }
+  }
+  hits = wave_sum(hits);
+  __syncthreads();                                     // (wtot is reused)
+  if (lane == 0) wtot[wv] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (tot) __hip_atomic_fetch_add(&fw->hit_unique, (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = __hip_atomic_fetch_add(&fw->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = ticket == gridDim.x - 1;
+    if (last_s) {
+      // ---- the plan (k_begin's reset + k_emit's workgroup 0): every workgroup's count is in
+      const long long hu = __hip_atomic_load(&fw->hit_unique, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ce_call_stats_t* const ring_slot = ring + (seq_arg % kRing);
+      const long long free0 = ctl->n_free;
+      int status = fw->bad ? CE_ERR_RANGE : CE_OK;
+      if (status == CE_OK && assume_free0 && free0 != 0) status = CE_ERR_HIP;      // (k_emit: the steady form's premise)
+      const long long tm = status == CE_OK ? (long long)m : 0;                   // a failed call admits nothing
+      const long long tu = hu + m;
       long long k = 0;
       if (status == CE_OK) {
-        k = tm - ctl->n_free;
+        k = tm - free0;
         if (k < 0) k = 0;
-        ctl->n_free = ctl->n_free + k - tm;
+        ctl->n_free = free0 + k - tm;
       }
-      __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ctl->seq = seq_arg;
+      ctl->n_free_start = free0;
       ctl->n_unique = tu;
       ctl->n_miss = tm;
       ctl->k_evict = k;
       ctl->sel_krem = k;
+      ctl->sel_prefix = 0;
+      ctl->miss_lookups = (long long)fw->miss_lookups;
+      ctl->n_eligible = 0;
+      ctl->victims_count = 0;
+      ctl->lost = 0;
+      __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ring_slot->n_ids = n_ids;
       ring_slot->n_unique = tu;
       ring_slot->n_miss = tm;
       ring_slot->n_evict = k;
-      ring_slot->miss_lookups = (status == CE_OK) ? ctl->miss_lookups : 0;
+      ring_slot->miss_lookups = (status == CE_OK) ? (long long)fw->miss_lookups : 0;
       ring_slot->n_free_after = ctl->n_free;
       ring_slot->status = status;
       ring_slot->kind = CE_CALL_PREPARE;
-      if (n_admit_out) {
-        const long long mrows = (status == CE_OK) ? tm : 0;
-        *n_admit_out = mrows < in_cap ? mrows : in_cap;
-      }
+      if (n_admit_out) *n_admit_out = tm < in_cap ? tm : in_cap;
+      fw_next->miss_lookups = 0;                       // the other parity's set, for the call after this one
+      fw_next->n_miss = 0;
+      fw_next->hit_unique = 0;
+      fw_next->done = 0;
+      fw_next->bad = 0;
     }
   }
-  __syncthreads();
-  if (ok) {
-    int pos = (int)base_s[1] + inc - m;
-    for (int k = 0; k < wv; ++k) pos += wsub[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t bits = mm[k];
-      const int64_t row0 = v * 128 + k * 32;
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        miss_list[pos++] = (int32_t)(row0 + b);
-      }
-    }
-  }
-  if (q.x | q.y | q.z | q.w) bitmap4[v] = make_uint4(0, 0, 0, 0);
 }
 
 struct StageArgs {

@@ -56,7 +56,8 @@ struct WbMail {              // pinned host mailbox: how many rows a worker job 
 
 struct Layout {              // byte offsets inside the caller-provided workspace
   size_t ctl, bitmap, blk_unique, blk_miss, coarse, miss_list, slot_epoch, keys, hist, victims, blk_free, free_list,
-      chain, lb_emit, lb_remap, miss_list2, free_list2, stage_idx, stage, stage_idx2, stage2, in_stage, total;
+      chain, lb_emit, lb_remap, miss_list2, free_list2, front, fine_cnt, coarse_cnt, stage_idx, stage, stage_idx2,
+      stage2, in_stage, total;
   int64_t n_chunks, n_slot_blocks, list_cap, bitmap_words, stage_rows;
 };
 
@@ -69,6 +70,22 @@ struct ChainWords {
   long long n_admit[2];
   long long n_unpack[2];
 };
+
+// Counters of the per-lookup front (k_touch / k_miss_rank, ce_cache_fused.h), one set per call parity: a call adds to
+// its own set and clears the other one for the call after it, so no kernel has to run before the first kernel of a
+// call just to zero them.
+struct FrontWords {
+  unsigned long long miss_lookups;   // lookups of rows that are not resident (with repeats)
+  unsigned int n_miss;               // distinct missing rows appended to the unordered list
+  unsigned int hit_unique;           // slots that carry the call's stamp = distinct resident rows it looked up
+  unsigned int done;                 // workgroups of k_miss_rank that have added their share of hit_unique
+  int bad;                           // an id outside [0, N) that is not accepted padding was met
+  unsigned int pad_[10];
+};
+static_assert(sizeof(FrontWords) == 64, "one 64-byte line per parity");
+constexpr int kFineShift = 10;       // rows per fine counter of the per-lookup front (32 bitmap words)
+constexpr int kFinePerChunk = 1 << (kChunkShift - kFineShift);
+constexpr int kRankMaxChunks = 16384;   // k_miss_rank keeps the chunk prefix in LDS (64 KB): tables up to 2^29 rows
 
 static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   Layout L{};
@@ -98,6 +115,11 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.lb_remap = o;   o = al(o + (size_t)(cdiv(C, 4096) + 1) * 8);
   L.miss_list2 = o; o = al(o + (size_t)L.list_cap * 4);
   L.free_list2 = o; o = al(o + (size_t)L.list_cap * 4);
+  // per-lookup front: its counters, and the distinct missing rows counted per 1024 / 32768 rows (zero between calls:
+  // the call that raised them clears them along its own miss list)
+  L.front = o;      o = al(o + 2 * sizeof(FrontWords));
+  L.fine_cnt = o;   o = al(o + (size_t)(L.n_chunks * kFinePerChunk + 4) * 4);
+  L.coarse_cnt = o; o = al(o + (size_t)(L.n_chunks + 1) * 4);
   L.stage_rows = std::min<int64_t>(L.list_cap, kStageRowsMax);
   L.stage_idx = o;  o = al(o + (size_t)L.stage_rows * 4);
   L.stage = o;      o = al(o + (size_t)L.stage_rows * (size_t)D * 4);
@@ -145,6 +167,20 @@ __device__ __forceinline__ int wave_sum(int v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
+
+// bits, counters of a call's missing rows back to zero, along its unordered list (the prologue of the kernel behind
+// k_miss_rank: every workgroup a share)
+__device__ __forceinline__ void front_cleanup(const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
+                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse) {
+  const unsigned m = fw->n_miss;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const int32_t r = miss_tmp[i];
+    bitmap[r >> 5] = 0;                 // (every set bit of the word is a row of this list)
+    fine[r >> kFineShift] = 0;
+    coarse[r >> kChunkShift] = 0;
+  }
+}
+
 
 // ----------------------------------------------------------------------------- kernels
 

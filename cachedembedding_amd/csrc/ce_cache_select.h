@@ -11,8 +11,12 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
                                               const int64_t* __restrict__ freq,
                                               const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
                                               long long seq_arg, int32_t depth, int slot_bits, int lfu, int top_pass,
-                                              unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
-  if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin)
+                                              unsigned long long* keys, uint32_t* hist, Ctl* ctl,
+                                              const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
+                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse_cnt) {
+  // behind the per-lookup front (miss_tmp != NULL): what it left in the bitmap and its counters goes first
+  if (miss_tmp) front_cleanup(miss_tmp, fw, bitmap, fine, coarse_cnt);
+  if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin / k_miss_rank)
   const int32_t epoch = call_epoch(call_seq(ctl, seq_arg));
   __shared__ uint32_t sh[kBins];
   for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
