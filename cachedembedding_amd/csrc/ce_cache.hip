@@ -799,7 +799,7 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
   const FrontTail ft = take_front_tail(h);
   hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
                      seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl, ft.miss_tmp, ft.fw,
-                     ft.bitmap, ft.fine, ft.coarse);
+                     ft.bitmap, ft.fine, ft.coarse, (int)L.n_chunks);
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
   // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs.  What works per launch: every
@@ -892,8 +892,7 @@ static MarkCfg mark_cfg(const ce_cache* h, int64_t n) {
   return m;
 }
 
-// calls the single-pass kernels take (ce_cache_fused.h): their look-back words hold 23-bit counts, and k_emit_scan
-// needs "unique rows <= cache rows" before it has counted them
+// calls k_rank_victims takes (ce_cache_fused.h): its look-back words hold 23-bit counts
 constexpr int64_t kScanMaxIds = (1 << 23) - 1;
 
 // front of a cache op: reset, ids -> bitmap, then the ascending list of the missing rows + the plan
@@ -906,12 +905,16 @@ static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int
   if (h->front_cleanup_pending) {
     // the call before took the per-lookup front and failed on the host before its k_keys was launched
     hipLaunchKernelGGL(k_front_cleanup, dim3(64), dim3(256), 0, s, (const int32_t*)h->victims,
-                       (const FrontWords*)(h->front + (h->front_calls & 1)), h->bitmap, h->fine_cnt, h->coarse_cnt);
+                       (const FrontWords*)(h->front + (h->front_calls & 1)), h->bitmap, h->fine_cnt, h->coarse_cnt,
+                       (int)L.n_chunks);
     h->front_cleanup_pending = false;
   }
-  if (single_pass_ok && !mail_in && !miss_host && n <= C && n <= kScanMaxIds && L.n_chunks <= kRankMaxChunks) {
-    // the per-lookup front (ce_cache_fused.h): two launches, no reset kernel, nothing proportional to the table
-    // (the host gather reads k_emit's mailbox; a captured call has no call number to stamp with)
+  if (single_pass_ok && !mail_in && !miss_host && n < (int64_t)INT32_MAX && L.n_chunks <= kRankMaxChunks) {
+    // the per-lookup front (ce_cache_fused.h): two launches, no reset kernel, nothing proportional to the table --
+    // every launched call of the zero-copy, staged and chained-admission transports, whatever its size (a window of
+    // 3.4 M ids: 0.108 against 0.140 ms for k_begin + k_mark + k_count + k_emit, profiles/r06_ab_front.txt).  The
+    // bitmap front stays for the host-gather admission (it reads k_emit's mailbox), for captured calls (no call number
+    // to stamp with) and for tables beyond 2^29 rows.
     const long long fc = ++h->front_calls;
     FrontWords* const fw = h->front + (fc & 1);
     FrontWords* const fw_next = h->front + ((fc + 1) & 1);
@@ -921,14 +924,14 @@ static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int
       const dim3 tg((unsigned)cdiv(n, (int64_t)threads * U)), tb(threads);
 #define CE_TOUCH(U_)                                                                                                \
   hipLaunchKernelGGL((k_touch<U_>), tg, tb, 0, s, ids, n, c.idx_map, c.inverted_cached_idx, N, h->bitmap, h->fine_cnt, \
-                     h->coarse_cnt, h->slot_epoch, seq_arg, fw, h->victims, slots_out, allow_pad)
+                     h->coarse_cnt, h->slot_epoch, seq_arg, fw, h->victims, (unsigned)L.list_cap, slots_out, allow_pad)
       if (U == 2) CE_TOUCH(2); else CE_TOUCH(1);
 #undef CE_TOUCH
     }
     const int rgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(std::max(n, C), 4096)));
     hipLaunchKernelGGL(k_miss_rank, dim3(rgrid), dim3(256), (size_t)L.n_chunks * 4, s, (const int32_t*)h->victims, fw, fw_next,
                        (const uint32_t*)h->bitmap, (const int32_t*)h->fine_cnt, (const int32_t*)h->coarse_cnt,
-                       (int)L.n_chunks, miss_list, (const int32_t*)h->slot_epoch, C, h->hist, seq_arg, h->ctl, n, h->ring_dev,
+                       (int)L.n_chunks, (unsigned)L.list_cap, miss_list, (const int32_t*)h->slot_epoch, C, h->hist, seq_arg, h->ctl, n, h->ring_dev,
                        (long long)L.stage_rows, steady ? 1 : 0, n_admit_out);
     h->front_cleanup_pending = true;
     return;
@@ -1066,7 +1069,7 @@ static int chained_second_half(ce_cache* h) {
     const FrontTail ft = take_front_tail(h);
     hipLaunchKernelGGL(k_keys, dim3(std::min(grid_for(C, 256 * 4), 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter,
                        h->slot_epoch, C, N, x.seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl,
-                       ft.miss_tmp, ft.fw, ft.bitmap, ft.fine, ft.coarse);
+                       ft.miss_tmp, ft.fw, ft.bitmap, ft.fine, ft.coarse, (int)L.n_chunks);
     const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
     for (int pass = top_pass - 1; pass >= 0; --pass)
       hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);

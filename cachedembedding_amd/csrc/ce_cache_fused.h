@@ -126,7 +126,8 @@ __global__ __launch_bounds__(1024) void k_touch(const int64_t* __restrict__ ids,
                                                const int32_t* __restrict__ idx_map,
                                                const int32_t* __restrict__ inverted, int64_t N, uint32_t* bitmap,
                                                int32_t* fine, int32_t* coarse, int32_t* slot_epoch, long long seq_arg,
-                                               FrontWords* fw, int32_t* miss_tmp, int64_t* rows_out, int allow_pad) {
+                                               FrontWords* fw, int32_t* miss_tmp, unsigned miss_cap, int64_t* rows_out,
+                                               int allow_pad) {
   __shared__ int wcnt[16], wcold[16];
   __shared__ unsigned base_s;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(1024) void k_touch(const int64_t* __restrict__ ids,
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (!first[u]) continue;
-    miss_tmp[pos++] = row[u];
+    if (pos < miss_cap) miss_tmp[pos] = row[u];        // (beyond the list: the call fails, k_miss_rank says so)
+    ++pos;
     atomicAdd(fine + (row[u] >> kFineShift), 1);
     atomicAdd(coarse + (row[u] >> kChunkShift), 1);
   }
@@ -203,15 +205,16 @@ __global__ __launch_bounds__(1024) void k_touch(const int64_t* __restrict__ ids,
 
 // (only when a call failed on the host between its front and its k_keys: the next call's front clears up first)
 __global__ __launch_bounds__(256) void k_front_cleanup(const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
-                                                       uint32_t* bitmap, int32_t* fine, int32_t* coarse) {
-  front_cleanup(miss_tmp, fw, bitmap, fine, coarse);
+                                                       uint32_t* bitmap, int32_t* fine, int32_t* coarse, int n_chunks) {
+  front_cleanup(miss_tmp, fw, bitmap, fine, coarse, n_chunks);
 }
 
 __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ miss_tmp, FrontWords* fw,
                                                    FrontWords* fw_next, const uint32_t* __restrict__ bitmap,
                                                    const int32_t* __restrict__ fine,
                                                    const int32_t* __restrict__ coarse, int n_chunks,
-                                                   int32_t* miss_list, const int32_t* __restrict__ slot_epoch,
+                                                   unsigned miss_cap, int32_t* miss_list,
+                                                   const int32_t* __restrict__ slot_epoch,
                                                    int64_t C, uint32_t* hist, long long seq_arg, Ctl* ctl,
                                                    int64_t n_ids, ce_call_stats_t* ring, long long in_cap,
                                                    int assume_free0, long long* n_admit_out) {
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
   __shared__ int last_s;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned gtid = blockIdx.x * 256u + threadIdx.x, gsize = gridDim.x * 256u;
-  const unsigned m = fw->n_miss;                       // (final: k_touch is a launch ago)
+  const unsigned m_all = fw->n_miss;                   // (final: k_touch is a launch ago)
+  const unsigned m = m_all <= miss_cap ? m_all : 0u;   // beyond the list: the call fails, nothing is ranked
   const int32_t epoch = call_epoch(seq_arg);
   // the stamps first: their loads are in flight while the prefix is worked out
   int hits = 0;
@@ -297,10 +301,12 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
       const long long hu = __hip_atomic_load(&fw->hit_unique, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ce_call_stats_t* const ring_slot = ring + (seq_arg % kRing);
       const long long free0 = ctl->n_free;
+      const long long tu = hu + m_all;
       int status = fw->bad ? CE_ERR_RANGE : CE_OK;
+      if (status == CE_OK && (tu > C || m_all > miss_cap)) status = CE_ERR_CAPACITY;    // [A.3-2]
       if (status == CE_OK && assume_free0 && free0 != 0) status = CE_ERR_HIP;      // (k_emit: the steady form's premise)
       const long long tm = status == CE_OK ? (long long)m : 0;                   // a failed call admits nothing
-      const long long tu = hu + m;
+      if (m_all > miss_cap) fw->overflow = 1;
       long long k = 0;
       if (status == CE_OK) {
         k = tm - free0;
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
       fw_next->hit_unique = 0;
       fw_next->done = 0;
       fw_next->bad = 0;
+      fw_next->overflow = 0;
     }
   }
 }

@@ -80,7 +80,8 @@ struct FrontWords {
   unsigned int hit_unique;           // slots that carry the call's stamp = distinct resident rows it looked up
   unsigned int done;                 // workgroups of k_miss_rank that have added their share of hit_unique
   int bad;                           // an id outside [0, N) that is not accepted padding was met
-  unsigned int pad_[10];
+  int overflow;                      // more distinct missing rows than the list holds (a call that fails: capacity)
+  unsigned int pad_[9];
 };
 static_assert(sizeof(FrontWords) == 64, "one 64-byte line per parity");
 constexpr int kFineShift = 10;       // rows per fine counter of the per-lookup front (32 bitmap words)
@@ -171,8 +172,18 @@ __device__ __forceinline__ int wave_sum(int v) {
 // bits, counters of a call's missing rows back to zero, along its unordered list (the prologue of the kernel behind
 // k_miss_rank: every workgroup a share)
 __device__ __forceinline__ void front_cleanup(const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
-                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse) {
+                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse, int n_chunks) {
   const unsigned m = fw->n_miss;
+  if (fw->overflow) {
+    // the list does not hold every row that was marked (the call failed: more distinct rows than cache slots):
+    // everything goes, at the price of a pass over the table's bitmap -- once per failed call
+    const int64_t nw = (int64_t)n_chunks * (kChunkRows / 32), nf = (int64_t)n_chunks * kFinePerChunk;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, ts = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t0; i < nw; i += ts) bitmap[i] = 0;
+    for (int64_t i = t0; i < nf; i += ts) fine[i] = 0;
+    for (int64_t i = t0; i < n_chunks; i += ts) coarse[i] = 0;
+    return;
+  }
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
     const int32_t r = miss_tmp[i];
     bitmap[r >> 5] = 0;                 // (every set bit of the word is a row of this list)

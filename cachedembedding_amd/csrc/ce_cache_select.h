@@ -13,9 +13,9 @@ __global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached
                                               long long seq_arg, int32_t depth, int slot_bits, int lfu, int top_pass,
                                               unsigned long long* keys, uint32_t* hist, Ctl* ctl,
                                               const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
-                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse_cnt) {
+                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse_cnt, int n_chunks) {
   // behind the per-lookup front (miss_tmp != NULL): what it left in the bitmap and its counters goes first
-  if (miss_tmp) front_cleanup(miss_tmp, fw, bitmap, fine, coarse_cnt);
+  if (miss_tmp) front_cleanup(miss_tmp, fw, bitmap, fine, coarse_cnt, n_chunks);
   if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin / k_miss_rank)
   const int32_t epoch = call_epoch(call_seq(ctl, seq_arg));
   __shared__ uint32_t sh[kBins];

@@ -1167,7 +1167,8 @@ class GraphedShardedWindow:
         """The P steps of a window with both row exchanges split (W > 1).  Communication stream, per step i:
             U(i-1) urgent deltas of the step before -> L(i) late rows of this step -> D(i-1) deferred deltas -> E(i+1)
             early rows of the NEXT step
-        Compute stream: wait for E(i) and L(i), pool, the caller's dense part, zero the delta buffers, fold + SGD.
+        Compute stream: wait for E(i) and L(i), pool, the caller's dense part, fold + SGD (into delta buffers the
+        communication stream zeroed behind L(i)).
         Only U(i-1) and L(i) sit between two steps' kernels; D(i-1) and E(i+1) travel while step i computes."""
         ex, ops, W, P = self.ex, self.ops, self.W, self.P
         lr = self.embed._lr[0]
@@ -1190,6 +1191,12 @@ class GraphedShardedWindow:
                 self._send_rows(buf, i, late=True)
                 ev_l = torch.cuda.Event()
                 ev_l.record(comm)
+                # the delta buffers step i folds into, zeroed HERE -- behind the messages that last carried them (U: the
+                # urgent return just above; D[i & 1]: step i - 2's deferred return, an iteration ago), beside step i's
+                # pooling -- instead of between the dense part and the fold on the training stream (6 us of every step)
+                self._bwd_zero[i & 1].zero_()
+                ev_z = torch.cuda.Event()
+                ev_z.record(comm)
                 if i > 0 and self._caps_host[i - 1][2] > 0:
                     self._return_grads(buf, i - 1, urgent=False)
                 if i + 1 < P:
@@ -1204,7 +1211,7 @@ class GraphedShardedWindow:
             else:
                 out = ops.pool(self._table, self._idx[buf][i], self.offsets, None, "sum", self.incl, self.hook)
             grad = self.dense_fn(out, i)
-            self._bwd_zero[i & 1].zero_()
+            cur.wait_event(ev_z)
             keys_b = SrcKeys(self._keys_b[buf][i], self.num_bags, self.incl, self.hook, None, self._identity)
             ops.update_table(self._table, grad, keys_b, self.n, lr)       # own rows: SGD in place; buffers: -lr * sum g
             ev_fold = torch.cuda.Event()

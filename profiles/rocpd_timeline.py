@@ -1,5 +1,5 @@
 """Timeline of one steady-state window from a rocprofv3 rocpd database: start/end (us, relative) and queue of
-every kernel between two consecutive k_begin dispatches.
+every kernel between two consecutive cache-op starts (k_begin, or k_touch -- the per-lookup front has no reset kernel).
 
     python profiles/rocpd_timeline.py results.db [which]
 
@@ -19,7 +19,7 @@ if not rows:
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     print(cols)
     sys.exit(0)
-begins = [i for i, r in enumerate(rows) if "k_begin" in r[0]]
+begins = [i for i, r in enumerate(rows) if "k_begin" in r[0] or "k_touch" in r[0]]
 if which == "steady":
     spans = []
     for k in range(len(begins) - 1):

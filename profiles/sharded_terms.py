@@ -16,8 +16,9 @@ Round 5: the same with the EARLY / LATE split of both exchanges (GraphedShardedW
 Every owner's classification is computed with the library's own ce_split_classify over what all W ranks ask it for,
 rank 0's places with ce_split_places, its two indices with ce_exchange_local_index_split; reported per W: the early /
 deferred fraction of the distinct rows on the bench id stream, the fitted capacities, the bytes each of the four
-messages carries, and the kernel terms ON the step's critical path (late gather, pooling, zero-fill, fold + SGD, urgent
-axpy) next to the ones that run beside the step (early gather, deferred axpy).
+messages carries, and the kernel terms ON the step's critical path (late gather, pooling, fold + SGD, urgent axpy) next
+to the ones that run beside the step (zero-fill of the delta buffers -- round 6: on the communication stream, behind the
+late rows --, early gather, deferred axpy).
 
 Usage: python profiles/sharded_terms.py [W ...]   (default 1 2 4 8) -> markdown on stdout
 """
@@ -193,7 +194,7 @@ for W in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         st["pooling from keys (critical)"] = timed(lambda r: check(lib.ce_bag_forward_src_keys(
             ptr(tab), tab.shape[0], D, n, ptr(keys_f[steps[r % len(steps)]].keys), ptr(out), sp)), REPS * P)
         b0 = 2 * ne + nl
-        st["zero-fill of the delta buffers (critical)"] = timed(lambda r: tail[b0 + (r & 1) * nd:b0 + (r & 1) * nd + nd + nu].zero_(), REPS * P)
+        st["zero-fill of the delta buffers (beside the step: behind the late rows on the communication stream, round 6)"] = timed(lambda r: tail[b0 + (r & 1) * nd:b0 + (r & 1) * nd + nd + nu].zero_(), REPS * P)
         st["fused fold + SGD (critical)"] = timed(lambda r: check(lib.ce_bag_backward_sgd_presorted_src(
             ptr(tab), tab.shape[0], D, n, ptr(grad), 1.0, ptr(keys_b[steps[r % len(steps)]].keys), sp)), REPS * P)
         st["urgent axpy (critical)"] = timed(lambda r: check(lib.ce_rows_axpy(
@@ -228,13 +229,13 @@ for r in rows_out:
     print(f"| {r['W']} | {r['capacity']} | {r['mean_bucket']:.0f} | {r['unique_rows_per_batch']:.0f} | {r['own_rows_per_batch']:.0f} | " +
           " | ".join(f"{r['kernels_us'].get(k, 0.0):.1f}" for k in names) +
           f" | {r['kernels_us_total']:.1f} | {r['wire_MB_per_exchange_and_direction']:.1f} |")
-print("\n## With the early / late split (round 5)\n")
+print("\n## With the early / late split (round 5; round 6: the delta buffers are zeroed on the communication stream)\n")
 print("early = share of a step's distinct remote rows that no rank looked up in the step before (they leave the owner while "
       "that step computes); deferred = share whose gradient no rank needs in the step after.  Capacities: mean + 4.5 sigma of "
       "each class over the window's (batch, peer) chunks, rounded to 128 rows.  Critical = between two steps' pooling; the "
       "early gather and the deferred axpy run on the communication stream beside the step.\n")
 print("| W | early | deferred | cap early / late / deferred / urgent | wire MB late + urgent (critical) | early + deferred (beside) | "
-      "unsplit, per exchange | critical kernels (us): late gather + pooling + zero + fold + urgent axpy | beside: early gather, deferred axpy (us) |")
+      "unsplit, per exchange | critical kernels (us): late gather + pooling + fold + urgent axpy | beside: zero-fill, early gather, deferred axpy (us) |")
 print("|---|---|---|---|---|---|---|---|---|")
 for r in rows_out:
     sp_ = r.get("split")
