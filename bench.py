@@ -123,9 +123,13 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--probe_lottery", action="store_true",
                     help="choose the static buffers by the probe pattern instead of the step's own kernels")
-    ap.add_argument("--no_buffer_lottery", action="store_true",
-                    help="let torch place the forward's output and the upstream gradient (default: the library tries "
-                         "--buffer_candidates allocations for each and keeps the one the row pattern is fastest on)")
+    ap.add_argument("--buffer_lottery", action="store_true",
+                    help="diagnostic (rounds 4-5; off since round 6): try --buffer_candidates allocations for the forward's "
+                         "output and the upstream gradient and keep the one the step's kernels are fastest on.  The same "
+                         "launch takes 38 or 45 us depending on how its output happens to be mapped; the bounded PMC "
+                         "experiment of round 6 (profiles/r06_alloc_pmc.md) found no counter that tells the two kinds "
+                         "apart and no allocation method that produces the fast one, so the default lets torch place "
+                         "both buffers")
     ap.add_argument("--buffer_candidates", type=int, default=12)
     ap.add_argument("--no_reference_semantics", action="store_true",
                     help="skip the extra block that runs the same steps with the reference's window semantics (one "
@@ -235,12 +239,12 @@ def main():
     need_windows(W + K)
     offsets = gen.offsets
     # The two static tensors of a step -- the forward's output and the fixed upstream gradient -- are visited a row per
-    # page (the hook-folded [B, F, D] layout), and how fast that is depends on how the allocation happens to be mapped:
-    # the library times a few candidates and keeps the fastest (functional.pick_fast_buffer; `config.static_buffers`).
+    # page (the hook-folded [B, F, D] layout), and how fast that is depends on how the allocation happens to be mapped.
+    # Torch places both (round 6); --buffer_lottery: time a few candidates and keep the fastest (`config.static_buffers`).
     from cachedembedding_amd.functional import pick_fast_buffer
     lottery = None
     out_static = None
-    want_lottery = not args.no_buffer_lottery and not args.unchanged_trainer and L == 1
+    want_lottery = args.buffer_lottery and not args.unchanged_trainer and L == 1
     grad = torch.randn(B, F, D, device=dev) * 1e-3                   # fixed upstream grad (benchmark_cache.py:64-65)
     # ... with zero mean over the batch, per feature and element.  The reference draws a fresh randn every iteration;
     # ONE tensor reused for thousands of steps at lr = 1 otherwise pushes the rows of the 3-row tables (a third of every
@@ -834,7 +838,8 @@ def main():
                    "transport": transport, "overlap": arrangement["mode"] == "overlap",
                    "interleaved": arrangement["mode"] == "interleaved", "arrangement": arrangement,
                    "plan_ahead_windows": (gw.plan_ahead if gw is not None else 1) if args.overlap else 0,
-                   "launch": "hipGraph per window" if use_graph else "python per step", "static_buffers": lottery,
+                   "launch": "hipGraph per window" if use_graph else "python per step",
+                   **({"static_buffers": lottery} if lottery else {}),
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "
                                          "(ce_bag_presort_window%s)" % ("" if args.tile_keys else "_src: keys = row | grad_out row, streaming backward") if presort else "1024-lookup tiles sorted inside every backward",
                    "update": ("torch.optim.SGD on the sparse COO gradient" if args.unchanged_trainer else
@@ -1207,7 +1212,7 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
     bucket_mean = float(st_.mean())
     tr = os.environ.get("CE_SHARDED_TRANSPORT", args.transport or pick_transport("auto", P * world * cap))
     lottery = {}
-    want_lottery = not args.no_buffer_lottery and L == 1 and args.buffer_candidates > 0
+    want_lottery = args.buffer_lottery and L == 1 and args.buffer_candidates > 0
 
     def pick_gradient(w):
         # the fixed upstream gradient in the fastest of a few candidate buffers for this window's own table update
@@ -1315,7 +1320,7 @@ def run_sharded_graphed(args, embed, gen, windows, need_windows, offsets, grad, 
                    "launch": "hipGraph per window" if gw._graphs is not None else
                              "fixed-capacity steps launched one by one (world > 1: CE_SHARDED_GRAPH=1 captures them)",
                    "transport": mgr.transport_name, "overlap": bool(args.overlap), "update": "atomic", "lr": args.lr,
-                   "windows_on_the_variable_size_path": gw.fallback_windows, "static_buffers": lottery or None,
+                   "windows_on_the_variable_size_path": gw.fallback_windows, **({"static_buffers": lottery} if lottery else {}),
                    "arrangement": (gw.trial.report() | {"mode": gw.arrangement}) if gw.trial is not None else {"mode": gw.arrangement},
                    "exchange_split": ({"on": True, "rows_per_peer_and_step": dict(zip(("early", "late", "deferred", "urgent"), gw.split_caps)),
                                        "measured_on_the_warmup_window": gw.split_stats,

@@ -88,6 +88,10 @@ def parse_args(argv=None):
                         "--fold_hook; one id per bag)")
     p.add_argument("--warmup_batches", type=int, default=16, help="iterations before the throughput clock starts "
                    "(library initialisation, GEMM algorithm search, pipeline fill)")
+    p.add_argument("--tunable_gemm", action="store_true",
+                   help="the dense part's GEMMs through torch's TunableOp (stock torch: every GEMM shape of the two MLPs and "
+                        "of the interaction is timed once over the rocBLAS / hipBLASLt solutions and the fastest kept; fp32 "
+                        "as before, nothing hand-written) -- VERDICT r5 #6")
     p.add_argument("--json_out", type=str, default=None, help="write the run's numbers as one JSON object")
     return p.parse_args(argv)
 
@@ -292,6 +296,12 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     torch.manual_seed(args.seed)
+    if args.tunable_gemm:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(50)                   # ms per solution: a dozen shapes, seconds in all
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ce_dlrm_tunableop_{rank}.csv"))
     sizes = synthetic.TABLES[args.dataset]
     if args.num_embeddings_per_feature:
         sizes = [int(x) for x in args.num_embeddings_per_feature.split(",")]
@@ -352,7 +362,7 @@ def main(argv=None):
                     "cuda_row_num": int(mgr.cuda_row_num), "dense_arch": args.dense_arch_layer_sizes,
                     "over_arch": args.over_arch_layer_sizes, "dtype": "f32", "data": "synthetic",
                     "surface": {k: bool(getattr(args, k)) for k in ("use_overlap", "overlap_cache_op", "fused_sgd",
-                                                                    "fold_hook", "window_keys",
+                                                                    "fold_hook", "window_keys", "tunable_gemm",
                                                                     "use_sparse_embed_grad", "use_lfu", "use_freq")},
                     "transport": mgr.transport_name, "iterations": done, "warmup_iterations": args.warmup_batches,
                     "it_per_s": train.steady_it_per_s, "it_per_s_scope": "whole model: data iterator + cache op + "

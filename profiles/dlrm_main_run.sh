@@ -8,3 +8,5 @@ python examples/dlrm_main.py $COMMON --overlap_cache_op --fused_sgd --fold_hook 
 python examples/dlrm_main.py $COMMON --overlap_cache_op --fused_sgd --fold_hook --window_keys --arrangement overlap --json_out gpurun_out/dlrm_main_overlap.json 2>&1 | tail -3
 python examples/dlrm_main.py $COMMON --overlap_cache_op --fused_sgd --fold_hook --window_keys --arrangement interleaved --json_out gpurun_out/dlrm_main_interleaved.json 2>&1 | tail -3
 python examples/dlrm_main.py $COMMON --use_sparse_embed_grad --json_out gpurun_out/dlrm_main_unchanged.json 2>&1 | tail -3
+# the dense part's GEMMs picked by torch's TunableOp (warm-up long enough for the tuning to finish)
+python examples/dlrm_main.py $COMMON --overlap_cache_op --fused_sgd --fold_hook --window_keys --arrangement auto --tunable_gemm --warmup_batches 64 --json_out gpurun_out/dlrm_main_auto_tunable.json 2>&1 | tail -4
