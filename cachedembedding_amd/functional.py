@@ -201,11 +201,11 @@ class _BagFn(torch.autograd.Function):
         return gw, None, None, gpsw, None, None, None, None, None, None, None, None, None
 
 
-# forward from the window's source-row keys when they were built for the one-id-per-bag layout (CE_FWD_KEYS=0: always
-# the gather-shaped kernel over slots + offsets)
-FORWARD_FROM_KEYS = __import__("os").environ.get("CE_FWD_KEYS", "1") != "0"
-# sparse=True: hand torch a coalesced COO gradient (CE_SPARSE_GRAD=rows restores one value row per lookup)
-COALESCED_SPARSE_GRAD = __import__("os").environ.get("CE_SPARSE_GRAD", "coalesced") != "rows"
+# forward from the window's source-row keys when they were built for the one-id-per-bag layout (False: always the
+# gather-shaped kernel over slots + offsets); sparse=True hands torch a coalesced COO gradient (False: one value row per
+# lookup).  Module constants (they were environment switches until round 6): a test or a probe may set them.
+FORWARD_FROM_KEYS = True
+COALESCED_SPARSE_GRAD = True
 
 
 class _BagMaxFn(torch.autograd.Function):

@@ -55,11 +55,11 @@ def pick_transport(transport: Optional[str], ids_per_call: int) -> Optional[str]
 
 # Owner-exclusive rows in the fused backward (presort_window(..., ids=...)): measured round 3 -- the presort that
 # marks them costs 4x (208 vs 50 us per window) and the backward gains 2-3 us per batch at best, so
-# the window pipelines only use it when asked to.
-EXCLUSIVE_ROWS = bool(int(__import__("os").environ.get("CE_EXCLUSIVE_ROWS", "0")))
+# the window pipelines only use it when this module constant is set (a probe's business).
+EXCLUSIVE_ROWS = False
 # the window's keys written by the cache op's last kernel (ce_cache_prepare_ids_keys) instead of by a presort launch
-# behind it (CE_FUSED_WINDOW_KEYS=0: two calls)
-FUSED_WINDOW_KEYS = bool(int(__import__("os").environ.get("CE_FUSED_WINDOW_KEYS", "1")))
+# behind it (False: two calls)
+FUSED_WINDOW_KEYS = True
 
 
 ARRANGEMENTS = ("overlap", "interleaved")
