@@ -285,6 +285,14 @@ class PrefetchWindow:
         self._begin_stream = None
         self.trial: Optional[ArrangementTrial] = None
         self._mode = "overlap" if overlap else "sequential"
+        # arrangement=None: the side stream ("overlap").  This window trains EAGER steps between its two calls: with the
+        # two halves of the cache op on the training stream of an eager trainer (chained admission), every dispatch of
+        # that stream cost ~40 us more from then on -- a DLRM iteration of ~60 kernels 4.5 -> 7.4 ms, in the windows
+        # trained with the side stream afterwards as well, so a trial cannot even measure its way out of it
+        # (profiles/r06_dlrm_interleaved_dispatch.md; not seen where the steps are hipGraph replays: GraphedWindow keeps
+        # "auto").  "auto" / "interleaved" remain for callers who ask.
+        if arrangement is None and overlap:
+            arrangement = "overlap"
         arrangement = _resolve_arrangement(arrangement, overlap) if (overlap or arrangement is not None) else None
         if arrangement == "auto":
             self.trial = ArrangementTrial(prefetch_num, **(arrangement_trial or {}))

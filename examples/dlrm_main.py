@@ -71,11 +71,14 @@ def parse_args(argv=None):
     p.add_argument("--use_overlap", action="store_true")
     p.add_argument("--overlap_cache_op", action="store_true",
                    help="run the cache op of window k+1 on a side stream while window k trains (not in the reference)")
-    p.add_argument("--arrangement", default="auto", choices=["auto", "overlap", "interleaved"],
+    p.add_argument("--arrangement", default="overlap", choices=["auto", "overlap", "interleaved"],
                    help="with --overlap_cache_op: where the next window's cache op runs -- on a side stream beside this "
-                        "window's steps (overlap), in two halves on the training stream around them (interleaved), or "
-                        "whichever of the two the library measures faster while training (auto, the library's default: "
-                        "pipeline.ArrangementTrial)")
+                        "window's steps (overlap, the default of an eager trainer since round 6), in two halves on the "
+                        "training stream around them (interleaved), or whichever of the two the library measures faster "
+                        "while training (auto: pipeline.ArrangementTrial).  With eager steps the interleaved form costs "
+                        "every later dispatch of the training stream ~40 us (217 -> 135 it/s at Criteo-1TB shapes, "
+                        "profiles/r06_dlrm_interleaved_dispatch.md), and a trial that starts with it measures both "
+                        "arrangements slow")
     p.add_argument("--arrangement_block_windows", type=int, default=8,
                    help="--arrangement auto: windows per block of the library's trial (3 blocks per arrangement; a window "
                         "of a whole model takes tens of milliseconds, so short blocks measure well)")
@@ -88,6 +91,15 @@ def parse_args(argv=None):
                         "--fold_hook; one id per bag)")
     p.add_argument("--warmup_batches", type=int, default=16, help="iterations before the throughput clock starts "
                    "(library initialisation, GEMM algorithm search, pipeline fill)")
+    p.add_argument("--graph_step", action="store_true",
+                   help="one process, --fused_sgd --fold_hook: after --graph_after eager iterations the whole iteration -- "
+                        "embedding forward, dense forward, loss, backward (with the embedding's fused update) and the dense "
+                        "optimizer step -- is captured ONCE in a hipGraph (torch.cuda.graph, stock torch) and replayed on "
+                        "static input buffers; the window's cache op stays outside it.  An iteration is ~60 kernels launched "
+                        "from Python: on a host with a small CPU quota the launch thread, not the GPU, sets the pace "
+                        "(VERDICT r5 #6)")
+    p.add_argument("--graph_after", type=int, default=8, help="--graph_step: eager iterations before the capture (lazy "
+                   "initialisation, GEMM algorithm selection / TunableOp tuning must be over)")
     p.add_argument("--tunable_gemm", action="store_true",
                    help="the dense part's GEMMs through torch's TunableOp (stock torch: every GEMM shape of the two MLPs and "
                         "of the interaction is timed once over the rocBLAS / hipBLASLt solutions and the fastest kept; fp32 "
@@ -215,7 +227,73 @@ def _window(data_iter, P, device, args, rank, world):
     return (dense, sparse, labels) if dense else None
 
 
+def _eager_step(model, optimizer, criterion, dense, sparse, labels, keys):
+    with phase("forward pass"):                               # the reference's ranges: recsys/dlrm_main.py:268-278
+        logits = model(dense, sparse, cache_op=False, presorted=keys).squeeze(-1)
+        loss = criterion(logits, labels)
+    with phase("backward pass"):
+        optimizer.zero_grad()
+        loss.backward()
+    with phase("optimization"):
+        optimizer.step()
+    return loss
+
+
+class _GraphedStep:
+    """One training iteration captured in a hipGraph on static inputs (--graph_step): torch.cuda.graph around exactly the
+    calls of _eager_step.  The embedding's kernels are launched through the C ABI on the current stream, so they are
+    captured with everything else; the slots and the window keys of the batch are copied into static tensors first."""
+
+    def __init__(self, model, optimizer, criterion, dense, sparse, labels, keys):
+        from cachedembedding_amd.functional import SrcKeys
+        self.dense, self.labels = dense.clone(), labels.clone()
+        self.sparse = [sparse[0].clone(), sparse[1].clone(), sparse[2]]
+        self.keys = None
+        if keys is not None:
+            self.keys = SrcKeys(keys.keys.clone(), keys.num_bags, keys.include_last_offset, keys.hook_features, None,
+                                keys.identity) if isinstance(keys, SrcKeys) else keys.clone()
+        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        optimizer.zero_grad(set_to_none=True)
+        # nothing of the pipeline may be in flight on the device while the step is captured, and what the library's swap
+        # workers do on their own threads meanwhile (copies, event waits) must not count as part of the capture
+        torch.cuda.synchronize()
+        model.sparse_modules.embed.cache_weight_mgr.writeback_wait()
+        self.graph = torch.cuda.CUDAGraph()
+        # captured on the stream the eager iterations ran on (train() leaves the legacy default stream for --graph_step):
+        # the gradient accumulators of the dense parameters were created there, and a capture must not wait for another
+        # stream's past
+        with torch.cuda.graph(self.graph, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+            logits = model(self.dense, self.sparse, cache_op=False, presorted=self.keys).squeeze(-1)
+            self.loss = criterion(logits, self.labels)
+            self.loss.backward()
+            optimizer.step()
+        # (the capture recorded the step without running it: the caller's eager step on this batch has trained it)
+
+    def step(self, dense, sparse, labels, keys):
+        from cachedembedding_amd.functional import SrcKeys
+        self.dense.copy_(dense)
+        self.labels.copy_(labels)
+        self.sparse[0].copy_(sparse[0])
+        if self.keys is not None:
+            (self.keys.keys if isinstance(self.keys, SrcKeys) else self.keys).copy_(keys.keys if isinstance(keys, SrcKeys) else keys)
+        self.graph.replay()
+        return self.loss
+
+
 def train(model, optimizer, loader, args, device, rank, world, record=None):
+    """recsys/dlrm_main.py:206-297 (see _train); --graph_step: on a stream of its own"""
+    if args.graph_step and torch.cuda.current_stream(device) == torch.cuda.default_stream(device):
+        # a step can only be captured on a stream of its own: the whole loop runs there
+        main = torch.cuda.Stream(device=device)
+        main.wait_stream(torch.cuda.default_stream(device))
+        with torch.cuda.stream(main):
+            out = train(model, optimizer, loader, args, device, rank, world, record)
+        torch.cuda.default_stream(device).wait_stream(main)
+        return out
+    return _train(model, optimizer, loader, args, device, rank, world, record)
+
+
+def _train(model, optimizer, loader, args, device, rank, world, record=None):
     """recsys/dlrm_main.py:206-297.  record: a list that receives every step's loss (as device scalars: no sync).  Default: the reference's window block (one synchronous prepare_ids per
     prefetch_num batches).  --overlap_cache_op: the cache op of window k+1 runs on a side stream while window k trains
     (pipeline.PrefetchWindow, protect_depth 1, swap traffic through the worker transport when the window is large)."""
@@ -235,6 +313,10 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
                          arrangement_trial=dict(block_windows=args.arrangement_block_windows, settle=2)
                          if (args.overlap_cache_op and args.arrangement == "auto") else None)
     train.window = win
+    graphed = None
+    if args.graph_step and (world > 1 or not (args.fused_sgd and args.fold_hook)):
+        raise ValueError("--graph_step needs --fused_sgd --fold_hook and one process (DDP's bucket hooks and the sparse "
+                         "COO gradient of the unfused path are not captured)")
     elapsed, done, loss = 0.0, 0, None
     steady = {"t0": None, "done0": 0}
     model.train()
@@ -254,17 +336,17 @@ def train(model, optimizer, loader, args, device, rank, world, record=None):
             slots = win.prepare([s[0] for s in sparse_l])
         for k in range(len(dense_l)):
             sparse_l[k][0] = slots[k]
-            with phase("forward pass"):                       # the reference's ranges: recsys/dlrm_main.py:268-278
-                logits = model(dense_l[k], sparse_l[k], cache_op=False,
-                               presorted=win.keys[k] if layout is not None else None).squeeze(-1)
-                loss = criterion(logits, labels_l[k])
-            with phase("backward pass"):
-                optimizer.zero_grad()
-                loss.backward()
-            with phase("optimization"):
-                optimizer.step()
+            keys_k = win.keys[k] if layout is not None else None
+            if graphed is not None and dense_l[k].shape[0] == args.batch_size:
+                with phase("forward + backward + optimization (one hipGraph replay)"):
+                    loss = graphed.step(dense_l[k], sparse_l[k], labels_l[k], keys_k)
+            else:
+                loss = _eager_step(model, optimizer, criterion, dense_l[k], sparse_l[k], labels_l[k], keys_k)
+                if args.graph_step and graphed is None and done + 1 >= args.graph_after \
+                        and dense_l[k].shape[0] == args.batch_size:
+                    graphed = _GraphedStep(model, optimizer, criterion, dense_l[k], sparse_l[k], labels_l[k], keys_k)
             if record is not None:
-                record.append(loss.detach())
+                record.append(loss.detach().clone() if graphed is not None else loss.detach())
             done += 1
         elapsed += time.time() - start
         start = time.time()
@@ -362,7 +444,7 @@ def main(argv=None):
                     "cuda_row_num": int(mgr.cuda_row_num), "dense_arch": args.dense_arch_layer_sizes,
                     "over_arch": args.over_arch_layer_sizes, "dtype": "f32", "data": "synthetic",
                     "surface": {k: bool(getattr(args, k)) for k in ("use_overlap", "overlap_cache_op", "fused_sgd",
-                                                                    "fold_hook", "window_keys", "tunable_gemm",
+                                                                    "fold_hook", "window_keys", "tunable_gemm", "graph_step",
                                                                     "use_sparse_embed_grad", "use_lfu", "use_freq")},
                     "transport": mgr.transport_name, "iterations": done, "warmup_iterations": args.warmup_batches,
                     "it_per_s": train.steady_it_per_s, "it_per_s_scope": "whole model: data iterator + cache op + "
