@@ -730,8 +730,13 @@ class GraphedShardedWindow:
         # window's steps; "interleaved": on the training stream, the owner-side cache op in two halves around this
         # window's steps (ce_cache_prepare_ids_begin_padded / _finish), so that no kernel of the plan runs beside a bag
         # kernel and only the PCIe admission overlaps -- what pipeline.GraphedWindow's one-stream arrangement is to the
-        # unsharded module; "auto" (W = 1 only: the verdict is local): pipeline.ArrangementTrial measures both while
-        # training.  None: "auto" at W = 1, "overlap" otherwise (no multi-GPU measurement exists to choose by).
+        # unsharded module; "auto": pipeline.ArrangementTrial measures both while training (W > 1: the verdict is
+        # COLLECTIVE -- the ranks' block times, MAX over the ranks, reduced in the same window on every rank).
+        # None: "auto" where the steps are hipGraph replays (W = 1; W > 1 with use_graph / CE_SHARDED_GRAPH=1),
+        # "overlap" where they are launched one by one: with EAGER steps the two halves of a cache op on the training
+        # stream cost every later dispatch of that stream ~40 us on the one box this could be measured on
+        # (profiles/r06_dlrm_interleaved_dispatch.md), and a trial that starts with such a block measures both
+        # arrangements slow.
         # split (W > 1; default on, CE_SHARDED_SPLIT=0 switches it off): the EARLY / LATE split of both row exchanges of
         # a step (class docstring).  split_caps = (cap_early, cap_late, cap_deferred, cap_urgent) rows per peer and
         # step; None: measured on the warm-up window (mean + 4.5 sigma of every class, agreed over the ranks).
@@ -771,8 +776,10 @@ class GraphedShardedWindow:
             if transport:
                 self.mgr.set_transport(transport)
         from .pipeline import ARRANGEMENTS, ArrangementTrial, DEFAULT_ARRANGEMENT
-        if arrangement is None:
-            arrangement = DEFAULT_ARRANGEMENT if overlap else None
+        if arrangement is None and overlap:
+            graphed = (self.W == 1 and use_graph is not False) or use_graph is True or \
+                (use_graph is None and os.environ.get("CE_SHARDED_GRAPH", "0") == "1")
+            arrangement = DEFAULT_ARRANGEMENT if graphed else "overlap"
         if arrangement is not None:
             if arrangement not in ("auto",) + ARRANGEMENTS:
                 raise ValueError(f"arrangement={arrangement!r}: 'auto', 'overlap' or 'interleaved'")
