@@ -912,7 +912,7 @@ static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int
   if (single_pass_ok && !mail_in && !miss_host && n < (int64_t)INT32_MAX && L.n_chunks <= kRankMaxChunks) {
     // the per-lookup front (ce_cache_fused.h): two launches, no reset kernel, nothing proportional to the table --
     // every launched call of the zero-copy, staged and chained-admission transports, whatever its size (a window of
-    // 3.4 M ids: 0.108 against 0.140 ms for k_begin + k_mark + k_count + k_emit, profiles/r06_ab_front.md).  The
+    // 3.4 M ids: 0.108 against 0.140 ms for k_begin + k_mark + k_count + k_emit, profiles/r06_ab_front.txt).  The
     // bitmap front stays for the host-gather admission (it reads k_emit's mailbox), for captured calls (no call number
     // to stamp with) and for tables beyond 2^29 rows.
     const long long fc = ++h->front_calls;
