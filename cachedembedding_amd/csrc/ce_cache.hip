@@ -65,10 +65,7 @@ struct ce_cache {
   ce::FrontWords* front;       // [2]: counters of the per-lookup front (k_touch / k_miss_rank), by parity of front_calls
   int32_t *fine_cnt, *coarse_cnt;
   long long front_calls;       // calls that took the per-lookup front
-  bool front_cleanup_pending;  // ... and whose next kernel has not been launched yet (it clears the front's bits and counters)
-  bool front_keys_done;        // the call in flight took the per-lookup front: its keys + top-digit histogram are written
-  int front_top_pass;          // ... with this many radix levels above the lowest (select_top_pass, called once per call)
-  uint32_t* hist_cur;          // the histogram set of the call in flight
+  bool front_cleanup_pending;  // ... and whose k_keys has not been launched yet (it clears the front's bits and counters)
   unsigned long long* keys;
   uint32_t* hist;
   ce_call_stats_t* ring;       // pinned host
@@ -260,9 +257,6 @@ extern "C" int ce_cache_create(const ce_cache_config_t* cfg, ce_stream_t stream,
   h->coarse_cnt = (int32_t*)(h->ws + L.coarse_cnt);
   h->front_calls = 0;
   h->front_cleanup_pending = false;
-  h->front_keys_done = false;
-  h->front_top_pass = 0;
-  h->hist_cur = h->hist + 2 * (size_t)kHistWords;
   h->seq = h->drained = 0;
   h->cpu_to_cuda_numel = h->cuda_to_cpu_numel = h->cache_miss = h->total_cache = 0;
   const int D = cfg->embedding_dim;
@@ -724,11 +718,17 @@ static int worker_selftest(ce_cache* h, hipStream_t s) {
   return CE_OK;
 }
 
-// what the per-lookup front left behind, for the first kernel launched after it (all NULL behind the bitmap front)
+// k_keys' arguments for what the per-lookup front left behind (all NULL behind the bitmap front)
+struct FrontTail {
+  const int32_t* miss_tmp;
+  const FrontWords* fw;
+  uint32_t* bitmap;
+  int32_t *fine, *coarse;
+};
 static FrontTail take_front_tail(ce_cache* h) {
-  if (!h->front_cleanup_pending) return FrontTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (!h->front_cleanup_pending) return FrontTail{nullptr, nullptr, nullptr, nullptr, nullptr};
   h->front_cleanup_pending = false;
-  return FrontTail{h->victims, h->front + (h->front_calls & 1), h->bitmap, h->fine_cnt, h->coarse_cnt, (int)h->L.n_chunks};
+  return FrontTail{h->victims, h->front + (h->front_calls & 1), h->bitmap, h->fine_cnt, h->coarse_cnt};
 }
 
 // Second part of a cache op's front: victim selection, staging of the victims (and the write-back job), free-slot list.
@@ -795,27 +795,20 @@ static int select_and_stage(ce_cache* h, const SelArgs& a, int* pmark_io) {
 #define CE_PHASE() do { if (prof) (void)hipEventRecord(prof->ev[pslot][pmark++], s); } while (0)
   // ---- victim selection (all kernels return at once when k == 0)
   const int cgrid = grid_for(C, 256 * 4);
-  // (behind the per-lookup front the keys and their top-digit histogram exist already: k_miss_rank wrote them)
-  const bool keyed = h->front_keys_done;
-  h->front_keys_done = false;
-  const int top_pass = keyed ? h->front_top_pass : select_top_pass(h, n, capturing);
-  uint32_t* const hist = h->hist_cur;              // (the set of whichever front this call took)
-  const FrontTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-  FrontTail ft = take_front_tail(h);             // for the first kernel launched below
-  if (!keyed)
-    hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
-                       seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, hist, h->ctl);
+  const int top_pass = select_top_pass(h, n, capturing);
+  const FrontTail ft = take_front_tail(h);
+  hipLaunchKernelGGL(k_keys, dim3(std::min(cgrid, 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter, h->slot_epoch, C, N,
+                     seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl, ft.miss_tmp, ft.fw,
+                     ft.bitmap, ft.fine, ft.coarse, (int)L.n_chunks);
   const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
   // (all passes in ONE workgroup for small caches was tried for the B = 2048 shapes: a single CU keeps too few key
   // loads in flight -- 0.38 ms per call against 0.05 ms for the 5 launch pairs.  What works per launch: every
   // workgroup of pass p recomputes the digits of the level above it from that level's histogram in its prologue --
   // select_level -- so there is no pick kernel at all)
-  for (int pass = top_pass - 1; pass >= 0; --pass) {
-    hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, hist, h->ctl, ft);
-    ft = no_tail;
-  }
+  for (int pass = top_pass - 1; pass >= 0; --pass)
+    hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
   hipLaunchKernelGGL(k_victims, dim3((unsigned)n_vblocks), dim3(256), 0, s, h->keys, C, h->victims, L.list_cap, h->ctl,
-                     (const uint32_t*)hist, top_pass, ring, seq_arg, steady ? h->blk_free : (int32_t*)nullptr, ft);
+                     (const uint32_t*)h->hist, top_pass, ring, seq_arg, steady ? h->blk_free : (int32_t*)nullptr);
   CE_PHASE();
   float* const stage_cur = (worker && wbuf) ? h->stage2 : h->stage;
   int32_t* const stage_idx_cur = (worker && wbuf) ? h->stage_idx2 : h->stage_idx;
@@ -935,33 +928,16 @@ static void launch_front_kernels(ce_cache* h, const int64_t* ids, int64_t n, int
       if (U == 2) CE_TOUCH(2); else CE_TOUCH(1);
 #undef CE_TOUCH
     }
-    // ... and the selection keys of every slot with the histogram of their top digit (keys_pass inside k_miss_rank):
-    // the radix levels are fixed here, once per call (select_top_pass keeps the LFU counter bound)
-    KeysArgs ka;
-    ka.cached_idx_map = c.cached_idx_map;
-    ka.freq = c.freq_cnter;
-    ka.N = N;
-    ka.depth = c.protect_depth;
-    ka.slot_bits = h->slot_bits;
-    ka.lfu = c.evict_strategy == CE_EVICT_LFU;
-    ka.top_pass = select_top_pass(h, n, false);
-    ka.keys = h->keys;
-    h->hist_cur = h->hist + (size_t)(fc & 1) * kHistWords;
-    ka.hist_next = h->hist + (size_t)((fc + 1) & 1) * kHistWords;
-    const int rgrid = (int)std::min<int64_t>(2 * kNumCU, std::max<int64_t>(1, cdiv(std::max(n, C), 2048)));
+    const int rgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(std::max(n, C), 4096)));
     hipLaunchKernelGGL(k_miss_rank, dim3(rgrid), dim3(256), (size_t)L.n_chunks * 4, s, (const int32_t*)h->victims, fw, fw_next,
                        (const uint32_t*)h->bitmap, (const int32_t*)h->fine_cnt, (const int32_t*)h->coarse_cnt,
-                       (int)L.n_chunks, (unsigned)L.list_cap, miss_list, (const int32_t*)h->slot_epoch, C, h->hist_cur, seq_arg,
-                       h->ctl, n, h->ring_dev, (long long)L.stage_rows, steady ? 1 : 0, n_admit_out, ka);
+                       (int)L.n_chunks, (unsigned)L.list_cap, miss_list, (const int32_t*)h->slot_epoch, C, h->hist, seq_arg, h->ctl, n, h->ring_dev,
+                       (long long)L.stage_rows, steady ? 1 : 0, n_admit_out);
     h->front_cleanup_pending = true;
-    h->front_keys_done = true;
-    h->front_top_pass = ka.top_pass;
     return;
   }
-  h->front_keys_done = false;
-  h->hist_cur = h->hist + 2 * (size_t)kHistWords;          // the bitmap front's own set
   hipLaunchKernelGGL(k_begin, dim3(16), dim3(256), 0, s, h->ctl, h->coarse,
-                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist_cur, seq_arg);
+                     (int)(((L.n_chunks >> kCoarseShift) + 1) * 2 * kCoarsePad), h->hist, seq_arg);
   if (n > 0) {
     const MarkCfg mc = mark_cfg(h, n);
     const dim3 mg(mc.blocks), mb(mc.threads);
@@ -1089,20 +1065,14 @@ static int chained_second_half(ce_cache* h) {
     // for staging + both maps
     const int64_t N = c.num_embeddings, C = c.cuda_row_num;
     const int lfu = c.evict_strategy == CE_EVICT_LFU;
-    const bool keyed = h->front_keys_done;       // (the per-lookup front wrote the keys: the chained calls' only front)
-    h->front_keys_done = false;
-    const int top_pass = keyed ? h->front_top_pass : select_top_pass(h, x.sel_n, false);
-    uint32_t* const hist = h->hist_cur;
-    const FrontTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    FrontTail ft = take_front_tail(h);
-    if (!keyed)
-      hipLaunchKernelGGL(k_keys, dim3(std::min(grid_for(C, 256 * 4), 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter,
-                         h->slot_epoch, C, N, x.seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, hist, h->ctl);
+    const int top_pass = select_top_pass(h, x.sel_n, false);
+    const FrontTail ft = take_front_tail(h);
+    hipLaunchKernelGGL(k_keys, dim3(std::min(grid_for(C, 256 * 4), 512)), dim3(256), 0, s, c.cached_idx_map, c.freq_cnter,
+                       h->slot_epoch, C, N, x.seq_arg, c.protect_depth, h->slot_bits, lfu, top_pass, h->keys, h->hist, h->ctl,
+                       ft.miss_tmp, ft.fw, ft.bitmap, ft.fine, ft.coarse, (int)L.n_chunks);
     const int hgrid = (int)std::min<int64_t>(kNumCU, std::max<int64_t>(1, cdiv(C, 1024 * 4)));
-    for (int pass = top_pass - 1; pass >= 0; --pass) {
-      hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, hist, h->ctl, ft);
-      ft = no_tail;
-    }
+    for (int pass = top_pass - 1; pass >= 0; --pass)
+      hipLaunchKernelGGL(k_hist, dim3(hgrid), dim3(1024), 0, s, h->keys, C, pass, top_pass, h->hist, h->ctl);
     if (prof) (void)hipEventRecord(prof->ev[pslot][x.pmark++], s);
     StageArgs a;
     a.cached_idx_map = c.cached_idx_map;
@@ -1113,8 +1083,7 @@ static int chained_second_half(ce_cache* h) {
     a.seq_arg = x.seq_arg;
     a.top_pass = top_pass;
     a.keys = h->keys;
-    a.hist = hist;
-    a.ft = ft;
+    a.hist = h->hist;
     a.ctl = h->ctl;
     a.lb = h->lb_remap;
     h->lb_tag = (h->lb_tag + 1) & 0xffffu;

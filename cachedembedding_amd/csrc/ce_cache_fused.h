@@ -116,8 +116,7 @@ __device__ __forceinline__ void lb_scan_wave(unsigned long long* words, int j, u
 //                the workgroup that finishes last writes the plan and the record -- what k_begin, k_emit_scan's
 //                look-back and its last workgroup did.
 //
-// The bits, counters of the missing rows are cleared by the next kernel of the call (the prologue of k_hist, or of
-// k_rank_victims / k_victims when the keys have a single digit) along the list.
+// The bits, counters of the missing rows are cleared by the next kernel of the call (k_keys' prologue) along the list.
 // A failed call (bad id) keeps its stamps: with protect_depth > 0 its resident rows stay protected for that many
 // calls more, which only ever keeps rows.
 
@@ -210,21 +209,6 @@ __global__ __launch_bounds__(256) void k_front_cleanup(const int32_t* __restrict
   front_cleanup(miss_tmp, fw, bitmap, fine, coarse, n_chunks);
 }
 
-// The selection keys of the cache's slots are written in the same pass that counts the stamps (keys_pass: the body of
-// k_keys -- one launch and one pass over the stamps less per call), whenever the call can evict at all: more distinct
-// missing rows than free slots, as far as this kernel can tell before the plan exists (a call that then fails -- bad
-// id, more distinct rows than cache slots -- has written keys nobody reads).  The radix histograms come in two sets: a
-// call adds to its own and clears the other one for the call after it.
-struct KeysArgs {
-  const int32_t* cached_idx_map;
-  const int64_t* freq;
-  int64_t N;
-  int32_t depth;
-  int slot_bits, lfu, top_pass;
-  unsigned long long* keys;
-  uint32_t* hist_next;           // the other set: cleared here
-};
-
 __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ miss_tmp, FrontWords* fw,
                                                    FrontWords* fw_next, const uint32_t* __restrict__ bitmap,
                                                    const int32_t* __restrict__ fine,
@@ -233,27 +217,18 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
                                                    const int32_t* __restrict__ slot_epoch,
                                                    int64_t C, uint32_t* hist, long long seq_arg, Ctl* ctl,
                                                    int64_t n_ids, ce_call_stats_t* ring, long long in_cap,
-                                                   int assume_free0, long long* n_admit_out, const KeysArgs ka) {
+                                                   int assume_free0, long long* n_admit_out) {
   extern __shared__ int cbase[];                       // [n_chunks]: missing rows in the chunks before
   __shared__ int wtot[4];
   __shared__ int last_s;
-  __shared__ uint32_t sh[kBins];                       // top-digit histogram of the keys this workgroup writes
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned gtid = blockIdx.x * 256u + threadIdx.x, gsize = gridDim.x * 256u;
   const unsigned m_all = fw->n_miss;                   // (final: k_touch is a launch ago)
   const unsigned m = m_all <= miss_cap ? m_all : 0u;   // beyond the list: the call fails, nothing is ranked
   const int32_t epoch = call_epoch(seq_arg);
-  // can the call evict?  (n_free is the count the call starts from: the plan -- the LAST workgroup to finish, below --
-  // is the only writer, and by then every workgroup has read it)
-  const bool with_keys = !fw->bad && (long long)m > ctl->n_free;
-  // the stamps (and the keys) first: their loads are in flight while the prefix is worked out
-  int hits = 0, elig = 0;
-  if (with_keys) {
-    for (int i = threadIdx.x; i < kBins; i += 256) sh[i] = 0;
-    __syncthreads();
-    keys_pass(ka.cached_idx_map, ka.freq, slot_epoch, C, ka.N, epoch, ka.depth, ka.slot_bits, ka.lfu, ka.top_pass, ka.keys,
-              sh, &elig, &hits);
-  } else {
+  // the stamps first: their loads are in flight while the prefix is worked out
+  int hits = 0;
+  {
     const int64_t c4 = C >> 2;
     const int4* const e4 = (const int4*)slot_epoch;
     for (int64_t q = gtid; q < c4; q += gsize) {
@@ -262,7 +237,7 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
     }
     for (int64_t s_ = (c4 << 2) + gtid; s_ < C; s_ += gsize) hits += slot_epoch[s_] == epoch;
   }
-  for (unsigned i = gtid; i < (unsigned)kHistWords; i += gsize) ka.hist_next[i] = 0;
+  for (unsigned i = gtid; i < (unsigned)kHistWords; i += gsize) hist[i] = 0;
   if (m) {                                             // (uniform over the grid)
     const int per = (n_chunks + 255) >> 8;
     const int c0 = (int)threadIdx.x * per;
@@ -312,20 +287,6 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
       miss_list[cnt] = r;
     }
   }
-  if (with_keys) {                                     // (uniform over the grid)
-    __syncthreads();
-    uint32_t* const mine = hist + ka.top_pass * kBins;
-    for (int i = threadIdx.x; i < kBins; i += 256)
-      if (sh[i]) atomicAdd(&mine[i], sh[i]);
-    elig = wave_sum(elig);
-    __syncthreads();                                   // (wtot is reused)
-    if (lane == 0) wtot[wv] = elig;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int te = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-      if (te) __hip_atomic_fetch_add(&fw->n_elig, (unsigned)te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   hits = wave_sum(hits);
   __syncthreads();                                     // (wtot is reused)
   if (lane == 0) wtot[wv] = hits;
@@ -360,7 +321,7 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
       ctl->sel_krem = k;
       ctl->sel_prefix = 0;
       ctl->miss_lookups = (long long)fw->miss_lookups;
-      ctl->n_eligible = (long long)__hip_atomic_load(&fw->n_elig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ctl->n_eligible = 0;
       ctl->victims_count = 0;
       ctl->lost = 0;
       __hip_atomic_store(&ctl->status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -379,7 +340,6 @@ __global__ __launch_bounds__(256) void k_miss_rank(const int32_t* __restrict__ m
       fw_next->done = 0;
       fw_next->bad = 0;
       fw_next->overflow = 0;
-      fw_next->n_elig = 0;
     }
   }
 }
@@ -410,7 +370,6 @@ struct StageArgs {
   long long job;
   EvTable evt;
   void* host_overflow;
-  FrontTail ft;                  // k_rank_victims, when it is the first kernel behind the per-lookup front
 };
 
 constexpr int kRemapSlots = 4096;      // slots per workgroup of k_rank_victims (k_victims' blocks)
@@ -428,7 +387,6 @@ __global__ __launch_bounds__(256) void k_rank_victims(const StageArgs a) {
   __shared__ int pre_s[65];
   __shared__ unsigned base_s;
   Ctl* const ctl = a.ctl;
-  front_cleanup(a.ft);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = (int)blockIdx.x;
   // wave wv holds the 64-slot groups wv, wv + 4, ... (in flight while wave 0 works out the threshold)

@@ -81,8 +81,7 @@ struct FrontWords {
   unsigned int done;                 // workgroups of k_miss_rank that have added their share of hit_unique
   int bad;                           // an id outside [0, N) that is not accepted padding was met
   int overflow;                      // more distinct missing rows than the list holds (a call that fails: capacity)
-  unsigned int n_elig;               // slots that may be evicted (k_miss_rank's key pass; the plan copies it to Ctl)
-  unsigned int pad_[8];
+  unsigned int pad_[9];
 };
 static_assert(sizeof(FrontWords) == 64, "one 64-byte line per parity");
 constexpr int kFineShift = 10;       // rows per fine counter of the per-lookup front (32 bitmap words)
@@ -105,9 +104,7 @@ static Layout make_layout(int64_t N, int64_t C, int64_t max_ids, int64_t D) {
   L.miss_list = o;  o = al(o + (size_t)L.list_cap * 4);
   L.slot_epoch = o; o = al(o + (size_t)C * 4);
   L.keys = o;       o = al(o + (size_t)C * 8);
-  // three sets: the per-lookup front's calls alternate between the first two (a call clears the other one for the call
-  // after it: k_miss_rank), the bitmap front has the third to itself (k_begin clears it)
-  L.hist = o;       o = al(o + (size_t)kHistWords * 4 * 3);
+  L.hist = o;       o = al(o + (size_t)kHistWords * 4);
   L.victims = o;    o = al(o + (size_t)L.list_cap * 4);
   L.blk_free = o;   o = al(o + (size_t)(L.n_slot_blocks + 1) * 4);
   L.free_list = o;  o = al(o + (size_t)L.list_cap * 4);
@@ -174,13 +171,6 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // bits, counters of a call's missing rows back to zero, along its unordered list (the prologue of the kernel behind
 // k_miss_rank: every workgroup a share)
-struct FrontTail {                   // what the per-lookup front left behind, for the kernel that runs next (all NULL: nothing)
-  const int32_t* miss_tmp;
-  const FrontWords* fw;
-  uint32_t* bitmap;
-  int32_t *fine, *coarse;
-  int n_chunks;
-};
 __device__ __forceinline__ void front_cleanup(const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
                                               uint32_t* bitmap, int32_t* fine, int32_t* coarse, int n_chunks) {
   const unsigned m = fw->n_miss;
@@ -202,10 +192,6 @@ __device__ __forceinline__ void front_cleanup(const int32_t* __restrict__ miss_t
   }
 }
 
-
-__device__ __forceinline__ void front_cleanup(const FrontTail& t) {
-  if (t.miss_tmp) front_cleanup(t.miss_tmp, t.fw, t.bitmap, t.fine, t.coarse, t.n_chunks);
-}
 
 // ----------------------------------------------------------------------------- kernels
 

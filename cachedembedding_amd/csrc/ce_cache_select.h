@@ -7,21 +7,27 @@ namespace ce {
 
 // selection keys: smaller = evicted first.  Ineligible (empty / protected) = all ones.  The histogram of the TOP digit
 // is taken here too (the keys are in registers): one pass over the keys less.
-//
-// keys_pass: the body, for whatever grid calls it (k_keys; k_miss_rank, which has the stamps in hand anyway) -- every
-// slot's key written, the top digit counted in the caller's LDS histogram `sh` ([kBins], zeroed by the caller), the
-// evictable slots and (count_hits) the slots that carry THIS call's stamp counted per thread.
-__device__ __forceinline__ void keys_pass(const int32_t* __restrict__ cached_idx_map, const int64_t* __restrict__ freq,
-                                          const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N, int32_t epoch,
-                                          int32_t depth, int slot_bits, int lfu, int top_pass, unsigned long long* keys,
-                                          uint32_t* sh, int* elig_out, int* hits_out) {
+__global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached_idx_map,
+                                              const int64_t* __restrict__ freq,
+                                              const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
+                                              long long seq_arg, int32_t depth, int slot_bits, int lfu, int top_pass,
+                                              unsigned long long* keys, uint32_t* hist, Ctl* ctl,
+                                              const int32_t* __restrict__ miss_tmp, const FrontWords* fw,
+                                              uint32_t* bitmap, int32_t* fine, int32_t* coarse_cnt, int n_chunks) {
+  // behind the per-lookup front (miss_tmp != NULL): what it left in the bitmap and its counters goes first
+  if (miss_tmp) front_cleanup(miss_tmp, fw, bitmap, fine, coarse_cnt, n_chunks);
+  if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin / k_miss_rank)
+  const int32_t epoch = call_epoch(call_seq(ctl, seq_arg));
+  __shared__ uint32_t sh[kBins];
+  for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
   const int shift = top_pass * kDigitBits;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // LFU: a counter is clamped so that the key stays inside the digits the select looks at (the host derives
   // top_pass from an upper bound of the counters; freq_cnter is the caller's tensor, so nothing else guarantees it)
   const int key_bits = (top_pass + 1) * kDigitBits;
   const unsigned long long fmax = (1ull << ((key_bits < 63 ? key_bits : 63) - slot_bits)) - 1;
-  int elig = 0, hits = 0;
+  int elig = 0;
   // four slots per thread in flight (one after the other, a thread of the 512-workgroup grid walked 13 slots of a
   // 1.7 M-slot cache in 13 dependent round trips)
   constexpr int UK = 4;
@@ -39,7 +45,6 @@ __device__ __forceinline__ void keys_pass(const int32_t* __restrict__ cached_idx
     for (int u = 0; u < UK; ++u) {
       const int64_t s = s0 + (int64_t)u * stride;
       if (s >= C) continue;
-      hits += ep[u] == epoch;
       const bool prot = (epoch - ep[u]) <= depth;
       unsigned long long key = ~0ull;
       if (row[u] >= 0 && !prot) {
@@ -56,22 +61,6 @@ __device__ __forceinline__ void keys_pass(const int32_t* __restrict__ cached_idx
       atomicAdd(&sh[(key >> shift) & (kBins - 1)], 1u);
     }
   }
-  *elig_out = elig;
-  *hits_out = hits;
-}
-
-__global__ __launch_bounds__(256) void k_keys(const int32_t* __restrict__ cached_idx_map,
-                                              const int64_t* __restrict__ freq,
-                                              const int32_t* __restrict__ slot_epoch, int64_t C, int64_t N,
-                                              long long seq_arg, int32_t depth, int slot_bits, int lfu, int top_pass,
-                                              unsigned long long* keys, uint32_t* hist, Ctl* ctl) {
-  if (ctl->k_evict == 0) return;          // (the histograms were cleared by k_begin)
-  const int32_t epoch = call_epoch(call_seq(ctl, seq_arg));
-  __shared__ uint32_t sh[kBins];
-  for (int i = threadIdx.x; i < kBins; i += blockDim.x) sh[i] = 0;
-  __syncthreads();
-  int elig = 0, hits = 0;
-  keys_pass(cached_idx_map, freq, slot_epoch, C, N, epoch, depth, slot_bits, lfu, top_pass, keys, sh, &elig, &hits);
   // evictable slots are counted here, not read off the top-digit histogram: a DATASET key N-1-row can share its
   // top digit with the all-ones key of an ineligible slot.
   // One atomic per WORKGROUP on a grid of at most 512: same-address device atomics serialise at ~7 ns each, and
@@ -164,8 +153,7 @@ __device__ __forceinline__ SelState select_level(const uint32_t* __restrict__ hi
 }
 
 __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restrict__ keys, int64_t C, int pass,
-                                               int top_pass, uint32_t* hist, Ctl* ctl, const FrontTail ft) {
-  front_cleanup(ft);                     // (the first kernel behind the per-lookup front: its bits and counters go first)
+                                               int top_pass, uint32_t* hist, Ctl* ctl) {
   if (ctl->k_evict == 0) return;
   __shared__ uint32_t sh[kBins];
   __shared__ unsigned long long prefix_s;
@@ -211,8 +199,7 @@ __global__ __launch_bounds__(1024) void k_hist(const unsigned long long* __restr
 __global__ __launch_bounds__(256) void k_victims(const unsigned long long* __restrict__ keys, int64_t C,
                                                  int32_t* victims, int64_t cap, Ctl* ctl, const uint32_t* hist,
                                                  int top_pass, ce_call_stats_t* ring, long long seq_arg,
-                                                 int32_t* blk_vic, const FrontTail ft) {
-  front_cleanup(ft);
+                                                 int32_t* blk_vic) {
   ce_call_stats_t* const ring_slot = ring + (call_seq(ctl, seq_arg) % kRing);
   __shared__ unsigned long long prefix_s;
   __shared__ int fail_s, go_s;
