@@ -121,6 +121,8 @@ def parse():
                          "build's additions (fused SGD, folded hook, window keys, overlapped cache op, hipGraph, "
                          "worker transport).  What a maintainer gets before opting into anything.")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--keep_gc", action="store_true", help="leave Python's cycle collector on during warm-up and timed "
+                    "region (default: off there, like timeit)")
     ap.add_argument("--probe_lottery", action="store_true",
                     help="choose the static buffers by the probe pattern instead of the step's own kernels")
     ap.add_argument("--buffer_lottery", action="store_true",
@@ -445,6 +447,15 @@ def main():
     box = {"what": "ce_box_probe: 20 streaming reads, then 20 fills, of a buffer the size of the forward's output "
                    "(>= 64 MB), hipEvent-bracketed; `before` the warm-up, `after` the timed region",
            "before": box_probe()}
+    # The launch thread is the clock of a `prefetch_num` 1 pipeline (~10 launches per 0.27 ms step), and the run keeps
+    # tens of thousands of tensors alive (every window's ids, for the end-of-run check): a generation-2 pass of
+    # Python's cycle collector over them is milliseconds in which the GPU runs dry.  No cycles are created in the
+    # loops below, so the collector is off from the warm-up to the end of the timed region (as `timeit` does) unless
+    # --keep_gc asks otherwise; `config.gc` says which.
+    import gc
+    if not args.keep_gc:
+        gc.collect()
+        gc.disable()
     barrier()
     tw = time.perf_counter()
     run_range(0, W)
@@ -520,6 +531,8 @@ def main():
     enqueue_cpu_s = time.thread_time() - c1      # CPU seconds of the launch thread: < enqueue_s means it waited
     barrier()
     region = time.perf_counter() - t1
+    if not args.keep_gc:
+        gc.enable()
     g += reps * K
     elapsed = region / reps                      # seconds per K steps
     blocks = [single]
@@ -839,6 +852,7 @@ def main():
                    "interleaved": arrangement["mode"] == "interleaved", "arrangement": arrangement,
                    "plan_ahead_windows": (gw.plan_ahead if gw is not None else 1) if args.overlap else 0,
                    "launch": "hipGraph per window" if use_graph else "python per step",
+                   "gc": "on" if args.keep_gc else "off during warm-up and timed region",
                    **({"static_buffers": lottery} if lottery else {}),
                    "bwd_duplicate_fold": "slots grouped by row per 16384-lookup segment, once per window "
                                          "(ce_bag_presort_window%s)" % ("" if args.tile_keys else "_src: keys = row | grad_out row, streaming backward") if presort else "1024-lookup tiles sorted inside every backward",
