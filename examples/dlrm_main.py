@@ -49,6 +49,11 @@ def parse_args(argv=None):
     p.add_argument("--shuffle_batches", action="store_true")
     p.add_argument("--epochs", type=int, default=1)
     p.add_argument("--limit_train_batches", type=int, default=200)
+    p.add_argument("--limit_val_batches", type=int, default=None)       # recsys/dlrm_main.py:50-61
+    p.add_argument("--limit_test_batches", type=int, default=None)
+    p.add_argument("--eval_acc", action="store_true",
+                   help="AUROC and accuracy over the val set after every epoch and over the test set at the end "
+                        "(recsys/dlrm_main.py:168,358-371)")
     p.add_argument("--batch_size", type=int, default=16384)
     p.add_argument("--num_dense_features", type=int, default=13)
     p.add_argument("--embedding_dim", type=int, default=128)
@@ -365,6 +370,91 @@ def _train(model, optimizer, loader, args, device, rank, world, record=None):
     return done, elapsed, float(loss.detach()) if done else float("nan")
 
 
+class BinaryMetrics:
+    """AUROC + accuracy accumulated over an evaluation pass and computed once at its end -- what the reference takes
+    from torchmetrics (`metrics.AUROC(compute_on_step=False)`, `metrics.Accuracy(compute_on_step=False)`,
+    recsys/dlrm_main.py:303-304), written out because torchmetrics is not part of this image.  Stock torch on whatever
+    device the predictions live on; one process-group gather at compute() when there are several ranks."""
+
+    def __init__(self, threshold: float = 0.5):
+        self.threshold = threshold
+        self.preds: List[torch.Tensor] = []
+        self.labels: List[torch.Tensor] = []
+
+    def __call__(self, preds: torch.Tensor, labels: torch.Tensor) -> None:
+        self.preds.append(preds.detach().reshape(-1).float())
+        self.labels.append(labels.detach().reshape(-1).to(torch.int32))
+
+    @staticmethod
+    def auroc(preds: torch.Tensor, labels: torch.Tensor) -> float:
+        """Area under the ROC curve with tied scores joined by straight segments (the trapezoid torchmetrics / sklearn
+        integrate) = the Mann-Whitney statistic with AVERAGE ranks over ties: (sum of the positives' ranks -
+        P (P + 1) / 2) / (P N).  NaN when one class is absent."""
+        n = preds.numel()
+        pos = int((labels != 0).sum())
+        if n == 0 or pos == 0 or pos == n:
+            return float("nan")
+        order = torch.argsort(preds)
+        p, y = preds[order], (labels[order] != 0).double()
+        new = torch.ones(n, dtype=torch.bool, device=p.device)
+        new[1:] = p[1:] != p[:-1]
+        gid = torch.cumsum(new, 0) - 1                                  # tie group of every sorted position
+        ranks = torch.arange(1, n + 1, dtype=torch.float64, device=p.device)
+        gsum = torch.zeros(int(gid[-1]) + 1, dtype=torch.float64, device=p.device).index_add_(0, gid, ranks)
+        avg = (gsum / torch.bincount(gid).double())[gid]
+        return float(((avg * y).sum() - pos * (pos + 1) / 2.0) / (float(pos) * float(n - pos)))
+
+    def gathered(self):
+        """every rank's predictions and labels (the ranks evaluate different slices of a batch / of the set)"""
+        preds = torch.cat(self.preds) if self.preds else torch.zeros(0)
+        labels = torch.cat(self.labels) if self.labels else torch.zeros(0, dtype=torch.int32)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            W = dist.get_world_size()
+            cnt = torch.tensor([preds.numel()], dtype=torch.int64, device=preds.device)
+            cnts = [torch.zeros_like(cnt) for _ in range(W)]
+            dist.all_gather(cnts, cnt)
+            cap = max(int(c) for c in cnts)
+            pp = torch.zeros(cap, dtype=torch.float32, device=preds.device)
+            ll = torch.zeros(cap, dtype=torch.int32, device=preds.device)
+            pp[:preds.numel()], ll[:labels.numel()] = preds, labels
+            gp = [torch.zeros_like(pp) for _ in range(W)]
+            gl = [torch.zeros_like(ll) for _ in range(W)]
+            dist.all_gather(gp, pp)
+            dist.all_gather(gl, ll)
+            preds = torch.cat([g[:int(c)] for g, c in zip(gp, cnts)])
+            labels = torch.cat([g[:int(c)] for g, c in zip(gl, cnts)])
+        return preds, labels
+
+    def compute(self):
+        preds, labels = self.gathered()
+        if preds.numel() == 0:
+            return float("nan"), float("nan")
+        acc = float(((preds >= self.threshold) == (labels != 0)).double().mean())
+        return self.auroc(preds, labels), acc
+
+
+def _evaluate(model, loader, stage, args, device, rank, world):
+    """recsys/dlrm_main.py:300-333: model.eval(), no gradients, the module's own cache op per batch (`model(dense,
+    sparse)`: prepare_ids on the batch's ids, then the gather -- evaluation rows are admitted and evicted like training
+    rows, nothing is updated), sigmoid of the logits into AUROC and accuracy.  Returns (auroc, accuracy)."""
+    model.eval()
+    meter = BinaryMetrics()
+    data_iter = FiniteDataIter(loader, device) if args.use_overlap else iter(loader)
+    n = 0
+    with torch.no_grad():
+        for batch in data_iter:
+            dense, sparse, labels = put_data_in_device(batch, device, args.use_distributed_dataloader, rank, world)
+            logits = model(dense, sparse).squeeze(-1)
+            meter(torch.sigmoid(logits), labels.int())
+            n += 1
+    auroc, acc = meter.compute()
+    if rank == 0:
+        print(f"AUROC over {stage} set: {auroc}")
+        print(f"Accuracy over {stage} set: {acc}")
+    _evaluate.batches = n
+    return auroc, acc
+
+
 def main(argv=None):
     args = parse_args(argv)
     if not args.use_cache:
@@ -419,9 +509,32 @@ def main(argv=None):
                                  args.seed + 17)
     elif args.limit_train_batches:
         loader = _Limit(loader, args.limit_train_batches)
+    val_loader = test_loader = None
+    if args.eval_acc:
+        # recsys/dlrm_main.py:411-412 + recsys/datasets/criteo.py:386-391: val = the first half of the held-out day,
+        # test = the other half (rank r of 2W and rank r + W of 2W); synthetic: two more seeded streams of the same tables
+        if args.dataset_dir:
+            held = criteo_files(args.dataset_dir, "val")
+            r, w = (rank, world) if args.use_distributed_dataloader else (0, 1)
+            val_loader, test_loader = (BinaryCriteoNpy(*held, args.batch_size, rr, 2 * w, mmap_mode=args.mmap_mode,
+                                                       hashes=sizes, seed=args.seed) for rr in (r, r + w))
+        else:
+            val_loader, test_loader = (SyntheticLoader(sizes, args.batch_size, args.num_dense_features, n or 8,
+                                                       args.seed + off)
+                                       for n, off in ((args.limit_val_batches, 29), (args.limit_test_batches, 43)))
+        if args.limit_val_batches:
+            val_loader = _Limit(val_loader, args.limit_val_batches)
+        if args.limit_test_batches:
+            test_loader = _Limit(test_loader, args.limit_test_batches)
+    results = {"val_aurocs": [], "val_accuracies": [], "test_auroc": None, "test_accuracy": None}   # TrainValTestResults
+    main.results, main.model, main.val_loader, main.test_loader = results, model, val_loader, test_loader
     for epoch in range(args.epochs):
         rec = []
         done, elapsed, loss = train(model, optimizer, loader, args, device, rank, world, record=rec)
+        if args.eval_acc:                                        # recsys/dlrm_main.py:358-363
+            auroc, acc = _evaluate(model, val_loader, "val", args, device, rank, world)
+            results["val_aurocs"].append(auroc)
+            results["val_accuracies"].append(acc)
         if rank == 0:
             lookups = done * args.batch_size * len(sizes)
             q = max(1, len(rec) // 4)
@@ -459,7 +572,11 @@ def main(argv=None):
                     # iterations) and without a GPU synchronisation at the end.  Not comparable with it_per_s, which
                     # is bracketed by synchronisation and starts after the warm-up; kept because the reference prints it.
                     "it_per_s_reference_print_host_clock_incl_warmup": done / max(elapsed, 1e-9),
-                    "loss_first_quarter": head, "loss_last_quarter": tail}, indent=1))
+                    "loss_first_quarter": head, "loss_last_quarter": tail,
+                    "eval": ({"val_auroc": results["val_aurocs"][-1], "val_accuracy": results["val_accuracies"][-1],
+                              "val_batches": _evaluate.batches} if args.eval_acc else None)}, indent=1))
+    if args.eval_acc:                                            # recsys/dlrm_main.py:365-369
+        results["test_auroc"], results["test_accuracy"] = _evaluate(model, test_loader, "test", args, device, rank, world)
     if world > 1:
         dist.destroy_process_group()
 

@@ -36,6 +36,9 @@ B, F, D = 16384, 26, 128
 known_rd, known_wr = B * F * (512 + 8 + 4) / 1024.0, B * F * 512 / 1024.0
 print("# Reuse sensitivity of the bag kernels at the headline shape (B = 16384, F = 26, D = 128, 1 % cache)\n")
 print("Regenerate: `bash profiles/reuse_sweep.sh` on an MI355X box, then `python profiles/reuse_sweep.py`.\n")
+if not cal:
+    print("(`NO_PMC=1`: bench lines only -- kernel times back to back and algorithmic bytes; the counted-traffic columns "
+          "need the counter passes, last collected in `r04_reuse_sweep.md`.)\n")
 if "k_bag_fwd" in cal:
     c = cal["k_bag_fwd"]
     print(f"Counter calibration (slot-driven forward over 425,984 DISTINCT rows of a 2 GB table: {known_rd:.0f} KB read, "
@@ -73,6 +76,7 @@ for tag, label in (("pl025", "long tail s = 0.25 (default)"), ("mix036", "long t
         hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 if len(c) == 2 else float("nan")
         us = o["avg_ms"] * 1e3
         fr = lambda b: b / (us * 1e-6) / 8e12
+        num = lambda v, fmt: "-" if v != v else format(v, fmt)           # NaN: the counter passes were not run
         print(f"| {label} | {r['config']['prefetch_num']} | {uniq:,.0f} ({100 * uniq / n:.1f} %) | {r['value'] / 1e9:.2f} G | {k} | "
-              f"{us:.1f} | {hbm / 1e6:.1f} | {comp_b / 1e6:.1f} | {alg_b / 1e6:.1f} | {hbm / comp_b:.2f} | {hbm / alg_b:.2f} | "
-              f"{fr(comp_b):.2f} | {fr(hbm):.2f} | {fr(alg_b):.2f} |")
+              f"{us:.1f} | {num(hbm / 1e6, '.1f')} | {comp_b / 1e6:.1f} | {alg_b / 1e6:.1f} | {num(hbm / comp_b, '.2f')} | "
+              f"{num(hbm / alg_b, '.2f')} | {fr(comp_b):.2f} | {num(fr(hbm), '.2f')} | {fr(alg_b):.2f} |")

@@ -207,3 +207,30 @@ def _collective_trial(rank, world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_arrangement_trial_reaches_one_verdict_on_all_ranks(world):
     _spawn(_collective_trial, world)
+
+
+def _eval_meter(rank, world):
+    sys.path.insert(0, str(ROOT / "examples"))
+    import importlib
+    from sklearn.metrics import accuracy_score, roc_auc_score
+    dm = importlib.import_module("dlrm_main")
+    rng = np.random.default_rng(5)                    # the same global problem on every rank ...
+    n_per = [700, 123, 400][:world]                   # ... of which the ranks hold shares of different sizes
+    labels = rng.integers(0, 2, sum(n_per)).astype(np.int32)
+    scores = (np.round(rng.random(sum(n_per)) * 50) / 50 * 0.7 + labels * 0.2).astype(np.float32)   # with ties
+    lo = sum(n_per[:rank])
+    mine = slice(lo, lo + n_per[rank])
+    meter = dm.BinaryMetrics()
+    for a in range(mine.start, mine.stop, 97):
+        b = min(a + 97, mine.stop)
+        meter(torch.from_numpy(scores[a:b]), torch.from_numpy(labels[a:b]))
+    auroc, acc = meter.compute()                      # collective: every rank gets the whole set's numbers
+    assert abs(auroc - roc_auc_score(labels, scores)) < 1e-12
+    assert abs(acc - accuracy_score(labels, scores >= 0.5)) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_evaluation_meter_gathers_every_ranks_share(world):
+    """examples/dlrm_main.py::_evaluate at W > 1 (recsys/dlrm_main.py:300-333: torchmetrics syncs across ranks at
+    compute()): ranks hold shares of different lengths, all of them report the set's AUROC / accuracy"""
+    _spawn(_eval_meter, world)

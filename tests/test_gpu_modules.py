@@ -379,6 +379,57 @@ def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):
     assert last < first - 0.01, f"the loss did not go down: {first} -> {last}"
 
 
+@pytest.mark.parametrize("extra", [[], ["--overlap_cache_op", "--fused_sgd", "--fold_hook"], ["--use_lfu"]])
+def test_dlrm_evaluate_through_the_cache_equals_a_plain_embedding_bag_model(extra, capsys):
+    """examples/dlrm_main.py --eval_acc (recsys/dlrm_main.py:300-333,358-369): after training, `_evaluate` runs the
+    module in eval mode -- its own cache op per batch on a cache that keeps evicting (30 % of the rows), no gradients.
+    Its predictions must be those of the same dense weights over a plain torch-CPU embedding of the FLUSHED table:
+    AUROC / accuracy over the test set equal scikit-learn's on the CPU model's predictions, the table is left as the
+    training left it (evaluation updates nothing), and the trained model separates the learnable target."""
+    import copy
+    import importlib
+    import numpy as np
+    from sklearn.metrics import accuracy_score, roc_auc_score
+    sys.path.insert(0, str(ROOT / "examples"))
+    dm = importlib.import_module("dlrm_main")
+    args = ["--dataset", "avazu", "--table_scale", "0.01", "--batch_size", "256", "--embedding_dim", "32",
+            "--dense_arch_layer_sizes", "64,32", "--over_arch_layer_sizes", "64,1", "--use_cache", "--cache_ratio", "0.3",
+            "--use_freq", "--prefetch_num", "4", "--use_overlap", "--use_sparse_embed_grad", "--limit_train_batches",
+            "48", "--learning_rate", "0.2", "--eval_acc", "--limit_val_batches", "5", "--limit_test_batches", "7",
+            "--epochs", "2"] + extra
+    dm.main(args)
+    out = capsys.readouterr().out
+    assert out.count("AUROC over val set") == 2 and out.count("AUROC over test set") == 1
+    assert out.count("Accuracy over val set") == 2 and out.count("Accuracy over test set") == 1
+    res, model = dm.main.results, dm.main.model
+    assert len(res["val_aurocs"]) == 2 and dm._evaluate.batches == 7
+    embed = model.sparse_modules.embed
+    writes = sum(embed.num_write_back_history)
+    assert writes > 0, "the cache never evicted: the test would not cover evaluation under eviction"
+    embed.flush()
+    table = embed.weight.detach().clone()
+    dense_cpu = copy.deepcopy(model.dense_modules).cpu().eval()
+    F = model.sparse_modules.sparse_feature_num
+    preds, labels = [], []
+    with torch.no_grad():
+        for b in dm.main.test_loader:
+            values, B = b["sparse"][0].long(), b["sparse"][2]
+            pooled = table[values].view(F, B, -1).transpose(0, 1).contiguous()        # one id per bag, feature-major KJT
+            preds.append(torch.sigmoid(dense_cpu(b["dense"], pooled).squeeze(-1)))
+            labels.append(b["labels"])
+    preds, labels = torch.cat(preds).numpy(), torch.cat(labels).numpy().astype(np.int32)
+    assert labels.min() == 0 and labels.max() == 1
+    # GPU and CPU GEMMs differ in the last bits of a prediction: a near-tie may swap, nothing more
+    assert abs(res["test_auroc"] - roc_auc_score(labels, preds)) < 2e-4
+    assert abs(res["test_accuracy"] - accuracy_score(labels, preds >= 0.5)) <= 3.0 / len(labels)
+    assert res["test_auroc"] > 0.6, f"the trained model does not separate the learnable target: {res}"
+    # a second evaluation pass gives the same numbers and leaves the table alone
+    again = dm._evaluate(model, dm.main.test_loader, "test", dm.parse_args(args), torch.device("cuda", 0), 0, 1)
+    assert abs(again[0] - res["test_auroc"]) < 1e-6 and abs(again[1] - res["test_accuracy"]) <= 1.0 / len(labels)
+    embed.flush()
+    assert torch.equal(embed.weight.detach(), table)
+
+
 def test_toy_dlrm_matches_torch_cpu_trajectory():
     """SURVEY 8(c) wiring fixture: a toy DLRM (13 -> 64 -> 32 dense, 4 tables, B = 64) trained 20 steps through
     examples/dlrm_main.py's model and training loop (prefetch window of 4, cached embedding with evictions) against
