@@ -428,10 +428,12 @@ class CachedParamMgr(torch.nn.Module):
         wb = self.writeback_stats()
         if wb["jobs"]:
             row_b = self.embedding_dim * esz
+            def rate(nbytes, busy_s):
+                # (the chained admission is a kernel on the library's admission stream: no worker thread times it)
+                return f"{nbytes / busy_s / 1e9:.1f} GB/s" if busy_s > 0 else "a rate no worker thread timed"
             msg += (f"; swap workers: out {wb['jobs']} jobs {wb['rows'] * row_b / 1e6:.2f} MB at "
-                    f"{wb['rows'] * row_b / max(wb['out_busy_s'], 1e-9) / 1e9:.1f} GB/s, in {wb['in_jobs']} jobs "
-                    f"{wb['in_rows'] * row_b / 1e6:.2f} MB at "
-                    f"{wb['in_rows'] * row_b / max(wb['in_busy_s'], 1e-9) / 1e9:.1f} GB/s")
+                    f"{rate(wb['rows'] * row_b, wb['out_busy_s'])}, in {wb['in_jobs']} jobs "
+                    f"{wb['in_rows'] * row_b / 1e6:.2f} MB at {rate(wb['in_rows'] * row_b, wb['in_busy_s'])}")
         print(msg)
         return msg
 

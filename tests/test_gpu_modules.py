@@ -382,7 +382,7 @@ def test_dlrm_trainer_counterpart_runs_and_learns(extra, capsys):
 @pytest.mark.parametrize("extra", [[], ["--overlap_cache_op", "--fused_sgd", "--fold_hook"], ["--use_lfu"]])
 def test_dlrm_evaluate_through_the_cache_equals_a_plain_embedding_bag_model(extra, capsys):
     """examples/dlrm_main.py --eval_acc (recsys/dlrm_main.py:300-333,358-369): after training, `_evaluate` runs the
-    module in eval mode -- its own cache op per batch on a cache that keeps evicting (30 % of the rows), no gradients.
+    module in eval mode -- its own cache op per batch on a cache that keeps evicting (3 % of the rows), no gradients.
     Its predictions must be those of the same dense weights over a plain torch-CPU embedding of the FLUSHED table:
     AUROC / accuracy over the test set equal scikit-learn's on the CPU model's predictions, the table is left as the
     training left it (evaluation updates nothing), and the trained model separates the learnable target."""
@@ -393,10 +393,12 @@ def test_dlrm_evaluate_through_the_cache_equals_a_plain_embedding_bag_model(extr
     sys.path.insert(0, str(ROOT / "examples"))
     dm = importlib.import_module("dlrm_main")
     args = ["--dataset", "avazu", "--table_scale", "0.01", "--batch_size", "256", "--embedding_dim", "32",
-            "--dense_arch_layer_sizes", "64,32", "--over_arch_layer_sizes", "64,1", "--use_cache", "--cache_ratio", "0.3",
+            "--dense_arch_layer_sizes", "64,32", "--over_arch_layer_sizes", "64,1", "--use_cache", "--cache_ratio", "0.03",
             "--use_freq", "--prefetch_num", "4", "--use_overlap", "--use_sparse_embed_grad", "--limit_train_batches",
             "48", "--learning_rate", "0.2", "--eval_acc", "--limit_val_batches", "5", "--limit_test_batches", "7",
             "--epochs", "2"] + extra
+    # (94,464 rows, a cache of 2,833: the 48 training batches touch ~4,400 distinct rows, a window of 4 under 1,000 --
+    # the cache must evict while it trains and while it evaluates, and two protected windows still fit)
     dm.main(args)
     out = capsys.readouterr().out
     assert out.count("AUROC over val set") == 2 and out.count("AUROC over test set") == 1
