@@ -50,6 +50,65 @@ PCIE_DUPLEX_PROBE = {
             "whose kernel half needs no host gather and whose copy half does not slow the kernels beside it (x1.02)"}
 
 
+class IdWindows(list):
+    """The run's id windows ([P, F*B*L] int64 each, resident in HBM before they are used), plus the generator state each
+    was drawn from -- so that a window given back to the allocator can be DRAWN AGAIN, bit for bit, when the end-of-run
+    check wants every trained batch's ids once more.  Why: with the check armed the run used to keep every window
+    resident (several GB of live allocations beside the buffers the steps use) and precompute the check's gradient rows
+    before the pipeline was built; processes of that shape fell into the slow kind of side-stream window in about half
+    of the lines (1.38-1.47 instead of 1.0-1.1 ms per window: 3 of 5 armed processes beside 0 of 52 without the check,
+    profiles/r06_kinds_sweep.md, r06_kinds_smi.md, r06_kinds_armed.txt).  With the re-draw, the device sees the same
+    allocations during the timed region whether the check is armed or not.  The generator is counter-based (Philox on
+    the device): the same state gives the same draws; `redraw_ok` says whether that was CONFIRMED in this process on the
+    first window (drawn twice, compared) -- windows are only given back when it was."""
+
+    def __init__(self, gen, P, selftest=True):
+        super().__init__()
+        self.gen, self.P = gen, P
+        self.states = []
+        self.redraw_ok = None if selftest else False
+
+    def draw(self):
+        try:
+            self.states.append(self.gen.gen.get_state())
+        except Exception:                          # no state to come back to: every window stays resident
+            self.states.append(None)
+            self.redraw_ok = False
+        self.append(self.gen.next_values(self.P))
+        if self.redraw_ok is None:
+            self.redraw_ok = self._confirm(len(self) - 1)
+
+    def _confirm(self, w):
+        """draw window w again from its state and compare; the generator carries on where it was"""
+        try:
+            after = self.gen.gen.get_state()
+        except Exception:
+            return False
+        try:
+            self.gen.gen.set_state(self.states[w])
+            return bool(torch.equal(self.gen.next_values(self.P), self[w]))
+        except Exception:
+            return False
+        finally:
+            try:
+                self.gen.gen.set_state(after)
+            except Exception:
+                pass
+
+    def release(self, upto):
+        """windows [0, upto) are not needed again before the run is over"""
+        for w in range(max(0, upto)):
+            self[w] = None
+
+    def again(self, w):
+        """window w's ids (drawn again if they were given back); only once the run draws no NEW window any more"""
+        if self[w] is None:
+            assert self.redraw_ok and self.states[w] is not None
+            self.gen.gen.set_state(self.states[w])
+            self[w] = self.gen.next_values(self.P)
+        return self[w]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +199,9 @@ def parse():
                     help="row-wise sharded runs at N > 1: the same end-of-run check per shard (every rank gathers all "
                          "ranks' ids of every trained step: steps x N x 3.4 MB of HBM per rank).  On by default for "
                          "--force_sharded at N = 1, where it costs what the unsharded check costs")
+    ap.add_argument("--keep_windows", action="store_true",
+                    help="diagnostic: the end-of-run check keeps every window's ids resident in HBM (and builds its "
+                         "gradient rows before the pipeline) as it did until round 6, instead of drawing the windows again")
     ap.add_argument("--no_verify", action="store_true",
                     help="skip the end-of-run check: after the timed region the cache is flushed and EVERY row the run "
                          "looked up is compared, in the host table, with w0[row] - lr * (sum of the gradient rows of its "
@@ -230,13 +292,13 @@ def main():
     if W % P:
         W = (W // P + 1) * P          # whole windows of untimed warm-up (the timed blocks then start on a window)
     # inputs resident in HBM before they are used; windows are generated on demand OUTSIDE the timed blocks
-    windows = []
+    windows = IdWindows(gen, P, selftest=not (args.no_verify or args.keep_windows))
 
     def need_windows(n_steps, first_step=0):
         while len(windows) * P < n_steps + P * args.plan_ahead:   # + the look-ahead windows of the overlapped cache op
-            windows.append(gen.next_values(P))          # each [P, F*B*L]
-        for w in range(max(0, first_step // P - 2) if args.no_verify else 0):   # windows long done: give the HBM back
-            windows[w] = None          # (kept when the end-of-run check will read them again)
+            windows.draw()                              # each [P, F*B*L]
+        if args.no_verify or windows.redraw_ok:         # windows long done: give the HBM back (the end-of-run check
+            windows.release(first_step // P - 2)        # draws them again: IdWindows)
 
     need_windows(W + K)
     offsets = gen.offsets
@@ -261,9 +323,13 @@ def main():
     if verify:
         from oracle.closed_form import SgdLedger       # checker only: nothing of it runs before the timing is done
         ledger = SgdLedger(N, D, args.lr, mgr._idx_map)
-        gflat = grad.transpose(0, 1).reshape(F * B, D).contiguous()       # gradient row of lookup j (bag j = f * B + b)
-        if L > 1:
-            gflat = gflat.repeat_interleave(L, dim=0)
+
+        def grad_rows():
+            g_ = grad.transpose(0, 1).reshape(F * B, D).contiguous()      # gradient row of lookup j (bag j = f * B + b)
+            return g_.repeat_interleave(L, dim=0) if L > 1 else g_
+        # (218 MB: built when the run is over -- the upstream gradient is a constant of the run --, so that the device
+        # holds the same allocations during the timed region as without the check; --keep_windows: up front, as before)
+        gflat = grad_rows() if args.keep_windows else None
 
     trained_log = []
 
@@ -903,10 +969,24 @@ def main():
                                 "gap can be negative there"}
 
     if ledger is not None:
-        for w_, i0_, i1_ in trained_log:
-            for i_ in range(i0_, i1_):
-                ledger.record(windows[w_][i_], gflat)
-        if pipe_error:
+        redraw_error = None
+        result["config"]["id_windows"] = ("given back behind the steps and drawn again for the end-of-run check (a re-draw "
+                                          "from the generator state was confirmed bit for bit on the first window)"
+                                          if windows.redraw_ok else "resident for the whole run")
+        try:
+            if gflat is None:
+                gflat = grad_rows()
+            gen_state = gen.gen.get_state()            # (the CPU baseline draws from the generator after this)
+            for w_, i0_, i1_ in trained_log:
+                ids_w = windows.again(w_)
+                for i_ in range(i0_, i1_):
+                    ledger.record(ids_w[i_], gflat)
+            gen.gen.set_state(gen_state)
+        except Exception as e:                         # the line survives; the check says why it did not run
+            redraw_error = f"{type(e).__name__}: {e}"
+        if redraw_error:
+            result["verified"] = {"pass": None, "skipped": "the trained windows' ids could not be drawn again (" + redraw_error + ")"}
+        elif pipe_error:
             # the diagnostic pass left the engine failed (it stays failed by design): the table cannot be flushed
             result["verified"] = {"pass": None, "skipped": "the in-pipeline diagnostic pass behind the timed region failed ("
                                   + pipe_error + "); the engine refuses further calls, so the end-of-run check could not run"}
